@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline workload on MI355X: O(N^2) all-pairs gravity + kick-drift.
+
+A "step" is one Tick body (OctreeSearch.cpp:25-31) over all N bodies: force pass + update.  The workload is
+BASELINE.json's metric configuration, N = 2^20 bodies, fp32, reference-compatible arithmetic (G = 1e4, no
+softening, d == 0 pairs skipped); it fits one GPU, so every --gpus value runs the same N (strong scaling:
+the bodies are range-partitioned over the ranks with one RCCL all-gather of positions per step).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3      # MI355X vector fp32 peak, MI355X_MICROARCH.md "Chip-level parameters"
+FLOP_PER_PAIR = 20            # 3 sub + 6 (dot) + 4 (rsqrt cubed) + 1 (mass) + 6 (3 FMA)
+# HBM bytes per force launch from the PMC pass recorded in profiles/ (None until measured)
+TRAFFIC_BYTES_PER_LAUNCH = {}
+
+
+def cpu_baseline(posm, target_seconds):
+    """The oracle's direct sum (reference arithmetic) on the host cores, on a bounded i-slice of the same
+    workload.  Test/bench infrastructure only — never part of the measured GPU path."""
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    n = posm.shape[0]
+    pos = np.ascontiguousarray(posm[:, :3]); mass = np.ascontiguousarray(posm[:, 3])
+    cores = min(O.max_threads(), os.cpu_count() or 1)
+    probe = min(n, 4 * cores)
+    t0 = time.perf_counter()
+    O.forces_direct_f32(pos, mass, i0=0, i1=probe, nthreads=cores)
+    t_probe = time.perf_counter() - t0
+    rate = probe * n / max(t_probe, 1e-9)
+    ni = int(min(n, max(probe, target_seconds * rate / n)))
+    ni = max(cores, ni // cores * cores)
+    t0 = time.perf_counter()
+    O.forces_direct_f32(pos, mass, i0=0, i1=ni, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": ni * n / dt, "unit": "pair-interactions/s", "cores": cores, "kind": "port",
+            "sample": f"oracle direct sum (reference fp32/double-pow arithmetic), bodies 0..{ni - 1} vs all {n} "
+                      f"of the same Plummer input, {dt:.1f} s, OpenMP over i"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1 << 20, help="bodies (default 2^20 = BASELINE metric)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32_kahan", "f64"])
+    ap.add_argument("--eps", type=float, default=0.0)
+    ap.add_argument("--dt", type=float, default=0.01)
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--ipt", type=int, default=0)
+    ap.add_argument("--jsplit", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length; 0 = skip")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import parallelnbody_amd as nb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: parallelnbody_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = torch.distributed
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.n
+    posm, vel = nb.ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
+    sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device=f"cuda:{local_rank}",
+                               precision=args.precision, eps=args.eps, tile=args.tile, i_per_thread=args.ipt,
+                               j_split=args.jsplit, time_kernels=True)
+    cfg = sim.engine.launch_config()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sim.step(args.dt, args.warmup)
+    fence()
+    sim.engine.kernel_time_reset()
+    t0 = time.perf_counter()
+    sim.step(args.dt, args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    f_ms, f_n = sim.engine.kernel_time(nb.KERNEL_FORCES)
+    u_ms, u_n = sim.engine.kernel_time(nb.KERNEL_UPDATE)
+    pairs_per_step = float(n) * float(n)
+    value = pairs_per_step * args.steps / elapsed
+    # dominant kernel: the force pass of this rank = i_count x n_total pair evaluations per launch
+    launch_pairs = float(sim.i_count) * float(n)
+    avg_launch_s = (f_ms / max(f_n, 1)) * 1e-3
+    achieved_tflops = launch_pairs * FLOP_PER_PAIR / avg_launch_s * 1e-12
+    peak = PEAK_FP32_TFLOPS if args.precision != "f64" else PEAK_FP32_TFLOPS / 2
+    p_end, _ = sim.gather_state()
+    finite = bool(np.isfinite(p_end).all())
+
+    if rank == 0:
+        out = {
+            "metric": "body-pair interactions/s at N=2^20" if n == (1 << 20) else f"body-pair interactions/s at N={n}",
+            "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": {"f32": "f32", "f32_kahan": "f32", "f64": "f64"}[args.precision], "data": "synthetic",
+            "config": {"workload": f"N={n} all-pairs {args.precision}, seeded Plummer sphere, G=1e4, eps={args.eps}, "
+                                   f"dt={args.dt}, one force pass + kick-drift per step",
+                       "parallelism": f"range-partition x{world}, 1 RCCL all-gather(posm)/step" if world > 1 else "1 GPU",
+                       "lds_tile_bodies": cfg["tile"], "i_per_lane": cfg["i_per_thread"], "j_split": cfg["j_split"],
+                       "workgroups": cfg["blocks"], "accumulate": args.precision, "finite": finite},
+            "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64",
+                         "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((n, world)),
+                         "kernel": "forces_tile_kernel", "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
+                         "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs,
+                         "update_kernel_avg_ms": u_ms / max(u_n, 1)},
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(posm, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+/*
+ * nbody.h — C-ABI of the MI355X-native N-body engine (libnbody_amd.so).
+ *
+ * The reference (Milias/ParallelNbody) has no FFI; its boundary for this path is the public
+ * surface of the UE4 actor AOctreeSearch (Source/NBody/OctreeSearch.h:111-149).  Each entry point
+ * below replaces one responsibility of that class and cites it.  Paths are relative to
+ * /root/reference/Source/NBody/.
+ *
+ * Conventions: plain C types only; every call returns 0 (NBODY_OK) or a negative NBODY_ERR_*;
+ * nothing throws across the boundary; the context is an opaque caller-owned pointer; all host
+ * buffers are caller-allocated; calls on one context are not thread-safe (the reference runs on
+ * the UE4 game thread only).  There is NO CPU fallback: without a HIP device nbody_create fails
+ * with NBODY_ERR_NO_DEVICE.
+ */
+#ifndef NBODY_AMD_H
+#define NBODY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBODY_API __attribute__((visibility("default")))
+
+#define NBODY_VERSION_MAJOR 0
+#define NBODY_VERSION_MINOR 1
+
+typedef struct nbody_ctx nbody_ctx;
+
+enum {
+  NBODY_OK = 0,
+  NBODY_ERR_INVALID = -1,     /* bad argument */
+  NBODY_ERR_NO_DEVICE = -2,   /* no HIP device / device ordinal out of range */
+  NBODY_ERR_HIP = -3,         /* a HIP runtime call failed; see nbody_last_error */
+  NBODY_ERR_STATE = -4,       /* call made in the wrong state (e.g. no particles set) */
+  NBODY_ERR_NOMEM = -5,
+  NBODY_ERR_UNSUPPORTED = -6
+};
+
+/* Arithmetic of the force accumulation. */
+enum {
+  NBODY_PREC_F32 = 0,         /* reference-compatible: fp32 pair law, fp32 accumulate */
+  NBODY_PREC_F32_KAHAN = 1,   /* fp32 pair law, Kahan-compensated fp32 accumulate */
+  NBODY_PREC_F64 = 2          /* fp64 state, pair law and accumulate */
+};
+
+/* Device buffers reachable through nbody_device_ptr / nbody_bind_device_state. */
+enum {
+  NBODY_BUF_POSM = 0,         /* [n_total] x,y,z,mass  (float4, or double4 for NBODY_PREC_F64) */
+  NBODY_BUF_VEL = 1,          /* [i_count] vx,vy,vz,0 */
+  NBODY_BUF_ACC = 2           /* [i_count] ax,ay,az,0 */
+};
+
+/* Kernels whose device time nbody_kernel_time reports. */
+enum { NBODY_KERNEL_FORCES = 0, NBODY_KERNEL_UPDATE = 1 };
+
+/* FParticle — OctreeSearch.h:8-18.  Same field order and offsets (40 bytes). */
+typedef struct nbody_particle {
+  float Mass;
+  float Position[3];
+  float Velocity[3];
+  float Acceleration[3];
+} nbody_particle;
+
+/*
+ * Engine parameters.  The reference hard-codes G = 1e4 (OctreeSearch.h:104), no softening
+ * (.h:101-104) and fp32; nbody_default_params fills in exactly those.
+ */
+typedef struct nbody_params {
+  uint32_t struct_size;   /* sizeof(nbody_params), for ABI versioning */
+  int32_t n_total;        /* bodies in the whole system (Particles.Num(), OctreeSearch.h:118) */
+  int32_t i_begin;        /* first body this context owns (range partition over GPUs); default 0 */
+  int32_t i_count;        /* bodies this context owns; 0 = n_total - i_begin */
+  int32_t device;         /* HIP device ordinal */
+  int32_t precision;      /* NBODY_PREC_* */
+  double G;               /* gravitational constant; reference 1e4 */
+  double eps;             /* Plummer softening length; reference 0 (d == 0 pairs are skipped) */
+  int32_t tile;           /* bodies per LDS tile: 64, 128, 256 (default), 512 */
+  int32_t i_per_thread;   /* i-bodies per lane: 1, 2, 4; 0 = auto */
+  int32_t j_split;        /* j-range chunks summed separately then combined in order; 0 = auto (a function of n_total only) */
+  int32_t time_kernels;   /* nonzero: bracket kernels with HIP events for nbody_kernel_time */
+} nbody_params;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+
+/* Fill `p` with the reference-compatible defaults (G=1e4, eps=0, fp32, device 0). */
+NBODY_API int nbody_default_params(nbody_params *p);
+
+/* AOctreeSearch ctor + CreateSpacePoints' allocation (OctreeSearch.cpp:8,62). */
+NBODY_API int nbody_create(const nbody_params *p, nbody_ctx **out);
+
+/* CleanParticles (OctreeSearch.cpp:91-97).  NULL is allowed, like `delete NULL` there. */
+NBODY_API void nbody_destroy(nbody_ctx *ctx);
+
+/* Message of the last error on `ctx` (or of the last failed nbody_create when ctx is NULL). */
+NBODY_API const char *nbody_last_error(const nbody_ctx *ctx);
+
+NBODY_API int nbody_version(void);
+
+/* Number of HIP devices visible (0 when there is none; never fails). */
+NBODY_API int nbody_device_count(void);
+
+/* ---- state in ----------------------------------------------------------------------------- */
+
+/* TArray<FParticle> contents (OctreeSearch.h:8-18,118): all n_total records, `stride` bytes apart (>= 40). */
+NBODY_API int nbody_set_particles(nbody_ctx *ctx, const void *aos, size_t stride, int32_t n);
+
+/* Native layout: posm4 = n_total x {x,y,z,m}, vel4 = n_total x {vx,vy,vz,unused}, fp32. */
+NBODY_API int nbody_set_state_soa(nbody_ctx *ctx, const float *posm4, const float *vel4, int32_t n);
+
+/* Same in fp64 (converted down for fp32 contexts). */
+NBODY_API int nbody_set_state_soa_f64(nbody_ctx *ctx, const double *posm4, const double *vel4, int32_t n);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+
+/*
+ * The force loop of CreateOctree (OctreeSearch.cpp:83-86) at theta = 0: Acceleration_i =
+ * sum over j of the pair law (OctreeSearch.h:101-104) for the owned bodies against all n_total.
+ */
+NBODY_API int nbody_compute_forces(nbody_ctx *ctx);
+
+/*
+ * The body of Tick (OctreeSearch.cpp:25-32), `nsteps` times: forces(x_n); v += dt*a; x += dt*v.
+ * dt <= 0 is a no-op, as PhDeltaTime <= 0 freezes the reference (.cpp:25).  Asynchronous on the
+ * context's stream; the getters synchronise.  On a sharded context (i_count < n_total) nsteps
+ * must be 1: the caller all-gathers NBODY_BUF_POSM across ranks between steps.
+ */
+NBODY_API int nbody_step(nbody_ctx *ctx, float dt, int32_t nsteps);
+
+/* ComputeCubeSize (OctreeSearch.cpp:47-56): max over owned bodies of max(|x|,|y|,|z|). */
+NBODY_API int nbody_get_bounds(nbody_ctx *ctx, float *size);
+
+/* ---- state out ---------------------------------------------------------------------------- */
+
+/* What DrawDebugPoint reads (OctreeSearch.cpp:41): positions of bodies [first, first+count) of the
+ * whole system, 3 floats each, `stride` bytes apart (>= 12). */
+NBODY_API int nbody_get_positions(nbody_ctx *ctx, float *xyz, size_t stride, int32_t first, int32_t count);
+
+/* Owned records [i_begin, i_begin+i_count) into aos[0..i_count): Mass, Position, Velocity, Acceleration. */
+NBODY_API int nbody_get_particles(nbody_ctx *ctx, void *aos, size_t stride);
+
+/* Owned bodies, native layout (fp32; converted down from fp64 contexts).  Either pointer may be NULL. */
+NBODY_API int nbody_get_state_soa(nbody_ctx *ctx, float *posm4, float *vel4, float *acc4);
+NBODY_API int nbody_get_state_soa_f64(nbody_ctx *ctx, double *posm4, double *vel4, double *acc4);
+
+/* Kinetic energy of the owned bodies and their share of the potential energy (1/2 m_i phi_i),
+ * evaluated in fp64 on the device.  Sum over contexts for the system total.  Build-defined (no
+ * reference counterpart). */
+NBODY_API int nbody_energy(nbody_ctx *ctx, double *ke, double *pe);
+
+/* ---- device plumbing (torch / RCCL interop) -------------------------------------------------- */
+
+/* Launch on the caller's HIP stream (hipStream_t as void*); NULL = the context's own stream. */
+NBODY_API int nbody_set_stream(nbody_ctx *ctx, void *hip_stream);
+
+/* Raw device pointer of one state buffer (e.g. as the send/recv buffer of an all-gather). */
+NBODY_API int nbody_device_ptr(nbody_ctx *ctx, int32_t which, void **ptr, size_t *bytes);
+
+/* Use caller-owned device memory for the state (any may be NULL = keep the context's own).
+ * Sizes as in NBODY_BUF_*.  The caller keeps them alive until nbody_destroy. */
+NBODY_API int nbody_bind_device_state(nbody_ctx *ctx, void *posm, void *vel, void *acc);
+
+/* Block until everything queued on the context's stream has finished. */
+NBODY_API int nbody_synchronize(nbody_ctx *ctx);
+
+/* Sum of device time (ms) and number of launches of one kernel since the last reset, from HIP
+ * events recorded on the launch stream (needs params.time_kernels).  Synchronises. */
+NBODY_API int nbody_kernel_time(nbody_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
+NBODY_API int nbody_kernel_time_reset(nbody_ctx *ctx);
+
+/* Launch geometry actually chosen (for logs and DESIGN.md tables). */
+NBODY_API int nbody_get_launch_config(nbody_ctx *ctx, int32_t *tile, int32_t *i_per_thread, int32_t *j_split,
+                                      int32_t *blocks, int32_t *threads);
+
+/* ---- initial conditions (host only; no device needed) ---------------------------------------- */
+
+/*
+ * CreateSpacePoints (OctreeSearch.cpp:58-72) with a seeded generator: uniform box
+ * (+-size, +-size, +-size/10) about `center`, isotropic velocities of magnitude 250..500, masses
+ * 1..5000, body 0 pinned at the origin at rest with mass 5000.  The reference uses the engine's
+ * unseeded RNG, so only the distribution is reproduced.  Out: n x 4 floats each.
+ */
+NBODY_API int nbody_ic_reference_box(int32_t n, float size, const float center[3], uint64_t seed,
+                                     float *posm4, float *vel4);
+
+/* Seeded equal-mass Plummer sphere in virial equilibrium for constant G (build-defined workload). */
+NBODY_API int nbody_ic_plummer(int32_t n, double total_mass, double scale_radius, double G, uint64_t seed,
+                               float *posm4, float *vel4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_AMD_H */

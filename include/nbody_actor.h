@@ -1,0 +1,51 @@
+/*
+ * nbody_actor.h — C view of nbody::OctreeSearchActor (nbody_actor.hpp), the mirror of the reference's
+ * AOctreeSearch (Source/NBody/OctreeSearch.h:111-149).  For hosts that cannot include C++ (ctypes,
+ * cgo-style bindings) and for the parity tests.  Same conventions as nbody.h; methods that are
+ * `void` in the reference return nothing here either — nbody_actor_last_status reports the last
+ * C-ABI code.
+ */
+#ifndef NBODY_AMD_ACTOR_H
+#define NBODY_AMD_ACTOR_H
+
+#include "nbody.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbody_actor nbody_actor;
+
+/* Draw callbacks: FlushPersistentDebugLines (OctreeSearch.cpp:24) and DrawDebugPoint (.cpp:41). */
+typedef void (*nbody_flush_fn)(void *user);
+typedef void (*nbody_draw_point_fn)(void *user, const float position[3], float point_size);
+
+NBODY_API nbody_actor *nbody_actor_create(void);                                   /* AOctreeSearch(), .cpp:8 */
+NBODY_API void nbody_actor_destroy(nbody_actor *a);
+NBODY_API void nbody_actor_create_space_points(nbody_actor *a, int32_t n, float size);   /* .cpp:58-72 */
+NBODY_API void nbody_actor_set_particles(nbody_actor *a, const nbody_particle *p, int32_t n);
+NBODY_API void nbody_actor_compute_cube_size(nbody_actor *a);                      /* .cpp:47-56 */
+NBODY_API void nbody_actor_create_octree(nbody_actor *a);                          /* .cpp:74-89 */
+NBODY_API void nbody_actor_tick(nbody_actor *a, float delta_seconds);              /* .cpp:21-34 */
+NBODY_API void nbody_actor_clean_particles(nbody_actor *a);                        /* .cpp:91-97 */
+NBODY_API void nbody_actor_set_draw_callbacks(nbody_actor *a, nbody_flush_fn flush, nbody_draw_point_fn point, void *user);
+
+/* Fields (OctreeSearch.h:117-127 + the build-defined knobs of nbody_actor.hpp). */
+NBODY_API float nbody_actor_get_size(const nbody_actor *a);
+NBODY_API int32_t nbody_actor_get_initialized(const nbody_actor *a);
+NBODY_API int32_t nbody_actor_num_particles(const nbody_actor *a);
+NBODY_API float nbody_actor_get_ph_delta_time(const nbody_actor *a);
+NBODY_API void nbody_actor_set_ph_delta_time(nbody_actor *a, float dt);
+NBODY_API int32_t nbody_actor_get_show_octree(const nbody_actor *a);
+NBODY_API void nbody_actor_set_show_octree(nbody_actor *a, int32_t show);
+NBODY_API void nbody_actor_set_theta(nbody_actor *a, float theta);
+NBODY_API void nbody_actor_set_seed(nbody_actor *a, uint64_t seed);
+NBODY_API void nbody_actor_set_engine(nbody_actor *a, int32_t device, int32_t precision, double G, double eps);
+NBODY_API int32_t nbody_actor_last_status(const nbody_actor *a);
+/* Copy the (synchronised) Particles array out; returns the number of records written. */
+NBODY_API int32_t nbody_actor_get_particles(nbody_actor *a, nbody_particle *out, int32_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,167 @@
+// nbody_actor.hpp — plain-C++ mirror of the reference's UE4 actor AOctreeSearch
+// (/root/reference/Source/NBody/OctreeSearch.h:111-149, OctreeSearch.cpp) on top of the C-ABI in
+// nbody.h.  Same member names, defaults, call order and silent-guard error behaviour; UE4 types are
+// replaced by standard ones (TArray -> std::vector, FVector -> float[3], DrawDebug* -> callbacks).
+// A real UE4 adapter derives from AActor and forwards to this class.
+//
+// Header-only: needs only nbody.h and libnbody_amd.so.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <vector>
+
+#include "nbody.h"
+
+namespace nbody {
+
+using FParticle = nbody_particle;   // OctreeSearch.h:8-18
+
+class OctreeSearchActor {
+ public:
+  // ---- reference members (OctreeSearch.h:117-127) ----
+  float Size = 0.0f;                    // .h:117
+  std::vector<FParticle> Particles;     // .h:118  (host mirror of the device state, see MirrorParticles)
+  bool Initialized = false;             // .h:121
+  bool ShowOctree = false;              // .h:124  BlueprintReadWrite
+  float PhDeltaTime = 0.01f;            // .h:127  BlueprintReadWrite; default from the ctor, .cpp:8
+
+  // ---- build-defined knobs (no reference counterpart) ----
+  // Opening angle.  The reference hard-codes 1.0 (.cpp:85); this engine implements the theta = 0
+  // limit of that walk (exact all-pairs).  Any other value makes the force pass report
+  // NBODY_ERR_UNSUPPORTED in LastStatus and leave the state untouched.
+  float Theta = 0.0f;
+  uint64_t Seed = 0x4E426F6479ull;      // CreateSpacePoints' generator seed (the reference is unseeded)
+  float ActorLocation[3] = {0, 0, 0};   // GetActorLocation(), .cpp:64
+  bool MirrorParticles = true;          // refresh `Particles` after every Tick, as the reference's TArray is live
+  int Device = 0;
+  int Precision = NBODY_PREC_F32;
+  double G = 1.0e4;                     // .h:104
+  double Eps = 0.0;
+  int LastStatus = NBODY_OK;            // last C-ABI return code (the reference's methods are void)
+
+  // Renderer hand-off (OctreeSearch.cpp:24,40-41): FlushPersistentDebugLines, DrawDebugPoint(Position, 10.0, Black),
+  // DrawDebugBox (never called here: there is no tree at theta = 0).
+  std::function<void()> OnFlushPersistentDebugLines;
+  std::function<void(const float position[3], float point_size)> OnDrawDebugPoint;
+
+  OctreeSearchActor() = default;        // .cpp:8
+  OctreeSearchActor(const OctreeSearchActor &) = delete;
+  OctreeSearchActor &operator=(const OctreeSearchActor &) = delete;
+  ~OctreeSearchActor() { nbody_destroy(ctx_); }
+
+  void BeginPlay() {}                   // .cpp:15-18
+
+  // .cpp:58-72
+  void CreateSpacePoints(int32_t N, float SizeArg = 200.0f) {
+    if (N <= 0) { LastStatus = NBODY_ERR_INVALID; return; }
+    Size = SizeArg;
+    std::vector<float> posm(4 * (size_t)N), vel(4 * (size_t)N);
+    LastStatus = nbody_ic_reference_box(N, SizeArg, ActorLocation, Seed, posm.data(), vel.data());
+    if (LastStatus) return;
+    Particles.assign((size_t)N, FParticle{});
+    for (int32_t i = 0; i < N; ++i) {
+      FParticle &p = Particles[(size_t)i];
+      p.Mass = posm[4 * (size_t)i + 3];
+      for (int k = 0; k < 3; ++k) { p.Position[k] = posm[4 * (size_t)i + k]; p.Velocity[k] = vel[4 * (size_t)i + k]; }
+    }
+    Upload();
+  }
+
+  // Build-defined: explicit initial state instead of the random one (same post-conditions as CreateSpacePoints).
+  void SetParticles(const FParticle *p, int32_t N) {
+    if (!p || N <= 0) { LastStatus = NBODY_ERR_INVALID; return; }
+    Particles.assign(p, p + N);
+    Upload();
+  }
+
+  // .cpp:47-56
+  void ComputeCubeSize() {
+    if (!Initialized) return;
+    float s = 0.0f;
+    LastStatus = nbody_get_bounds(ctx_, &s);
+    if (LastStatus == NBODY_OK) Size = s;
+  }
+
+  // .cpp:74-89 — the force pass (tree build + walk in the reference; all-pairs kernel here).
+  void CreateOctree() {
+    if (!Initialized) return;
+    if (Theta != 0.0f) { LastStatus = NBODY_ERR_UNSUPPORTED; return; }
+    LastStatus = nbody_compute_forces(ctx_);
+    forces_fresh_ = LastStatus == NBODY_OK;
+  }
+
+  // .cpp:21-34
+  void Tick(float /*DeltaSeconds: ignored by the reference too*/) {
+    if (OnFlushPersistentDebugLines) OnFlushPersistentDebugLines();            // .cpp:24
+    if (PhDeltaTime > 0 && Initialized) {                                      // .cpp:25 (+ guards .cpp:49,76)
+      if (Theta != 0.0f) {
+        LastStatus = NBODY_ERR_UNSUPPORTED;
+      } else {
+        ComputeCubeSize();                                                     // .cpp:26
+        LastStatus = nbody_step(ctx_, PhDeltaTime, 1);                         // .cpp:27-31
+        if (LastStatus == NBODY_OK) { dirty_ = true; forces_fresh_ = true; }
+      }
+    }
+    DrawOctreeBoxes();                                                         // .cpp:33
+  }
+
+  // .cpp:36-45 — one DrawDebugPoint per body.
+  void DrawOctreeBoxes() {
+    if (!Initialized || !forces_fresh_) return;   // the reference draws from the tree: nothing before the first force pass (.cpp:38)
+    if (MirrorParticles) SyncParticles(); else SyncPositions();
+    if (OnDrawDebugPoint)
+      for (const FParticle &p : Particles) OnDrawDebugPoint(p.Position, 10.0f);
+  }
+
+  // .cpp:91-97
+  void CleanParticles() {
+    Initialized = false;
+    nbody_destroy(ctx_);
+    ctx_ = nullptr;
+    forces_fresh_ = false;
+    dirty_ = false;
+    Particles.clear();
+  }
+
+  // Pull the whole device state into `Particles`.
+  void SyncParticles() {
+    if (!ctx_ || !dirty_) return;
+    LastStatus = nbody_get_particles(ctx_, Particles.data(), sizeof(FParticle));
+    if (LastStatus == NBODY_OK) dirty_ = false;
+  }
+
+  nbody_ctx *Context() const { return ctx_; }
+
+ private:
+  void SyncPositions() {
+    if (!ctx_ || !dirty_) return;
+    LastStatus = nbody_get_positions(ctx_, Particles.data()->Position, sizeof(FParticle), 0, (int32_t)Particles.size());
+  }
+
+  void Upload() {
+    nbody_destroy(ctx_);
+    ctx_ = nullptr;
+    Initialized = false;
+    nbody_params p;
+    nbody_default_params(&p);
+    p.n_total = (int32_t)Particles.size();
+    p.device = Device;
+    p.precision = Precision;
+    p.G = G;
+    p.eps = Eps;
+    LastStatus = nbody_create(&p, &ctx_);
+    if (LastStatus) return;
+    LastStatus = nbody_set_particles(ctx_, Particles.data(), sizeof(FParticle), (int32_t)Particles.size());
+    if (LastStatus) return;
+    Initialized = true;                                                        // .cpp:71
+    forces_fresh_ = false;
+    dirty_ = false;
+  }
+
+  nbody_ctx *ctx_ = nullptr;
+  bool forces_fresh_ = false;
+  bool dirty_ = false;
+};
+
+}  // namespace nbody

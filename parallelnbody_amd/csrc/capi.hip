@@ -1,0 +1,540 @@
+// C-ABI of libnbody_amd.so (include/nbody.h): context, device state, launches.  Host C++ over the
+// HIP runtime; no torch types, no exceptions across the boundary, no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nbody.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair { hipEvent_t a, b; };
+
+struct KernelTimer {
+  std::vector<EventPair> pending;   // recorded, not yet read
+  std::vector<EventPair> pool;      // free
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+
+}  // namespace
+
+struct nbody_ctx {
+  nbody_params p;
+  size_t elem;                 // bytes per float4/double4 element
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  void *posm = nullptr, *vel = nullptr, *acc = nullptr, *accp = nullptr;
+  bool own_posm = false, own_vel = false, own_acc = false;
+  void *scratch = nullptr;     // 64 B device scratch (bounds bits, energy sums)
+  void *h_scratch = nullptr;   // pinned mirror
+  int j_split = 1, j_chunk = 0, ipt = 1, tile = 256;
+  bool have_state = false;
+  bool forces_valid = false;   // acc holds forces of the current positions
+  KernelTimer timers[2];
+  std::string err;
+};
+
+namespace {
+
+int fail(nbody_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail((c), NBODY_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+int floor_pow2(long long v) { int p = 1; while ((long long)p * 2 <= v) p *= 2; return p; }
+
+// Launch geometry.  j_split is a function of n_total only, so that the per-body summation order
+// (and hence every bit of the trajectory) does not depend on how many GPUs share the bodies.
+void choose_geometry(nbody_ctx *c) {
+  const nbody_params &p = c->p;
+  c->tile = p.tile > 0 ? p.tile : 256;
+  if (p.i_per_thread > 0) c->ipt = p.i_per_thread;
+  else c->ipt = (p.precision == NBODY_PREC_F64) ? 1 : (p.n_total >= 32768 ? 2 : 1);
+  int js;
+  if (p.j_split > 0) {
+    js = p.j_split;
+  } else {
+    // aim at >= 2048 workgroups (8 per CU) down to an 8-way body partition, keep >= 4 tiles per chunk
+    const long long per_block = 256LL * c->ipt;
+    long long iblocks8 = (p.n_total / 8 + per_block - 1) / per_block;
+    if (iblocks8 < 1) iblocks8 = 1;
+    js = floor_pow2((2048 + iblocks8 - 1) / iblocks8);
+    const int max_js = p.n_total / (4 * c->tile);
+    if (js > max_js) js = max_js;
+    if (js < 1) js = 1;
+  }
+  int chunk = (p.n_total + js - 1) / js;
+  chunk = (chunk + c->tile - 1) / c->tile * c->tile;
+  js = (p.n_total + chunk - 1) / chunk;
+  c->j_split = js;
+  c->j_chunk = chunk;
+}
+
+nbody::ForceLaunch make_launch(const nbody_ctx *c) {
+  nbody::ForceLaunch L;
+  L.posm = c->posm; L.accp = c->accp;
+  L.n_total = c->p.n_total; L.i_begin = c->p.i_begin; L.i_count = c->p.i_count;
+  L.tile = c->tile; L.ipt = c->ipt; L.j_split = c->j_split; L.j_chunk = c->j_chunk;
+  L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps; L.precision = c->p.precision;
+  return L;
+}
+
+int timer_begin(nbody_ctx *c, int which, EventPair *ev) {
+  KernelTimer &t = c->timers[which];
+  if (t.pool.empty()) {
+    EventPair e;
+    HIP_TRY(c, hipEventCreate(&e.a));
+    HIP_TRY(c, hipEventCreate(&e.b));
+    t.pool.push_back(e);
+  }
+  *ev = t.pool.back();
+  t.pool.pop_back();
+  HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+  return NBODY_OK;
+}
+
+int timer_end(nbody_ctx *c, int which, const EventPair &ev) {
+  HIP_TRY(c, hipEventRecord(ev.b, c->stream));
+  c->timers[which].pending.push_back(ev);
+  return NBODY_OK;
+}
+
+int timer_drain(nbody_ctx *c, int which) {
+  KernelTimer &t = c->timers[which];
+  for (const EventPair &e : t.pending) {
+    HIP_TRY(c, hipEventSynchronize(e.b));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e.a, e.b));
+    t.total_ms += ms;
+    t.launches += 1;
+    t.pool.push_back(e);
+  }
+  t.pending.clear();
+  return NBODY_OK;
+}
+
+int run_forces(nbody_ctx *c) {
+  EventPair ev;
+  const bool timed = c->p.time_kernels != 0;
+  if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
+  HIP_TRY(c, nbody::launch_forces(make_launch(c), c->stream));
+  if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
+  // bound the number of live events on long untimed-drain runs
+  if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) return timer_drain(c, NBODY_KERNEL_FORCES);
+  return NBODY_OK;
+}
+
+int run_update(nbody_ctx *c, float dt) {
+  EventPair ev;
+  const bool timed = c->p.time_kernels != 0;
+  if (timed) { int rc = timer_begin(c, NBODY_KERNEL_UPDATE, &ev); if (rc) return rc; }
+  HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->accp, c->p.i_begin, c->p.i_count,
+                                  c->j_split, dt, c->stream));
+  if (timed) { int rc = timer_end(c, NBODY_KERNEL_UPDATE, ev); if (rc) return rc; }
+  if (timed && c->timers[NBODY_KERNEL_UPDATE].pending.size() >= 1024) return timer_drain(c, NBODY_KERNEL_UPDATE);
+  return NBODY_OK;
+}
+
+template <typename SRC, typename DST>
+void convert4(const SRC *src, DST *dst, size_t n_elems4, bool zero_w) {
+  for (size_t i = 0; i < n_elems4; ++i) {
+    dst[4 * i + 0] = (DST)src[4 * i + 0];
+    dst[4 * i + 1] = (DST)src[4 * i + 1];
+    dst[4 * i + 2] = (DST)src[4 * i + 2];
+    dst[4 * i + 3] = zero_w ? (DST)0 : (DST)src[4 * i + 3];
+  }
+}
+
+// Upload host SoA state given as T (float or double); converts to the context's precision.
+template <typename T>
+int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
+  const int n = c->p.n_total, ib = c->p.i_begin, ic = c->p.i_count;
+  const bool ctx64 = c->p.precision == NBODY_PREC_F64;
+  const bool same = ctx64 == (sizeof(T) == 8);
+  if (same) {
+    HIP_TRY(c, hipMemcpyAsync(c->posm, posm4, (size_t)n * c->elem, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->vel, vel4 + 4 * (size_t)ib, (size_t)ic * c->elem, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else if (ctx64) {
+    std::vector<double> tp((size_t)n * 4), tv((size_t)ic * 4);
+    convert4(posm4, tp.data(), (size_t)n, false);
+    convert4(vel4 + 4 * (size_t)ib, tv.data(), (size_t)ic, true);
+    HIP_TRY(c, hipMemcpy(c->posm, tp.data(), tp.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->vel, tv.data(), tv.size() * 8, hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> tp((size_t)n * 4), tv((size_t)ic * 4);
+    convert4(posm4, tp.data(), (size_t)n, false);
+    convert4(vel4 + 4 * (size_t)ib, tv.data(), (size_t)ic, true);
+    HIP_TRY(c, hipMemcpy(c->posm, tp.data(), tp.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->vel, tv.data(), tv.size() * 4, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(c, hipMemsetAsync(c->acc, 0, (size_t)ic * c->elem, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_state = true;
+  c->forces_valid = false;
+  return NBODY_OK;
+}
+
+// Download `count` elements starting at element `first` of a device buffer as T x 4.
+template <typename T>
+int download4(nbody_ctx *c, const void *dev, size_t first, size_t count, T *out) {
+  const bool ctx64 = c->p.precision == NBODY_PREC_F64;
+  const char *src = (const char *)dev + first * c->elem;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (ctx64 == (sizeof(T) == 8)) {
+    HIP_TRY(c, hipMemcpy(out, src, count * c->elem, hipMemcpyDeviceToHost));
+  } else if (ctx64) {
+    std::vector<double> tmp(count * 4);
+    HIP_TRY(c, hipMemcpy(tmp.data(), src, count * 32, hipMemcpyDeviceToHost));
+    convert4(tmp.data(), out, count, false);
+  } else {
+    std::vector<float> tmp(count * 4);
+    HIP_TRY(c, hipMemcpy(tmp.data(), src, count * 16, hipMemcpyDeviceToHost));
+    convert4(tmp.data(), out, count, false);
+  }
+  return NBODY_OK;
+}
+
+int check_ready(nbody_ctx *c) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!c->have_state) return fail(c, NBODY_ERR_STATE, "no particles set (call nbody_set_particles / nbody_set_state_soa first)");
+  return NBODY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbody_version(void) { return NBODY_VERSION_MAJOR * 100 + NBODY_VERSION_MINOR; }
+
+int nbody_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int nbody_default_params(nbody_params *p) {
+  if (!p) return NBODY_ERR_INVALID;
+  memset(p, 0, sizeof *p);
+  p->struct_size = (uint32_t)sizeof(nbody_params);
+  p->precision = NBODY_PREC_F32;
+  p->G = 1.0e4;      // OctreeSearch.h:104
+  p->eps = 0.0;      // OctreeSearch.h:101-104: no softening
+  return NBODY_OK;
+}
+
+const char *nbody_last_error(const nbody_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int nbody_create(const nbody_params *pin, nbody_ctx **out) {
+  if (!pin || !out) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: null argument");
+  *out = nullptr;
+  if (pin->struct_size != sizeof(nbody_params))
+    return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: struct_size %u != %zu", pin->struct_size, sizeof(nbody_params));
+  nbody_params p = *pin;
+  if (p.n_total <= 0) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: n_total must be > 0");
+  if (p.i_begin < 0 || p.i_begin >= p.n_total) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: i_begin out of range");
+  if (p.i_count == 0) p.i_count = p.n_total - p.i_begin;
+  if (p.i_count < 0 || p.i_begin + p.i_count > p.n_total)
+    return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: owned range [%d,%d) exceeds n_total %d", p.i_begin,
+                p.i_begin + p.i_count, p.n_total);
+  if (p.precision != NBODY_PREC_F32 && p.precision != NBODY_PREC_F32_KAHAN && p.precision != NBODY_PREC_F64)
+    return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown precision %d", p.precision);
+  if (!(p.eps >= 0.0) || !std::isfinite(p.G)) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: bad G/eps");
+  if (p.tile != 0 && p.tile != 64 && p.tile != 128 && p.tile != 256 && p.tile != 512)
+    return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: tile must be 64, 128, 256 or 512");
+  if (p.i_per_thread != 0 && p.i_per_thread != 1 && p.i_per_thread != 2 && p.i_per_thread != 4)
+    return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: i_per_thread must be 1, 2 or 4");
+  if (p.j_split < 0) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: j_split must be >= 0");
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, NBODY_ERR_NO_DEVICE, "nbody_create: no HIP device (%s); this engine has no CPU path",
+                e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (p.device < 0 || p.device >= ndev)
+    return fail(nullptr, NBODY_ERR_NO_DEVICE, "nbody_create: device %d not in [0,%d)", p.device, ndev);
+
+  nbody_ctx *c = new (std::nothrow) nbody_ctx();
+  if (!c) return fail(nullptr, NBODY_ERR_NOMEM, "nbody_create: out of host memory");
+  c->p = p;
+  c->elem = (p.precision == NBODY_PREC_F64) ? 32 : 16;
+  choose_geometry(c);
+
+  auto bail = [&](hipError_t he, const char *what) {
+    fail(nullptr, NBODY_ERR_HIP, "nbody_create: %s: %s", what, hipGetErrorString(he));
+    nbody_destroy(c);
+    return NBODY_ERR_HIP;
+  };
+  if ((e = hipSetDevice(p.device)) != hipSuccess) return bail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  c->stream = c->own_stream;
+  if ((e = hipMalloc(&c->posm, (size_t)p.n_total * c->elem)) != hipSuccess) return bail(e, "hipMalloc posm");
+  c->own_posm = true;
+  if ((e = hipMalloc(&c->vel, (size_t)p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc vel");
+  c->own_vel = true;
+  if ((e = hipMalloc(&c->acc, (size_t)p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc acc");
+  c->own_acc = true;
+  if ((e = hipMalloc(&c->accp, (size_t)c->j_split * p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc accp");
+  if ((e = hipMalloc(&c->scratch, 64)) != hipSuccess) return bail(e, "hipMalloc scratch");
+  if ((e = hipHostMalloc(&c->h_scratch, 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+  *out = c;
+  return NBODY_OK;
+}
+
+void nbody_destroy(nbody_ctx *c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (KernelTimer &t : c->timers) {
+    for (EventPair &e : t.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (EventPair &e : t.pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  }
+  if (c->own_posm && c->posm) (void)hipFree(c->posm);
+  if (c->own_vel && c->vel) (void)hipFree(c->vel);
+  if (c->own_acc && c->acc) (void)hipFree(c->acc);
+  if (c->accp) (void)hipFree(c->accp);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int nbody_set_stream(nbody_ctx *c, void *hip_stream) {
+  if (!c) return NBODY_ERR_INVALID;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return NBODY_OK;
+}
+
+int nbody_device_ptr(nbody_ctx *c, int32_t which, void **ptr, size_t *bytes) {
+  if (!c || !ptr) return NBODY_ERR_INVALID;
+  switch (which) {
+    case NBODY_BUF_POSM: *ptr = c->posm; if (bytes) *bytes = (size_t)c->p.n_total * c->elem; break;
+    case NBODY_BUF_VEL:  *ptr = c->vel;  if (bytes) *bytes = (size_t)c->p.i_count * c->elem; break;
+    case NBODY_BUF_ACC:  *ptr = c->acc;  if (bytes) *bytes = (size_t)c->p.i_count * c->elem; break;
+    default: return fail(c, NBODY_ERR_INVALID, "nbody_device_ptr: unknown buffer %d", which);
+  }
+  return NBODY_OK;
+}
+
+int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
+  if (!c) return NBODY_ERR_INVALID;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (posm) { if (c->own_posm) (void)hipFree(c->posm); c->posm = posm; c->own_posm = false; }
+  if (vel)  { if (c->own_vel) (void)hipFree(c->vel);   c->vel = vel;   c->own_vel = false; }
+  if (acc)  { if (c->own_acc) (void)hipFree(c->acc);   c->acc = acc;   c->own_acc = false; }
+  // the caller vouches that bound buffers hold a valid state
+  if (posm && vel) c->have_state = true;
+  c->forces_valid = false;
+  return NBODY_OK;
+}
+
+int nbody_synchronize(nbody_ctx *c) {
+  if (!c) return NBODY_ERR_INVALID;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NBODY_OK;
+}
+
+int nbody_set_state_soa(nbody_ctx *c, const float *posm4, const float *vel4, int32_t n) {
+  if (!c || !posm4 || !vel4) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa: null buffer") : NBODY_ERR_INVALID;
+  if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa: n = %d but the context holds %d bodies", n, c->p.n_total);
+  return upload_soa<float>(c, posm4, vel4);
+}
+
+int nbody_set_state_soa_f64(nbody_ctx *c, const double *posm4, const double *vel4, int32_t n) {
+  if (!c || !posm4 || !vel4) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa_f64: null buffer") : NBODY_ERR_INVALID;
+  if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa_f64: n = %d but the context holds %d bodies", n, c->p.n_total);
+  return upload_soa<double>(c, posm4, vel4);
+}
+
+int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n) {
+  if (!c || !aos) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_particles: null buffer") : NBODY_ERR_INVALID;
+  if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_particles: n = %d but the context holds %d bodies", n, c->p.n_total);
+  if (stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "nbody_set_particles: stride %zu < %zu", stride, sizeof(nbody_particle));
+  std::vector<float> posm((size_t)n * 4), vel((size_t)n * 4);
+  const char *base = (const char *)aos;
+  for (int i = 0; i < n; ++i) {
+    nbody_particle q;
+    memcpy(&q, base + (size_t)i * stride, sizeof q);
+    posm[4 * (size_t)i + 0] = q.Position[0]; posm[4 * (size_t)i + 1] = q.Position[1];
+    posm[4 * (size_t)i + 2] = q.Position[2]; posm[4 * (size_t)i + 3] = q.Mass;
+    vel[4 * (size_t)i + 0] = q.Velocity[0]; vel[4 * (size_t)i + 1] = q.Velocity[1];
+    vel[4 * (size_t)i + 2] = q.Velocity[2]; vel[4 * (size_t)i + 3] = 0.f;
+  }
+  int rc = upload_soa<float>(c, posm.data(), vel.data());
+  if (rc) return rc;
+  // carry the records' Acceleration field over too (the reference keeps whatever was there until the next force pass)
+  std::vector<float> acc((size_t)c->p.i_count * 4);
+  for (int i = 0; i < c->p.i_count; ++i) {
+    nbody_particle q;
+    memcpy(&q, base + (size_t)(c->p.i_begin + i) * stride, sizeof q);
+    acc[4 * (size_t)i + 0] = q.Acceleration[0]; acc[4 * (size_t)i + 1] = q.Acceleration[1];
+    acc[4 * (size_t)i + 2] = q.Acceleration[2]; acc[4 * (size_t)i + 3] = 0.f;
+  }
+  if (c->p.precision == NBODY_PREC_F64) {
+    std::vector<double> a64(acc.begin(), acc.end());
+    HIP_TRY(c, hipMemcpy(c->acc, a64.data(), a64.size() * 8, hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size() * 4, hipMemcpyHostToDevice));
+  }
+  return NBODY_OK;
+}
+
+int nbody_compute_forces(nbody_ctx *c) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->p.device));
+  if ((rc = run_forces(c))) return rc;
+  if ((rc = run_update(c, 0.0f))) return rc;
+  c->forces_valid = true;
+  return NBODY_OK;
+}
+
+int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (nsteps < 0) return fail(c, NBODY_ERR_INVALID, "nbody_step: nsteps < 0");
+  if (!(dt > 0.0f)) return NBODY_OK;   // OctreeSearch.cpp:25: PhDeltaTime <= 0 freezes the physics
+  if (nsteps > 1 && c->p.i_count != c->p.n_total)
+    return fail(c, NBODY_ERR_STATE, "nbody_step: a sharded context advances one step per call (all-gather NBODY_BUF_POSM in between)");
+  HIP_TRY(c, hipSetDevice(c->p.device));
+  for (int s = 0; s < nsteps; ++s) {
+    if ((rc = run_forces(c))) return rc;
+    if ((rc = run_update(c, dt))) return rc;
+  }
+  if (nsteps > 0) c->forces_valid = false;   // acc belongs to the pre-update positions, as in the reference
+  return NBODY_OK;
+}
+
+int nbody_get_bounds(nbody_ctx *c, float *size) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!size) return fail(c, NBODY_ERR_INVALID, "nbody_get_bounds: null output");
+  HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
+  HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, c->p.i_begin, c->p.i_count, (unsigned int *)c->scratch, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->scratch, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  memcpy(size, c->h_scratch, 4);
+  return NBODY_OK;
+}
+
+int nbody_energy(nbody_ctx *c, double *ke, double *pe) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 16, c->stream));
+  HIP_TRY(c, nbody::launch_energy(c->p.precision, c->posm, c->vel, c->p.n_total, c->p.i_begin, c->p.i_count, c->p.G,
+                                  c->p.eps * c->p.eps, (double *)c->scratch, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->scratch, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  double v[2];
+  memcpy(v, c->h_scratch, 16);
+  if (ke) *ke = v[0];
+  if (pe) *pe = v[1];
+  return NBODY_OK;
+}
+
+int nbody_get_positions(nbody_ctx *c, float *xyz, size_t stride, int32_t first, int32_t count) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!xyz || stride < 12) return fail(c, NBODY_ERR_INVALID, "nbody_get_positions: null buffer or stride < 12");
+  if (first < 0 || count < 0 || first + count > c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_get_positions: range out of bounds");
+  if (count == 0) return NBODY_OK;
+  std::vector<float> tmp((size_t)count * 4);
+  if ((rc = download4<float>(c, c->posm, (size_t)first, (size_t)count, tmp.data()))) return rc;
+  char *o = (char *)xyz;
+  for (int i = 0; i < count; ++i) memcpy(o + (size_t)i * stride, &tmp[4 * (size_t)i], 12);
+  return NBODY_OK;
+}
+
+int nbody_get_state_soa(nbody_ctx *c, float *posm4, float *vel4, float *acc4) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (posm4 && (rc = download4<float>(c, c->posm, (size_t)c->p.i_begin, (size_t)c->p.i_count, posm4))) return rc;
+  if (vel4 && (rc = download4<float>(c, c->vel, 0, (size_t)c->p.i_count, vel4))) return rc;
+  if (acc4 && (rc = download4<float>(c, c->acc, 0, (size_t)c->p.i_count, acc4))) return rc;
+  return NBODY_OK;
+}
+
+int nbody_get_state_soa_f64(nbody_ctx *c, double *posm4, double *vel4, double *acc4) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (posm4 && (rc = download4<double>(c, c->posm, (size_t)c->p.i_begin, (size_t)c->p.i_count, posm4))) return rc;
+  if (vel4 && (rc = download4<double>(c, c->vel, 0, (size_t)c->p.i_count, vel4))) return rc;
+  if (acc4 && (rc = download4<double>(c, c->acc, 0, (size_t)c->p.i_count, acc4))) return rc;
+  return NBODY_OK;
+}
+
+int nbody_get_particles(nbody_ctx *c, void *aos, size_t stride) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!aos || stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "nbody_get_particles: null buffer or stride < 40");
+  const size_t ic = (size_t)c->p.i_count;
+  std::vector<float> posm(ic * 4), vel(ic * 4), acc(ic * 4);
+  if ((rc = nbody_get_state_soa(c, posm.data(), vel.data(), acc.data()))) return rc;
+  char *base = (char *)aos;
+  for (size_t i = 0; i < ic; ++i) {
+    nbody_particle q;
+    q.Mass = posm[4 * i + 3];
+    memcpy(q.Position, &posm[4 * i], 12);
+    memcpy(q.Velocity, &vel[4 * i], 12);
+    memcpy(q.Acceleration, &acc[4 * i], 12);
+    memcpy(base + i * stride, &q, sizeof q);
+  }
+  return NBODY_OK;
+}
+
+int nbody_kernel_time(nbody_ctx *c, int32_t which, double *total_ms, int64_t *launches) {
+  if (!c || which < 0 || which > 1) return NBODY_ERR_INVALID;
+  int rc = timer_drain(c, which);
+  if (rc) return rc;
+  if (total_ms) *total_ms = c->timers[which].total_ms;
+  if (launches) *launches = c->timers[which].launches;
+  return NBODY_OK;
+}
+
+int nbody_kernel_time_reset(nbody_ctx *c) {
+  if (!c) return NBODY_ERR_INVALID;
+  for (int w = 0; w < 2; ++w) {
+    int rc = timer_drain(c, w);
+    if (rc) return rc;
+    c->timers[w].total_ms = 0.0;
+    c->timers[w].launches = 0;
+  }
+  return NBODY_OK;
+}
+
+int nbody_get_launch_config(nbody_ctx *c, int32_t *tile, int32_t *i_per_thread, int32_t *j_split, int32_t *blocks,
+                            int32_t *threads) {
+  if (!c) return NBODY_ERR_INVALID;
+  int b = 0, t = 0;
+  nbody::forces_geometry(make_launch(c), &b, &t);
+  if (tile) *tile = c->tile;
+  if (i_per_thread) *i_per_thread = c->ipt;
+  if (j_split) *j_split = c->j_split;
+  if (blocks) *blocks = b;
+  if (threads) *threads = t;
+  return NBODY_OK;
+}
+
+}  // extern "C"

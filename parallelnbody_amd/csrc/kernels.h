@@ -1,0 +1,40 @@
+// Internal launcher interface between the C-ABI (capi.hip) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbody {
+
+struct ForceLaunch {
+  const void *posm;     // [n_total] float4 / double4 : x,y,z,m
+  void *accp;           // [j_split][i_count] float4 / double4 partial accelerations
+  int n_total;
+  int i_begin;
+  int i_count;
+  int tile;             // LDS tile, bodies
+  int ipt;              // i-bodies per lane
+  int j_split;          // number of j chunks
+  int j_chunk;          // bodies per chunk (multiple of tile)
+  double G;
+  double eps2;
+  int precision;        // NBODY_PREC_*
+};
+
+// All-pairs force partials.  Returns hipSuccess or the launch error.
+hipError_t launch_forces(const ForceLaunch &L, hipStream_t s);
+// Blocks / threads launch_forces will use for L (for logs).
+void forces_geometry(const ForceLaunch &L, int *blocks, int *threads);
+
+// acc[i] = sum_c accp[c][i] in chunk order; if dt > 0 also v += dt*a; x += dt*v (owned slice of posm).
+hipError_t launch_update(int precision, void *posm, void *vel, void *acc, const void *accp, int i_begin,
+                         int i_count, int j_split, float dt, hipStream_t s);
+
+// out_bits (uint32, pre-zeroed) = bit pattern of max_i max(|x|,|y|,|z|) over the owned slice.
+hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_count, unsigned int *out_bits,
+                         hipStream_t s);
+
+// fp64 energy pieces: out[0] += KE of owned bodies, out[1] += sum_i 1/2 m_i phi_i  (out pre-zeroed).
+hipError_t launch_energy(int precision, const void *posm, const void *vel, int n_total, int i_begin, int i_count,
+                         double G, double eps2, double *out, hipStream_t s);
+
+}  // namespace nbody

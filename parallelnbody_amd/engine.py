@@ -1,0 +1,190 @@
+"""NBodyEngine — Python handle on one nbody_ctx (include/nbody.h).  All arithmetic happens in the HIP
+kernels of libnbody_amd.so; this file only moves numpy buffers across the C-ABI."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import NBodyError, Params
+
+# FParticle, /root/reference/Source/NBody/OctreeSearch.h:8-18 (40 bytes)
+PARTICLE_DTYPE = np.dtype(
+    [("Mass", "<f4"), ("Position", "<f4", (3,)), ("Velocity", "<f4", (3,)), ("Acceleration", "<f4", (3,))])
+
+REF_G = 1.0e4       # OctreeSearch.h:104
+REF_DT = 0.01       # OctreeSearch.cpp:8
+
+_PREC = {"f32": _lib.PREC_F32, "f32_kahan": _lib.PREC_F32_KAHAN, "f64": _lib.PREC_F64}
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def ic_reference_box(n, size=200.0, center=(0.0, 0.0, 0.0), seed=1):
+    """Seeded CreateSpacePoints distribution (OctreeSearch.cpp:58-72).  Returns (posm[n,4], vel[n,4]) fp32."""
+    posm = np.empty((n, 4), np.float32)
+    vel = np.empty((n, 4), np.float32)
+    c = np.asarray(center, np.float32)
+    rc = _lib.lib().nbody_ic_reference_box(n, size, _fp(c), seed, _fp(posm), _fp(vel))
+    if rc:
+        raise NBodyError(rc, "nbody_ic_reference_box: invalid argument")
+    return posm, vel
+
+
+def ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=REF_G, seed=1):
+    """Seeded equal-mass Plummer sphere in virial equilibrium.  Returns (posm[n,4], vel[n,4]) fp32."""
+    posm = np.empty((n, 4), np.float32)
+    vel = np.empty((n, 4), np.float32)
+    rc = _lib.lib().nbody_ic_plummer(n, total_mass, scale_radius, G, seed, _fp(posm), _fp(vel))
+    if rc:
+        raise NBodyError(rc, "nbody_ic_plummer: invalid argument")
+    return posm, vel
+
+
+def device_count():
+    return int(_lib.lib().nbody_device_count())
+
+
+class NBodyEngine:
+    """One context = one GPU's share [i_begin, i_begin+i_count) of an n_total-body system."""
+
+    def __init__(self, n_total, *, i_begin=0, i_count=0, device=0, precision="f32", G=REF_G, eps=0.0, tile=0,
+                 i_per_thread=0, j_split=0, time_kernels=False):
+        L = _lib.lib()
+        p = Params()
+        L.nbody_default_params(ctypes.byref(p))
+        p.n_total, p.i_begin, p.i_count, p.device = n_total, i_begin, i_count, device
+        p.precision = _PREC[precision] if isinstance(precision, str) else int(precision)
+        p.G, p.eps = G, eps
+        p.tile, p.i_per_thread, p.j_split = tile, i_per_thread, j_split
+        p.time_kernels = 1 if time_kernels else 0
+        h = ctypes.c_void_p()
+        rc = L.nbody_create(ctypes.byref(p), ctypes.byref(h))
+        if rc:
+            raise NBodyError(rc, L.nbody_last_error(None).decode())
+        self._L, self._h = L, h
+        self.n_total = n_total
+        self.i_begin = i_begin
+        self.i_count = i_count if i_count else n_total - i_begin
+        self.f64 = p.precision == _lib.PREC_F64
+        self._keep = []   # externally bound tensors kept alive
+
+    # -- plumbing --
+    def _check(self, rc):
+        if rc:
+            raise NBodyError(rc, self._L.nbody_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nbody_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state in --
+    def set_particles(self, particles):
+        a = np.ascontiguousarray(particles)
+        assert a.dtype.itemsize >= 40
+        self._check(self._L.nbody_set_particles(self._h, a.ctypes.data, a.dtype.itemsize, a.shape[0]))
+
+    def set_state(self, posm, vel):
+        if np.asarray(posm).dtype == np.float64:
+            p = np.ascontiguousarray(posm, np.float64); v = np.ascontiguousarray(vel, np.float64)
+            assert p.shape == (self.n_total, 4) and v.shape == (self.n_total, 4)
+            self._check(self._L.nbody_set_state_soa_f64(self._h, _dp(p), _dp(v), self.n_total))
+        else:
+            p = np.ascontiguousarray(posm, np.float32); v = np.ascontiguousarray(vel, np.float32)
+            assert p.shape == (self.n_total, 4) and v.shape == (self.n_total, 4)
+            self._check(self._L.nbody_set_state_soa(self._h, _fp(p), _fp(v), self.n_total))
+
+    # -- hot path --
+    def compute_forces(self):
+        self._check(self._L.nbody_compute_forces(self._h))
+
+    def step(self, dt=REF_DT, nsteps=1):
+        self._check(self._L.nbody_step(self._h, dt, nsteps))
+
+    def synchronize(self):
+        self._check(self._L.nbody_synchronize(self._h))
+
+    def bounds(self):
+        s = ctypes.c_float()
+        self._check(self._L.nbody_get_bounds(self._h, ctypes.byref(s)))
+        return s.value
+
+    def energy(self):
+        ke, pe = ctypes.c_double(), ctypes.c_double()
+        self._check(self._L.nbody_energy(self._h, ctypes.byref(ke), ctypes.byref(pe)))
+        return ke.value, pe.value
+
+    # -- state out --
+    def positions(self, first=0, count=None):
+        count = self.n_total - first if count is None else count
+        out = np.empty((count, 3), np.float32)
+        self._check(self._L.nbody_get_positions(self._h, _fp(out), 12, first, count))
+        return out
+
+    def particles(self):
+        out = np.zeros(self.i_count, PARTICLE_DTYPE)
+        self._check(self._L.nbody_get_particles(self._h, out.ctypes.data, PARTICLE_DTYPE.itemsize))
+        return out
+
+    def state(self, dtype=np.float32):
+        """(posm, vel, acc) of the owned bodies, [i_count,4] each."""
+        n = self.i_count
+        if dtype == np.float64:
+            p, v, a = (np.empty((n, 4), np.float64) for _ in range(3))
+            self._check(self._L.nbody_get_state_soa_f64(self._h, _dp(p), _dp(v), _dp(a)))
+        else:
+            p, v, a = (np.empty((n, 4), np.float32) for _ in range(3))
+            self._check(self._L.nbody_get_state_soa(self._h, _fp(p), _fp(v), _fp(a)))
+        return p, v, a
+
+    def accelerations(self, dtype=np.float32):
+        return self.state(dtype)[2][:, :3]
+
+    # -- device plumbing --
+    def set_stream(self, hip_stream_handle):
+        self._check(self._L.nbody_set_stream(self._h, ctypes.c_void_p(hip_stream_handle)))
+
+    def device_ptr(self, which):
+        ptr, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self._L.nbody_device_ptr(self._h, which, ctypes.byref(ptr), ctypes.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def bind_device_state(self, posm=None, vel=None, acc=None):
+        """Use caller-owned device buffers (objects with .data_ptr(), e.g. torch tensors)."""
+        ptrs = []
+        for t in (posm, vel, acc):
+            ptrs.append(ctypes.c_void_p(t.data_ptr()) if t is not None else None)
+            if t is not None:
+                self._keep.append(t)
+        self._check(self._L.nbody_bind_device_state(self._h, *ptrs))
+
+    def kernel_time(self, which=_lib.KERNEL_FORCES):
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        self._check(self._L.nbody_kernel_time(self._h, which, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def kernel_time_reset(self):
+        self._check(self._L.nbody_kernel_time_reset(self._h))
+
+    def launch_config(self):
+        v = [ctypes.c_int32() for _ in range(5)]
+        self._check(self._L.nbody_get_launch_config(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("tile", "i_per_thread", "j_split", "blocks", "threads"), (x.value for x in v)))

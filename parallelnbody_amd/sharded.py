@@ -1,0 +1,93 @@
+"""Range-partitioned multi-GPU stepping: one process per GPU, one all-gather of positions per step.
+
+Body i of an n_total-body system belongs to rank r = i // (n_total / world).  Every rank keeps the full
+position+mass array (16 B/body; 16 MiB at N = 2^20) and the velocities/accelerations of its own slice only.
+Per step (the reference's Tick body, OctreeSearch.cpp:25-31, per slice):
+
+    forces(own slice vs all bodies) -> kick-drift(own slice, in place in the full array)
+    all_gather_into_tensor(full array, own slice)          # RCCL over xGMI; the path's only exchange
+
+No all-reduce anywhere: the force on a body needs every position but no other body's velocity.  The summation
+order per body does not depend on the partition (j_split is a function of n_total only), so the trajectory is
+bit-identical for any world size.
+
+torch is plumbing here: device memory, the current stream and torch.distributed.  The compute engine is
+injected (`engine_factory`) so that the world_size-2 gloo test can run the host logic on CPU with a stand-in
+defined in tests/; the default factory is the HIP engine and nothing else.
+"""
+import numpy as np
+
+from .engine import REF_DT, NBodyEngine
+
+
+def partition(n_total, world_size, rank):
+    """Contiguous equal slices (what all_gather_into_tensor needs).  Returns (i_begin, i_count)."""
+    if n_total % world_size != 0:
+        raise ValueError(f"n_total={n_total} must be divisible by world_size={world_size}")
+    cnt = n_total // world_size
+    return rank * cnt, cnt
+
+
+def _hip_engine_factory(n_total, i_begin, i_count, posm_tensor, device_index, **kw):
+    import torch
+    eng = NBodyEngine(n_total, i_begin=i_begin, i_count=i_count, device=device_index, **kw)
+    eng.bind_device_state(posm=posm_tensor)
+    eng.set_stream(torch.cuda.current_stream(posm_tensor.device).cuda_stream)
+    return eng
+
+
+class ShardedSimulation:
+    def __init__(self, posm, vel, *, rank=0, world_size=1, device=None, group=None, engine_factory=None,
+                 **engine_kw):
+        import torch
+        self.torch = torch
+        posm = np.ascontiguousarray(posm)
+        self.n_total = posm.shape[0]
+        self.rank, self.world_size, self.group = rank, world_size, group
+        self.i_begin, self.i_count = partition(self.n_total, world_size, rank)
+        self.f64 = engine_kw.get("precision") in ("f64", 2)
+        tdt = torch.float64 if self.f64 else torch.float32
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # the replicated position+mass array lives in a torch tensor so that torch.distributed can gather into it
+        self.posm = torch.empty((self.n_total, 4), dtype=tdt, device=self.device)
+        factory = engine_factory or _hip_engine_factory
+        dev_index = self.device.index if self.device.type == "cuda" else -1
+        self.engine = factory(self.n_total, self.i_begin, self.i_count, self.posm, dev_index, **engine_kw)
+        self.engine.set_state(posm.astype(np.float64 if self.f64 else np.float32, copy=False),
+                              np.ascontiguousarray(vel).astype(np.float64 if self.f64 else np.float32, copy=False))
+        self.steps_done = 0
+
+    def step(self, dt=REF_DT, nsteps=1):
+        dist = self.torch.distributed
+        own = self.posm[self.i_begin:self.i_begin + self.i_count]
+        for _ in range(nsteps):
+            self.engine.step(dt, 1)
+            if self.world_size > 1 and dt > 0:
+                dist.all_gather_into_tensor(self.posm, own, group=self.group)
+            self.steps_done += 1
+
+    def gather_state(self):
+        """(posm[n_total,4], vel[n_total,4]) on every rank, as numpy (for tests and checkpoints)."""
+        torch, dist = self.torch, self.torch.distributed
+        p, v, _ = self.engine.state(np.float64 if self.f64 else np.float32)
+        if self.world_size == 1:
+            return p, v
+        out = []
+        for a in (p, v):
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            full = torch.empty((self.n_total, 4), dtype=t.dtype, device=self.device)
+            dist.all_gather_into_tensor(full, t, group=self.group)
+            out.append(full.cpu().numpy())
+        return out[0], out[1]
+
+    def energy(self):
+        """System kinetic and potential energy (sum of the ranks' shares)."""
+        ke, pe = self.engine.energy()
+        if self.world_size > 1:
+            t = self.torch.tensor([ke, pe], dtype=self.torch.float64, device=self.device)
+            self.torch.distributed.all_reduce(t, group=self.group)
+            ke, pe = float(t[0]), float(t[1])
+        return ke, pe
+
+    def close(self):
+        self.engine.close()

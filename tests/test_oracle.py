@@ -1,0 +1,167 @@
+"""The CPU oracle against analytic answers, an independent fp64 sum, its own tree walk and the
+committed fixtures.  No GPU.  (The reference ships no tests or vectors for this path and cannot be
+built here: the oracle is 'parity unpinned' — these tests pin the restatement to physics and to
+itself, which is the most this image allows.)"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_particle_layout(oracle):
+    # FParticle: OctreeSearch.h:8-18 -> Mass@0, Position@4, Velocity@16, Acceleration@28, 40 bytes
+    assert oracle.lib().oracle_sizeof_particle() == 40
+    d = oracle.PARTICLE_DTYPE
+    assert d.itemsize == 40
+    assert [d.fields[k][1] for k in ("Mass", "Position", "Velocity", "Acceleration")] == [0, 4, 16, 28]
+
+
+def test_two_body_analytic(oracle):
+    # a = G m / d^2 along the separation; G = 1e4 (OctreeSearch.h:104)
+    pos = np.array([[0, 0, 0], [3, 4, 0]], np.float32)
+    m = np.array([2.0, 5.0], np.float32)
+    a = oracle.forces_direct_f32(pos, m)
+    d = 5.0
+    np.testing.assert_allclose(a[0], 1e4 * 5.0 / d**2 * np.array([3, 4, 0]) / d, rtol=1e-6)
+    np.testing.assert_allclose(a[1], -1e4 * 2.0 / d**2 * np.array([3, 4, 0]) / d, rtol=1e-6)
+
+
+def test_coincident_pair_is_skipped(oracle):
+    # OctreeSearch.h:102: d == 0 -> no contribution (direct sum only: the tree cannot hold duplicates)
+    pos = np.array([[1, 1, 1], [1, 1, 1], [2, 1, 1]], np.float32)
+    m = np.array([1.0, 1.0, 1.0], np.float32)
+    a = oracle.forces_direct_f32(pos, m)
+    assert np.all(np.isfinite(a))
+    np.testing.assert_allclose(a[0], [1e4, 0, 0], rtol=1e-6)
+    np.testing.assert_allclose(a[0], a[1])
+    with pytest.raises(RuntimeError):
+        oracle.octree_forces_f32(pos, m, 0.0)      # the reference's Add recurses without bound here
+
+
+def test_single_body_and_empty_ranges(oracle):
+    a = oracle.forces_direct_f32(np.zeros((1, 3), np.float32), np.ones(1, np.float32))
+    assert a.shape == (1, 3) and np.all(a == 0)
+    a = oracle.forces_direct_f32(np.zeros((4, 3), np.float32), np.ones(4, np.float32), i0=2, i1=2)
+    assert a.shape == (0, 3)
+
+
+@pytest.mark.parametrize("fixture", ["plummer_n1024_seed1", "refbox_n2000_seed1"])
+def test_golden_fixtures_reproduce(oracle, fixture):
+    g = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    pos = np.ascontiguousarray(g["posm"][:, :3]); m = np.ascontiguousarray(g["posm"][:, 3])
+    a = oracle.forces_direct_f32(pos, m)
+    # same compiler flags -> bit-identical; allow 1e-6 in case libm's pow differs by an ulp
+    assert rel_err(a, g["acc_direct"]).max() < 1e-6
+    t, _, _ = oracle.octree_forces_f32(pos, m, 0.0)
+    assert rel_err(t, g["acc_tree0"]).max() < 1e-6
+    p1, v1 = oracle.kick_drift_f32(pos, g["vel"][:, :3], g["acc_direct"], float(g["dt"]))
+    np.testing.assert_array_equal(p1, g["pos1"])
+    np.testing.assert_array_equal(v1, g["vel1"])
+    assert oracle.bounds_f32(pos) == float(g["bounds"])
+
+
+@pytest.mark.parametrize("fixture", ["plummer_n1024_seed1", "refbox_n2000_seed1"])
+def test_fp32_restatement_vs_fp64(oracle, fixture):
+    g = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    # fp32 pair law in the reference's arithmetic vs an independent double-precision sum
+    assert rel_err(g["acc_direct"], g["acc_f64"]).max() < 2e-5
+    # the reference's own traversal order at theta = 0 is all-pairs too
+    assert rel_err(g["acc_tree0"], g["acc_f64"]).max() < 2e-5
+
+
+def test_theta0_walk_equals_all_pairs_and_theta1_does_not(oracle):
+    rng = np.random.default_rng(7)
+    n = 512
+    pos = rng.uniform(-100, 100, (n, 3)).astype(np.float32)
+    m = rng.uniform(1, 5000, n).astype(np.float32)
+    direct = oracle.forces_direct_f32(pos, m)
+    t0, com, cnt = oracle.octree_forces_f32(pos, m, 0.0)
+    assert rel_err(t0, direct).max() < 2e-5
+    assert cnt >= n
+    # root CoM = mass-weighted mean
+    np.testing.assert_allclose(com, (pos * m[:, None]).sum(0) / m.sum(), rtol=1e-4, atol=1e-2)
+    t1, _, _ = oracle.octree_forces_f32(pos, m, 1.0)      # the shipped opening angle is far from all-pairs
+    assert rel_err(t1, direct).mean() > 0.05
+
+
+def test_pow_readings_agree_to_a_few_ulp(oracle):
+    g = np.load(os.path.join(GOLDEN, "plummer_n1024_seed1.npz"))
+    pos = np.ascontiguousarray(g["posm"][:, :3]); m = np.ascontiguousarray(g["posm"][:, 3])
+    for mode in (1, 2):
+        a = oracle.forces_direct_f32(pos, m, pow_mode=mode)
+        assert rel_err(a, g["acc_direct"]).max() < 3e-6
+
+
+def test_kick_drift_uses_new_velocity(oracle):
+    # OctreeSearch.cpp:29-30: v += dt*a first, then x += dt*v with the NEW v
+    pos = np.array([[1, 2, 3]], np.float32); vel = np.array([[10, 0, -10]], np.float32)
+    acc = np.array([[100, 200, 300]], np.float32)
+    p1, v1 = oracle.kick_drift_f32(pos, vel, acc, 0.5)
+    np.testing.assert_array_equal(v1, [[60, 100, 140]])
+    np.testing.assert_array_equal(p1, [[31, 52, 73]])
+
+
+def test_bounds(oracle):
+    pos = np.array([[1, -7, 3], [2, 2, -6.5], [0, 0, 0]], np.float32)
+    assert oracle.bounds_f32(pos) == 7.0
+
+
+def test_tick_direct_matches_pieces_and_pause(oracle):
+    g = np.load(os.path.join(GOLDEN, "plummer_n1024_seed1.npz"))
+    n = 256
+    p = np.zeros(n, oracle.PARTICLE_DTYPE)
+    p["Mass"] = g["posm"][:n, 3]; p["Position"] = g["posm"][:n, :3]; p["Velocity"] = g["vel"][:n, :3]
+    q = p.copy()
+    com, size = oracle.tick_aos_f32(q, 0.01, theta=-1.0)
+    a = oracle.forces_direct_f32(p["Position"], p["Mass"])
+    p1, v1 = oracle.kick_drift_f32(p["Position"], p["Velocity"], a, 0.01)
+    np.testing.assert_array_equal(q["Acceleration"], a)
+    np.testing.assert_array_equal(q["Position"], p1)
+    np.testing.assert_array_equal(q["Velocity"], v1)
+    assert size == oracle.bounds_f32(p["Position"])
+    # PhDeltaTime <= 0 freezes the physics (OctreeSearch.cpp:25)
+    r = p.copy()
+    oracle.tick_aos_f32(r, 0.0)
+    assert r.tobytes() == p.tobytes()
+
+
+def test_tick_tree_uses_previous_com_as_root(oracle):
+    # OctreeSearch.cpp:77-79: the root of frame k+1 is centred on the CoM of frame k's tree
+    rng = np.random.default_rng(3)
+    n = 300
+    p = np.zeros(n, oracle.PARTICLE_DTYPE)
+    p["Mass"] = rng.uniform(1, 10, n); p["Position"] = rng.uniform(-50, 50, (n, 3)) + 5.0
+    com0, _ = oracle.tick_aos_f32(p, 0.01, theta=1.0)
+    assert np.linalg.norm(com0) > 1.0
+    com1, _ = oracle.tick_aos_f32(p, 0.01, theta=1.0, root_com=com0)
+    assert np.all(np.isfinite(p["Position"]))
+    assert np.linalg.norm(com1 - com0) < 5.0
+
+
+def test_energy_and_fp64_step_conserve(oracle):
+    # circular two-body orbit in fp64: energy stays put under the symplectic update
+    G, m, d = 1.0e4, 1.0, 10.0
+    v = np.sqrt(G * m / (2 * d))
+    pos = np.array([[-d / 2, 0, 0], [d / 2, 0, 0]], np.float64)
+    vel = np.array([[0, -v, 0], [0, v, 0]], np.float64)
+    mass = np.array([m, m], np.float64)
+    ke0, pe0 = oracle.energy_f64(pos, vel, mass, g=G)
+    assert pe0 == pytest.approx(-G * m * m / d)
+    dt = 1e-4
+    for _ in range(2000):
+        a = oracle.forces_direct_f64(pos, mass, g=G)
+        pos, vel = oracle.kick_drift_f64(pos, vel, a, dt)
+    ke, pe = oracle.energy_f64(pos, vel, mass, g=G)
+    assert abs((ke + pe) - (ke0 + pe0)) / abs(ke0 + pe0) < 5e-3   # staggered-velocity O(dt) offset only
+    assert np.linalg.norm(pos[1] - pos[0]) == pytest.approx(d, rel=1e-2)
+
+
+def test_openmp_threads_do_not_change_results(oracle):
+    g = np.load(os.path.join(GOLDEN, "plummer_n1024_seed1.npz"))
+    pos = np.ascontiguousarray(g["posm"][:, :3]); m = np.ascontiguousarray(g["posm"][:, 3])
+    a = oracle.forces_direct_f32(pos, m, nthreads=max(2, min(4, oracle.max_threads())))
+    np.testing.assert_array_equal(a, g["acc_direct"])

@@ -1,0 +1,104 @@
+"""Host logic of the multi-GPU path on CPU: world_size 2 over gloo.  The compute engine is replaced by a
+stand-in built on the CPU oracle (test-only; the product's default factory is the HIP engine), so this
+covers partitioning, the in-place all-gather of positions, gather_state and the energy all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+class OracleEngine:
+    """Test stand-in with NBodyEngine's interface; advances its slice with the oracle."""
+
+    def __init__(self, n_total, i_begin, i_count, posm_tensor, device_index, **kw):
+        from oracle import oracle as O
+        self.O = O
+        self.n, self.lo, self.cnt = n_total, i_begin, i_count
+        self.posm = posm_tensor.numpy()          # shares memory with the torch tensor that gets gathered into
+        self.vel = np.zeros((i_count, 4), np.float32)
+        self.acc = np.zeros((i_count, 4), np.float32)
+
+    def set_state(self, posm, vel):
+        self.posm[:] = posm
+        self.vel[:] = vel[self.lo:self.lo + self.cnt]
+
+    def step(self, dt, nsteps):
+        assert nsteps == 1
+        pos = np.ascontiguousarray(self.posm[:, :3]); m = np.ascontiguousarray(self.posm[:, 3])
+        a = self.O.forces_direct_f32(pos, m, i0=self.lo, i1=self.lo + self.cnt)
+        p1, v1 = self.O.kick_drift_f32(pos[self.lo:self.lo + self.cnt], self.vel[:, :3], a, dt)
+        self.acc[:, :3] = a
+        self.vel[:, :3] = v1
+        self.posm[self.lo:self.lo + self.cnt, :3] = p1
+
+    def state(self, dtype=np.float32):
+        return self.posm[self.lo:self.lo + self.cnt].copy(), self.vel.copy(), self.acc.copy()
+
+    def energy(self):
+        # this rank's share: KE of its bodies, half of m_i*phi_i for its bodies
+        pos = self.posm[:, :3].astype(np.float64); m = self.posm[:, 3].astype(np.float64)
+        ke = 0.5 * (m[self.lo:self.lo + self.cnt] * (self.vel[:, :3].astype(np.float64) ** 2).sum(1)).sum()
+        pe = 0.0
+        for i in range(self.lo, self.lo + self.cnt):
+            d = np.linalg.norm(pos - pos[i], axis=1)
+            d[i] = np.inf
+            pe += -0.5 * 1e4 * m[i] * (m / d).sum()
+        return ke, pe
+
+    def close(self):
+        pass
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, steps, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import parallelnbody_amd as nb
+    posm, vel = nb.ic_plummer(n, seed=9)
+    sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device="cpu", engine_factory=OracleEngine)
+    assert (sim.i_begin, sim.i_count) == (rank * n // world, n // world)
+    sim.step(0.01, steps)
+    sim.step(0.0, 3)                       # paused: no exchange, no change
+    p, v = sim.gather_state()
+    ke, pe = sim.energy()
+    # every rank must hold the same replicated positions after the last all-gather
+    np.testing.assert_array_equal(sim.posm.numpy(), p)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), p=p, v=v, ke=ke, pe=pe)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partition_helper(nb):
+    assert nb.partition(1 << 20, 8, 0) == (0, 131072) and nb.partition(1 << 20, 8, 7) == (917504, 131072)
+    with pytest.raises(ValueError):
+        nb.partition(1000, 3, 0)
+
+
+def test_two_ranks_reproduce_one_rank(nb, oracle, tmp_path):
+    import torch.multiprocessing as mp
+    n, steps = 256, 3
+    mp.spawn(_worker, args=(2, _free_port(), n, steps, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["p"], r1["p"])
+    np.testing.assert_array_equal(r0["v"], r1["v"])
+    # single-process reference run of the same three ticks
+    posm, vel = nb.ic_plummer(n, seed=9)
+    pos = posm[:, :3].copy(); v = vel[:, :3].copy()
+    for _ in range(steps):
+        a = oracle.forces_direct_f32(pos, posm[:, 3])
+        pos, v = oracle.kick_drift_f32(pos, v, a, 0.01)
+    np.testing.assert_array_equal(r0["p"][:, :3], pos)
+    np.testing.assert_array_equal(r0["v"][:, :3], v)
+    ke, pe = oracle.energy_f64(pos, v, posm[:, 3])
+    assert float(r0["ke"]) == pytest.approx(ke, rel=1e-6) and float(r0["pe"]) == pytest.approx(pe, rel=1e-6)
+    assert float(r1["ke"]) == pytest.approx(ke, rel=1e-6)
