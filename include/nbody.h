@@ -46,6 +46,18 @@ enum {
   NBODY_PREC_F64 = 2          /* fp64 state, pair law and accumulate */
 };
 
+/*
+ * Handling of pairs at distance exactly 0 when eps == 0 (OctreeSearch.h:102, `if (d == 0) return;`).
+ * EXACT and SELECT reproduce it for every representable distance; FLOOR adds the smallest eps^2 that
+ * keeps G*m_max/d^3 finite in fp32 (about 1e-20: d == 0 pairs still contribute exactly 0, but pairs
+ * closer than ~4e-7 length units are softened) and saves two vector instructions per pair.
+ */
+enum {
+  NBODY_ZERO_EXACT = 0,       /* default: r2 += clamp01(1 - r2*2^126), 2 full-rate VALU ops */
+  NBODY_ZERO_SELECT = 1,      /* compare + select (half-rate ops on gfx950); for A/B measurements */
+  NBODY_ZERO_FLOOR = 2        /* eps^2 floor, not bit-faithful below d ~ 4e-7 */
+};
+
 /* Device buffers reachable through nbody_device_ptr / nbody_bind_device_state. */
 enum {
   NBODY_BUF_POSM = 0,         /* [n_total] x,y,z,mass  (float4, or double4 for NBODY_PREC_F64) */
@@ -81,6 +93,7 @@ typedef struct nbody_params {
   int32_t i_per_thread;   /* i-bodies per lane: 1, 2, 4; 0 = auto */
   int32_t j_split;        /* j-range chunks summed separately then combined in order; 0 = auto (a function of n_total only) */
   int32_t time_kernels;   /* nonzero: bracket kernels with HIP events for nbody_kernel_time */
+  int32_t zero_mode;      /* how d == 0 pairs are dropped when eps == 0 (NBODY_ZERO_*); 0 = default */
 } nbody_params;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */

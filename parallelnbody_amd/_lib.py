@@ -15,6 +15,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED = -1,
 PREC_F32, PREC_F32_KAHAN, PREC_F64 = 0, 1, 2
 BUF_POSM, BUF_VEL, BUF_ACC = 0, 1, 2
 KERNEL_FORCES, KERNEL_UPDATE = 0, 1
+ZERO_EXACT, ZERO_SELECT, ZERO_FLOOR = 0, 1, 2
 
 
 class NBodyError(RuntimeError):
@@ -38,6 +39,7 @@ class Params(ctypes.Structure):
         ("i_per_thread", ctypes.c_int32),
         ("j_split", ctypes.c_int32),
         ("time_kernels", ctypes.c_int32),
+        ("zero_mode", ctypes.c_int32),
     ]
 
 

@@ -41,6 +41,7 @@ struct nbody_ctx {
   int j_split = 1, j_chunk = 0, ipt = 1, tile = 256;
   bool have_state = false;
   bool forces_valid = false;   // acc holds forces of the current positions
+  double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
   KernelTimer timers[2];
   std::string err;
 };
@@ -71,7 +72,7 @@ void choose_geometry(nbody_ctx *c) {
   const nbody_params &p = c->p;
   c->tile = p.tile > 0 ? p.tile : 256;
   if (p.i_per_thread > 0) c->ipt = p.i_per_thread;
-  else c->ipt = (p.precision == NBODY_PREC_F64) ? 1 : (p.n_total >= 32768 ? 2 : 1);
+  else c->ipt = (p.precision == NBODY_PREC_F64) ? 1 : (p.n_total >= 65536 ? 4 : (p.n_total >= 8192 ? 2 : 1));
   int js;
   if (p.j_split > 0) {
     js = p.j_split;
@@ -98,6 +99,8 @@ nbody::ForceLaunch make_launch(const nbody_ctx *c) {
   L.n_total = c->p.n_total; L.i_begin = c->p.i_begin; L.i_count = c->p.i_count;
   L.tile = c->tile; L.ipt = c->ipt; L.j_split = c->j_split; L.j_chunk = c->j_chunk;
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps; L.precision = c->p.precision;
+  L.zero_mode = (c->p.zero_mode == NBODY_ZERO_SELECT) ? 2 : 1;
+  if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
   return L;
 }
 
@@ -135,7 +138,25 @@ int timer_drain(nbody_ctx *c, int which) {
   return NBODY_OK;
 }
 
+// NBODY_ZERO_FLOOR: the smallest eps^2 for which G*m_max*(eps^2)^(-3/2) stays below FLT_MAX/8.
+int ensure_floor(nbody_ctx *c) {
+  if (c->p.zero_mode != NBODY_ZERO_FLOOR || c->p.eps > 0.0 || c->floor_eps2 > 0.0) return NBODY_OK;
+  HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
+  HIP_TRY(c, nbody::launch_massmax(c->p.precision, c->posm, c->p.n_total, (unsigned int *)c->scratch, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->scratch, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float mmax;
+  memcpy(&mmax, c->h_scratch, 4);
+  const double gm = std::fabs(c->p.G) * (double)mmax;
+  const double lim = (c->p.precision == NBODY_PREC_F64) ? 1e300 : 3.0e38 / 8.0;
+  double f = gm > 0 ? std::pow(gm / lim, 2.0 / 3.0) : 0.0;
+  const double tiny = (c->p.precision == NBODY_PREC_F64) ? 1e-280 : 1e-30;
+  c->floor_eps2 = f > tiny ? f : tiny;
+  return NBODY_OK;
+}
+
 int run_forces(nbody_ctx *c) {
+  { int rc = ensure_floor(c); if (rc) return rc; }
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
@@ -194,6 +215,7 @@ int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_state = true;
   c->forces_valid = false;
+  c->floor_eps2 = -1.0;
   return NBODY_OK;
 }
 
@@ -267,6 +289,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if (p.i_per_thread != 0 && p.i_per_thread != 1 && p.i_per_thread != 2 && p.i_per_thread != 4)
     return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: i_per_thread must be 1, 2 or 4");
   if (p.j_split < 0) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: j_split must be >= 0");
+  if (p.zero_mode < 0 || p.zero_mode > NBODY_ZERO_FLOOR) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown zero_mode %d", p.zero_mode);
 
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -347,6 +370,7 @@ int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
   // the caller vouches that bound buffers hold a valid state
   if (posm && vel) c->have_state = true;
   c->forces_valid = false;
+  c->floor_eps2 = -1.0;
   return NBODY_OK;
 }
 

@@ -16,7 +16,8 @@ struct ForceLaunch {
   int j_split;          // number of j chunks
   int j_chunk;          // bodies per chunk (multiple of tile)
   double G;
-  double eps2;
+  double eps2;          // > 0: softened (also the "floor" mode); == 0: exact d == 0 skip
+  int zero_mode;        // for eps2 == 0: 1 = clamp trick (default), 2 = compare+select (A/B only)
   int precision;        // NBODY_PREC_*
 };
 
@@ -32,6 +33,9 @@ hipError_t launch_update(int precision, void *posm, void *vel, void *acc, const 
 // out_bits (uint32, pre-zeroed) = bit pattern of max_i max(|x|,|y|,|z|) over the owned slice.
 hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_count, unsigned int *out_bits,
                          hipStream_t s);
+
+// out_bits (uint32, pre-zeroed) = bit pattern of max_j |m_j| over all n_total bodies.
+hipError_t launch_massmax(int precision, const void *posm, int n_total, unsigned int *out_bits, hipStream_t s);
 
 // fp64 energy pieces: out[0] += KE of owned bodies, out[1] += sum_i 1/2 m_i phi_i  (out pre-zeroed).
 hipError_t launch_energy(int precision, const void *posm, const void *vel, int n_total, int i_begin, int i_count,

@@ -50,19 +50,78 @@ template <typename T> struct Acc3<T, true> {
   }
 };
 
-// One evaluation of the pair law.  mj already carries G.  EXACT = the reference's "d == 0 -> skip"
-// (eps2 == 0); otherwise eps2 > 0 keeps rsq finite and coincident pairs contribute s*0 = 0.
-template <typename T, bool EXACT, bool KAHAN>
-__device__ __forceinline__ void interact(T xi, T yi, T zi, T xj, T yj, T zj, T mj, T eps2, Acc3<T, KAHAN> &a) {
-  const T dx = xj - xi, dy = yj - yi, dz = zj - zi;
-  T r2;
-  if (EXACT) r2 = fma(dx, dx, fma(dy, dy, dz * dz));
-  else       r2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2)));
-  T rinv = rsq_dev(r2);
-  if (EXACT) rinv = (r2 > T(0)) ? rinv : T(0);
-  const T rinv2 = rinv * rinv;
-  const T s = (mj * rinv) * rinv2;
-  a.add(s, dx, dy, dz);
+// How a pair at distance exactly 0 (the self pair, or two bodies on one point) is kept out of the sum —
+// the reference's `if (d == 0) return;` (OctreeSearch.h:102):
+//   Z_SOFT   : eps2 > 0 is added to r^2; rsq stays finite and the pair contributes s*0 = 0.
+//   Z_CLAMP  : r2' = r2 + clamp01(1 - r2*2^126): exactly r2 for every normal r2 > 0, exactly 1 for r2 == 0
+//              (then s = G*m is finite and s*0 = 0).  Two full-rate VALU ops (v_fma ... clamp, v_add).
+//   Z_SELECT : rinv = r2 > 0 ? rsq(r2) : 0 — v_cmp + v_cndmask, both half-rate on gfx950; kept for A/B.
+enum { Z_SOFT = 0, Z_CLAMP = 1, Z_SELECT = 2 };
+
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }   // folds into the clamp bit
+
+// The pair law for a group of JB j-bodies against the lane's IPT i-bodies, written stage by stage (all
+// differences, then all r^2, then all rsq, ...) so that each instruction's consumers sit JB*IPT issue slots
+// behind it: no dependent back-to-back VALU pairs and no wait states behind the quarter-rate v_rsq_f32.
+// mj already carries G.  `zp` is eps2 (Z_SOFT) or -2^126 (Z_CLAMP).
+template <typename T, int IPT, int JB, int ZMODE, bool KAHAN, typename V>
+__device__ __forceinline__ void interact_group(const T (&xi)[IPT], const T (&yi)[IPT], const T (&zi)[IPT],
+                                               const V (&pj)[JB], T zp, Acc3<T, KAHAN> (&a)[IPT]) {
+  T dx[JB][IPT], dy[JB][IPT], dz[JB][IPT], w[JB][IPT];
+#pragma unroll
+  for (int b = 0; b < JB; ++b)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) { dx[b][k] = pj[b].x - xi[k]; dy[b][k] = pj[b].y - yi[k]; dz[b][k] = pj[b].z - zi[k]; }
+#pragma unroll
+  for (int b = 0; b < JB; ++b)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      if (ZMODE == Z_SOFT) w[b][k] = fma(dz[b][k], dz[b][k], zp);
+      else                 w[b][k] = dz[b][k] * dz[b][k];
+    }
+#pragma unroll
+  for (int b = 0; b < JB; ++b)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) w[b][k] = fma(dy[b][k], dy[b][k], w[b][k]);
+#pragma unroll
+  for (int b = 0; b < JB; ++b)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) w[b][k] = fma(dx[b][k], dx[b][k], w[b][k]);
+  if (ZMODE == Z_CLAMP && sizeof(T) == 4) {
+    T nf[JB][IPT];
+#pragma unroll
+    for (int b = 0; b < JB; ++b)
+#pragma unroll
+      for (int k = 0; k < IPT; ++k) nf[b][k] = (T)clamp01((float)fma(w[b][k], zp, T(1)));
+#pragma unroll
+    for (int b = 0; b < JB; ++b)
+#pragma unroll
+      for (int k = 0; k < IPT; ++k) w[b][k] = w[b][k] + nf[b][k];
+  }
+  T rinv[JB][IPT];
+#pragma unroll
+  for (int b = 0; b < JB; ++b)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      rinv[b][k] = rsq_dev(w[b][k]);
+      if (ZMODE == Z_SELECT || (ZMODE == Z_CLAMP && sizeof(T) == 8)) rinv[b][k] = (w[b][k] > T(0)) ? rinv[b][k] : T(0);
+    }
+#pragma unroll
+  for (int b = 0; b < JB; ++b)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) w[b][k] = rinv[b][k] * rinv[b][k];
+#pragma unroll
+  for (int b = 0; b < JB; ++b)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) rinv[b][k] = pj[b].w * rinv[b][k];
+#pragma unroll
+  for (int b = 0; b < JB; ++b)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) w[b][k] = rinv[b][k] * w[b][k];
+#pragma unroll
+  for (int b = 0; b < JB; ++b)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) a[k].add(w[b][k], dx[b][k], dy[b][k], dz[b][k]);
 }
 
 // All-pairs partial accelerations.
@@ -70,10 +129,10 @@ __device__ __forceinline__ void interact(T xi, T yi, T zi, T xj, T yj, T zj, T m
 //   grid.y : j chunks [c*j_chunk, min((c+1)*j_chunk, n_total)); each writes its own partial row
 //   LDS    : double-buffered tile of TILE bodies (x,y,z,G*m); every lane reads the same address
 //            (broadcast ds_read_b128), one barrier per tile
-template <typename T, int IPT, int TILE, bool EXACT, bool KAHAN>
+template <typename T, int IPT, int TILE, int ZMODE, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T>::type *__restrict__ posm,
                                                              typename V4<T>::type *__restrict__ accp, int n_total,
-                                                             int i_begin, int i_count, int j_chunk, T gscale, T eps2) {
+                                                             int i_begin, int i_count, int j_chunk, T gscale, T zp) {
   using V = typename V4<T>::type;
   constexpr int LPT = (TILE + kBlock - 1) / kBlock;   // tile elements loaded per lane
   __shared__ V sh[2][TILE];
@@ -93,6 +152,10 @@ __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T
     const V p = posm[i_begin + il];
     xi[k] = p.x; yi[k] = p.y; zi[k] = p.z;
   }
+  // Consume the i-body loads here, so that their s_waitcnt sits in front of the loops and not at the
+  // registers' first use inside the j loop (where vmcnt(0) would also drain the next tile's prefetch).
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) asm volatile("" ::"v"(xi[k]), "v"(yi[k]), "v"(zi[k]));
 
   V r[LPT];
   auto load_tile = [&](int tile) {
@@ -101,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T
       const int e = t + l * kBlock;
       if (e < TILE) {
         const int j = j0 + tile * TILE + e;
-        if (j < j1) { r[l] = posm[j]; r[l].w *= gscale; }
+        if (j < j1) r[l] = posm[j];
         else        { r[l].x = 0; r[l].y = 0; r[l].z = 0; r[l].w = 0; }   // zero-mass padding
       }
     }
@@ -110,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
       const int e = t + l * kBlock;
-      if (e < TILE) sh[buf][e] = r[l];
+      if (e < TILE) { V q = r[l]; q.w *= gscale; sh[buf][e] = q; }   // G folded into the mass here, after the wait
     }
   };
 
@@ -120,11 +183,13 @@ __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T
     const int buf = tile & 1;
     const bool more = tile + 1 < ntiles;
     if (more) load_tile(tile + 1);          // global loads in flight under the tile's arithmetic
-#pragma unroll 8
-    for (int jj = 0; jj < TILE; ++jj) {
-      const V pj = sh[buf][jj];
+    constexpr int JB = (IPT >= 4) ? 2 : (8 / (IPT * (sizeof(T) / 4)) > 0 ? 8 / (IPT * (int)(sizeof(T) / 4)) : 1);
+#pragma unroll 2
+    for (int jj = 0; jj < TILE; jj += JB) {
+      V pj[JB];
 #pragma unroll
-      for (int k = 0; k < IPT; ++k) interact<T, EXACT, KAHAN>(xi[k], yi[k], zi[k], pj.x, pj.y, pj.z, pj.w, eps2, a[k]);
+      for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
+      interact_group<T, IPT, JB, ZMODE, KAHAN, V>(xi, yi, zi, pj, zp, a);
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
@@ -140,13 +205,173 @@ __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Packed-fp32 force kernel (the fp32 production path).
+//
+// Measured on MI355X (tools/microbench*.hip, DESIGN.md "VALU issue model"): v_fma/v_mul/v_add/v_sub issue in
+// ~2.2 cycles per wave64, v_rsq_f32 in 8.2; a 3-source op whose three VGPRs all have the same register-number
+// parity, and ANY op with an SGPR operand, takes 4.2; v_max/v_min/v_cmp/v_med3 take 4.2 and v_cndmask far
+// more.  v_pk_{fma,mul,add}_f32 take 4.2 for two results and, reading even-aligned register PAIRS, can never
+// hit the parity conflict.  So each lane carries its i-bodies two by two in register pairs and the whole pair
+// law runs on packed instructions with every constant in VGPRs: 12 packed ops + 2 v_rsq_f32 per two pairs.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// a * b.y in both halves: one v_pk_mul_f32 reading the (z, G*m) half of the LDS quad in place (hipcc would
+// first copy the mass down with a v_mov_b32)
+__device__ __forceinline__ f2 mul_bcast_hi(f2 a, f2 b) {
+  f2 o;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
+
+template <bool KAHAN> struct Acc3pk;
+template <> struct Acc3pk<false> {
+  f2 x = splat2(0.f), y = splat2(0.f), z = splat2(0.f);
+  __device__ __forceinline__ void add(f2 s, f2 dx, f2 dy, f2 dz) { x = fma2(s, dx, x); y = fma2(s, dy, y); z = fma2(s, dz, z); }
+};
+template <> struct Acc3pk<true> {
+  f2 x = splat2(0.f), y = splat2(0.f), z = splat2(0.f), cx = splat2(0.f), cy = splat2(0.f), cz = splat2(0.f);
+  static __device__ __forceinline__ void kadd(f2 &sum, f2 &c, f2 s, f2 d) {
+    const f2 yv = fma2(s, d, -c);
+    const f2 t = sum + yv;
+    c = (t - sum) - yv;
+    sum = t;
+  }
+  __device__ __forceinline__ void add(f2 s, f2 dx, f2 dy, f2 dz) { kadd(x, cx, s, dx); kadd(y, cy, s, dy); kadd(z, cz, s, dz); }
+};
+
+// NP register pairs of i-bodies per lane (IPT = 2*NP); JB j-bodies per staged group.
+template <int NP, int TILE, int ZMODE, bool KAHAN>
+__global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__restrict__ posm,
+                                                                float4 *__restrict__ accp, int n_total, int i_begin,
+                                                                int i_count, int j_chunk, float gscale, float zp) {
+  constexpr int IPT = 2 * NP;
+  constexpr int LPT = (TILE + kBlock - 1) / kBlock;
+  __shared__ float4 sh[2][TILE];
+
+  const int t = threadIdx.x;
+  const int ibase = blockIdx.x * (kBlock * IPT);
+  const int c = blockIdx.y;
+  const int j0 = c * j_chunk;
+  const int j1 = min(j0 + j_chunk, n_total);
+  const int ntiles = (j1 > j0) ? (j1 - j0 + TILE - 1) / TILE : 0;
+
+  f2 xi[NP], yi[NP], zi[NP];
+  Acc3pk<KAHAN> a[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const float4 p0 = posm[i_begin + min(ibase + t + (2 * p) * kBlock, i_count - 1)];
+    const float4 p1 = posm[i_begin + min(ibase + t + (2 * p + 1) * kBlock, i_count - 1)];
+    xi[p] = f2{p0.x, p1.x}; yi[p] = f2{p0.y, p1.y}; zi[p] = f2{p0.z, p1.z};
+  }
+  // every loop-invariant operand in VGPRs (an SGPR operand halves the issue rate), loads consumed before the loops
+  f2 zp2 = splat2(zp), one2 = splat2(1.0f);
+  asm volatile("" : "+v"(zp2), "+v"(one2));
+#pragma unroll
+  for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(xi[p]), "v"(yi[p]), "v"(zi[p]));
+
+  float4 r[LPT];
+  auto load_tile = [&](int tile) {
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) {
+      const int e = t + l * kBlock;
+      if (e < TILE) {
+        const int j = j0 + tile * TILE + e;
+        if (j < j1) r[l] = posm[j];
+        else        r[l] = make_float4(0.f, 0.f, 0.f, 0.f);   // zero-mass padding
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) {
+      const int e = t + l * kBlock;
+      if (e < TILE) { float4 q = r[l]; q.w *= gscale; sh[buf][e] = q; }
+    }
+  };
+
+  if (ntiles > 0) { load_tile(0); store_tile(0); }
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int buf = tile & 1;
+    const bool more = tile + 1 < ntiles;
+    if (more) load_tile(tile + 1);
+    constexpr int JB = (NP == 1) ? 4 : 2;
+#pragma unroll 2
+    for (int jj = 0; jj < TILE; jj += JB) {
+      float4 pj[JB];
+#pragma unroll
+      for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
+      f2 dx[JB][NP], dy[JB][NP], dz[JB][NP], w[JB][NP], u[JB][NP];
+#pragma unroll
+      for (int b = 0; b < JB; ++b)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          dx[b][p] = splat2(pj[b].x) - xi[p]; dy[b][p] = splat2(pj[b].y) - yi[p]; dz[b][p] = splat2(pj[b].z) - zi[p];
+        }
+#pragma unroll
+      for (int b = 0; b < JB; ++b)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          if (ZMODE == Z_SOFT) w[b][p] = fma2(dz[b][p], dz[b][p], zp2);
+          else                 w[b][p] = dz[b][p] * dz[b][p];
+          w[b][p] = fma2(dy[b][p], dy[b][p], w[b][p]);
+          w[b][p] = fma2(dx[b][p], dx[b][p], w[b][p]);
+        }
+      if (ZMODE == Z_CLAMP) {
+#pragma unroll
+        for (int b = 0; b < JB; ++b)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            f2 nf;   // clamp01(1 - r2*2^126): 1 for r2 == 0, 0 for every normal r2 > 0
+            asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nf) : "v"(w[b][p]), "v"(zp2), "v"(one2));
+            w[b][p] = w[b][p] + nf;
+          }
+      }
+#pragma unroll
+      for (int b = 0; b < JB; ++b)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) u[b][p] = f2{rsq_dev(w[b][p].x), rsq_dev(w[b][p].y)};
+#pragma unroll
+      for (int b = 0; b < JB; ++b)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          // The inline-asm multiply must not read a v_rsq_f32 result directly: hipcc pads the trans->VALU
+          // hazard only for its own instructions.  It therefore takes rinv^3, produced by two ordinary ops.
+          w[b][p] = u[b][p] * u[b][p];
+          w[b][p] = w[b][p] * u[b][p];
+          w[b][p] = mul_bcast_hi(w[b][p], f2{pj[b].z, pj[b].w});   // * G*m_j
+        }
+#pragma unroll
+      for (int b = 0; b < JB; ++b)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[p].add(w[b][p], dx[b][p], dy[b][p], dz[b][p]);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int il0 = ibase + t + (2 * p) * kBlock, il1 = il0 + kBlock;
+    if (il0 < i_count) accp[(size_t)c * i_count + il0] = make_float4(a[p].x.x, a[p].y.x, a[p].z.x, 0.f);
+    if (il1 < i_count) accp[(size_t)c * i_count + il1] = make_float4(a[p].x.y, a[p].y.y, a[p].z.y, 0.f);
+  }
+}
+
 // Combine the j-chunk partials in chunk order (deterministic), store the acceleration, and — when
 // integrate != 0 — apply the reference's update with separate multiply and add (no FMA), exactly
 // as FVector's operators do: v = v + dt*a; x = x + dt*v   (OctreeSearch.cpp:29-30).
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+// HIP's __fmul_rn/__fadd_rn are plain * and + and get contracted into FMAs under the default
+// -ffp-contract=fast; the pragma keeps the two roundings of the reference's operators.
+template <typename T> __device__ __forceinline__ T mul_add_sep(T a, T b, T c) {
+#pragma clang fp contract(off)
+  const T p = a * b;
+  return c + p;
+}
 
 template <typename T, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void update_kernel(typename V4<T>::type *__restrict__ posm,
@@ -165,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void update_kernel(typename V4<T>::type *__
       yv = p.y - cy; tt = ay + yv; cy = (tt - ay) - yv; ay = tt;
       yv = p.z - cz; tt = az + yv; cz = (tt - az) - yv; az = tt;
     } else {
-      ax = add_rn(ax, p.x); ay = add_rn(ay, p.y); az = add_rn(az, p.z);
+      ax = ax + p.x; ay = ay + p.y; az = az + p.z;
     }
   }
   V a; a.x = ax; a.y = ay; a.z = az; a.w = 0;
@@ -173,14 +398,14 @@ __global__ __launch_bounds__(kBlock) void update_kernel(typename V4<T>::type *__
   if (integrate) {
     V v = vel[il];
     V x = posm[i_begin + il];
-    v.x = add_rn(v.x, mul_rn(dt, ax)); v.y = add_rn(v.y, mul_rn(dt, ay)); v.z = add_rn(v.z, mul_rn(dt, az));
-    x.x = add_rn(x.x, mul_rn(dt, v.x)); x.y = add_rn(x.y, mul_rn(dt, v.y)); x.z = add_rn(x.z, mul_rn(dt, v.z));
+    v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
+    x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
     vel[il] = v;
     posm[i_begin + il] = x;
   }
 }
 
-template <typename T>
+template <typename T, bool MASS>
 __global__ __launch_bounds__(kBlock) void bounds_kernel(const typename V4<T>::type *__restrict__ posm, int i_begin,
                                                         int i_count, unsigned int *__restrict__ out_bits) {
   using V = typename V4<T>::type;
@@ -188,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const typename V4<T>::ty
   for (int il = blockIdx.x * kBlock + threadIdx.x; il < i_count; il += gridDim.x * kBlock) {
     const V p = posm[i_begin + il];
     // GetAbsMax: max(max(|X|,|Y|),|Z|); compared in fp32 like the reference's float Size
-    const float v = fmaxf(fmaxf(fabsf((float)p.x), fabsf((float)p.y)), fabsf((float)p.z));
+    const float v = MASS ? fabsf((float)p.w) : fmaxf(fmaxf(fabsf((float)p.x), fabsf((float)p.y)), fabsf((float)p.z));
     m = fmaxf(m, v);
   }
 #pragma unroll
@@ -256,13 +481,26 @@ hipError_t launch_forces_t(const ForceLaunch &L, hipStream_t s) {
   using V = typename V4<T>::type;
   const int iblocks = (L.i_count + kBlock * IPT - 1) / (kBlock * IPT);
   dim3 grid(iblocks, L.j_split), block(kBlock);
-  const T gscale = (T)L.G, eps2 = (T)L.eps2;
-  if (L.eps2 == 0.0)
-    hipLaunchKernelGGL((forces_tile_kernel<T, IPT, TILE, true, KAHAN>), grid, block, 0, s, (const V *)L.posm,
-                       (V *)L.accp, L.n_total, L.i_begin, L.i_count, L.j_chunk, gscale, eps2);
-  else
-    hipLaunchKernelGGL((forces_tile_kernel<T, IPT, TILE, false, KAHAN>), grid, block, 0, s, (const V *)L.posm,
-                       (V *)L.accp, L.n_total, L.i_begin, L.i_count, L.j_chunk, gscale, eps2);
+  const T gscale = (T)L.G;
+  if constexpr (sizeof(T) == 4 && IPT % 2 == 0) {
+    // production fp32 path: packed kernel (compare+select only exists in the scalar kernel, for A/B)
+    if (L.eps2 > 0.0 || L.zero_mode != Z_SELECT) {
+#define NBODY_LAUNCH_PK(ZM, ZP)                                                                                  \
+  hipLaunchKernelGGL((forces_tile_pk_kernel<IPT / 2, TILE, ZM, KAHAN>), grid, block, 0, s, (const float4 *)L.posm, \
+                     (float4 *)L.accp, L.n_total, L.i_begin, L.i_count, L.j_chunk, (float)L.G, (float)(ZP))
+      if (L.eps2 > 0.0) NBODY_LAUNCH_PK(Z_SOFT, L.eps2);
+      else NBODY_LAUNCH_PK(Z_CLAMP, -0x1p126);
+#undef NBODY_LAUNCH_PK
+      return hipGetLastError();
+    }
+  }
+#define NBODY_LAUNCH(ZM, ZP)                                                                                   \
+  hipLaunchKernelGGL((forces_tile_kernel<T, IPT, TILE, ZM, KAHAN>), grid, block, 0, s, (const V *)L.posm,      \
+                     (V *)L.accp, L.n_total, L.i_begin, L.i_count, L.j_chunk, gscale, (T)(ZP))
+  if (L.eps2 > 0.0) NBODY_LAUNCH(Z_SOFT, L.eps2);
+  else if (L.zero_mode == Z_SELECT || sizeof(T) == 8) NBODY_LAUNCH(Z_SELECT, 0.0);
+  else NBODY_LAUNCH(Z_CLAMP, -0x1p126);
+#undef NBODY_LAUNCH
   return hipGetLastError();
 }
 
@@ -335,10 +573,23 @@ hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_cou
   int blocks = (i_count + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
   if (precision == NBODY_PREC_F64)
-    hipLaunchKernelGGL((bounds_kernel<double>), dim3(blocks), dim3(kBlock), 0, s, (const double4 *)posm, i_begin,
+    hipLaunchKernelGGL((bounds_kernel<double, false>), dim3(blocks), dim3(kBlock), 0, s, (const double4 *)posm, i_begin,
                        i_count, out_bits);
   else
-    hipLaunchKernelGGL((bounds_kernel<float>), dim3(blocks), dim3(kBlock), 0, s, (const float4 *)posm, i_begin, i_count,
+    hipLaunchKernelGGL((bounds_kernel<float, false>), dim3(blocks), dim3(kBlock), 0, s, (const float4 *)posm, i_begin,
+                       i_count, out_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_massmax(int precision, const void *posm, int n_total, unsigned int *out_bits, hipStream_t s) {
+  if (n_total <= 0) return hipErrorInvalidValue;
+  int blocks = (n_total + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  if (precision == NBODY_PREC_F64)
+    hipLaunchKernelGGL((bounds_kernel<double, true>), dim3(blocks), dim3(kBlock), 0, s, (const double4 *)posm, 0, n_total,
+                       out_bits);
+  else
+    hipLaunchKernelGGL((bounds_kernel<float, true>), dim3(blocks), dim3(kBlock), 0, s, (const float4 *)posm, 0, n_total,
                        out_bits);
   return hipGetLastError();
 }

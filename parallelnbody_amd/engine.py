@@ -54,7 +54,7 @@ class NBodyEngine:
     """One context = one GPU's share [i_begin, i_begin+i_count) of an n_total-body system."""
 
     def __init__(self, n_total, *, i_begin=0, i_count=0, device=0, precision="f32", G=REF_G, eps=0.0, tile=0,
-                 i_per_thread=0, j_split=0, time_kernels=False):
+                 i_per_thread=0, j_split=0, time_kernels=False, zero_mode=0):
         L = _lib.lib()
         p = Params()
         L.nbody_default_params(ctypes.byref(p))
@@ -63,6 +63,7 @@ class NBodyEngine:
         p.G, p.eps = G, eps
         p.tile, p.i_per_thread, p.j_split = tile, i_per_thread, j_split
         p.time_kernels = 1 if time_kernels else 0
+        p.zero_mode = zero_mode
         h = ctypes.c_void_p()
         rc = L.nbody_create(ctypes.byref(p), ctypes.byref(h))
         if rc:
@@ -105,12 +106,14 @@ class NBodyEngine:
     def set_state(self, posm, vel):
         if np.asarray(posm).dtype == np.float64:
             p = np.ascontiguousarray(posm, np.float64); v = np.ascontiguousarray(vel, np.float64)
-            assert p.shape == (self.n_total, 4) and v.shape == (self.n_total, 4)
-            self._check(self._L.nbody_set_state_soa_f64(self._h, _dp(p), _dp(v), self.n_total))
+            if p.ndim != 2 or p.shape[1] != 4 or v.shape != p.shape:
+                raise ValueError("posm and vel must both be [n, 4]")
+            self._check(self._L.nbody_set_state_soa_f64(self._h, _dp(p), _dp(v), p.shape[0]))
         else:
             p = np.ascontiguousarray(posm, np.float32); v = np.ascontiguousarray(vel, np.float32)
-            assert p.shape == (self.n_total, 4) and v.shape == (self.n_total, 4)
-            self._check(self._L.nbody_set_state_soa(self._h, _fp(p), _fp(v), self.n_total))
+            if p.ndim != 2 or p.shape[1] != 4 or v.shape != p.shape:
+                raise ValueError("posm and vel must both be [n, 4]")
+            self._check(self._L.nbody_set_state_soa(self._h, _fp(p), _fp(v), p.shape[0]))
 
     # -- hot path --
     def compute_forces(self):
