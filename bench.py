@@ -23,8 +23,9 @@ if ROOT not in sys.path:
 
 PEAK_FP32_TFLOPS = 157.3      # MI355X vector fp32 peak, MI355X_MICROARCH.md "Chip-level parameters"
 FLOP_PER_PAIR = 20            # 3 sub + 6 (dot) + 4 (rsqrt cubed) + 1 (mass) + 6 (3 FMA)
-# HBM bytes per force launch from the PMC pass recorded in profiles/ (None until measured)
-TRAFFIC_BYTES_PER_LAUNCH = {}
+# HBM bytes per force launch from the PMC passes in profiles/r01_pmc_forces_kernel.txt, keyed by
+# (n, gpus, j_split): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE.  None for configurations not profiled.
+TRAFFIC_BYTES_PER_LAUNCH = {(1 << 20, 1, 16): 2 * 173606 * 1024 + 262144 * 1024}
 
 
 def cpu_baseline(posm, target_seconds):
@@ -134,8 +135,9 @@ def main():
                        "workgroups": cfg["blocks"], "accumulate": args.precision, "finite": finite},
             "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64",
                          "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
-                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((n, world)),
-                         "kernel": "forces_tile_kernel", "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((n, world, cfg["j_split"])) if args.precision == "f32" else None,
+                         "kernel": "forces_tile_pk_kernel" if (args.precision != "f64" and cfg["i_per_thread"] % 2 == 0)
+                         else "forces_tile_kernel", "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
                          "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs,
                          "update_kernel_avg_ms": u_ms / max(u_n, 1)},
         }
