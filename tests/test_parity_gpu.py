@@ -303,3 +303,53 @@ def test_config1_size_properties(nb, oracle):
     fscale = (np.linalg.norm(a, axis=1) * posm[:, 3]).sum()
     assert np.linalg.norm(f) / fscale < 1e-6
     assert rel_err(acc[128], a).max() < TOL_ACC
+
+
+def _sync_energy(e, dt):
+    """Total energy with the staggered velocity pulled back to the positions' time (v_n = v_{n+1/2} - dt/2 a_n)."""
+    e.compute_forces()
+    p, v, a = e.state(np.float64)
+    _, pe = e.energy()
+    m = p[:, 3]
+    vs = v[:, :3] - 0.5 * dt * a[:, :3]
+    return 0.5 * (m * (vs ** 2).sum(1)).sum() + pe
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32_kahan", "f64"])
+def test_energy_drift_1k_steps(nb, precision):
+    # north-star acceptance: total-energy drift < 1e-4 over 1000 steps on a softened Plummer sphere.
+    # The reference's update stores velocities half a step behind the positions; the diagnostic synchronises them.
+    n, a_pl, M, G = 4096, 100.0, 1000.0, 1.0e4
+    dt = 0.002                                  # crossing time a / sqrt(GM/a) = 0.32 -> 160 steps per crossing
+    posm, vel = nb.ic_plummer(n, M, a_pl, G, seed=5)
+    with nb.NBodyEngine(n, precision=precision, eps=0.05 * a_pl) as e:
+        e.set_state(posm, vel)
+        # start the leapfrog: v_{-1/2} = v_0 - dt/2 a_0, so that the stored velocity is the staggered one
+        e.compute_forces()
+        p0, v0, a0 = e.state(np.float64)
+        v_half = v0.copy(); v_half[:, :3] -= 0.5 * dt * a0[:, :3]
+        e.set_state(p0 if precision == "f64" else p0.astype(np.float32),
+                    v_half if precision == "f64" else v_half.astype(np.float32))
+        e0 = _sync_energy(e, -dt)               # stored v is half a step BEHIND here: v_0 = v_{-1/2} + dt/2 a_0
+        worst = 0.0
+        for _ in range(10):
+            e.step(dt, 100)
+            worst = max(worst, abs(_sync_energy(e, -dt) - e0) / abs(e0))
+    assert worst < 1e-4, worst
+
+
+def test_config3_fp64_size_properties(nb, oracle):
+    # N = 262144 fp64 (BASELINE configs[3]) is a 6.9e10-pair pass: checked on a sample + momentum, smaller N here
+    n = 32768
+    posm, vel = nb.ic_plummer(n, seed=4)
+    with nb.NBodyEngine(n, precision="f64") as e:
+        e.set_state(posm.astype(np.float64), vel.astype(np.float64))
+        e.compute_forces()
+        a = e.accelerations(np.float64)
+    rng = np.random.default_rng(1)
+    p64 = posm.astype(np.float64)
+    for i in rng.choice(n, 32, replace=False):
+        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1)
+        assert rel_err(a[i:i + 1], ref).max() < 1e-12
+    f = (a * p64[:, 3:4]).sum(0)
+    assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * p64[:, 3]).sum() < 1e-13
