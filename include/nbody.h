@@ -58,6 +58,14 @@ enum {
   NBODY_ZERO_FLOOR = 2        /* eps^2 floor, not bit-faithful below d ~ 4e-7 */
 };
 
+/*
+ * Force algorithm.  Both evaluate the same pair law over all pairs; they differ in summation order only.
+ * TILED: every ordered pair (i, j), one-sided (kernels.hip).  SYMMETRIC: every unordered pair once, feeding
+ * both bodies (kernels_sym.hip): fp32 non-Kahan contexts that own all bodies (i_count == n_total).
+ * AUTO picks SYMMETRIC where it applies and n_total is large enough to fill the chip, else TILED.
+ */
+enum { NBODY_ALGO_AUTO = 0, NBODY_ALGO_TILED = 1, NBODY_ALGO_SYMMETRIC = 2 };
+
 /* Device buffers reachable through nbody_device_ptr / nbody_bind_device_state. */
 enum {
   NBODY_BUF_POSM = 0,         /* [n_total] x,y,z,mass  (float4, or double4 for NBODY_PREC_F64) */
@@ -94,6 +102,7 @@ typedef struct nbody_params {
   int32_t j_split;        /* j-range chunks summed separately then combined in order; 0 = auto (a function of n_total only) */
   int32_t time_kernels;   /* nonzero: bracket kernels with HIP events for nbody_kernel_time */
   int32_t zero_mode;      /* how d == 0 pairs are dropped when eps == 0 (NBODY_ZERO_*); 0 = default */
+  int32_t algorithm;      /* NBODY_ALGO_*; 0 = auto */
 } nbody_params;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
@@ -186,6 +195,9 @@ NBODY_API int nbody_kernel_time_reset(nbody_ctx *ctx);
 /* Launch geometry actually chosen (for logs and DESIGN.md tables). */
 NBODY_API int nbody_get_launch_config(nbody_ctx *ctx, int32_t *tile, int32_t *i_per_thread, int32_t *j_split,
                                       int32_t *blocks, int32_t *threads);
+
+/* NBODY_ALGO_* actually in use, and (symmetric only) the super-tile size in bodies. */
+NBODY_API int nbody_get_algorithm(nbody_ctx *ctx, int32_t *algorithm, int32_t *super_tile);
 
 /* ---- initial conditions (host only; no device needed) ---------------------------------------- */
 

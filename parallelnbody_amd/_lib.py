@@ -16,6 +16,7 @@ PREC_F32, PREC_F32_KAHAN, PREC_F64 = 0, 1, 2
 BUF_POSM, BUF_VEL, BUF_ACC = 0, 1, 2
 KERNEL_FORCES, KERNEL_UPDATE = 0, 1
 ZERO_EXACT, ZERO_SELECT, ZERO_FLOOR = 0, 1, 2
+ALGO_AUTO, ALGO_TILED, ALGO_SYMMETRIC = 0, 1, 2
 
 
 class NBodyError(RuntimeError):
@@ -40,6 +41,7 @@ class Params(ctypes.Structure):
         ("j_split", ctypes.c_int32),
         ("time_kernels", ctypes.c_int32),
         ("zero_mode", ctypes.c_int32),
+        ("algorithm", ctypes.c_int32),
     ]
 
 
@@ -101,6 +103,7 @@ def lib():
     sig("nbody_kernel_time", c_int, vp, c_i32, dp, ctypes.POINTER(c_i64))
     sig("nbody_kernel_time_reset", c_int, vp)
     sig("nbody_get_launch_config", c_int, vp, *([ctypes.POINTER(c_i32)] * 5))
+    sig("nbody_get_algorithm", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32))
     sig("nbody_ic_reference_box", c_int, c_i32, c_f, fp, ctypes.c_uint64, fp, fp)
     sig("nbody_ic_plummer", c_int, c_i32, c_d, c_d, c_d, ctypes.c_uint64, fp, fp)
     # actor mirror (include/nbody_actor.h)

@@ -42,6 +42,10 @@ struct nbody_ctx {
   bool have_state = false;
   bool forces_valid = false;   // acc holds forces of the current positions
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
+  // symmetric algorithm (kernels_sym.hip)
+  bool sym = false;
+  int sym_S = 0, sym_T = 0, sym_pad = 0, sym_pairs = 0;
+  void *sym_part = nullptr, *sym_pair_tab = nullptr;
   KernelTimer timers[2];
   std::string err;
 };
@@ -91,6 +95,35 @@ void choose_geometry(nbody_ctx *c) {
   js = (p.n_total + chunk - 1) / chunk;
   c->j_split = js;
   c->j_chunk = chunk;
+}
+
+// Symmetric algorithm: applicability and super-tile geometry.
+void choose_algorithm(nbody_ctx *c) {
+  const nbody_params &p = c->p;
+  const bool can = p.precision == NBODY_PREC_F32 && p.i_count == p.n_total && p.zero_mode != NBODY_ZERO_SELECT &&
+                   (c->ipt == 2 || c->ipt == 4);
+  bool want = false;
+  if (p.algorithm == NBODY_ALGO_SYMMETRIC) want = can;
+  else if (p.algorithm == NBODY_ALGO_AUTO) want = can && p.n_total >= 262144;
+  c->sym = want;
+  if (!want) return;
+  const int BI = 256 * c->ipt;
+  long long S = (p.n_total + 127) / 128;           // ~128 super tiles -> ~8000 workgroups
+  S = (S + BI - 1) / BI * BI;
+  if (S < BI) S = BI;
+  c->sym_S = (int)S;
+  c->sym_T = (int)((p.n_total + S - 1) / S);
+  c->sym_pad = c->sym_T * c->sym_S;
+  c->sym_pairs = c->sym_T * (c->sym_T + 1) / 2;
+}
+
+nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
+  nbody::SymLaunch L;
+  L.posm = c->posm; L.part = c->sym_part; L.pairs = c->sym_pair_tab; L.n_pairs = c->sym_pairs;
+  L.n_total = c->p.n_total; L.S = c->sym_S; L.T = c->sym_T; L.n_pad = c->sym_pad; L.np = c->ipt / 2;
+  L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps;
+  if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
+  return L;
 }
 
 nbody::ForceLaunch make_launch(const nbody_ctx *c) {
@@ -160,7 +193,8 @@ int run_forces(nbody_ctx *c) {
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
-  HIP_TRY(c, nbody::launch_forces(make_launch(c), c->stream));
+  if (c->sym) HIP_TRY(c, nbody::launch_forces_sym(make_sym_launch(c), c->stream));
+  else HIP_TRY(c, nbody::launch_forces(make_launch(c), c->stream));
   if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
   // bound the number of live events on long untimed-drain runs
   if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) return timer_drain(c, NBODY_KERNEL_FORCES);
@@ -171,8 +205,12 @@ int run_update(nbody_ctx *c, float dt) {
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_UPDATE, &ev); if (rc) return rc; }
-  HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->accp, c->p.i_begin, c->p.i_count,
-                                  c->j_split, dt, c->stream));
+  if (c->sym)
+    HIP_TRY(c, nbody::launch_update_sym(c->posm, c->vel, c->acc, c->sym_part, c->p.n_total, c->sym_S, c->sym_T,
+                                        c->sym_pad, dt, c->stream));
+  else
+    HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->accp, c->p.i_begin, c->p.i_count,
+                                    c->j_split, dt, c->stream));
   if (timed) { int rc = timer_end(c, NBODY_KERNEL_UPDATE, ev); if (rc) return rc; }
   if (timed && c->timers[NBODY_KERNEL_UPDATE].pending.size() >= 1024) return timer_drain(c, NBODY_KERNEL_UPDATE);
   return NBODY_OK;
@@ -290,6 +328,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
     return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: i_per_thread must be 1, 2 or 4");
   if (p.j_split < 0) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: j_split must be >= 0");
   if (p.zero_mode < 0 || p.zero_mode > NBODY_ZERO_FLOOR) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown zero_mode %d", p.zero_mode);
+  if (p.algorithm < 0 || p.algorithm > NBODY_ALGO_SYMMETRIC) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown algorithm %d", p.algorithm);
 
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -304,6 +343,12 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   c->p = p;
   c->elem = (p.precision == NBODY_PREC_F64) ? 32 : 16;
   choose_geometry(c);
+  choose_algorithm(c);
+  if (p.algorithm == NBODY_ALGO_SYMMETRIC && !c->sym) {
+    delete c;
+    return fail(nullptr, NBODY_ERR_UNSUPPORTED,
+                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (no Kahan), i_count == n_total, i_per_thread 2 or 4 and zero_mode != SELECT");
+  }
 
   auto bail = [&](hipError_t he, const char *what) {
     fail(nullptr, NBODY_ERR_HIP, "nbody_create: %s: %s", what, hipGetErrorString(he));
@@ -319,7 +364,18 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   c->own_vel = true;
   if ((e = hipMalloc(&c->acc, (size_t)p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc acc");
   c->own_acc = true;
-  if ((e = hipMalloc(&c->accp, (size_t)c->j_split * p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc accp");
+  if (c->sym) {
+    if ((e = hipMalloc(&c->sym_part, (size_t)2 * c->sym_T * c->sym_pad * 16)) != hipSuccess) return bail(e, "hipMalloc partial rows");
+    std::vector<int> tab;
+    tab.reserve((size_t)c->sym_pairs * 2);
+    for (int a = 0; a < c->sym_T; ++a)                       // full super-tile pairs first, the half-size diagonal ones last
+      for (int b = a + 1; b < c->sym_T; ++b) { tab.push_back(a); tab.push_back(b); }
+    for (int a = 0; a < c->sym_T; ++a) { tab.push_back(a); tab.push_back(a); }
+    if ((e = hipMalloc(&c->sym_pair_tab, tab.size() * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc pair table");
+    if ((e = hipMemcpy(c->sym_pair_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy pair table");
+  } else {
+    if ((e = hipMalloc(&c->accp, (size_t)c->j_split * p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc accp");
+  }
   if ((e = hipMalloc(&c->scratch, 64)) != hipSuccess) return bail(e, "hipMalloc scratch");
   if ((e = hipHostMalloc(&c->h_scratch, 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   *out = c;
@@ -337,6 +393,8 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->own_vel && c->vel) (void)hipFree(c->vel);
   if (c->own_acc && c->acc) (void)hipFree(c->acc);
   if (c->accp) (void)hipFree(c->accp);
+  if (c->sym_part) (void)hipFree(c->sym_part);
+  if (c->sym_pair_tab) (void)hipFree(c->sym_pair_tab);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->h_scratch) (void)hipHostFree(c->h_scratch);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -548,11 +606,19 @@ int nbody_kernel_time_reset(nbody_ctx *c) {
   return NBODY_OK;
 }
 
+int nbody_get_algorithm(nbody_ctx *c, int32_t *algorithm, int32_t *super_tile) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (algorithm) *algorithm = c->sym ? NBODY_ALGO_SYMMETRIC : NBODY_ALGO_TILED;
+  if (super_tile) *super_tile = c->sym ? c->sym_S : 0;
+  return NBODY_OK;
+}
+
 int nbody_get_launch_config(nbody_ctx *c, int32_t *tile, int32_t *i_per_thread, int32_t *j_split, int32_t *blocks,
                             int32_t *threads) {
   if (!c) return NBODY_ERR_INVALID;
   int b = 0, t = 0;
   nbody::forces_geometry(make_launch(c), &b, &t);
+  if (c->sym) { b = c->sym_pairs; t = 256; }
   if (tile) *tile = c->tile;
   if (i_per_thread) *i_per_thread = c->ipt;
   if (j_split) *j_split = c->j_split;

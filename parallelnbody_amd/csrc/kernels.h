@@ -30,6 +30,24 @@ void forces_geometry(const ForceLaunch &L, int *blocks, int *threads);
 hipError_t launch_update(int precision, void *posm, void *vel, void *acc, const void *accp, int i_begin,
                          int i_count, int j_split, float dt, hipStream_t s);
 
+// Symmetric (each pair once) fp32 force pass of a context that owns all bodies — kernels_sym.hip.
+struct SymLaunch {
+  const void *posm;     // [n_total] float4
+  void *part;           // [2*T][n_pad] float4: rows 0..T-1 i-side sums (slot = partner super tile), T..2T-1 j-side sums
+  const void *pairs;    // [n_pairs] int2 (si, sj), si <= sj: one workgroup each
+  int n_pairs;
+  int n_total;
+  int S;                // bodies per super tile (multiple of 256*2*np)
+  int T;                // super tiles = ceil(n_total / S)
+  int n_pad;            // T * S
+  int np;               // register pairs of i-bodies per lane (1 or 2)
+  double G;
+  double eps2;          // > 0 softened / floor; == 0 exact d == 0 skip (clamp form)
+};
+hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);
+hipError_t launch_update_sym(void *posm, void *vel, void *acc, const void *part, int n_total, int S, int T, int n_pad,
+                             float dt, hipStream_t s);
+
 // out_bits (uint32, pre-zeroed) = bit pattern of max_i max(|x|,|y|,|z|) over the owned slice.
 hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_count, unsigned int *out_bits,
                          hipStream_t s);

@@ -9,18 +9,16 @@
 #include "kernels.h"
 
 #include "../../include/nbody.h"
+#include "pk_common.h"
 
 namespace nbody {
 
 namespace {
 
-constexpr int kBlock = 256;   // 4 waves of 64 lanes: one per SIMD of a CU
-
 template <typename T> struct V4;
 template <> struct V4<float> { using type = float4; };
 template <> struct V4<double> { using type = double4; };
 
-__device__ __forceinline__ float rsq_dev(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
 __device__ __forceinline__ double rsq_dev(double x) {
   double y = __builtin_amdgcn_rsq(x);            // v_rsq_f64: ~2^-26 relative
   const double h = 0.5 * x;
@@ -49,14 +47,6 @@ template <typename T> struct Acc3<T, true> {
     kadd(x, cx, s, dx); kadd(y, cy, s, dy); kadd(z, cz, s, dz);
   }
 };
-
-// How a pair at distance exactly 0 (the self pair, or two bodies on one point) is kept out of the sum —
-// the reference's `if (d == 0) return;` (OctreeSearch.h:102):
-//   Z_SOFT   : eps2 > 0 is added to r^2; rsq stays finite and the pair contributes s*0 = 0.
-//   Z_CLAMP  : r2' = r2 + clamp01(1 - r2*2^126): exactly r2 for every normal r2 > 0, exactly 1 for r2 == 0
-//              (then s = G*m is finite and s*0 = 0).  Two full-rate VALU ops (v_fma ... clamp, v_add).
-//   Z_SELECT : rinv = r2 > 0 ? rsq(r2) : 0 — v_cmp + v_cndmask, both half-rate on gfx950; kept for A/B.
-enum { Z_SOFT = 0, Z_CLAMP = 1, Z_SELECT = 2 };
 
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }   // folds into the clamp bit
 
@@ -215,34 +205,6 @@ __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T
 // hit the parity conflict.  So each lane carries its i-bodies two by two in register pairs and the whole pair
 // law runs on packed instructions with every constant in VGPRs: 12 packed ops + 2 v_rsq_f32 per two pairs.
 // ---------------------------------------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-// a * b.y in both halves: one v_pk_mul_f32 reading the (z, G*m) half of the LDS quad in place (hipcc would
-// first copy the mass down with a v_mov_b32)
-__device__ __forceinline__ f2 mul_bcast_hi(f2 a, f2 b) {
-  f2 o;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(o) : "v"(a), "v"(b));
-  return o;
-}
-
-template <bool KAHAN> struct Acc3pk;
-template <> struct Acc3pk<false> {
-  f2 x = splat2(0.f), y = splat2(0.f), z = splat2(0.f);
-  __device__ __forceinline__ void add(f2 s, f2 dx, f2 dy, f2 dz) { x = fma2(s, dx, x); y = fma2(s, dy, y); z = fma2(s, dz, z); }
-};
-template <> struct Acc3pk<true> {
-  f2 x = splat2(0.f), y = splat2(0.f), z = splat2(0.f), cx = splat2(0.f), cy = splat2(0.f), cz = splat2(0.f);
-  static __device__ __forceinline__ void kadd(f2 &sum, f2 &c, f2 s, f2 d) {
-    const f2 yv = fma2(s, d, -c);
-    const f2 t = sum + yv;
-    c = (t - sum) - yv;
-    sum = t;
-  }
-  __device__ __forceinline__ void add(f2 s, f2 dx, f2 dy, f2 dz) { kadd(x, cx, s, dx); kadd(y, cy, s, dy); kadd(z, cz, s, dz); }
-};
-
 // NP register pairs of i-bodies per lane (IPT = 2*NP); JB j-bodies per staged group.
 template <int NP, int TILE, int ZMODE, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__restrict__ posm,
@@ -305,50 +267,7 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
       float4 pj[JB];
 #pragma unroll
       for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
-      f2 dx[JB][NP], dy[JB][NP], dz[JB][NP], w[JB][NP], u[JB][NP];
-#pragma unroll
-      for (int b = 0; b < JB; ++b)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          dx[b][p] = splat2(pj[b].x) - xi[p]; dy[b][p] = splat2(pj[b].y) - yi[p]; dz[b][p] = splat2(pj[b].z) - zi[p];
-        }
-#pragma unroll
-      for (int b = 0; b < JB; ++b)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          if (ZMODE == Z_SOFT) w[b][p] = fma2(dz[b][p], dz[b][p], zp2);
-          else                 w[b][p] = dz[b][p] * dz[b][p];
-          w[b][p] = fma2(dy[b][p], dy[b][p], w[b][p]);
-          w[b][p] = fma2(dx[b][p], dx[b][p], w[b][p]);
-        }
-      if (ZMODE == Z_CLAMP) {
-#pragma unroll
-        for (int b = 0; b < JB; ++b)
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            f2 nf;   // clamp01(1 - r2*2^126): 1 for r2 == 0, 0 for every normal r2 > 0
-            asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nf) : "v"(w[b][p]), "v"(zp2), "v"(one2));
-            w[b][p] = w[b][p] + nf;
-          }
-      }
-#pragma unroll
-      for (int b = 0; b < JB; ++b)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) u[b][p] = f2{rsq_dev(w[b][p].x), rsq_dev(w[b][p].y)};
-#pragma unroll
-      for (int b = 0; b < JB; ++b)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          // The inline-asm multiply must not read a v_rsq_f32 result directly: hipcc pads the trans->VALU
-          // hazard only for its own instructions.  It therefore takes rinv^3, produced by two ordinary ops.
-          w[b][p] = u[b][p] * u[b][p];
-          w[b][p] = w[b][p] * u[b][p];
-          w[b][p] = mul_bcast_hi(w[b][p], f2{pj[b].z, pj[b].w});   // * G*m_j
-        }
-#pragma unroll
-      for (int b = 0; b < JB; ++b)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) a[p].add(w[b][p], dx[b][p], dy[b][p], dz[b][p]);
+      pair_group_pk<NP, JB, ZMODE, KAHAN>(xi, yi, zi, pj, zp2, one2, a);
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();

@@ -1,0 +1,263 @@
+// Symmetric all-pairs force kernel for gfx950: every unordered pair {i, j} is evaluated ONCE and feeds both
+// accelerations (a_i += G m_j s d, a_j -= G m_i s d with s = |d|^-3, d = r_j - r_i) — the same pair law,
+// OctreeSearch.h:101-104, at 18 packed ops + 2 v_rsq_f32 per two pairs (four interactions) instead of 14 + 2 per
+// two interactions.
+//
+// Structure (single context owning all bodies):
+//   * bodies are cut into super tiles of S bodies; workgroup (si, sj), si <= sj, owns every pair between them;
+//   * it walks i-sets of 256*IPT bodies of si (register pairs, as in kernels.hip) against 256-body j tiles of sj
+//     staged in LDS; tiles wholly after the i-set (always, when si < sj) run the SYMMETRIC step, the tiles that
+//     overlap the i-set's own range run the plain one-sided step (all ordered pairs, d == 0 skipped), tiles
+//     before it are skipped (they were handled when their bodies were the i-set);
+//   * symmetric step: in round r wave w takes 64-body subtile (r + w) & 3; at step k lane l meets body
+//     (l - k) & 63 of it — a per-lane ds_read_b128 from a doubled subtile image — and the body's running j-side
+//     sum travels with it from lane to lane (three v_mov_b32_dpp wave_ror:1 per step; ds_add_f32 on LDS was
+//     measured ~190 cycles per wave instruction and is not used).  After 64 steps the sums are home and are added
+//     to the tile's LDS accumulators; within a round no two waves touch the same subtile and rounds are separated
+//     by a barrier, so the summation order is fixed;
+//   * results go to block-private rows of a partial buffer: i-side sums to row [sj], j-side sums to row
+//     [T + si] (read-modify-write by the same thread every time); update_sym_kernel adds a body's rows in a fixed
+//     order.  No global atomics: bit-reproducible.
+#include "kernels.h"
+
+#include "../../include/nbody.h"
+#include "pk_common.h"
+
+namespace nbody {
+
+namespace {
+
+constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
+
+// lane l+1 <- lane l, lane 0 <- lane 63 (v_mov_b32_dpp wave_ror:1; a half-rate VALU op on gfx950)
+__device__ __forceinline__ float wave_ror1(float v) {
+  const int i = __builtin_bit_cast(int, v);   // every lane is written, so `old` is irrelevant: pass the source (no v_mov to seed it)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x13C, 0xf, 0xf, false));
+}
+
+// (a.y*b.y, a.x*b.x): the product with its halves swapped.  The j-side scale factors are kept this way so that the
+// scalar v_fmac_f32 that adds `scale(hi body) * d(hi body)` reads an even and an odd register — a 3-source op whose
+// registers all share a parity issues at half rate on gfx950 (VALU issue model).
+__device__ __forceinline__ f2 mul_swap(f2 a, f2 b) {
+  f2 o;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
+
+#ifndef NBODY_SYM_WAVES
+#define NBODY_SYM_WAVES 4
+#endif
+template <int NP, int ZMODE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NBODY_SYM_WAVES, NBODY_SYM_WAVES)))
+void forces_sym_pk_kernel(const float4 *__restrict__ posm,
+                                                               float4 *__restrict__ part,
+                                                               const int2 *__restrict__ pairs, int n_total, int S,
+                                                               int T, int n_pad, float gscale, float zp) {
+  constexpr int IPT = 2 * NP;
+  constexpr int BI = kBlock * IPT;
+  __shared__ float4 sh_pos[2][4][128];   // double-buffered subtile images, doubled: entries l and l+64 hold body l
+  __shared__ float sh_acc[4][3][kJT];    // per-WAVE j-side sums of the tile (private: no ordering between waves needed)
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int2 pr = pairs[blockIdx.x];
+  const int si = pr.x, sj = pr.y;
+  const bool diag_super = si == sj;
+  float4 *__restrict__ Pi = part + (size_t)sj * n_pad;         // i-side sums of bodies in si
+  float4 *__restrict__ Pj = part + (size_t)(T + si) * n_pad;   // j-side sums of bodies in sj
+
+  // This workgroup's j-side row segment starts from zero; element e is only ever touched by thread e % 256.
+  for (int e = t; e < S; e += kBlock) Pj[(size_t)sj * S + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  f2 zp2 = splat2(zp), one2 = splat2(1.0f);
+  asm volatile("" : "+v"(zp2), "+v"(one2));
+
+  const int tiles_in_super = S / kJT;
+  int c_end = (n_total - sj * S + kJT - 1) / kJT;               // tiles of sj that hold at least one body
+  if (c_end > tiles_in_super) c_end = tiles_in_super;
+
+  for (int b = 0; b < S / BI; ++b) {
+    const int i0 = si * S + b * BI;
+    if (i0 >= n_total) break;
+    f2 xi[NP], yi[NP], zi[NP], nmi[NP];
+    Acc3pk<false> a[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int ia = i0 + t + (2 * p) * kBlock, ib = ia + kBlock;
+      const float4 pa = ia < n_total ? posm[ia] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 pb = ib < n_total ? posm[ib] : make_float4(0.f, 0.f, 0.f, 0.f);
+      xi[p] = f2{pa.x, pb.x}; yi[p] = f2{pa.y, pb.y}; zi[p] = f2{pa.z, pb.z};
+      nmi[p] = f2{-gscale * pa.w, -gscale * pb.w};             // -G m_i: the j side gets a_j -= G m_i s d
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(xi[p]), "v"(yi[p]), "v"(zi[p]), "v"(nmi[p]));
+
+    // tiles before the i-set (same super tile only) were handled when their bodies were the i-set
+    const int c_begin = diag_super ? b * (BI / kJT) : 0;
+    auto fetch = [&](int c) {                                   // thread t owns body j0 + t of the tile
+      const int j = sj * S + c * kJT + t;
+      return (j < n_total) ? posm[j] : make_float4(0.f, 0.f, 0.f, 0.f);   // zero-mass padding
+    };
+    auto stage = [&](int buf, float4 q) {
+      q.w *= gscale;
+      sh_pos[buf][wave][lane] = q;
+      sh_pos[buf][wave][lane + 64] = q;
+    };
+    if (c_begin < c_end) stage(c_begin & 1, fetch(c_begin));
+    __syncthreads();
+
+    for (int c = c_begin; c < c_end; ++c) {
+      const int buf = c & 1;
+      const int j0 = sj * S + c * kJT;
+      const bool sym = !diag_super || j0 >= i0 + BI;
+      const bool more = c + 1 < c_end;
+      float4 nxt;
+      if (more) nxt = fetch(c + 1);                             // in flight under this tile's arithmetic
+
+      if (sym) {
+        for (int r = 0; r < 4; ++r) {
+          const int sub = (r + wave) & 3;                       // waves start on different subtiles
+          // At step k lane l meets body (l - k) & 63 of the subtile; that body's running j-side sum sits in the
+          // same lane and moves on with it (wave_ror:1: lane l+1 takes lane l's value) after every step.
+          const float4 *sp = &sh_pos[buf][sub][lane + 64];
+          float jx = 0.f, jy = 0.f, jz = 0.f;
+#pragma unroll 4
+          for (int k = 0; k < 64; ++k) {
+            const float4 pj = sp[-k];
+            f2 dx[NP], dy[NP], dz[NP], w[NP], u[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { dx[p] = splat2(pj.x) - xi[p]; dy[p] = splat2(pj.y) - yi[p]; dz[p] = splat2(pj.z) - zi[p]; }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              if (ZMODE == Z_SOFT) w[p] = fma2(dz[p], dz[p], zp2);
+              else                 w[p] = dz[p] * dz[p];
+              w[p] = fma2(dy[p], dy[p], w[p]);
+              w[p] = fma2(dx[p], dx[p], w[p]);
+            }
+            if (ZMODE == Z_CLAMP) {
+#pragma unroll
+              for (int p = 0; p < NP; ++p) {
+                f2 nf;
+                asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nf) : "v"(w[p]), "v"(zp2), "v"(one2));
+                w[p] = w[p] + nf;
+              }
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) u[p] = f2{rsq_dev(w[p].x), rsq_dev(w[p].y)};
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              w[p] = u[p] * u[p];
+              w[p] = w[p] * u[p];                                     // |d|^-3 (ordinary ops between rsq and the asm)
+              u[p] = mul_swap(w[p], nmi[p]);                          // -G m_i |d|^-3, halves swapped
+              w[p] = mul_bcast_hi(w[p], f2{pj.z, pj.w});              //  G m_j |d|^-3
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              a[p].add(w[p], dx[p], dy[p], dz[p]);
+              // both of the lane's bodies act on the same j: scalar FMAs straight into its running sum
+              jx = fmaf(u[p].x, dx[p].y, jx); jy = fmaf(u[p].x, dy[p].y, jy); jz = fmaf(u[p].x, dz[p].y, jz);
+              jx = fmaf(u[p].y, dx[p].x, jx); jy = fmaf(u[p].y, dy[p].x, jy); jz = fmaf(u[p].y, dz[p].x, jz);
+            }
+            jx = wave_ror1(jx); jy = wave_ror1(jy); jz = wave_ror1(jz);      // the sum moves on with its body
+          }
+          // after 64 moves lane l holds the sum of body l of the subtile again
+          sh_acc[wave][0][sub * 64 + lane] = jx; sh_acc[wave][1][sub * 64 + lane] = jy; sh_acc[wave][2][sub * 64 + lane] = jz;
+        }
+      } else {
+        // one-sided step on the tiles that overlap the i-set: every ordered pair, self pairs dropped by ZMODE
+        constexpr int JB = (NP == 1) ? 4 : 2;
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll 2
+          for (int k = 0; k < 64; k += JB) {
+            float4 pj[JB];
+#pragma unroll
+            for (int g = 0; g < JB; ++g) pj[g] = sh_pos[buf][q][k + g];
+            pair_group_pk<NP, JB, ZMODE, false>(xi, yi, zi, pj, zp2, one2, a);
+          }
+        }
+      }
+      if (more) stage(buf ^ 1, nxt);
+      __syncthreads();   // the four waves' tile sums are complete; the next tile is staged
+      if (sym) {
+        // thread t adds body j0 + t's sum (waves in fixed order) to this workgroup's private row
+        float4 *dst = &Pj[j0 + t];
+        float4 o = *dst;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) { o.x += sh_acc[wv][0][t]; o.y += sh_acc[wv][1][t]; o.z += sh_acc[wv][2][t]; }
+        *dst = o;
+        __syncthreads(); // sh_acc is rewritten by the next tile
+      }
+    }
+
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int ia = i0 + t + (2 * p) * kBlock, ib = ia + kBlock;
+      if (ia < n_pad) Pi[ia] = make_float4(a[p].x.x, a[p].y.x, a[p].z.x, 0.f);
+      if (ib < n_pad) Pi[ib] = make_float4(a[p].x.y, a[p].y.y, a[p].z.y, 0.f);
+    }
+  }
+}
+
+// acc[b] = sum of body b's rows in a fixed order: i-side rows sj = s .. T-1 (s = b / S), then j-side rows
+// si = 0 .. s; optionally the reference's update (OctreeSearch.cpp:29-30) with separate multiply and add.
+template <typename T> __device__ __forceinline__ T mul_add_sep2(T a, T b, T c) {
+#pragma clang fp contract(off)
+  const T p = a * b;
+  return c + p;
+}
+
+__global__ __launch_bounds__(kBlock) void update_sym_kernel(float4 *__restrict__ posm, float4 *__restrict__ vel,
+                                                            float4 *__restrict__ acc, const float4 *__restrict__ part,
+                                                            int n_total, int S, int T, int n_pad, float dt,
+                                                            int integrate) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= n_total) return;
+  const int s = b / S;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int sj = s; sj < T; ++sj) {
+    const float4 p = part[(size_t)sj * n_pad + b];
+    ax += p.x; ay += p.y; az += p.z;
+  }
+  for (int si = 0; si <= s; ++si) {
+    const float4 p = part[(size_t)(T + si) * n_pad + b];
+    ax += p.x; ay += p.y; az += p.z;
+  }
+  acc[b] = make_float4(ax, ay, az, 0.f);
+  if (integrate) {
+    float4 v = vel[b], x = posm[b];
+    v.x = mul_add_sep2(dt, ax, v.x); v.y = mul_add_sep2(dt, ay, v.y); v.z = mul_add_sep2(dt, az, v.z);
+    x.x = mul_add_sep2(dt, v.x, x.x); x.y = mul_add_sep2(dt, v.y, x.y); x.z = mul_add_sep2(dt, v.z, x.z);
+    vel[b] = v;
+    posm[b] = x;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
+  if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0) return hipErrorInvalidValue;
+  if (L.S % (kBlock * 2 * L.np) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
+  dim3 grid(L.n_pairs), block(kBlock);
+#define NBODY_SYM(NPV, ZM, ZP)                                                                                  \
+  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)L.part, \
+                     (const int2 *)L.pairs, L.n_total, L.S, L.T, L.n_pad, (float)L.G, (float)(ZP))
+  if (L.np == 1) {
+    if (L.eps2 > 0.0) NBODY_SYM(1, Z_SOFT, L.eps2); else NBODY_SYM(1, Z_CLAMP, -0x1p126);
+  } else if (L.np == 2) {
+    if (L.eps2 > 0.0) NBODY_SYM(2, Z_SOFT, L.eps2); else NBODY_SYM(2, Z_CLAMP, -0x1p126);
+  } else {
+    return hipErrorInvalidValue;
+  }
+#undef NBODY_SYM
+  return hipGetLastError();
+}
+
+hipError_t launch_update_sym(void *posm, void *vel, void *acc, const void *part, int n_total, int S, int T, int n_pad,
+                             float dt, hipStream_t s) {
+  if (n_total <= 0) return hipErrorInvalidValue;
+  dim3 grid((n_total + kBlock - 1) / kBlock), block(kBlock);
+  hipLaunchKernelGGL(update_sym_kernel, grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
+                     (const float4 *)part, n_total, S, T, n_pad, dt, dt > 0.0f ? 1 : 0);
+  return hipGetLastError();
+}
+
+}  // namespace nbody

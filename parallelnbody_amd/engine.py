@@ -54,7 +54,7 @@ class NBodyEngine:
     """One context = one GPU's share [i_begin, i_begin+i_count) of an n_total-body system."""
 
     def __init__(self, n_total, *, i_begin=0, i_count=0, device=0, precision="f32", G=REF_G, eps=0.0, tile=0,
-                 i_per_thread=0, j_split=0, time_kernels=False, zero_mode=0):
+                 i_per_thread=0, j_split=0, time_kernels=False, zero_mode=0, algorithm=0):
         L = _lib.lib()
         p = Params()
         L.nbody_default_params(ctypes.byref(p))
@@ -64,6 +64,7 @@ class NBodyEngine:
         p.tile, p.i_per_thread, p.j_split = tile, i_per_thread, j_split
         p.time_kernels = 1 if time_kernels else 0
         p.zero_mode = zero_mode
+        p.algorithm = algorithm
         h = ctypes.c_void_p()
         rc = L.nbody_create(ctypes.byref(p), ctypes.byref(h))
         if rc:
@@ -190,4 +191,9 @@ class NBodyEngine:
     def launch_config(self):
         v = [ctypes.c_int32() for _ in range(5)]
         self._check(self._L.nbody_get_launch_config(self._h, *[ctypes.byref(x) for x in v]))
-        return dict(zip(("tile", "i_per_thread", "j_split", "blocks", "threads"), (x.value for x in v)))
+        cfg = dict(zip(("tile", "i_per_thread", "j_split", "blocks", "threads"), (x.value for x in v)))
+        algo, st = ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._L.nbody_get_algorithm(self._h, ctypes.byref(algo), ctypes.byref(st)))
+        cfg["algorithm"] = {_lib.ALGO_TILED: "tiled", _lib.ALGO_SYMMETRIC: "symmetric"}[algo.value]
+        cfg["super_tile"] = st.value
+        return cfg

@@ -23,14 +23,15 @@ def main():
     ap.add_argument("--zeros", default="0,1,2")
     ap.add_argument("--precisions", default="f32")
     ap.add_argument("--eps", type=float, default=0.0)
+    ap.add_argument("--algos", default="1", help="1 = tiled, 2 = symmetric")
     a = ap.parse_args()
     posm, vel = nb.ic_plummer(a.n, seed=1)
     ints = lambda s: [int(x) for x in s.split(",")]
-    print(f"{'prec':>9} {'tile':>5} {'ipt':>4} {'jsplit':>6} {'zero':>5} {'blocks':>7} {'ms':>10} {'pairs/s':>12} {'%peak':>7}")
-    for prec, tile, ipt, js, zm in itertools.product(a.precisions.split(","), ints(a.tiles), ints(a.ipts),
-                                                     ints(a.jsplits), ints(a.zeros)):
+    print(f"{'algo':>9} {'prec':>9} {'tile':>5} {'ipt':>4} {'jsplit':>6} {'zero':>5} {'blocks':>7} {'ms':>10} {'pairs/s':>12} {'%peak':>7}")
+    for algo, prec, tile, ipt, js, zm in itertools.product(ints(a.algos), a.precisions.split(","), ints(a.tiles),
+                                                           ints(a.ipts), ints(a.jsplits), ints(a.zeros)):
         with nb.NBodyEngine(a.n, precision=prec, tile=tile, i_per_thread=ipt, j_split=js, zero_mode=zm, eps=a.eps,
-                            time_kernels=True) as e:
+                            time_kernels=True, algorithm=algo) as e:
             e.set_state(posm, vel)
             e.compute_forces()
             e.synchronize()
@@ -42,7 +43,7 @@ def main():
         ms /= n
         pps = float(a.n) ** 2 / (ms * 1e-3)
         peak = 157.3e12 if prec != "f64" else 78.6e12
-        print(f"{prec:>9} {cfg['tile']:>5} {cfg['i_per_thread']:>4} {cfg['j_split']:>6} {zm:>5} {cfg['blocks']:>7} "
+        print(f"{cfg['algorithm']:>9} {prec:>9} {cfg['tile']:>5} {cfg['i_per_thread']:>4} {cfg['j_split']:>6} {zm:>5} {cfg['blocks']:>7} "
               f"{ms:>10.3f} {pps:>12.4e} {100 * pps * 20 / peak:>7.2f}", flush=True)
 
 
