@@ -25,7 +25,8 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X vector fp32 peak, MI355X_MICROARCH.md "Ch
 FLOP_PER_PAIR = 20            # 3 sub + 6 (dot) + 4 (rsqrt cubed) + 1 (mass) + 6 (3 FMA)
 # HBM bytes per force launch from the PMC passes in profiles/r01_pmc_forces_kernel.txt, keyed by
 # (n, gpus, j_split): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE.  None for configurations not profiled.
-TRAFFIC_BYTES_PER_LAUNCH = {(1 << 20, 1, 16): 2 * 173606 * 1024 + 262144 * 1024}
+TRAFFIC_BYTES_PER_LAUNCH = {("tiled", 1 << 20, 1): 2 * 173606 * 1024 + 262144 * 1024,
+                            ("symmetric", 1 << 20, 1): 2 * 7728600 * 1024 + 10485000 * 1024}
 
 
 def cpu_baseline(posm, target_seconds):
@@ -64,6 +65,9 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--ipt", type=int, default=0)
     ap.add_argument("--jsplit", type=int, default=0)
+    ap.add_argument("--algorithm", default="auto", choices=["auto", "tiled", "symmetric"])
+    ap.add_argument("--zero-mode", default="exact", choices=["exact", "floor"],
+                    help="exact = the reference's d == 0 skip for every distance; floor = ~1e-20 eps^2 floor")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length; 0 = skip")
     args = ap.parse_args()
 
@@ -89,7 +93,9 @@ def main():
     posm, vel = nb.ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
     sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device=f"cuda:{local_rank}",
                                precision=args.precision, eps=args.eps, tile=args.tile, i_per_thread=args.ipt,
-                               j_split=args.jsplit, time_kernels=True)
+                               j_split=args.jsplit, time_kernels=True,
+                               algorithm={"auto": 0, "tiled": 1, "symmetric": 2}[args.algorithm],
+                               zero_mode={"exact": 0, "floor": 2}[args.zero_mode])
     cfg = sim.engine.launch_config()
 
     def fence():
@@ -113,7 +119,8 @@ def main():
     u_ms, u_n = sim.engine.kernel_time(nb.KERNEL_UPDATE)
     pairs_per_step = float(n) * float(n)
     value = pairs_per_step * args.steps / elapsed
-    # dominant kernel: the force pass of this rank = i_count x n_total pair evaluations per launch
+    # dominant kernel: the force pass of this rank = i_count x n_total pair interactions per launch (the symmetric
+    # kernel evaluates each unordered pair once and credits both bodies: same interaction count, fewer instructions)
     launch_pairs = float(sim.i_count) * float(n)
     avg_launch_s = (f_ms / max(f_n, 1)) * 1e-3
     achieved_tflops = launch_pairs * FLOP_PER_PAIR / avg_launch_s * 1e-12
@@ -130,14 +137,20 @@ def main():
             "dtype": {"f32": "f32", "f32_kahan": "f32", "f64": "f64"}[args.precision], "data": "synthetic",
             "config": {"workload": f"N={n} all-pairs {args.precision}, seeded Plummer sphere, G=1e4, eps={args.eps}, "
                                    f"dt={args.dt}, one force pass + kick-drift per step",
-                       "parallelism": f"range-partition x{world}, 1 RCCL all-gather(posm)/step" if world > 1 else "1 GPU",
-                       "lds_tile_bodies": cfg["tile"], "i_per_lane": cfg["i_per_thread"], "j_split": cfg["j_split"],
+                       "parallelism": (f"range-partition x{world}, per step 1 RCCL all-gather(posm)"
+                                       + (" + 1 all-to-all(j-side sums)" if cfg["algorithm"] == "symmetric" else ""))
+                       if world > 1 else "1 GPU",
+                       "algorithm": cfg["algorithm"], "zero_distance": args.zero_mode,
+                       "lds_tile_bodies": cfg["tile"], "i_per_lane": cfg["i_per_thread"],
+                       "j_split": cfg["j_split"] if cfg["algorithm"] == "tiled" else None,
+                       "super_tile_bodies": cfg["super_tile"] or None,
                        "workgroups": cfg["blocks"], "accumulate": args.precision, "finite": finite},
             "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64",
                          "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
-                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((n, world, cfg["j_split"])) if args.precision == "f32" else None,
-                         "kernel": "forces_tile_pk_kernel" if (args.precision != "f64" and cfg["i_per_thread"] % 2 == 0)
-                         else "forces_tile_kernel", "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, world)) if args.precision == "f32" else None,
+                         "kernel": "forces_sym_pk_kernel (+reduce_j_kernel)" if cfg["algorithm"] == "symmetric"
+                         else ("forces_tile_pk_kernel" if (args.precision != "f64" and cfg["i_per_thread"] % 2 == 0)
+                               else "forces_tile_kernel"), "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
                          "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs,
                          "update_kernel_avg_ms": u_ms / max(u_n, 1)},
         }

@@ -61,8 +61,10 @@ enum {
 /*
  * Force algorithm.  Both evaluate the same pair law over all pairs; they differ in summation order only.
  * TILED: every ordered pair (i, j), one-sided (kernels.hip).  SYMMETRIC: every unordered pair once, feeding
- * both bodies (kernels_sym.hip): fp32 non-Kahan contexts that own all bodies (i_count == n_total).
- * AUTO picks SYMMETRIC where it applies and n_total is large enough to fill the chip, else TILED.
+ * both bodies (kernels_sym.hip): fp32 non-Kahan contexts; when the bodies are sharded the slices must be equal
+ * and the host drives nbody_step_begin / all-to-all / nbody_step_end.  The per-body summation order then depends
+ * on the number of ranks (TILED's does not).
+ * AUTO picks SYMMETRIC where it applies and n_total >= 32768, else TILED.
  */
 enum { NBODY_ALGO_AUTO = 0, NBODY_ALGO_TILED = 1, NBODY_ALGO_SYMMETRIC = 2 };
 
@@ -150,6 +152,26 @@ NBODY_API int nbody_compute_forces(nbody_ctx *ctx);
  * must be 1: the caller all-gathers NBODY_BUF_POSM across ranks between steps.
  */
 NBODY_API int nbody_step(nbody_ctx *ctx, float dt, int32_t nsteps);
+
+/*
+ * The same step in two phases, for hosts that share the bodies over several GPUs:
+ *   nbody_step_begin : force pass (OctreeSearch.cpp:83-86 at theta = 0) for the owned bodies
+ *   nbody_step_end   : v += dt*a; x += dt*v for the owned bodies (OctreeSearch.cpp:28-31); dt <= 0 only stores a
+ * Between them a sharded context running NBODY_ALGO_SYMMETRIC needs ONE all-to-all: it has evaluated each body pair
+ * once and holds, in `send`, what its pairs contribute to every other rank's bodies (n_ranks segments of
+ * bytes_per_rank, segment q for rank q); `recv` must receive segment r of every rank's `send`.  nbody_exchange_info
+ * reports n_ranks = 0 when no exchange is needed.  After nbody_step_end the owned slice of NBODY_BUF_POSM is
+ * all-gathered as with nbody_step.
+ */
+NBODY_API int nbody_step_begin(nbody_ctx *ctx);
+NBODY_API int nbody_step_end(nbody_ctx *ctx, float dt);
+NBODY_API int nbody_exchange_info(nbody_ctx *ctx, void **send, void **recv, size_t *bytes_per_rank, int32_t *n_ranks);
+/* Use caller-owned device buffers (e.g. torch tensors) for the exchange: send = n_total x float4, recv = n_ranks x i_count x float4. */
+NBODY_API int nbody_bind_exchange(nbody_ctx *ctx, void *send, void *recv);
+/* Host-staged exchange for callers without a device-side collective: copy `send` out (n_total x 4 floats) /
+ * copy `recv` in (n_ranks x i_count x 4 floats). */
+NBODY_API int nbody_exchange_read_send(nbody_ctx *ctx, float *host);
+NBODY_API int nbody_exchange_write_recv(nbody_ctx *ctx, const float *host);
 
 /* ComputeCubeSize (OctreeSearch.cpp:47-56): max over owned bodies of max(|x|,|y|,|z|). */
 NBODY_API int nbody_get_bounds(nbody_ctx *ctx, float *size);

@@ -90,6 +90,12 @@ def lib():
     sig("nbody_set_state_soa_f64", c_int, vp, dp, dp, c_i32)
     sig("nbody_compute_forces", c_int, vp)
     sig("nbody_step", c_int, vp, c_f, c_i32)
+    sig("nbody_step_begin", c_int, vp)
+    sig("nbody_step_end", c_int, vp, c_f)
+    sig("nbody_exchange_info", c_int, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(c_i32))
+    sig("nbody_bind_exchange", c_int, vp, vp, vp)
+    sig("nbody_exchange_read_send", c_int, vp, fp)
+    sig("nbody_exchange_write_recv", c_int, vp, fp)
     sig("nbody_get_bounds", c_int, vp, fp)
     sig("nbody_get_positions", c_int, vp, fp, sz, c_i32, c_i32)
     sig("nbody_get_particles", c_int, vp, vp, sz)

@@ -44,8 +44,11 @@ struct nbody_ctx {
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
   // symmetric algorithm (kernels_sym.hip)
   bool sym = false;
-  int sym_S = 0, sym_T = 0, sym_pad = 0, sym_pairs = 0;
-  void *sym_part = nullptr, *sym_pair_tab = nullptr;
+  int sym_S = 0, sym_T = 0, sym_pad = 0, sym_pairs = 0, sym_own_tile0 = 0, sym_tiles_own = 0, sym_nsrc = 1;
+  void *sym_part_i = nullptr, *sym_part_j = nullptr, *sym_pair_tab = nullptr;
+  void *sym_send = nullptr, *sym_recv = nullptr;   // exchange buffers (recv == send when the context owns all bodies)
+  bool own_send = false, own_recv = false;
+  bool step_open = false;      // nbody_step_begin done, nbody_step_end pending
   KernelTimer timers[2];
   std::string err;
 };
@@ -97,30 +100,52 @@ void choose_geometry(nbody_ctx *c) {
   c->j_chunk = chunk;
 }
 
-// Symmetric algorithm: applicability and super-tile geometry.
+// Symmetric algorithm: applicability and super-tile geometry.  The bodies of the system are cut into T super tiles
+// of S bodies; a context owns a whole number of them.
 void choose_algorithm(nbody_ctx *c) {
   const nbody_params &p = c->p;
-  const bool can = p.precision == NBODY_PREC_F32 && p.i_count == p.n_total && p.zero_mode != NBODY_ZERO_SELECT &&
-                   (c->ipt == 2 || c->ipt == 4);
-  bool want = false;
-  if (p.algorithm == NBODY_ALGO_SYMMETRIC) want = can;
-  else if (p.algorithm == NBODY_ALGO_AUTO) want = can && p.n_total >= 262144;
-  c->sym = want;
-  if (!want) return;
+  c->sym = false;
+  if (p.algorithm == NBODY_ALGO_TILED) return;
+  if (!(p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4))) return;
+  if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < 32768) return;
   const int BI = 256 * c->ipt;
-  long long S = (p.n_total + 127) / 128;           // ~128 super tiles -> ~8000 workgroups
-  S = (S + BI - 1) / BI * BI;
-  if (S < BI) S = BI;
-  c->sym_S = (int)S;
-  c->sym_T = (int)((p.n_total + S - 1) / S);
+  if (p.i_count == p.n_total) {
+    long long S = (p.n_total + 127) / 128;           // ~128 super tiles -> ~8000 workgroups
+    S = (S + BI - 1) / BI * BI;
+    if (S < BI) S = BI;
+    c->sym_S = (int)S;
+    c->sym_T = (int)((p.n_total + S - 1) / S);
+    c->sym_own_tile0 = 0;
+    c->sym_tiles_own = c->sym_T;
+    c->sym_nsrc = 1;
+  } else {
+    // sharded: equal slices, each a whole number k of super tiles; T = ranks * k as close to 128 as divides
+    if (p.n_total % p.i_count != 0 || p.i_begin % p.i_count != 0 || p.i_count % BI != 0) return;
+    const int ranks = p.n_total / p.i_count;
+    int k = 128 / ranks;
+    if (k < 1) k = 1;
+    while (k > 1 && p.i_count % (k * BI) != 0) --k;
+    if (p.i_count % (k * BI) != 0) return;
+    c->sym_S = p.i_count / k;
+    c->sym_T = ranks * k;
+    c->sym_own_tile0 = (p.i_begin / p.i_count) * k;
+    c->sym_tiles_own = k;
+    c->sym_nsrc = ranks;
+  }
   c->sym_pad = c->sym_T * c->sym_S;
-  c->sym_pairs = c->sym_T * (c->sym_T + 1) / 2;
+  int pairs = 0;
+  for (int a = c->sym_own_tile0; a < c->sym_own_tile0 + c->sym_tiles_own; ++a)
+    for (int b = 0; b < c->sym_T; ++b) pairs += nbody::sym_pair_assigned(a, b, c->sym_T) ? 1 : 0;
+  c->sym_pairs = pairs;
+  c->sym = true;
 }
 
 nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   nbody::SymLaunch L;
-  L.posm = c->posm; L.part = c->sym_part; L.pairs = c->sym_pair_tab; L.n_pairs = c->sym_pairs;
-  L.n_total = c->p.n_total; L.S = c->sym_S; L.T = c->sym_T; L.n_pad = c->sym_pad; L.np = c->ipt / 2;
+  L.posm = c->posm; L.part_i = c->sym_part_i; L.part_j = c->sym_part_j; L.send = c->sym_send; L.recv = c->sym_recv;
+  L.pairs = c->sym_pair_tab; L.n_pairs = c->sym_pairs;
+  L.n_total = c->p.n_total; L.S = c->sym_S; L.T = c->sym_T; L.n_pad = c->sym_pad;
+  L.own_tile0 = c->sym_own_tile0; L.tiles_own = c->sym_tiles_own; L.n_src = c->sym_nsrc; L.np = c->ipt / 2;
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps;
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
   return L;
@@ -206,8 +231,8 @@ int run_update(nbody_ctx *c, float dt) {
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_UPDATE, &ev); if (rc) return rc; }
   if (c->sym)
-    HIP_TRY(c, nbody::launch_update_sym(c->posm, c->vel, c->acc, c->sym_part, c->p.n_total, c->sym_S, c->sym_T,
-                                        c->sym_pad, dt, c->stream));
+    HIP_TRY(c, nbody::launch_update_sym(make_sym_launch(c), c->posm, c->vel, c->acc, c->p.i_begin, c->p.i_count, dt,
+                                        c->stream));
   else
     HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->accp, c->p.i_begin, c->p.i_count,
                                     c->j_split, dt, c->stream));
@@ -347,7 +372,8 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if (p.algorithm == NBODY_ALGO_SYMMETRIC && !c->sym) {
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
-                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (no Kahan), i_count == n_total, i_per_thread 2 or 4 and zero_mode != SELECT");
+                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (no Kahan), i_per_thread 2 or 4, zero_mode != SELECT and, "
+                "when sharded, equal slices that are a multiple of 256*i_per_thread bodies");
   }
 
   auto bail = [&](hipError_t he, const char *what) {
@@ -365,12 +391,28 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if ((e = hipMalloc(&c->acc, (size_t)p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc acc");
   c->own_acc = true;
   if (c->sym) {
-    if ((e = hipMalloc(&c->sym_part, (size_t)2 * c->sym_T * c->sym_pad * 16)) != hipSuccess) return bail(e, "hipMalloc partial rows");
+    const size_t n_own_pad = (size_t)c->sym_tiles_own * c->sym_S;
+    if ((e = hipMalloc(&c->sym_part_i, (size_t)c->sym_T * n_own_pad * 16)) != hipSuccess) return bail(e, "hipMalloc i-side rows");
+    if ((e = hipMalloc(&c->sym_part_j, (size_t)c->sym_tiles_own * c->sym_pad * 16)) != hipSuccess) return bail(e, "hipMalloc j-side rows");
+    if ((e = hipMemset(c->sym_part_j, 0, (size_t)c->sym_tiles_own * c->sym_pad * 16)) != hipSuccess) return bail(e, "hipMemset j-side rows");
+    if ((e = hipMalloc(&c->sym_send, (size_t)p.n_total * 16)) != hipSuccess) return bail(e, "hipMalloc send row");
+    c->own_send = true;
+    if (c->sym_nsrc > 1) {
+      if ((e = hipMalloc(&c->sym_recv, (size_t)c->sym_nsrc * p.i_count * 16)) != hipSuccess) return bail(e, "hipMalloc recv rows");
+      c->own_recv = true;
+    } else {
+      c->sym_recv = c->sym_send;
+    }
     std::vector<int> tab;
     tab.reserve((size_t)c->sym_pairs * 2);
-    for (int a = 0; a < c->sym_T; ++a)                       // full super-tile pairs first, the half-size diagonal ones last
-      for (int b = a + 1; b < c->sym_T; ++b) { tab.push_back(a); tab.push_back(b); }
-    for (int a = 0; a < c->sym_T; ++a) { tab.push_back(a); tab.push_back(a); }
+    const int a0 = c->sym_own_tile0, a1 = a0 + c->sym_tiles_own;
+    for (int a = a0; a < a1; ++a)                            // full super-tile pairs first, the half-size diagonal ones last
+      for (int d = 1; d < c->sym_T; ++d) {
+        const int b = (a + d) % c->sym_T;
+        if (nbody::sym_pair_assigned(a, b, c->sym_T)) { tab.push_back(a); tab.push_back(b); }
+      }
+    for (int a = a0; a < a1; ++a) { tab.push_back(a); tab.push_back(a); }
+    if ((int)tab.size() != 2 * c->sym_pairs) return bail(hipErrorUnknown, "pair table size");
     if ((e = hipMalloc(&c->sym_pair_tab, tab.size() * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc pair table");
     if ((e = hipMemcpy(c->sym_pair_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy pair table");
   } else {
@@ -393,7 +435,10 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->own_vel && c->vel) (void)hipFree(c->vel);
   if (c->own_acc && c->acc) (void)hipFree(c->acc);
   if (c->accp) (void)hipFree(c->accp);
-  if (c->sym_part) (void)hipFree(c->sym_part);
+  if (c->sym_part_i) (void)hipFree(c->sym_part_i);
+  if (c->sym_part_j) (void)hipFree(c->sym_part_j);
+  if (c->own_send && c->sym_send) (void)hipFree(c->sym_send);
+  if (c->own_recv && c->sym_recv) (void)hipFree(c->sym_recv);
   if (c->sym_pair_tab) (void)hipFree(c->sym_pair_tab);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->h_scratch) (void)hipHostFree(c->h_scratch);
@@ -483,9 +528,77 @@ int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n)
   return NBODY_OK;
 }
 
+// A sharded symmetric context has an exchange between the force pass and the update: the caller must drive
+// nbody_step_begin -> all-to-all(nbody_exchange_info) -> nbody_step_end.
+static int needs_phases(nbody_ctx *c, const char *who) {
+  if (c->sym && c->sym_nsrc > 1)
+    return fail(c, NBODY_ERR_STATE, "%s: this sharded context uses the symmetric algorithm; drive it with "
+                "nbody_step_begin / all-to-all of nbody_exchange_info buffers / nbody_step_end", who);
+  return NBODY_OK;
+}
+
+int nbody_step_begin(nbody_ctx *c) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (c->step_open) return fail(c, NBODY_ERR_STATE, "nbody_step_begin: previous step not ended");
+  HIP_TRY(c, hipSetDevice(c->p.device));
+  if ((rc = run_forces(c))) return rc;
+  c->step_open = true;
+  return NBODY_OK;
+}
+
+int nbody_step_end(nbody_ctx *c, float dt) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!c->step_open) return fail(c, NBODY_ERR_STATE, "nbody_step_end: no step begun");
+  HIP_TRY(c, hipSetDevice(c->p.device));
+  c->step_open = false;
+  if ((rc = run_update(c, dt > 0.0f ? dt : 0.0f))) return rc;
+  c->forces_valid = !(dt > 0.0f);
+  return NBODY_OK;
+}
+
+int nbody_exchange_info(nbody_ctx *c, void **send, void **recv, size_t *bytes_per_rank, int32_t *n_ranks) {
+  if (!c) return NBODY_ERR_INVALID;
+  const bool ex = c->sym && c->sym_nsrc > 1;
+  if (send) *send = ex ? c->sym_send : nullptr;
+  if (recv) *recv = ex ? c->sym_recv : nullptr;
+  if (bytes_per_rank) *bytes_per_rank = ex ? (size_t)c->p.i_count * 16 : 0;
+  if (n_ranks) *n_ranks = ex ? c->sym_nsrc : 0;
+  return NBODY_OK;
+}
+
+int nbody_exchange_read_send(nbody_ctx *c, float *host) {
+  if (!c || !host) return NBODY_ERR_INVALID;
+  if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_exchange_read_send: this context has no exchange step");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(host, c->sym_send, (size_t)c->p.n_total * 16, hipMemcpyDeviceToHost));
+  return NBODY_OK;
+}
+
+int nbody_exchange_write_recv(nbody_ctx *c, const float *host) {
+  if (!c || !host) return NBODY_ERR_INVALID;
+  if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_exchange_write_recv: this context has no exchange step");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(c->sym_recv, host, (size_t)c->sym_nsrc * c->p.i_count * 16, hipMemcpyHostToDevice));
+  return NBODY_OK;
+}
+
+int nbody_bind_exchange(nbody_ctx *c, void *send, void *recv) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_bind_exchange: this context has no exchange step");
+  if (!send || !recv) return fail(c, NBODY_ERR_INVALID, "nbody_bind_exchange: null buffer");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->own_send) (void)hipFree(c->sym_send);
+  if (c->own_recv) (void)hipFree(c->sym_recv);
+  c->sym_send = send; c->sym_recv = recv; c->own_send = c->own_recv = false;
+  return NBODY_OK;
+}
+
 int nbody_compute_forces(nbody_ctx *c) {
   int rc = check_ready(c);
   if (rc) return rc;
+  if ((rc = needs_phases(c, "nbody_compute_forces"))) return rc;
   HIP_TRY(c, hipSetDevice(c->p.device));
   if ((rc = run_forces(c))) return rc;
   if ((rc = run_update(c, 0.0f))) return rc;
@@ -498,6 +611,7 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
   if (rc) return rc;
   if (nsteps < 0) return fail(c, NBODY_ERR_INVALID, "nbody_step: nsteps < 0");
   if (!(dt > 0.0f)) return NBODY_OK;   // OctreeSearch.cpp:25: PhDeltaTime <= 0 freezes the physics
+  if ((rc = needs_phases(c, "nbody_step"))) return rc;
   if (nsteps > 1 && c->p.i_count != c->p.n_total)
     return fail(c, NBODY_ERR_STATE, "nbody_step: a sharded context advances one step per call (all-gather NBODY_BUF_POSM in between)");
   HIP_TRY(c, hipSetDevice(c->p.device));

@@ -30,23 +30,32 @@ void forces_geometry(const ForceLaunch &L, int *blocks, int *threads);
 hipError_t launch_update(int precision, void *posm, void *vel, void *acc, const void *accp, int i_begin,
                          int i_count, int j_split, float dt, hipStream_t s);
 
-// Symmetric (each pair once) fp32 force pass of a context that owns all bodies — kernels_sym.hip.
+// Symmetric (each unordered pair once) fp32 force pass — kernels_sym.hip.  The context owns the contiguous run of
+// super tiles [own_tile0, own_tile0 + tiles_own) of the T = n_pad / S super tiles of the system.
 struct SymLaunch {
-  const void *posm;     // [n_total] float4
-  void *part;           // [2*T][n_pad] float4: rows 0..T-1 i-side sums (slot = partner super tile), T..2T-1 j-side sums
-  const void *pairs;    // [n_pairs] int2 (si, sj), si <= sj: one workgroup each
+  const void *posm;     // [n_total] float4, all bodies
+  void *part_i;         // [T][tiles_own*S] float4: i-side sums of own bodies, row = partner super tile
+  void *part_j;         // [tiles_own][n_pad] float4: j-side sums of any body, row = own super tile (zeroed once at creation)
+  void *send;           // [n_total] float4: this rank's j-side contribution to every body (n_src segments of i_count)
+  const void *recv;     // [n_src][i_count] float4: what every rank contributed to the own bodies (== send when n_src == 1)
+  const void *pairs;    // [n_pairs] int2 (si, sj): one workgroup each
   int n_pairs;
   int n_total;
   int S;                // bodies per super tile (multiple of 256*2*np)
-  int T;                // super tiles = ceil(n_total / S)
+  int T;                // super tiles in the system = ceil(n_total / S)
   int n_pad;            // T * S
+  int own_tile0, tiles_own;
+  int n_src;            // ranks sharing the bodies
   int np;               // register pairs of i-bodies per lane (1 or 2)
   double G;
   double eps2;          // > 0 softened / floor; == 0 exact d == 0 skip (clamp form)
 };
+bool sym_pair_assigned(int a, int b, int T);   // does super tile a own the pair {a, b}?
+// forces + fold of the j-side rows into L.send
 hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);
-hipError_t launch_update_sym(void *posm, void *vel, void *acc, const void *part, int n_total, int S, int T, int n_pad,
-                             float dt, hipStream_t s);
+// acc = own i-side rows + L.recv segments; dt > 0: kick-drift of the owned slice
+hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *acc, int i_begin, int i_count, float dt,
+                             hipStream_t s);
 
 // out_bits (uint32, pre-zeroed) = bit pattern of max_i max(|x|,|y|,|z|) over the owned slice.
 hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_count, unsigned int *out_bits,

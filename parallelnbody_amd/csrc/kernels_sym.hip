@@ -3,8 +3,11 @@
 // OctreeSearch.h:101-104, at 18 packed ops + 2 v_rsq_f32 per two pairs (four interactions) instead of 14 + 2 per
 // two interactions.
 //
-// Structure (single context owning all bodies):
-//   * bodies are cut into super tiles of S bodies; workgroup (si, sj), si <= sj, owns every pair between them;
+// Structure:
+//   * bodies are cut into T super tiles of S bodies.  Super-tile pair {a, b} belongs to a if b lies in the forward
+//     half of the ring from a (sym_assigned below) — a circulant assignment, so every super tile (and every rank,
+//     which owns a contiguous run of them) gets the same number of pairs.  Workgroup (si, sj) owns every body
+//     pair between si (as the i side) and sj;
 //   * it walks i-sets of 256*IPT bodies of si (register pairs, as in kernels.hip) against 256-body j tiles of sj
 //     staged in LDS; tiles wholly after the i-set (always, when si < sj) run the SYMMETRIC step, the tiles that
 //     overlap the i-set's own range run the plain one-sided step (all ordered pairs, d == 0 skipped), tiles
@@ -15,9 +18,11 @@
 //     measured ~190 cycles per wave instruction and is not used).  After 64 steps the sums are home and are added
 //     to the tile's LDS accumulators; within a round no two waves touch the same subtile and rounds are separated
 //     by a barrier, so the summation order is fixed;
-//   * results go to block-private rows of a partial buffer: i-side sums to row [sj], j-side sums to row
-//     [T + si] (read-modify-write by the same thread every time); update_sym_kernel adds a body's rows in a fixed
-//     order.  No global atomics: bit-reproducible.
+//   * results go to workgroup-private rows: i-side sums of the rank's own bodies to part_i[sj], j-side sums (of any
+//     body) to part_j[si] (read-modify-write by the same thread every time).  reduce_j_kernel folds the rank's
+//     j-side rows into one row per destination rank (the send buffer of the all-to-all when the bodies are
+//     sharded over GPUs); update_sym_kernel adds a body's i-side rows and the received rows in a fixed order.
+//     No global atomics: bit-reproducible for a given number of ranks.
 #include "kernels.h"
 
 #include "../../include/nbody.h"
@@ -28,6 +33,15 @@ namespace nbody {
 namespace {
 
 constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
+
+// Does super tile a own the pair {a, b}?  (a == b, or b within the forward half of the ring of T super tiles;
+// the antipodal pair of an even ring goes to the smaller index.)
+__host__ __device__ inline bool sym_assigned(int a, int b, int T) {
+  if (a == b) return true;
+  const int d = (b - a + T) % T;
+  if (2 * d < T) return true;
+  return 2 * d == T && a < b;
+}
 
 // lane l+1 <- lane l, lane 0 <- lane 63 (v_mov_b32_dpp wave_ror:1; a half-rate VALU op on gfx950)
 __device__ __forceinline__ float wave_ror1(float v) {
@@ -49,10 +63,9 @@ __device__ __forceinline__ f2 mul_swap(f2 a, f2 b) {
 #endif
 template <int NP, int ZMODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NBODY_SYM_WAVES, NBODY_SYM_WAVES)))
-void forces_sym_pk_kernel(const float4 *__restrict__ posm,
-                                                               float4 *__restrict__ part,
-                                                               const int2 *__restrict__ pairs, int n_total, int S,
-                                                               int T, int n_pad, float gscale, float zp) {
+void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ part_i, float4 *__restrict__ part_j,
+                          const int2 *__restrict__ pairs, int n_total, int S, int n_pad, int own_tile0, int n_own_pad,
+                          float gscale, float zp) {
   constexpr int IPT = 2 * NP;
   constexpr int BI = kBlock * IPT;
   __shared__ float4 sh_pos[2][4][128];   // double-buffered subtile images, doubled: entries l and l+64 hold body l
@@ -62,8 +75,9 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm,
   const int2 pr = pairs[blockIdx.x];
   const int si = pr.x, sj = pr.y;
   const bool diag_super = si == sj;
-  float4 *__restrict__ Pi = part + (size_t)sj * n_pad;         // i-side sums of bodies in si
-  float4 *__restrict__ Pj = part + (size_t)(T + si) * n_pad;   // j-side sums of bodies in sj
+  const int own0 = own_tile0 * S;                                                   // first body this rank owns
+  float4 *__restrict__ Pi = part_i + (size_t)sj * n_own_pad;                         // i-side sums, index i - own0
+  float4 *__restrict__ Pj = part_j + (size_t)(si - own_tile0) * n_pad;               // j-side sums, index j
 
   // This workgroup's j-side row segment starts from zero; element e is only ever touched by thread e % 256.
   for (int e = t; e < S; e += kBlock) Pj[(size_t)sj * S + e] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -191,55 +205,78 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm,
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int ia = i0 + t + (2 * p) * kBlock, ib = ia + kBlock;
-      if (ia < n_pad) Pi[ia] = make_float4(a[p].x.x, a[p].y.x, a[p].z.x, 0.f);
-      if (ib < n_pad) Pi[ib] = make_float4(a[p].x.y, a[p].y.y, a[p].z.y, 0.f);
+      if (ia < n_pad) Pi[ia - own0] = make_float4(a[p].x.x, a[p].y.x, a[p].z.x, 0.f);
+      if (ib < n_pad) Pi[ib - own0] = make_float4(a[p].x.y, a[p].y.y, a[p].z.y, 0.f);
     }
   }
 }
 
-// acc[b] = sum of body b's rows in a fixed order: i-side rows sj = s .. T-1 (s = b / S), then j-side rows
-// si = 0 .. s; optionally the reference's update (OctreeSearch.cpp:29-30) with separate multiply and add.
+// send[b] = sum over the rank's own super tiles a (ascending) of the j-side row part_j[a][b], for every body b of
+// the system: what this rank contributes to b's acceleration as the "other" body of its pairs.
+__global__ __launch_bounds__(kBlock) void reduce_j_kernel(const float4 *__restrict__ part_j, float4 *__restrict__ send,
+                                                          int n_total, int S, int T, int n_pad, int own_tile0,
+                                                          int tiles_own) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= n_total) return;
+  const int tb = b / S;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int al = 0; al < tiles_own; ++al) {
+    if (!sym_assigned(own_tile0 + al, tb, T)) continue;        // that workgroup does not exist: row never written
+    const float4 p = part_j[(size_t)al * n_pad + b];
+    sx += p.x; sy += p.y; sz += p.z;
+  }
+  send[b] = make_float4(sx, sy, sz, 0.f);
+}
+
 template <typename T> __device__ __forceinline__ T mul_add_sep2(T a, T b, T c) {
 #pragma clang fp contract(off)
   const T p = a * b;
   return c + p;
 }
 
+// Own body bl: acc = its i-side rows (partners in ring order from its own super tile) + the rows received from
+// every rank (rank order); then optionally the reference's update (OctreeSearch.cpp:29-30), multiply and add kept apart.
 __global__ __launch_bounds__(kBlock) void update_sym_kernel(float4 *__restrict__ posm, float4 *__restrict__ vel,
-                                                            float4 *__restrict__ acc, const float4 *__restrict__ part,
-                                                            int n_total, int S, int T, int n_pad, float dt,
+                                                            float4 *__restrict__ acc, const float4 *__restrict__ part_i,
+                                                            const float4 *__restrict__ recv, int i_begin, int i_count,
+                                                            int S, int T, int n_own_pad, int n_src, float dt,
                                                             int integrate) {
-  const int b = blockIdx.x * kBlock + threadIdx.x;
-  if (b >= n_total) return;
-  const int s = b / S;
+  const int bl = blockIdx.x * kBlock + threadIdx.x;
+  if (bl >= i_count) return;
+  const int s = (i_begin + bl) / S;
   float ax = 0.f, ay = 0.f, az = 0.f;
-  for (int sj = s; sj < T; ++sj) {
-    const float4 p = part[(size_t)sj * n_pad + b];
+  for (int d = 0; d < T; ++d) {
+    const int sj = (s + d) % T;
+    if (!sym_assigned(s, sj, T)) continue;
+    const float4 p = part_i[(size_t)sj * n_own_pad + bl];
     ax += p.x; ay += p.y; az += p.z;
   }
-  for (int si = 0; si <= s; ++si) {
-    const float4 p = part[(size_t)(T + si) * n_pad + b];
+  for (int q = 0; q < n_src; ++q) {
+    const float4 p = recv[(size_t)q * i_count + bl];
     ax += p.x; ay += p.y; az += p.z;
   }
-  acc[b] = make_float4(ax, ay, az, 0.f);
+  acc[bl] = make_float4(ax, ay, az, 0.f);
   if (integrate) {
-    float4 v = vel[b], x = posm[b];
+    float4 v = vel[bl], x = posm[i_begin + bl];
     v.x = mul_add_sep2(dt, ax, v.x); v.y = mul_add_sep2(dt, ay, v.y); v.z = mul_add_sep2(dt, az, v.z);
     x.x = mul_add_sep2(dt, v.x, x.x); x.y = mul_add_sep2(dt, v.y, x.y); x.z = mul_add_sep2(dt, v.z, x.z);
-    vel[b] = v;
-    posm[b] = x;
+    vel[bl] = v;
+    posm[i_begin + bl] = x;
   }
 }
 
 }  // namespace
 
+bool sym_pair_assigned(int a, int b, int T) { return sym_assigned(a, b, T); }
+
 hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
-  if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0) return hipErrorInvalidValue;
+  if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0 || L.tiles_own <= 0) return hipErrorInvalidValue;
   if (L.S % (kBlock * 2 * L.np) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
   dim3 grid(L.n_pairs), block(kBlock);
 #define NBODY_SYM(NPV, ZM, ZP)                                                                                  \
-  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)L.part, \
-                     (const int2 *)L.pairs, L.n_total, L.S, L.T, L.n_pad, (float)L.G, (float)(ZP))
+  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)L.part_i, \
+                     (float4 *)L.part_j, (const int2 *)L.pairs, L.n_total, L.S, L.n_pad, L.own_tile0,          \
+                     L.tiles_own * L.S, (float)L.G, (float)(ZP))
   if (L.np == 1) {
     if (L.eps2 > 0.0) NBODY_SYM(1, Z_SOFT, L.eps2); else NBODY_SYM(1, Z_CLAMP, -0x1p126);
   } else if (L.np == 2) {
@@ -248,15 +285,20 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
     return hipErrorInvalidValue;
   }
 #undef NBODY_SYM
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(reduce_j_kernel, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.part_j,
+                     (float4 *)L.send, L.n_total, L.S, L.T, L.n_pad, L.own_tile0, L.tiles_own);
   return hipGetLastError();
 }
 
-hipError_t launch_update_sym(void *posm, void *vel, void *acc, const void *part, int n_total, int S, int T, int n_pad,
-                             float dt, hipStream_t s) {
-  if (n_total <= 0) return hipErrorInvalidValue;
-  dim3 grid((n_total + kBlock - 1) / kBlock), block(kBlock);
+hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *acc, int i_begin, int i_count, float dt,
+                             hipStream_t s) {
+  if (i_count <= 0) return hipErrorInvalidValue;
+  dim3 grid((i_count + kBlock - 1) / kBlock), block(kBlock);
   hipLaunchKernelGGL(update_sym_kernel, grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
-                     (const float4 *)part, n_total, S, T, n_pad, dt, dt > 0.0f ? 1 : 0);
+                     (const float4 *)L.part_i, (const float4 *)L.recv, i_begin, i_count, L.S, L.T, L.tiles_own * L.S,
+                     L.n_src, dt, dt > 0.0f ? 1 : 0);
   return hipGetLastError();
 }
 

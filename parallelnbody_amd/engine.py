@@ -123,6 +123,35 @@ class NBodyEngine:
     def step(self, dt=REF_DT, nsteps=1):
         self._check(self._L.nbody_step(self._h, dt, nsteps))
 
+    def step_begin(self):
+        """Force pass of the owned bodies (first phase of a step driven by a multi-GPU host)."""
+        self._check(self._L.nbody_step_begin(self._h))
+
+    def step_end(self, dt=REF_DT):
+        """Kick-drift of the owned bodies (dt <= 0: only store the accelerations)."""
+        self._check(self._L.nbody_step_end(self._h, dt))
+
+    def exchange_ranks(self):
+        """Number of ranks in the all-to-all between step_begin and step_end (0: no exchange)."""
+        n = ctypes.c_int32()
+        self._check(self._L.nbody_exchange_info(self._h, None, None, None, ctypes.byref(n)))
+        return n.value
+
+    def bind_exchange(self, send, recv):
+        """Caller-owned device tensors for the exchange: send [n_total,4], recv [ranks*i_count,4] fp32."""
+        self._keep += [send, recv]
+        self._check(self._L.nbody_bind_exchange(self._h, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr())))
+
+    def exchange_read_send(self):
+        out = np.empty((self.n_total, 4), np.float32)
+        self._check(self._L.nbody_exchange_read_send(self._h, _fp(out)))
+        return out
+
+    def exchange_write_recv(self, recv):
+        r = np.ascontiguousarray(recv, np.float32)
+        assert r.shape == (self.exchange_ranks() * self.i_count, 4)
+        self._check(self._L.nbody_exchange_write_recv(self._h, _fp(r)))
+
     def synchronize(self):
         self._check(self._L.nbody_synchronize(self._h))
 

@@ -4,12 +4,17 @@ Body i of an n_total-body system belongs to rank r = i // (n_total / world).  Ev
 position+mass array (16 B/body; 16 MiB at N = 2^20) and the velocities/accelerations of its own slice only.
 Per step (the reference's Tick body, OctreeSearch.cpp:25-31, per slice):
 
-    forces(own slice vs all bodies) -> kick-drift(own slice, in place in the full array)
-    all_gather_into_tensor(full array, own slice)          # RCCL over xGMI; the path's only exchange
+    step_begin: forces of the owned bodies
+    [symmetric algorithm only] all_to_all_single(recv, send)   # 16 B/body: what my pairs add to your bodies
+    step_end:   kick-drift(own slice, in place in the full array)
+    all_gather_into_tensor(full array, own slice)               # 16 B/body over RCCL/xGMI
 
-No all-reduce anywhere: the force on a body needs every position but no other body's velocity.  The summation
-order per body does not depend on the partition (j_split is a function of n_total only), so the trajectory is
-bit-identical for any world size.
+No all-reduce anywhere: the force on a body needs every position but no other body's velocity.  With the TILED
+algorithm every rank evaluates its bodies against all others (no all-to-all) and the summation order per body
+does not depend on the partition, so the trajectory is bit-identical for any world size.  With the SYMMETRIC
+algorithm (the fp32 default for large N) each body PAIR is evaluated once in the whole job, so half of every
+interaction is computed on another rank and travels through one all-to-all per step; results are
+deterministic for a given world size.
 
 torch is plumbing here: device memory, the current stream and torch.distributed.  The compute engine is
 injected (`engine_factory`) so that the world_size-2 gloo test can run the host logic on CPU with a stand-in
@@ -56,14 +61,33 @@ class ShardedSimulation:
         self.engine.set_state(posm.astype(np.float64 if self.f64 else np.float32, copy=False),
                               np.ascontiguousarray(vel).astype(np.float64 if self.f64 else np.float32, copy=False))
         self.steps_done = 0
+        # exchange buffers of the symmetric algorithm (none for the tiled one)
+        self.ex_ranks = self.engine.exchange_ranks() if hasattr(self.engine, "exchange_ranks") else 0
+        if self.ex_ranks:
+            assert self.ex_ranks == world_size
+            self.ex_send = torch.zeros((self.n_total, 4), dtype=torch.float32, device=self.device)
+            self.ex_recv = torch.zeros((world_size * self.i_count, 4), dtype=torch.float32, device=self.device)
+            self.engine.bind_exchange(self.ex_send, self.ex_recv)
+
+    def _forces(self):
+        self.engine.step_begin()
+        if self.ex_ranks:
+            self.torch.distributed.all_to_all_single(self.ex_recv, self.ex_send, group=self.group)
+
+    def compute_forces(self):
+        """Accelerations of the current positions (the reference's CreateOctree force loop), no update."""
+        self._forces()
+        self.engine.step_end(0.0)
 
     def step(self, dt=REF_DT, nsteps=1):
         dist = self.torch.distributed
         own = self.posm[self.i_begin:self.i_begin + self.i_count]
         for _ in range(nsteps):
-            self.engine.step(dt, 1)
-            if self.world_size > 1 and dt > 0:
-                dist.all_gather_into_tensor(self.posm, own, group=self.group)
+            if dt > 0:                     # OctreeSearch.cpp:25: PhDeltaTime <= 0 freezes the physics
+                self._forces()
+                self.engine.step_end(dt)
+                if self.world_size > 1:
+                    dist.all_gather_into_tensor(self.posm, own, group=self.group)
             self.steps_done += 1
 
     def gather_state(self):

@@ -23,14 +23,19 @@ class OracleEngine:
         self.posm[:] = posm
         self.vel[:] = vel[self.lo:self.lo + self.cnt]
 
-    def step(self, dt, nsteps):
-        assert nsteps == 1
+    def exchange_ranks(self):
+        return 0                                  # one-sided forces: nothing to exchange
+
+    def step_begin(self):
         pos = np.ascontiguousarray(self.posm[:, :3]); m = np.ascontiguousarray(self.posm[:, 3])
-        a = self.O.forces_direct_f32(pos, m, i0=self.lo, i1=self.lo + self.cnt)
-        p1, v1 = self.O.kick_drift_f32(pos[self.lo:self.lo + self.cnt], self.vel[:, :3], a, dt)
-        self.acc[:, :3] = a
-        self.vel[:, :3] = v1
-        self.posm[self.lo:self.lo + self.cnt, :3] = p1
+        self.acc[:, :3] = self.O.forces_direct_f32(pos, m, i0=self.lo, i1=self.lo + self.cnt)
+
+    def step_end(self, dt):
+        if dt > 0:
+            pos = np.ascontiguousarray(self.posm[self.lo:self.lo + self.cnt, :3])
+            p1, v1 = self.O.kick_drift_f32(pos, self.vel[:, :3], self.acc[:, :3], dt)
+            self.vel[:, :3] = v1
+            self.posm[self.lo:self.lo + self.cnt, :3] = p1
 
     def state(self, dtype=np.float32):
         return self.posm[self.lo:self.lo + self.cnt].copy(), self.vel.copy(), self.acc.copy()
