@@ -467,3 +467,23 @@ def test_symmetric_config_size_properties(nb, oracle):
     f = (a.astype(np.float64) * posm[:, 3:4]).sum(0)
     assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * posm[:, 3]).sum() < 1e-6
     assert rel_err(a, acc[1][1]).max() < TOL_ACC
+
+
+@pytest.mark.parametrize("n", [40000, 100003])
+def test_auto_algorithm_on_ragged_large_sizes(nb, oracle, n):
+    # AUTO picks the symmetric kernel from 32768 bodies; sizes that are multiples of nothing: ragged last super
+    # tile, zero-mass padding inside tiles and i-sets
+    rng = np.random.default_rng(n)
+    posm = np.concatenate([rng.normal(0, 300, (n, 3)), rng.uniform(1, 100, (n, 1))], 1).astype(np.float32)
+    with nb.NBodyEngine(n) as e:
+        assert e.launch_config()["algorithm"] == "symmetric"
+        e.set_state(posm, np.zeros((n, 4), np.float32))
+        e.compute_forces()
+        a = e.accelerations()
+    assert np.all(np.isfinite(a))
+    p64 = posm.astype(np.float64)
+    for i in list(rng.choice(n, 20, replace=False)) + [0, n - 1]:
+        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1)
+        assert rel_err(a[i:i + 1], ref).max() < TOL_ACC
+    f = (a.astype(np.float64) * posm[:, 3:4]).sum(0)
+    assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * posm[:, 3]).sum() < 1e-6

@@ -55,6 +55,73 @@ class OracleEngine:
         pass
 
 
+class ExchangingEngine(OracleEngine):
+    """Stand-in with the exchange step of the symmetric algorithm: this rank computes, for EVERY body of the system,
+    the acceleration due to the sources in its own slice (`send`); after the all-to-all a rank holds one such row per
+    source rank for its own bodies (`recv`) and adds them in rank order.  Same transport as the HIP engine's."""
+
+    def __init__(self, n_total, i_begin, i_count, posm_tensor, device_index, **kw):
+        super().__init__(n_total, i_begin, i_count, posm_tensor, device_index, **kw)
+        self.ranks = n_total // i_count
+
+    def exchange_ranks(self):
+        return self.ranks
+
+    def bind_exchange(self, send, recv):
+        self.send, self.recv = send.numpy(), recv.numpy()
+
+    def step_begin(self):
+        pos = self.posm[:, :3].astype(np.float64); m = self.posm[:, 3].astype(np.float64)
+        out = np.zeros((self.n, 3))
+        for j in range(self.lo, self.lo + self.cnt):          # sources: my slice; targets: everybody
+            d = pos[j] - pos
+            r2 = (d * d).sum(1)
+            r2[j] = np.inf
+            out += (1e4 * m[j] / (r2 * np.sqrt(r2)))[:, None] * d
+        self.send[:, :3] = out
+        self.send[:, 3] = 0
+
+    def step_end(self, dt):
+        a = self.recv.reshape(self.ranks, self.cnt, 4).astype(np.float64).sum(0)[:, :3]
+        self.acc[:, :3] = a
+        super().step_end(dt)
+
+
+def _worker_exchange(rank, world, port, n, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import parallelnbody_amd as nb
+    posm, vel = nb.ic_plummer(n, seed=9)
+    sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device="cpu", engine_factory=ExchangingEngine)
+    assert sim.ex_ranks == world and sim.ex_recv.shape == (world * sim.i_count, 4)
+    sim.compute_forces()
+    _, _, a = sim.engine.state()
+    sim.step(0.01, 2)
+    p, v = sim.gather_state()
+    np.savez(os.path.join(out_dir, f"x{rank}.npz"), p=p, v=v, a=a)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_all_to_all_exchange(nb, oracle, tmp_path):
+    import torch.multiprocessing as mp
+    n = 128
+    mp.spawn(_worker_exchange, args=(2, _free_port(), n, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "x0.npz"); r1 = np.load(tmp_path / "x1.npz")
+    np.testing.assert_array_equal(r0["p"], r1["p"])
+    posm, vel = nb.ic_plummer(n, seed=9)
+    ref = oracle.forces_direct_f64(posm[:, :3].astype(np.float64), posm[:, 3].astype(np.float64))
+    a = np.concatenate([r0["a"], r1["a"]])[:, :3]
+    assert (np.linalg.norm(a - ref, axis=1) / np.linalg.norm(ref, axis=1)).max() < 1e-5
+    pos = posm[:, :3].astype(np.float64); v = vel[:, :3].astype(np.float64)
+    for _ in range(2):
+        acc = oracle.forces_direct_f64(pos, posm[:, 3].astype(np.float64))
+        pos, v = oracle.kick_drift_f64(pos, v, acc, float(np.float32(0.01)))
+    assert np.abs(r0["p"][:, :3] - pos).max() / np.abs(pos).max() < 1e-5
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
