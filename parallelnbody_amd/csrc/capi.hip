@@ -36,9 +36,12 @@ struct nbody_ctx {
   hipStream_t stream = nullptr;
   void *posm = nullptr, *vel = nullptr, *acc = nullptr, *accp = nullptr;
   bool own_posm = false, own_vel = false, own_acc = false;
+  void *d_stage = nullptr, *h_stage = nullptr;   // renderer hand-off staging (device repack target, pinned mirror)
+  size_t stage_bytes = 0;
   void *scratch = nullptr;     // 64 B device scratch (bounds bits, energy sums)
   void *h_scratch = nullptr;   // pinned mirror
   int j_split = 1, j_chunk = 0, ipt = 1, tile = 256;
+  int wave = 0;                // small-N wave kernel: register pairs per wave (0 = tile kernels)
   bool have_state = false;
   bool forces_valid = false;   // acc holds forces of the current positions
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
@@ -98,6 +101,15 @@ void choose_geometry(nbody_ctx *c) {
   js = (p.n_total + chunk - 1) / chunk;
   c->j_split = js;
   c->j_chunk = chunk;
+  // Small systems (the reference ships N = 2000): one wave per few bodies fills the chip where one lane per body
+  // cannot.  Only when the caller left the geometry to us.
+  c->wave = 0;
+  if (p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && p.algorithm != NBODY_ALGO_SYMMETRIC &&
+      p.tile == 0 && p.i_per_thread == 0 && p.j_split == 0 && p.n_total < 8192) {
+    c->wave = (p.i_count >= 4096) ? 2 : 1;
+    c->j_split = 1;
+    c->j_chunk = (p.n_total + c->tile - 1) / c->tile * c->tile;
+  }
 }
 
 // Symmetric algorithm: applicability and super-tile geometry.  The bodies of the system are cut into T super tiles
@@ -158,6 +170,7 @@ nbody::ForceLaunch make_launch(const nbody_ctx *c) {
   L.tile = c->tile; L.ipt = c->ipt; L.j_split = c->j_split; L.j_chunk = c->j_chunk;
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps; L.precision = c->p.precision;
   L.zero_mode = (c->p.zero_mode == NBODY_ZERO_SELECT) ? 2 : 1;
+  L.wave = c->wave;
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
   return L;
 }
@@ -302,6 +315,18 @@ int download4(nbody_ctx *c, const void *dev, size_t first, size_t count, T *out)
   return NBODY_OK;
 }
 
+// (Re)allocate the hand-off staging pair for `bytes`.
+int ensure_stage(nbody_ctx *c, size_t bytes) {
+  if (bytes <= c->stage_bytes) return NBODY_OK;
+  if (c->d_stage) (void)hipFree(c->d_stage);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  c->d_stage = c->h_stage = nullptr; c->stage_bytes = 0;
+  HIP_TRY(c, hipMalloc(&c->d_stage, bytes));
+  HIP_TRY(c, hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault));
+  c->stage_bytes = bytes;
+  return NBODY_OK;
+}
+
 int check_ready(nbody_ctx *c) {
   if (!c) return NBODY_ERR_INVALID;
   if (!c->have_state) return fail(c, NBODY_ERR_STATE, "no particles set (call nbody_set_particles / nbody_set_state_soa first)");
@@ -440,6 +465,8 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->own_send && c->sym_send) (void)hipFree(c->sym_send);
   if (c->own_recv && c->sym_recv) (void)hipFree(c->sym_recv);
   if (c->sym_pair_tab) (void)hipFree(c->sym_pair_tab);
+  if (c->d_stage) (void)hipFree(c->d_stage);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->h_scratch) (void)hipHostFree(c->h_scratch);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -656,10 +683,19 @@ int nbody_get_positions(nbody_ctx *c, float *xyz, size_t stride, int32_t first, 
   if (!xyz || stride < 12) return fail(c, NBODY_ERR_INVALID, "nbody_get_positions: null buffer or stride < 12");
   if (first < 0 || count < 0 || first + count > c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_get_positions: range out of bounds");
   if (count == 0) return NBODY_OK;
-  std::vector<float> tmp((size_t)count * 4);
-  if ((rc = download4<float>(c, c->posm, (size_t)first, (size_t)count, tmp.data()))) return rc;
-  char *o = (char *)xyz;
-  for (int i = 0; i < count; ++i) memcpy(o + (size_t)i * stride, &tmp[4 * (size_t)i], 12);
+  // one repack kernel + one pinned D2H copy (OctreeSearch.cpp:41 reads Position of every body each frame)
+  const size_t bytes = (size_t)count * 12;
+  if ((rc = ensure_stage(c, bytes))) return rc;
+  HIP_TRY(c, nbody::launch_pack_positions(c->p.precision, c->posm, (float *)c->d_stage, first, count, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (stride == 12) {
+    memcpy(xyz, c->h_stage, bytes);
+  } else {
+    char *o = (char *)xyz;
+    const char *src = (const char *)c->h_stage;
+    for (int i = 0; i < count; ++i) memcpy(o + (size_t)i * stride, src + (size_t)i * 12, 12);
+  }
   return NBODY_OK;
 }
 
@@ -686,16 +722,18 @@ int nbody_get_particles(nbody_ctx *c, void *aos, size_t stride) {
   if (rc) return rc;
   if (!aos || stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "nbody_get_particles: null buffer or stride < 40");
   const size_t ic = (size_t)c->p.i_count;
-  std::vector<float> posm(ic * 4), vel(ic * 4), acc(ic * 4);
-  if ((rc = nbody_get_state_soa(c, posm.data(), vel.data(), acc.data()))) return rc;
-  char *base = (char *)aos;
-  for (size_t i = 0; i < ic; ++i) {
-    nbody_particle q;
-    q.Mass = posm[4 * i + 3];
-    memcpy(q.Position, &posm[4 * i], 12);
-    memcpy(q.Velocity, &vel[4 * i], 12);
-    memcpy(q.Acceleration, &acc[4 * i], 12);
-    memcpy(base + i * stride, &q, sizeof q);
+  const size_t bytes = ic * sizeof(nbody_particle);
+  if ((rc = ensure_stage(c, bytes))) return rc;
+  HIP_TRY(c, nbody::launch_pack_particles(c->p.precision, c->posm, c->vel, c->acc, (float *)c->d_stage, c->p.i_begin,
+                                          c->p.i_count, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (stride == sizeof(nbody_particle)) {
+    memcpy(aos, c->h_stage, bytes);
+  } else {
+    char *base = (char *)aos;
+    const char *src = (const char *)c->h_stage;
+    for (size_t i = 0; i < ic; ++i) memcpy(base + i * stride, src + i * sizeof(nbody_particle), sizeof(nbody_particle));
   }
   return NBODY_OK;
 }

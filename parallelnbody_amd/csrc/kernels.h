@@ -19,6 +19,7 @@ struct ForceLaunch {
   double eps2;          // > 0: softened (also the "floor" mode); == 0: exact d == 0 skip
   int zero_mode;        // for eps2 == 0: 1 = clamp trick (default), 2 = compare+select (A/B only)
   int precision;        // NBODY_PREC_*
+  int wave;             // 0: tile kernels; 1 or 2: small-N wave-per-bodies kernel with that many register pairs (j_split must be 1)
 };
 
 // All-pairs force partials.  Returns hipSuccess or the launch error.
@@ -63,6 +64,11 @@ hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_cou
 
 // out_bits (uint32, pre-zeroed) = bit pattern of max_j |m_j| over all n_total bodies.
 hipError_t launch_massmax(int precision, const void *posm, int n_total, unsigned int *out_bits, hipStream_t s);
+
+// Device-side repack for the renderer hand-off: FParticle records (10 floats) of the owned slice / packed xyz.
+hipError_t launch_pack_particles(int precision, const void *posm, const void *vel, const void *acc, float *out,
+                                 int i_begin, int i_count, hipStream_t s);
+hipError_t launch_pack_positions(int precision, const void *posm, float *out, int first, int count, hipStream_t s);
 
 // fp64 energy pieces: out[0] += KE of owned bodies, out[1] += sum_i 1/2 m_i phi_i  (out pre-zeroed).
 hipError_t launch_energy(int precision, const void *posm, const void *vel, int n_total, int i_begin, int i_count,

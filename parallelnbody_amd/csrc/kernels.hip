@@ -281,6 +281,69 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small-N force kernel: one WAVE per 2*NP bodies, the j range spread over the 64 lanes.
+//
+// The reference ships N = 2000 (BP_NBodyHUD: CreateSpacePoints(2000, 1000)).  With one lane per i-body that is 8
+// workgroups on a 256-CU chip (72 us per pass, measured); here it is 1000 waves.  The wave's i-bodies sit in
+// register pairs with the same value in every lane (moved out of SGPRs: an SGPR operand halves the issue rate),
+// lane l walks bodies l, l+64, ... with coalesced global loads (positions are L2-resident at this size: no LDS
+// staging, no barrier), the packed pair law of pk_common.h does the arithmetic, and the 64 partial sums are
+// folded with wavefront shuffles.  Same summation order on every run: deterministic.
+// ---------------------------------------------------------------------------------------------------------
+template <int NP, int ZMODE>
+__global__ __launch_bounds__(kBlock) void forces_wave_pk_kernel(const float4 *__restrict__ posm,
+                                                                float4 *__restrict__ acc_out, int n_total, int i_begin,
+                                                                int i_count, float gscale, float zp) {
+  constexpr int IPW = 2 * NP;                                    // i-bodies per wave
+  const int lane = threadIdx.x & 63;
+  const int wg = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int ifirst = wg * IPW;
+  if (ifirst >= i_count) return;                                 // whole wave idle (no barriers in this kernel)
+
+  f2 xi[NP], yi[NP], zi[NP];
+  Acc3pk<false> a[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const float4 p0 = posm[i_begin + min(ifirst + 2 * p, i_count - 1)];
+    const float4 p1 = posm[i_begin + min(ifirst + 2 * p + 1, i_count - 1)];
+    xi[p] = f2{p0.x, p1.x}; yi[p] = f2{p0.y, p1.y}; zi[p] = f2{p0.z, p1.z};
+    asm volatile("" : "+v"(xi[p]), "+v"(yi[p]), "+v"(zi[p]));   // wave-uniform values: keep them in VGPRs
+  }
+  f2 zp2 = splat2(zp), one2 = splat2(1.0f);
+  asm volatile("" : "+v"(zp2), "+v"(one2));
+
+  // JB bodies per lane per trip: their loads are all in flight before the first is used (the loop is bound by
+  // load latency otherwise: 0.5 us per dependent trip)
+  constexpr int JB = (NP == 1) ? 8 : 4;
+  const int trips = (n_total + 64 * JB - 1) / (64 * JB);         // the same for every lane
+  for (int it = 0; it < trips; ++it) {
+    float4 pj[JB];
+#pragma unroll
+    for (int g = 0; g < JB; ++g) {
+      const int j = (it * JB + g) * 64 + lane;
+      pj[g] = (j < n_total) ? posm[j] : make_float4(0.f, 0.f, 0.f, 0.f);   // zero-mass padding
+    }
+#pragma unroll
+    for (int g = 0; g < JB; ++g) pj[g].w *= gscale;
+    pair_group_pk<NP, JB, ZMODE, false>(xi, yi, zi, pj, zp2, one2, a);
+  }
+
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    float v[6] = {a[p].x.x, a[p].y.x, a[p].z.x, a[p].x.y, a[p].y.y, a[p].z.y};
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) v[q] += __shfl_xor(v[q], off, 64);
+    if (lane == 0) {
+      const int ia = ifirst + 2 * p, ib = ia + 1;
+      if (ia < i_count) acc_out[ia] = make_float4(v[0], v[1], v[2], 0.f);
+      if (ib < i_count) acc_out[ib] = make_float4(v[3], v[4], v[5], 0.f);
+    }
+  }
+}
+
 // Combine the j-chunk partials in chunk order (deterministic), store the acceleration, and — when
 // integrate != 0 — apply the reference's update with separate multiply and add (no FMA), exactly
 // as FVector's operators do: v = v + dt*a; x = x + dt*v   (OctreeSearch.cpp:29-30).
@@ -446,8 +509,24 @@ hipError_t launch_forces_ipt(const ForceLaunch &L, hipStream_t s) {
 
 }  // namespace
 
+static hipError_t launch_forces_wave(const ForceLaunch &L, hipStream_t s) {
+  const int waves = (L.i_count + 2 * L.wave - 1) / (2 * L.wave);
+  dim3 grid((waves + 3) / 4), block(kBlock);
+#define NBODY_WAVE(NPV, ZM, ZP)                                                                              \
+  hipLaunchKernelGGL((forces_wave_pk_kernel<NPV, ZM>), grid, block, 0, s, (const float4 *)L.posm,           \
+                     (float4 *)L.accp, L.n_total, L.i_begin, L.i_count, (float)L.G, (float)(ZP))
+  if (L.wave == 1) { if (L.eps2 > 0.0) NBODY_WAVE(1, Z_SOFT, L.eps2); else NBODY_WAVE(1, Z_CLAMP, -0x1p126); }
+  else             { if (L.eps2 > 0.0) NBODY_WAVE(2, Z_SOFT, L.eps2); else NBODY_WAVE(2, Z_CLAMP, -0x1p126); }
+#undef NBODY_WAVE
+  return hipGetLastError();
+}
+
 hipError_t launch_forces(const ForceLaunch &L, hipStream_t s) {
   if (L.i_count <= 0 || L.n_total <= 0 || L.j_split <= 0 || L.j_chunk <= 0) return hipErrorInvalidValue;
+  if (L.wave != 0) {
+    if (L.precision != NBODY_PREC_F32 || L.j_split != 1 || (L.wave != 1 && L.wave != 2)) return hipErrorInvalidValue;
+    return launch_forces_wave(L, s);
+  }
   if (L.j_chunk % L.tile != 0 && L.j_split > 1) return hipErrorInvalidValue;
   switch (L.precision) {
     case NBODY_PREC_F32:       return launch_forces_ipt<float, false>(L, s);
@@ -458,6 +537,12 @@ hipError_t launch_forces(const ForceLaunch &L, hipStream_t s) {
 }
 
 void forces_geometry(const ForceLaunch &L, int *blocks, int *threads) {
+  if (L.wave != 0) {
+    const int waves = (L.i_count + 2 * L.wave - 1) / (2 * L.wave);
+    if (blocks) *blocks = (waves + 3) / 4;
+    if (threads) *threads = kBlock;
+    return;
+  }
   const int iblocks = (L.i_count + kBlock * L.ipt - 1) / (kBlock * L.ipt);
   if (blocks) *blocks = iblocks * L.j_split;
   if (threads) *threads = kBlock;
@@ -510,6 +595,57 @@ hipError_t launch_massmax(int precision, const void *posm, int n_total, unsigned
   else
     hipLaunchKernelGGL((bounds_kernel<float, true>), dim3(blocks), dim3(kBlock), 0, s, (const float4 *)posm, 0, n_total,
                        out_bits);
+  return hipGetLastError();
+}
+
+// Renderer hand-off: repack the owned slice into FParticle records (OctreeSearch.h:8-18, 40 bytes) on the device,
+// so that one D2H copy feeds what DrawDebugPoint reads (OctreeSearch.cpp:41) instead of three SoA copies.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pack_particles_kernel(const typename V4<T>::type *__restrict__ posm,
+                                                                const typename V4<T>::type *__restrict__ vel,
+                                                                const typename V4<T>::type *__restrict__ acc,
+                                                                float *__restrict__ out, int i_begin, int i_count) {
+  const int il = blockIdx.x * kBlock + threadIdx.x;
+  if (il >= i_count) return;
+  const auto p = posm[i_begin + il];
+  const auto v = vel[il];
+  const auto a = acc[il];
+  float *o = out + (size_t)il * 10;
+  o[0] = (float)p.w; o[1] = (float)p.x; o[2] = (float)p.y; o[3] = (float)p.z;
+  o[4] = (float)v.x; o[5] = (float)v.y; o[6] = (float)v.z;
+  o[7] = (float)a.x; o[8] = (float)a.y; o[9] = (float)a.z;
+}
+
+// xyz of bodies [first, first+count) of the whole system as packed float3.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pack_positions_kernel(const typename V4<T>::type *__restrict__ posm,
+                                                                float *__restrict__ out, int first, int count) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const auto p = posm[first + i];
+  out[3 * (size_t)i] = (float)p.x; out[3 * (size_t)i + 1] = (float)p.y; out[3 * (size_t)i + 2] = (float)p.z;
+}
+
+hipError_t launch_pack_particles(int precision, const void *posm, const void *vel, const void *acc, float *out,
+                                 int i_begin, int i_count, hipStream_t s) {
+  if (i_count <= 0) return hipErrorInvalidValue;
+  dim3 grid((i_count + kBlock - 1) / kBlock), block(kBlock);
+  if (precision == NBODY_PREC_F64)
+    hipLaunchKernelGGL((pack_particles_kernel<double>), grid, block, 0, s, (const double4 *)posm, (const double4 *)vel,
+                       (const double4 *)acc, out, i_begin, i_count);
+  else
+    hipLaunchKernelGGL((pack_particles_kernel<float>), grid, block, 0, s, (const float4 *)posm, (const float4 *)vel,
+                       (const float4 *)acc, out, i_begin, i_count);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_positions(int precision, const void *posm, float *out, int first, int count, hipStream_t s) {
+  if (count <= 0) return hipErrorInvalidValue;
+  dim3 grid((count + kBlock - 1) / kBlock), block(kBlock);
+  if (precision == NBODY_PREC_F64)
+    hipLaunchKernelGGL((pack_positions_kernel<double>), grid, block, 0, s, (const double4 *)posm, out, first, count);
+  else
+    hipLaunchKernelGGL((pack_positions_kernel<float>), grid, block, 0, s, (const float4 *)posm, out, first, count);
   return hipGetLastError();
 }
 
