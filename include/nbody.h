@@ -221,6 +221,16 @@ NBODY_API int nbody_get_launch_config(nbody_ctx *ctx, int32_t *tile, int32_t *i_
 /* NBODY_ALGO_* actually in use, and (symmetric only) the super-tile size in bodies. */
 NBODY_API int nbody_get_algorithm(nbody_ctx *ctx, int32_t *algorithm, int32_t *super_tile);
 
+/* ---- checkpoint / resume (build-defined: the reference keeps its state in a non-serialised TArray) ---------- */
+
+/* Raw little-endian dump of the context's state: header, all positions+masses, owned velocities and accelerations.
+ * Resuming from it continues the trajectory bit for bit.  A sharded job writes one file per rank. */
+NBODY_API int nbody_save_checkpoint(nbody_ctx *ctx, const char *path);
+/* The context must have the same n_total / owned range / precision as the one that saved the file. */
+NBODY_API int nbody_load_checkpoint(nbody_ctx *ctx, const char *path, int64_t *steps_done);
+/* Updates applied since the state was set or loaded. */
+NBODY_API int nbody_steps_done(nbody_ctx *ctx, int64_t *steps);
+
 /* ---- initial conditions (host only; no device needed) ---------------------------------------- */
 
 /*

@@ -1,0 +1,64 @@
+"""Command-line replay of the reference's scene: the parameter surface of BP_ScreenUI
+(NParticles, BoxSize, DeltaTime, Pause via --dt 0) driving the AOctreeSearch-shaped engine.
+
+    python -m parallelnbody_amd --n 2000 --size 1000 --dt 0.01 --steps 600          # the shipped scene
+    python -m parallelnbody_amd --plummer --n 65536 --eps 1 --steps 100 --energy-every 20
+    python -m parallelnbody_amd --n 2000 --steps 300 --checkpoint run.ckpt ; python -m parallelnbody_amd --n 2000 --resume run.ckpt --steps 300
+"""
+import argparse
+import json
+import time
+
+import numpy as np
+
+from . import NBodyEngine, ic_plummer, ic_reference_box
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m parallelnbody_amd", description=__doc__.split("\n")[0])
+    ap.add_argument("--n", type=int, default=2000, help="NParticles (BP_ScreenUI default 2000)")
+    ap.add_argument("--size", type=float, default=1000.0, help="BoxSize (BP_ScreenUI default 1000)")
+    ap.add_argument("--dt", type=float, default=0.01, help="DeltaTime = PhDeltaTime (default 0.01; <= 0 pauses)")
+    ap.add_argument("--steps", type=int, default=100, help="frames to advance")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--plummer", action="store_true", help="seeded Plummer sphere instead of CreateSpacePoints' box")
+    ap.add_argument("--eps", type=float, default=0.0, help="softening length (reference: 0)")
+    ap.add_argument("--G", type=float, default=1.0e4, help="gravitational constant (reference: 1e4)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32_kahan", "f64"])
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--energy-every", type=int, default=0, help="print kinetic/potential energy every K frames")
+    ap.add_argument("--checkpoint", help="write the final state here")
+    ap.add_argument("--resume", help="start from this checkpoint instead of fresh initial conditions")
+    ap.add_argument("--dump-positions", help="write the final positions (n x 3 float32, .npy)")
+    a = ap.parse_args(argv)
+
+    posm, vel = (ic_plummer(a.n, G=a.G, seed=a.seed) if a.plummer else ic_reference_box(a.n, a.size, seed=a.seed))
+    with NBodyEngine(a.n, device=a.device, precision=a.precision, G=a.G, eps=a.eps) as e:
+        e.set_state(posm, vel)
+        start = e.load_checkpoint(a.resume) if a.resume else 0
+        chunk = a.energy_every if a.energy_every > 0 else a.steps
+        t0 = time.perf_counter()
+        done = 0
+        while done < a.steps:
+            k = min(chunk, a.steps - done)
+            e.step(a.dt, k)
+            done += k
+            if a.energy_every > 0:
+                ke, pe = e.energy()
+                print(json.dumps({"frame": start + done, "kinetic": ke, "potential": pe, "total": ke + pe}))
+        e.synchronize()
+        wall = time.perf_counter() - t0
+        size = e.bounds()
+        if a.checkpoint:
+            e.save_checkpoint(a.checkpoint)
+        if a.dump_positions:
+            np.save(a.dump_positions, e.positions())
+        cfg = e.launch_config()
+        print(json.dumps({"n": a.n, "frames": a.steps, "first_frame": start, "dt": a.dt, "wall_s": wall,
+                          "frames_per_s": a.steps / wall if wall > 0 else None,
+                          "pair_interactions_per_s": a.n * a.n * a.steps / wall if wall > 0 and a.dt > 0 else 0.0,
+                          "Size": size, "algorithm": cfg["algorithm"], "steps_done": e.steps_done()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -110,6 +110,9 @@ def lib():
     sig("nbody_kernel_time_reset", c_int, vp)
     sig("nbody_get_launch_config", c_int, vp, *([ctypes.POINTER(c_i32)] * 5))
     sig("nbody_get_algorithm", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32))
+    sig("nbody_save_checkpoint", c_int, vp, ctypes.c_char_p)
+    sig("nbody_load_checkpoint", c_int, vp, ctypes.c_char_p, ctypes.POINTER(c_i64))
+    sig("nbody_steps_done", c_int, vp, ctypes.POINTER(c_i64))
     sig("nbody_ic_reference_box", c_int, c_i32, c_f, fp, ctypes.c_uint64, fp, fp)
     sig("nbody_ic_plummer", c_int, c_i32, c_d, c_d, c_d, ctypes.c_uint64, fp, fp)
     # actor mirror (include/nbody_actor.h)

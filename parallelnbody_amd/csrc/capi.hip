@@ -52,6 +52,7 @@ struct nbody_ctx {
   void *sym_send = nullptr, *sym_recv = nullptr;   // exchange buffers (recv == send when the context owns all bodies)
   bool own_send = false, own_recv = false;
   bool step_open = false;      // nbody_step_begin done, nbody_step_end pending
+  int64_t steps_done = 0;      // updates applied since the state was set (saved in checkpoints)
   KernelTimer timers[2];
   std::string err;
 };
@@ -292,6 +293,7 @@ int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
   c->have_state = true;
   c->forces_valid = false;
   c->floor_eps2 = -1.0;
+  c->steps_done = 0;
   return NBODY_OK;
 }
 
@@ -582,6 +584,7 @@ int nbody_step_end(nbody_ctx *c, float dt) {
   c->step_open = false;
   if ((rc = run_update(c, dt > 0.0f ? dt : 0.0f))) return rc;
   c->forces_valid = !(dt > 0.0f);
+  if (dt > 0.0f) c->steps_done += 1;
   return NBODY_OK;
 }
 
@@ -647,6 +650,7 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
     if ((rc = run_update(c, dt))) return rc;
   }
   if (nsteps > 0) c->forces_valid = false;   // acc belongs to the pre-update positions, as in the reference
+  c->steps_done += nsteps;
   return NBODY_OK;
 }
 
@@ -735,6 +739,79 @@ int nbody_get_particles(nbody_ctx *c, void *aos, size_t stride) {
     const char *src = (const char *)c->h_stage;
     for (size_t i = 0; i < ic; ++i) memcpy(base + i * stride, src + i * sizeof(nbody_particle), sizeof(nbody_particle));
   }
+  return NBODY_OK;
+}
+
+// ---- checkpoint / resume (nothing in the reference to mirror: its state is not even a UPROPERTY) ----
+namespace {
+struct CkptHeader {
+  char magic[8];          // "NBDYCKP1"
+  uint32_t header_bytes;
+  int32_t n_total, i_begin, i_count;
+  int32_t elem_bytes;     // 4 (fp32 state) or 8 (fp64 state)
+  int32_t reserved;
+  int64_t steps_done;
+  double G, eps;
+};
+}  // namespace
+
+int nbody_save_checkpoint(nbody_ctx *c, const char *path) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!path) return fail(c, NBODY_ERR_INVALID, "nbody_save_checkpoint: null path");
+  const bool f64 = c->p.precision == NBODY_PREC_F64;
+  const size_t eb = f64 ? 8 : 4, n = (size_t)c->p.n_total, ic = (size_t)c->p.i_count;
+  std::vector<char> posm(n * 4 * eb), vel(ic * 4 * eb), acc(ic * 4 * eb);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(posm.data(), c->posm, posm.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(vel.data(), c->vel, vel.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(acc.data(), c->acc, acc.size(), hipMemcpyDeviceToHost));
+  CkptHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "NBDYCKP1", 8);
+  h.header_bytes = (uint32_t)sizeof h;
+  h.n_total = c->p.n_total; h.i_begin = c->p.i_begin; h.i_count = c->p.i_count;
+  h.elem_bytes = (int32_t)eb; h.steps_done = c->steps_done; h.G = c->p.G; h.eps = c->p.eps;
+  FILE *f = fopen(path, "wb");
+  if (!f) return fail(c, NBODY_ERR_INVALID, "nbody_save_checkpoint: cannot open %s for writing", path);
+  const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(posm.data(), 1, posm.size(), f) == posm.size() &&
+                  fwrite(vel.data(), 1, vel.size(), f) == vel.size() && fwrite(acc.data(), 1, acc.size(), f) == acc.size();
+  if (fclose(f) != 0 || !ok) return fail(c, NBODY_ERR_INVALID, "nbody_save_checkpoint: short write to %s", path);
+  return NBODY_OK;
+}
+
+int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
+  if (!c || !path) return c ? fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: null path") : NBODY_ERR_INVALID;
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: cannot open %s", path);
+  CkptHeader h;
+  const bool f64 = c->p.precision == NBODY_PREC_F64;
+  const size_t eb = f64 ? 8 : 4, n = (size_t)c->p.n_total, ic = (size_t)c->p.i_count;
+  int rc = NBODY_OK;
+  std::vector<char> posm(n * 4 * eb), vel(ic * 4 * eb), acc(ic * 4 * eb);
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "NBDYCKP1", 8) != 0 || h.header_bytes != sizeof h)
+    rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: %s is not a checkpoint of this engine", path);
+  else if (h.n_total != c->p.n_total || h.i_begin != c->p.i_begin || h.i_count != c->p.i_count || h.elem_bytes != (int32_t)eb)
+    rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: layout mismatch (file n=%d [%d,+%d) %d-byte, context n=%d [%d,+%d) %zu-byte)",
+              h.n_total, h.i_begin, h.i_count, h.elem_bytes, c->p.n_total, c->p.i_begin, c->p.i_count, eb);
+  else if (fread(posm.data(), 1, posm.size(), f) != posm.size() || fread(vel.data(), 1, vel.size(), f) != vel.size() ||
+           fread(acc.data(), 1, acc.size(), f) != acc.size())
+    rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: %s is truncated", path);
+  fclose(f);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(c->posm, posm.data(), posm.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size(), hipMemcpyHostToDevice));
+  c->have_state = true; c->forces_valid = false; c->floor_eps2 = -1.0; c->step_open = false;
+  c->steps_done = h.steps_done;
+  if (steps_done) *steps_done = h.steps_done;
+  return NBODY_OK;
+}
+
+int nbody_steps_done(nbody_ctx *c, int64_t *steps) {
+  if (!c || !steps) return NBODY_ERR_INVALID;
+  *steps = c->steps_done;
   return NBODY_OK;
 }
 

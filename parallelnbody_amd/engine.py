@@ -1,6 +1,7 @@
 """NBodyEngine — Python handle on one nbody_ctx (include/nbody.h).  All arithmetic happens in the HIP
 kernels of libnbody_amd.so; this file only moves numpy buffers across the C-ABI."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -190,6 +191,20 @@ class NBodyEngine:
 
     def accelerations(self, dtype=np.float32):
         return self.state(dtype)[2][:, :3]
+
+    # -- checkpoint / resume --
+    def save_checkpoint(self, path):
+        self._check(self._L.nbody_save_checkpoint(self._h, os.fsencode(path)))
+
+    def load_checkpoint(self, path):
+        n = ctypes.c_int64()
+        self._check(self._L.nbody_load_checkpoint(self._h, os.fsencode(path), ctypes.byref(n)))
+        return n.value
+
+    def steps_done(self):
+        n = ctypes.c_int64()
+        self._check(self._L.nbody_steps_done(self._h, ctypes.byref(n)))
+        return n.value
 
     # -- device plumbing --
     def set_stream(self, hip_stream_handle):
