@@ -97,6 +97,7 @@ def main():
                                algorithm={"auto": 0, "tiled": 1, "symmetric": 2}[args.algorithm],
                                zero_mode={"exact": 0, "floor": 2}[args.zero_mode])
     cfg = sim.engine.launch_config()
+    sim.warm_collectives()
 
     def fence():
         if world > 1:

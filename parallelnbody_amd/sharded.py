@@ -69,6 +69,22 @@ class ShardedSimulation:
             self.ex_recv = torch.zeros((world_size * self.i_count, 4), dtype=torch.float32, device=self.device)
             self.engine.bind_exchange(self.ex_send, self.ex_recv)
 
+    def warm_collectives(self):
+        """Run each collective of the step once on scratch tensors, so that RCCL's lazy communicator/channel setup
+        (seconds, first call only) never lands in a timed region."""
+        if self.world_size == 1:
+            return
+        torch, dist = self.torch, self.torch.distributed
+        scratch = torch.zeros((self.world_size * 8, 4), dtype=self.posm.dtype, device=self.device)
+        dist.all_gather_into_tensor(scratch, scratch[self.rank * 8:(self.rank + 1) * 8], group=self.group)
+        if self.ex_ranks:
+            a = torch.zeros((self.world_size * 8, 4), dtype=torch.float32, device=self.device)
+            dist.all_to_all_single(torch.empty_like(a), a, group=self.group)
+        t = torch.zeros(2, dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, group=self.group)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
     def _forces(self):
         self.engine.step_begin()
         if self.ex_ranks:

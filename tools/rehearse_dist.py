@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Rehearsal of the multi-GPU plumbing on ONE GPU: torchrun with a single rank, backend nccl (= RCCL).
+Exercises init_process_group(device_id), barrier, all_reduce, the in-place all_gather_into_tensor of a slice of the
+replicated tensor and all_to_all_single on device tensors, then a ShardedSimulation step loop and bench.py's timing code."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+import parallelnbody_amd as nb
+
+rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); lr = int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(lr)
+dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+dev = torch.device("cuda", lr)
+n = 65536
+full = torch.arange(n * 4, dtype=torch.float32, device=dev).reshape(n, 4)
+ic = n // world
+own = full[rank * ic:(rank + 1) * ic]
+ref = full.clone()
+dist.all_gather_into_tensor(full, own)                      # in place: input is a view of the output
+torch.cuda.synchronize()
+assert torch.equal(full, ref), "in-place all_gather_into_tensor corrupted the tensor"
+send = torch.randn(n, 4, device=dev); recv = torch.empty(world * ic, 4, device=dev)
+dist.all_to_all_single(recv, send)
+torch.cuda.synchronize()
+assert torch.equal(recv[:ic], send[rank * ic:(rank + 1) * ic])
+t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
+posm, vel = nb.ic_plummer(n, seed=1)
+sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device=f"cuda:{lr}", time_kernels=True)
+sim.step(0.01, 3); torch.cuda.synchronize()
+p, v = sim.gather_state(); ke, pe = sim.energy()
+print("rehearsal ok: rank", rank, "of", world, "algorithm", sim.engine.launch_config()["algorithm"], "finite", bool(np.isfinite(p).all()), "E", ke + pe)
+sim.close(); dist.barrier(); dist.destroy_process_group()
