@@ -105,6 +105,9 @@ typedef struct nbody_params {
   int32_t time_kernels;   /* nonzero: bracket kernels with HIP events for nbody_kernel_time */
   int32_t zero_mode;      /* how d == 0 pairs are dropped when eps == 0 (NBODY_ZERO_*); 0 = default */
   int32_t algorithm;      /* NBODY_ALGO_*; 0 = auto */
+  float theta;            /* Barnes-Hut opening angle.  0 (default) = exact all-pairs, the hot path of this engine.  > 0 =
+                             the reference's own tree walk (OctreeSearch.h:99-108; it ships 1.0, OctreeSearch.cpp:85) */
+  int32_t reserved0;
 } nbody_params;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
@@ -172,6 +175,16 @@ NBODY_API int nbody_bind_exchange(nbody_ctx *ctx, void *send, void *recv);
  * copy `recv` in (n_ranks x i_count x 4 floats). */
 NBODY_API int nbody_exchange_read_send(nbody_ctx *ctx, float *host);
 NBODY_API int nbody_exchange_write_recv(nbody_ctx *ctx, const float *host);
+
+/*
+ * Barnes-Hut mode: with theta > 0 the force pass is the reference's CreateOctree (OctreeSearch.cpp:
+ * 74-89) on the device — same region octree (root centre = previous tree's CoM, half-width = ComputeCubeSize), same
+ * mass upsweep, same depth-first walk with `Size/d < Theta`, same arithmetic — instead of the all-pairs kernels.
+ * fp32 contexts that own all bodies only.  nbody_set_particles / nbody_set_state_* reset the "previous CoM" to zero.
+ */
+NBODY_API int nbody_set_theta(nbody_ctx *ctx, float theta);
+/* Nodes and levels of the last tree built, and its root CoM (= the next frame's root centre). */
+NBODY_API int nbody_bh_stats(nbody_ctx *ctx, int32_t *nodes, int32_t *levels, float root_com[3]);
 
 /* ComputeCubeSize (OctreeSearch.cpp:47-56): max over owned bodies of max(|x|,|y|,|z|). */
 NBODY_API int nbody_get_bounds(nbody_ctx *ctx, float *size);

@@ -27,9 +27,9 @@ class OctreeSearchActor {
   float PhDeltaTime = 0.01f;            // .h:127  BlueprintReadWrite; default from the ctor, .cpp:8
 
   // ---- build-defined knobs (no reference counterpart) ----
-  // Opening angle.  The reference hard-codes 1.0 (.cpp:85); this engine implements the theta = 0
-  // limit of that walk (exact all-pairs).  Any other value makes the force pass report
-  // NBODY_ERR_UNSUPPORTED in LastStatus and leave the state untouched.
+  // Opening angle.  The reference hard-codes 1.0 (.cpp:85).  0 (the default here) is the theta = 0 limit of that
+  // walk — exact all-pairs, the hot path this engine exists for; any value > 0 runs the reference's own tree walk
+  // on the device (fp32 only; other precisions report NBODY_ERR_UNSUPPORTED in LastStatus).
   float Theta = 0.0f;
   uint64_t Seed = 0x4E426F6479ull;      // CreateSpacePoints' generator seed (the reference is unseeded)
   float ActorLocation[3] = {0, 0, 0};   // GetActorLocation(), .cpp:64
@@ -86,7 +86,8 @@ class OctreeSearchActor {
   // .cpp:74-89 — the force pass (tree build + walk in the reference; all-pairs kernel here).
   void CreateOctree() {
     if (!Initialized) return;
-    if (Theta != 0.0f) { LastStatus = NBODY_ERR_UNSUPPORTED; return; }
+    LastStatus = nbody_set_theta(ctx_, Theta);
+    if (LastStatus) return;
     LastStatus = nbody_compute_forces(ctx_);
     forces_fresh_ = LastStatus == NBODY_OK;
   }
@@ -95,9 +96,8 @@ class OctreeSearchActor {
   void Tick(float /*DeltaSeconds: ignored by the reference too*/) {
     if (OnFlushPersistentDebugLines) OnFlushPersistentDebugLines();            // .cpp:24
     if (PhDeltaTime > 0 && Initialized) {                                      // .cpp:25 (+ guards .cpp:49,76)
-      if (Theta != 0.0f) {
-        LastStatus = NBODY_ERR_UNSUPPORTED;
-      } else {
+      LastStatus = nbody_set_theta(ctx_, Theta);
+      if (LastStatus == NBODY_OK) {
         ComputeCubeSize();                                                     // .cpp:26
         LastStatus = nbody_step(ctx_, PhDeltaTime, 1);                         // .cpp:27-31
         if (LastStatus == NBODY_OK) { dirty_ = true; forces_fresh_ = true; }

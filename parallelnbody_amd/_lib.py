@@ -42,6 +42,8 @@ class Params(ctypes.Structure):
         ("time_kernels", ctypes.c_int32),
         ("zero_mode", ctypes.c_int32),
         ("algorithm", ctypes.c_int32),
+        ("theta", ctypes.c_float),
+        ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -96,6 +98,8 @@ def lib():
     sig("nbody_bind_exchange", c_int, vp, vp, vp)
     sig("nbody_exchange_read_send", c_int, vp, fp)
     sig("nbody_exchange_write_recv", c_int, vp, fp)
+    sig("nbody_set_theta", c_int, vp, c_f)
+    sig("nbody_bh_stats", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), fp)
     sig("nbody_get_bounds", c_int, vp, fp)
     sig("nbody_get_positions", c_int, vp, fp, sz, c_i32, c_i32)
     sig("nbody_get_particles", c_int, vp, vp, sz)

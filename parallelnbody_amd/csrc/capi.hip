@@ -53,6 +53,10 @@ struct nbody_ctx {
   bool own_send = false, own_recv = false;
   bool step_open = false;      // nbody_step_begin done, nbody_step_end pending
   int64_t steps_done = 0;      // updates applied since the state was set (saved in checkpoints)
+  // Barnes-Hut mode (kernels_bh.hip)
+  float theta = 0.0f;
+  nbody::BhState *bh = nullptr;
+  void *bh_acc = nullptr;      // [n_total] float4: the walk's output, summed (j_split = 1) by update_kernel
   KernelTimer timers[2];
   std::string err;
 };
@@ -227,7 +231,30 @@ int ensure_floor(nbody_ctx *c) {
   return NBODY_OK;
 }
 
+// Barnes-Hut force pass: ComputeCubeSize -> CreateOctree, all on the device.
+int run_forces_bh(nbody_ctx *c) {
+  if (c->p.precision != NBODY_PREC_F32 || c->p.i_count != c->p.n_total)
+    return fail(c, NBODY_ERR_UNSUPPORTED, "theta > 0 (Barnes-Hut) needs an fp32 context that owns all bodies");
+  if (!c->bh) {
+    hipError_t e = nbody::bh_create(&c->bh, c->p.n_total);
+    if (e != hipSuccess) return fail(c, NBODY_ERR_HIP, "bh_create: %s", hipGetErrorString(e));
+    HIP_TRY(c, hipMalloc(&c->bh_acc, (size_t)c->p.n_total * 16));
+  }
+  EventPair ev;
+  const bool timed = c->p.time_kernels != 0;
+  if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
+  HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
+  HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, 0, c->p.n_total, (unsigned int *)c->scratch, c->stream));
+  int status = 0;
+  HIP_TRY(c, nbody::bh_forces(c->bh, c->posm, c->bh_acc, (const unsigned int *)c->scratch, c->theta, c->p.G, c->stream, &status));
+  if (status == 1) return fail(c, NBODY_ERR_UNSUPPORTED, "Barnes-Hut tree deeper than 42 levels: two bodies closer than Size/2^42 (the reference's Add would recurse without bound on coincident bodies)");
+  if (status == 2) return fail(c, NBODY_ERR_NOMEM, "Barnes-Hut node pool exhausted");
+  if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
+  return NBODY_OK;
+}
+
 int run_forces(nbody_ctx *c) {
+  if (c->theta > 0.0f) return run_forces_bh(c);
   { int rc = ensure_floor(c); if (rc) return rc; }
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
@@ -244,7 +271,9 @@ int run_update(nbody_ctx *c, float dt) {
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_UPDATE, &ev); if (rc) return rc; }
-  if (c->sym)
+  if (c->theta > 0.0f)
+    HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->bh_acc, 0, c->p.n_total, 1, dt, c->stream));
+  else if (c->sym)
     HIP_TRY(c, nbody::launch_update_sym(make_sym_launch(c), c->posm, c->vel, c->acc, c->p.i_begin, c->p.i_count, dt,
                                         c->stream));
   else
@@ -294,6 +323,7 @@ int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
   c->forces_valid = false;
   c->floor_eps2 = -1.0;
   c->steps_done = 0;
+  if (c->bh) HIP_TRY(c, nbody::bh_reset_root(c->bh, c->stream));   // a new scene: root centre starts at zero again
   return NBODY_OK;
 }
 
@@ -374,6 +404,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if (p.precision != NBODY_PREC_F32 && p.precision != NBODY_PREC_F32_KAHAN && p.precision != NBODY_PREC_F64)
     return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown precision %d", p.precision);
   if (!(p.eps >= 0.0) || !std::isfinite(p.G)) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: bad G/eps");
+  if (!(p.theta >= 0.0f)) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: theta must be >= 0");
   if (p.tile != 0 && p.tile != 64 && p.tile != 128 && p.tile != 256 && p.tile != 512)
     return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: tile must be 64, 128, 256 or 512");
   if (p.i_per_thread != 0 && p.i_per_thread != 1 && p.i_per_thread != 2 && p.i_per_thread != 4)
@@ -393,6 +424,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   nbody_ctx *c = new (std::nothrow) nbody_ctx();
   if (!c) return fail(nullptr, NBODY_ERR_NOMEM, "nbody_create: out of host memory");
   c->p = p;
+  c->theta = p.theta;
   c->elem = (p.precision == NBODY_PREC_F64) ? 32 : 16;
   choose_geometry(c);
   choose_algorithm(c);
@@ -467,6 +499,8 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->own_send && c->sym_send) (void)hipFree(c->sym_send);
   if (c->own_recv && c->sym_recv) (void)hipFree(c->sym_recv);
   if (c->sym_pair_tab) (void)hipFree(c->sym_pair_tab);
+  if (c->bh) nbody::bh_destroy(c->bh);
+  if (c->bh_acc) (void)hipFree(c->bh_acc);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->scratch) (void)hipFree(c->scratch);
@@ -560,6 +594,7 @@ int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n)
 // A sharded symmetric context has an exchange between the force pass and the update: the caller must drive
 // nbody_step_begin -> all-to-all(nbody_exchange_info) -> nbody_step_end.
 static int needs_phases(nbody_ctx *c, const char *who) {
+  if (c->theta > 0.0f) return NBODY_OK;
   if (c->sym && c->sym_nsrc > 1)
     return fail(c, NBODY_ERR_STATE, "%s: this sharded context uses the symmetric algorithm; drive it with "
                 "nbody_step_begin / all-to-all of nbody_exchange_info buffers / nbody_step_end", who);
@@ -806,6 +841,27 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
   c->have_state = true; c->forces_valid = false; c->floor_eps2 = -1.0; c->step_open = false;
   c->steps_done = h.steps_done;
   if (steps_done) *steps_done = h.steps_done;
+  return NBODY_OK;
+}
+
+int nbody_set_theta(nbody_ctx *c, float theta) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!(theta >= 0.0f)) return fail(c, NBODY_ERR_INVALID, "nbody_set_theta: theta must be >= 0");
+  if (theta > 0.0f && (c->p.precision != NBODY_PREC_F32 || c->p.i_count != c->p.n_total))
+    return fail(c, NBODY_ERR_UNSUPPORTED, "nbody_set_theta: Barnes-Hut needs an fp32 context that owns all bodies");
+  c->theta = theta;
+  c->forces_valid = false;
+  return NBODY_OK;
+}
+
+int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com[3]) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_stats: no tree has been built on this context");
+  int n = 0, l = 0;
+  nbody::bh_stats(c->bh, &n, &l);
+  if (nodes) *nodes = n;
+  if (levels) *levels = l;
+  if (root_com) HIP_TRY(c, nbody::bh_get_root_com(c->bh, root_com, c->stream));
   return NBODY_OK;
 }
 

@@ -58,6 +58,19 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);
 hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *acc, int i_begin, int i_count, float dt,
                              hipStream_t s);
 
+// GPU Barnes-Hut with the reference's tree and opening rule — kernels_bh.hip.  fp32, all bodies in one context.
+struct BhState;
+hipError_t bh_create(BhState **out, int n);
+void bh_destroy(BhState *b);
+hipError_t bh_reset_root(BhState *b, hipStream_t s);          // previous CoM := 0 (a new scene, OctreeSearch.cpp:77)
+// acc[body] = Octree::ComputeForces(body, theta) on the tree rooted at (previous CoM, *size_bits as float).
+// *status: 0 ok, 1 tree deeper than 42 levels, 2 node pool exhausted.  Synchronises the stream once per tree level.
+hipError_t bh_forces(BhState *b, const void *posm, void *acc, const unsigned int *size_bits, float theta, double G,
+                     hipStream_t s, int *status);
+void bh_stats(const BhState *b, int *nodes, int *levels);
+hipError_t bh_get_root_com(BhState *b, float out[3], hipStream_t s);
+hipError_t bh_set_root_com(BhState *b, const float in[3], hipStream_t s);
+
 // out_bits (uint32, pre-zeroed) = bit pattern of max_i max(|x|,|y|,|z|) over the owned slice.
 hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_count, unsigned int *out_bits,
                          hipStream_t s);

@@ -1,0 +1,354 @@
+// GPU Barnes-Hut force pass with the reference's own tree and opening rule.
+//
+// Restated on the device, operation by operation in the reference's types (paths relative to
+// /root/reference/Source/NBody/):
+//   class Octree           OctreeSearch.h:21-109   region octree, <= 1 body per leaf, 8 children per split
+//   Octree::Add            .h:60-81    -> bh_keys_kernel + radix sort + bh_split_kernel.  The tree the reference
+//                                          builds depends only on the SET of positions and on the root box, not on
+//                                          the insertion order: a cell is internal iff it holds >= 2 bodies.  A
+//                                          body's path (octant = 4[x>=ox] + 2[y>=oy] + [z>=oz] per level, child
+//                                          centre = centre +- Size*0.5 evaluated as float(double + double)) is
+//                                          computed exactly as Add walks it, packed 3 bits per level into two
+//                                          64-bit keys (42 levels), sorted, and cells are split level by level.
+//   Octree::ComputeMass    .h:83-97    -> bh_upsweep_kernel, children 0..7 in order, fp32, /= as reciprocal multiply
+//   Octree::ComputeForces  .h:99-108   -> bh_walk_kernel: depth-first, children 0..7, `Size/d < Theta || leaf`,
+//                                          d == 0 skips (also a whole subtree whose CoM coincides with the body),
+//                                          scale factor 1e4*M/d^3 in double rounded once to float, separate fp32
+//                                          multiply and add.  (d*d)*d in double is the correctly rounded d^3: d*d
+//                                          is exact for a float d.
+//   CreateOctree root rule .cpp:77-79  root centre = previous tree's CoM (zero the first time), half-width = Size
+//                                          from ComputeCubeSize (.cpp:47-56, about the WORLD origin — bodies may lie
+//                                          outside the root box; octant tests do not care).
+// Every thread follows the reference's arithmetic exactly, so accelerations agree with a CPU restatement of the same
+// lines bit for bit (tests/test_bh_gpu.py).  This is latency/divergence-bound integer+fp work, not the FMA-bound
+// all-pairs path; it is the drop-in for the reference's SHIPPED configuration (theta = 1.0).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "kernels.h"
+
+namespace nbody {
+
+namespace {
+
+constexpr int kB = 256;
+constexpr int kLevelsPerKey = 21;
+constexpr int kMaxLevels = 2 * kLevelsPerKey;   // 42
+
+__device__ __forceinline__ int key_digit(unsigned long long hi, unsigned long long lo, int level) {
+  const unsigned long long k = level < kLevelsPerKey ? hi : lo;
+  const int l = level < kLevelsPerKey ? level : level - kLevelsPerKey;
+  return (int)((k >> (3 * (kLevelsPerKey - 1 - l))) & 7ull);
+}
+
+// child centre and size exactly as Octree::Add computes them (.h:71-74)
+__device__ __forceinline__ void child_box(const float o[3], float size, int c, float out[3], float *csize) {
+  out[0] = (float)((double)o[0] + (double)size * ((c & 4) ? 0.5 : -0.5));
+  out[1] = (float)((double)o[1] + (double)size * ((c & 2) ? 0.5 : -0.5));
+  out[2] = (float)((double)o[2] + (double)size * ((c & 1) ? 0.5 : -0.5));
+  *csize = (float)(0.5 * (double)size);
+}
+
+__global__ __launch_bounds__(kB) void bh_keys_kernel(const float4 *__restrict__ posm, int n,
+                                                     const float *__restrict__ root /* ox,oy,oz,size */,
+                                                     unsigned long long *__restrict__ key_hi,
+                                                     unsigned long long *__restrict__ key_lo,
+                                                     unsigned int *__restrict__ idx) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = posm[i];
+  float o[3] = {root[0], root[1], root[2]};
+  float size = root[3];
+  unsigned long long hi = 0, lo = 0;
+  for (int l = 0; l < kMaxLevels; ++l) {
+    int c = 0;                                            // GetOctant, .h:50-56
+    if (p.x >= o[0]) c |= 4;
+    if (p.y >= o[1]) c |= 2;
+    if (p.z >= o[2]) c |= 1;
+    if (l < kLevelsPerKey) hi = (hi << 3) | (unsigned long long)c;
+    else lo = (lo << 3) | (unsigned long long)c;
+    float no[3], ns;
+    child_box(o, size, c, no, &ns);
+    o[0] = no[0]; o[1] = no[1]; o[2] = no[2]; size = ns;
+  }
+  key_hi[i] = hi; key_lo[i] = lo; idx[i] = (unsigned int)i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kB) void bh_gather_kernel(const T *__restrict__ src, const unsigned int *__restrict__ idx,
+                                                       T *__restrict__ dst, int n) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+// Node storage (SoA).  link = (first_child or -1, particle or -1, skip, level); range = [lo, hi) in sorted order.
+struct Nodes {
+  float4 *box;     // ox, oy, oz, size
+  float4 *com;     // cx, cy, cz, M
+  int4 *link;
+  int2 *range;
+};
+
+__global__ void bh_root_kernel(Nodes nd, const float *__restrict__ root, const float4 *__restrict__ posm,
+                               const unsigned int *__restrict__ sidx, int n, int *__restrict__ counters,
+                               int *__restrict__ frontier) {
+  // counters: [0] nodes used, [1] next-frontier size, [2] error flag, [3] current frontier size
+  nd.box[0] = make_float4(root[0], root[1], root[2], root[3]);
+  nd.range[0] = make_int2(0, n);
+  counters[0] = 1; counters[1] = 0; counters[2] = 0;
+  if (n >= 2) {
+    nd.link[0] = make_int4(-1, -1, -1, 0);
+    nd.com[0] = make_float4(0.f, 0.f, 0.f, 0.f);          // TotalMass(0), CenterOfMass(ZeroVector): ctor .h:33
+    frontier[0] = 0; counters[3] = 1;
+  } else {
+    const unsigned int b = sidx[0];
+    const float4 p = posm[b];
+    nd.link[0] = make_int4(-1, (int)b, -1, 0);
+    nd.com[0] = p;                                         // leaf: CoM = Position, TotalMass = Mass (.h:85-88)
+    counters[3] = 0;
+  }
+}
+
+// One thread per cell of the current level that holds >= 2 bodies: create its 8 children (.h:68-75).
+__global__ __launch_bounds__(kB) void bh_split_kernel(Nodes nd, const unsigned long long *__restrict__ khi,
+                                                      const unsigned long long *__restrict__ klo,
+                                                      const unsigned int *__restrict__ sidx,
+                                                      const float4 *__restrict__ posm, const int *__restrict__ cur,
+                                                      int ncur, int *__restrict__ nxt, int *__restrict__ counters,
+                                                      int node_cap) {
+  const int f = blockIdx.x * kB + threadIdx.x;
+  if (f >= ncur) return;
+  const int me = cur[f];
+  const int4 lk = nd.link[me];
+  const int level = lk.w;
+  const int2 rg = nd.range[me];
+  if (level >= kMaxLevels) { atomicExch(&counters[2], 1); return; }     // bodies closer than Size/2^42: the reference would recurse on
+  const int base = atomicAdd(&counters[0], 8);
+  if (base + 8 > node_cap) { atomicExch(&counters[2], 2); return; }
+  nd.link[me] = make_int4(base, -1, lk.z, level);
+  const float4 bx = nd.box[me];
+  const float o[3] = {bx.x, bx.y, bx.z};
+  int lo = rg.x;
+  for (int c = 0; c < 8; ++c) {
+    // bodies of this cell are sorted by key, so those of child c are contiguous: find where digit > c starts
+    int a = lo, b = rg.y;
+    while (a < b) {
+      const int m = (a + b) >> 1;
+      if (key_digit(khi[m], klo[m], level) <= c) a = m + 1; else b = m;
+    }
+    const int hi = a, cnt = hi - lo, id = base + c;
+    float co[3], cs;
+    child_box(o, bx.w, c, co, &cs);
+    nd.box[id] = make_float4(co[0], co[1], co[2], cs);
+    nd.range[id] = make_int2(lo, hi);
+    const int skip = (c < 7) ? id + 1 : lk.z;              // next node of a depth-first walk that does not descend
+    if (cnt >= 2) {
+      nd.link[id] = make_int4(-1, -1, skip, level + 1);
+      nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+      nxt[atomicAdd(&counters[1], 1)] = id;
+    } else if (cnt == 1) {
+      const unsigned int body = sidx[lo];
+      nd.link[id] = make_int4(-1, (int)body, skip, level + 1);
+      nd.com[id] = posm[body];
+    } else {
+      nd.link[id] = make_int4(-1, -1, skip, level + 1);
+      nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);        // empty leaf: TotalMass 0, CoM ZeroVector
+    }
+    lo = hi;
+  }
+}
+
+// Octree::ComputeMass of the cells of one level (deepest level first), .h:89-95.
+__global__ __launch_bounds__(kB) void bh_upsweep_kernel(Nodes nd, const int *__restrict__ cells, int ncells) {
+#pragma clang fp contract(off)
+  const int f = blockIdx.x * kB + threadIdx.x;
+  if (f >= ncells) return;
+  const int me = cells[f];
+  const int base = nd.link[me].x;
+  float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+  for (int c = 0; c < 8; ++c) {
+    const float4 ch = nd.com[base + c];
+    M = M + ch.w;
+    cx = cx + ch.w * ch.x; cy = cy + ch.w * ch.y; cz = cz + ch.w * ch.z;
+  }
+  if (M != 0.f) {
+    const float rv = 1.0f / M;                             // FVector::operator/=(float): multiply by the reciprocal
+    cx = cx * rv; cy = cy * rv; cz = cz * rv;
+  } else {
+    const float4 bx = nd.box[me];
+    cx = bx.x; cy = bx.y; cz = bx.z;
+  }
+  nd.com[me] = make_float4(cx, cy, cz, M);
+}
+
+// Octree::ComputeForces for every body (.h:99-108), bodies taken in key order for coherence.
+__global__ __launch_bounds__(kB) void bh_walk_kernel(Nodes nd, const float4 *__restrict__ posm,
+                                                     const unsigned int *__restrict__ sidx, int n, float theta, double G,
+                                                     float4 *__restrict__ acc) {
+#pragma clang fp contract(off)
+  const int k = blockIdx.x * kB + threadIdx.x;
+  if (k >= n) return;
+  const unsigned int body = sidx[k];
+  const float4 p = posm[body];
+  float ax = 0.f, ay = 0.f, az = 0.f;                      // Acceleration = ZeroVector, .cpp:84
+  int node = 0;
+  while (node >= 0) {
+    const int4 lk = nd.link[node];
+    const bool leaf = lk.x < 0;
+    if (leaf && lk.y < 0) { node = lk.z; continue; }                      // .h:100
+    const float4 cm = nd.com[node];
+    const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
+    float d2 = ex * ex + ey * ey;
+    d2 = d2 + ez * ez;
+    const float d = sqrtf(d2);   // FVector::Dist, .h:101 — correctly rounded (hipcc default); __fsqrt_rn is the 1-ulp native op
+    if (d == 0.f) { node = lk.z; continue; }                              // .h:102
+    const float size = nd.box[node].w;
+    if (size / d < theta || lk.y >= 0) {                                  // .h:103
+      const double dd = (double)d;
+      const float s = (float)(G * (double)cm.w / ((dd * dd) * dd));       // .h:104
+      ax = ax + s * (cm.x - p.x); ay = ay + s * (cm.y - p.y); az = az + s * (cm.z - p.z);
+      node = lk.z;
+    } else if (!leaf) {
+      node = lk.x;                                                        // children 0..7, .h:105-107
+    } else {
+      node = lk.z;
+    }
+  }
+  acc[body] = make_float4(ax, ay, az, 0.f);
+}
+
+// root = (previous CoM, Size): Size arrives as the bit pattern bounds_kernel leaves; the CoM is the last tree's root.
+__global__ void bh_set_root_kernel(float *__restrict__ root, const float *__restrict__ prev_com,
+                                   const unsigned int *__restrict__ size_bits) {
+  root[0] = prev_com[0]; root[1] = prev_com[1]; root[2] = prev_com[2];
+  root[3] = __uint_as_float(*size_bits);
+}
+
+__global__ void bh_save_com_kernel(Nodes nd, float *__restrict__ prev_com) {
+  const float4 c = nd.com[0];
+  prev_com[0] = c.x; prev_com[1] = c.y; prev_com[2] = c.z;
+}
+
+}  // namespace
+
+struct BhState {
+  int n = 0, node_cap = 0;
+  unsigned long long *khi = nullptr, *klo = nullptr, *khi2 = nullptr, *klo2 = nullptr;
+  unsigned int *idx = nullptr, *idx2 = nullptr;
+  void *sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  Nodes nd{};
+  int *frontier = nullptr;     // all levels' internal cells, level after level
+  int *counters = nullptr;     // device: nodes used, next-frontier size, error, current size
+  int *h_counters = nullptr;   // pinned
+  float *root = nullptr;       // ox, oy, oz, size
+  float *prev_com = nullptr;   // the previous tree's root CoM (zero before the first frame)
+  int last_nodes = 0, last_levels = 0;
+};
+
+#define BH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t bh_create(BhState **out, int n) {
+  BhState *b = new BhState();
+  b->n = n;
+  b->node_cap = 8 * (4 * n + 1024) + 1;
+  BH_TRY(hipMalloc(&b->khi, sizeof(unsigned long long) * n));
+  BH_TRY(hipMalloc(&b->klo, sizeof(unsigned long long) * n));
+  BH_TRY(hipMalloc(&b->khi2, sizeof(unsigned long long) * n));
+  BH_TRY(hipMalloc(&b->klo2, sizeof(unsigned long long) * n));
+  BH_TRY(hipMalloc(&b->idx, sizeof(unsigned int) * n));
+  BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
+  size_t bytes = 0;
+  BH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, b->klo, b->klo2, b->idx, b->idx2, n));
+  b->sort_tmp_bytes = bytes;
+  BH_TRY(hipMalloc(&b->sort_tmp, bytes));
+  BH_TRY(hipMalloc(&b->nd.box, sizeof(float4) * b->node_cap));
+  BH_TRY(hipMalloc(&b->nd.com, sizeof(float4) * b->node_cap));
+  BH_TRY(hipMalloc(&b->nd.link, sizeof(int4) * b->node_cap));
+  BH_TRY(hipMalloc(&b->nd.range, sizeof(int2) * b->node_cap));
+  BH_TRY(hipMalloc(&b->frontier, sizeof(int) * (b->node_cap / 8 + 8)));
+  BH_TRY(hipMalloc(&b->counters, sizeof(int) * 4));
+  BH_TRY(hipHostMalloc(&b->h_counters, sizeof(int) * 4, hipHostMallocDefault));
+  BH_TRY(hipMalloc(&b->root, sizeof(float) * 4));
+  BH_TRY(hipMalloc(&b->prev_com, sizeof(float) * 3));
+  BH_TRY(hipMemset(b->prev_com, 0, sizeof(float) * 3));    // FVector t = ZeroVector, .cpp:77
+  *out = b;
+  return hipSuccess;
+}
+
+void bh_destroy(BhState *b) {
+  if (!b) return;
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->sort_tmp, b->nd.box, b->nd.com, b->nd.link,
+                  b->nd.range, b->frontier, b->counters, b->root, b->prev_com};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  if (b->h_counters) (void)hipHostFree(b->h_counters);
+  delete b;
+}
+
+hipError_t bh_reset_root(BhState *b, hipStream_t s) { return hipMemsetAsync(b->prev_com, 0, sizeof(float) * 3, s); }
+
+// One CreateOctree (.cpp:74-89) on the device.  size_bits: device word holding Size as left by the bounds kernel.
+// *status: 0 ok, 1 depth limit (bodies closer than Size/2^42 — the reference would keep recursing), 2 node pool full.
+hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned int *size_bits, float theta, double G,
+                     hipStream_t s, int *status) {
+  const float4 *posm = (const float4 *)posm_v;
+  float4 *acc = (float4 *)acc_v;
+  const int n = b->n;
+  const dim3 blk(kB), grd((n + kB - 1) / kB);
+  *status = 0;
+  hipLaunchKernelGGL(bh_set_root_kernel, dim3(1), dim3(1), 0, s, b->root, b->prev_com, size_bits);
+  hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, posm, n, b->root, b->khi, b->klo, b->idx);
+  // stable LSD sort over the 126-bit key: low word first, then the high word
+  size_t tb = b->sort_tmp_bytes;
+  BH_TRY(hipcub::DeviceRadixSort::SortPairs(b->sort_tmp, tb, b->klo, b->klo2, b->idx, b->idx2, n, 0, 63, s));
+  hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->khi, b->idx2, b->khi2, n);
+  tb = b->sort_tmp_bytes;
+  BH_TRY(hipcub::DeviceRadixSort::SortPairs(b->sort_tmp, tb, b->khi2, b->khi, b->idx2, b->idx, n, 0, 63, s));
+  // b->khi / b->idx are final; bring the low words (b->klo is still in body order) into the same order
+  hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->klo, b->idx, b->klo2, n);
+
+  hipLaunchKernelGGL(bh_root_kernel, dim3(1), dim3(1), 0, s, b->nd, b->root, posm, b->idx, n, b->counters, b->frontier);
+  // level by level; the frontier of level l sits at frontier[off[l] .. off[l] + cnt[l])
+  int off[kMaxLevels + 2], cnt[kMaxLevels + 2];
+  int levels = 0, cur_off = 0;
+  BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  BH_TRY(hipStreamSynchronize(s));
+  int ncur = b->h_counters[3];
+  while (ncur > 0) {
+    if (levels > kMaxLevels) { *status = 1; return hipSuccess; }
+    off[levels] = cur_off; cnt[levels] = ncur; ++levels;
+    int *cur = b->frontier + cur_off, *nxt = cur + ncur;
+    hipLaunchKernelGGL(bh_split_kernel, dim3((ncur + kB - 1) / kB), blk, 0, s, b->nd, b->khi, b->klo2, b->idx, posm, cur,
+                       ncur, nxt, b->counters, b->node_cap);
+    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    BH_TRY(hipMemsetAsync(b->counters + 1, 0, sizeof(int), s));
+    BH_TRY(hipStreamSynchronize(s));
+    if (b->h_counters[2] != 0) { *status = b->h_counters[2]; return hipSuccess; }
+    cur_off += ncur;
+    ncur = b->h_counters[1];
+    b->last_nodes = b->h_counters[0];
+  }
+  b->last_levels = levels;
+  for (int l = levels - 1; l >= 0; --l)                      // ComputeMass: children before parents
+    hipLaunchKernelGGL(bh_upsweep_kernel, dim3((cnt[l] + kB - 1) / kB), blk, 0, s, b->nd, b->frontier + off[l], cnt[l]);
+  hipLaunchKernelGGL(bh_save_com_kernel, dim3(1), dim3(1), 0, s, b->nd, b->prev_com);   // next frame's root centre, .cpp:78
+  hipLaunchKernelGGL(bh_walk_kernel, grd, blk, 0, s, b->nd, posm, b->idx, n, theta, G, acc);
+  return hipGetLastError();
+}
+
+void bh_stats(const BhState *b, int *nodes, int *levels) {
+  if (nodes) *nodes = b->last_nodes;
+  if (levels) *levels = b->last_levels;
+}
+
+hipError_t bh_get_root_com(BhState *b, float out[3], hipStream_t s) {
+  BH_TRY(hipStreamSynchronize(s));
+  return hipMemcpy(out, b->prev_com, sizeof(float) * 3, hipMemcpyDeviceToHost);
+}
+
+hipError_t bh_set_root_com(BhState *b, const float in[3], hipStream_t s) {
+  BH_TRY(hipStreamSynchronize(s));
+  return hipMemcpy(b->prev_com, in, sizeof(float) * 3, hipMemcpyHostToDevice);
+}
+
+}  // namespace nbody

@@ -55,7 +55,7 @@ class NBodyEngine:
     """One context = one GPU's share [i_begin, i_begin+i_count) of an n_total-body system."""
 
     def __init__(self, n_total, *, i_begin=0, i_count=0, device=0, precision="f32", G=REF_G, eps=0.0, tile=0,
-                 i_per_thread=0, j_split=0, time_kernels=False, zero_mode=0, algorithm=0):
+                 i_per_thread=0, j_split=0, time_kernels=False, zero_mode=0, algorithm=0, theta=0.0):
         L = _lib.lib()
         p = Params()
         L.nbody_default_params(ctypes.byref(p))
@@ -66,6 +66,7 @@ class NBodyEngine:
         p.time_kernels = 1 if time_kernels else 0
         p.zero_mode = zero_mode
         p.algorithm = algorithm
+        p.theta = theta
         h = ctypes.c_void_p()
         rc = L.nbody_create(ctypes.byref(p), ctypes.byref(h))
         if rc:
@@ -152,6 +153,16 @@ class NBodyEngine:
         r = np.ascontiguousarray(recv, np.float32)
         assert r.shape == (self.exchange_ranks() * self.i_count, 4)
         self._check(self._L.nbody_exchange_write_recv(self._h, _fp(r)))
+
+    def set_theta(self, theta):
+        """Barnes-Hut opening angle (0 = exact all-pairs; the reference ships 1.0, OctreeSearch.cpp:85)."""
+        self._check(self._L.nbody_set_theta(self._h, theta))
+
+    def bh_stats(self):
+        n, l = ctypes.c_int32(), ctypes.c_int32()
+        com = np.zeros(3, np.float32)
+        self._check(self._L.nbody_bh_stats(self._h, ctypes.byref(n), ctypes.byref(l), _fp(com)))
+        return {"nodes": n.value, "levels": l.value, "root_com": com}
 
     def synchronize(self):
         self._check(self._L.nbody_synchronize(self._h))

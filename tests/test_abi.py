@@ -35,7 +35,7 @@ def test_ctypes_binding_covers_the_header(nb):
 def test_params_struct_matches_header(nb):
     p = nb._lib.Params()
     assert nb.lib().nbody_default_params(ctypes.byref(p)) == 0
-    assert p.struct_size == ctypes.sizeof(nb._lib.Params) == 64
+    assert p.struct_size == ctypes.sizeof(nb._lib.Params) == 72
     assert p.G == 1.0e4 and p.eps == 0.0 and p.precision == nb.PREC_F32     # reference constants
     assert nb.PARTICLE_DTYPE.itemsize == 40
 

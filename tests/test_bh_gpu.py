@@ -1,0 +1,118 @@
+"""GPU Barnes-Hut (theta > 0): the reference's own tree, upsweep and walk on the device, against the
+oracle's restatement of Octree::Add / ComputeMass / ComputeForces.  The device follows the reference's arithmetic step
+by step in the same depth-first order, so the comparison is (almost always) bit for bit; the assertions allow one fp32
+ulp on a vanishing fraction of bodies for the one place the two sides differ: glibc's pow(d, 3.0) vs the device's
+correctly rounded (d*d)*d in double."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import particles_from, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+REF_THETA = 1.0     # OctreeSearch.cpp:85
+
+
+def _check_same(a, ref):
+    a = np.asarray(a, np.float32); ref = np.asarray(ref, np.float32)
+    same = np.all(a == ref, axis=1)
+    assert same.mean() > 0.999, same.mean()
+    assert rel_err(a, ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("theta", [1.0, 0.5, 0.25])
+@pytest.mark.parametrize("fixture", ["refbox_n2000_seed1", "plummer_n1024_seed1"])
+def test_bh_forces_match_the_oracle_tree(nb, oracle, fixture, theta):
+    g = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    n = g["posm"].shape[0]
+    pos = np.ascontiguousarray(g["posm"][:, :3]); m = np.ascontiguousarray(g["posm"][:, 3])
+    ref, com, nodes = oracle.octree_forces_f32(pos, m, theta)           # root: centre 0, half-width = ComputeCubeSize
+    with nb.NBodyEngine(n, theta=theta) as e:
+        e.set_state(g["posm"], g["vel"])
+        e.compute_forces()
+        a = e.accelerations()
+        st = e.bh_stats()
+    _check_same(a, ref)
+    assert st["nodes"] == nodes
+    np.testing.assert_array_equal(st["root_com"], com)
+    # and it really is an approximation of the all-pairs answer, not the all-pairs kernel
+    assert 0.001 < rel_err(a, g["acc_direct"]).mean() < 1.5
+
+
+def test_bh_ticks_follow_the_reference_frame_loop(nb, oracle):
+    # Tick (OctreeSearch.cpp:25-32) with theta = 1.0: bounds -> tree rooted at the PREVIOUS tree's CoM -> walk -> kick-drift
+    g = np.load(os.path.join(GOLDEN, "refbox_n2000_seed1.npz"))
+    q = particles_from(nb, g["posm"], g["vel"])
+    com, size = None, 0.0
+    with nb.NBodyEngine(2000, theta=REF_THETA) as e:
+        e.set_state(g["posm"], g["vel"])
+        for _ in range(4):
+            e.step(0.01, 1)
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size)
+            out = e.particles()
+            _check_same(out["Acceleration"], q["Acceleration"])
+            np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
+        assert np.abs(out["Position"] - q["Position"]).max() / np.abs(q["Position"]).max() < 1e-6
+        # switching back to theta = 0 gives the exact all-pairs pass again
+        e.set_theta(0.0)
+        e.compute_forces()
+        a0 = e.accelerations()
+    ref = oracle.forces_direct_f32(out["Position"], out["Mass"])
+    assert rel_err(a0, ref).max() < 2e-5
+
+
+def test_bh_actor_with_the_shipped_opening_angle(nb, oracle):
+    g = np.load(os.path.join(GOLDEN, "refbox_n2000_seed1.npz"))
+    p = particles_from(nb, g["posm"], g["vel"])
+    a = nb.OctreeSearch()
+    a.SetParticles(p)
+    a.set_theta(REF_THETA)
+    q = p.copy()
+    com, size = None, 0.0
+    for _ in range(3):
+        a.Tick(0.0)
+        com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size)
+    assert a.LastStatus == 0
+    out = a.Particles
+    _check_same(out["Acceleration"], q["Acceleration"])
+    assert a.Size == pytest.approx(size)
+
+
+def test_bh_large_n(nb, oracle):
+    n = 65536
+    posm, vel = nb.ic_plummer(n, seed=8)
+    ref, com, nodes = oracle.octree_forces_f32(posm[:, :3], posm[:, 3], REF_THETA)
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+        st = e.bh_stats()
+    _check_same(a, ref)
+    assert st["nodes"] == nodes and st["levels"] >= 8
+
+
+def test_bh_limits(nb):
+    g = np.load(os.path.join(GOLDEN, "plummer_n1024_seed1.npz"))
+    with pytest.raises(nb.NBodyError) as err:
+        nb.NBodyEngine(1024, precision="f64", theta=1.0).step(0.01, 1)
+    with nb.NBodyEngine(1024, precision="f64") as e:
+        with pytest.raises(nb.NBodyError) as err:
+            e.set_theta(1.0)
+        assert err.value.code == nb._lib.ERR_UNSUPPORTED
+    with nb.NBodyEngine(1024, i_begin=0, i_count=512) as e:
+        with pytest.raises(nb.NBodyError):
+            e.set_theta(0.5)
+    # coincident bodies: the reference's Add recurses without bound; here the frame is refused
+    posm = g["posm"].copy(); posm[7, :3] = posm[900, :3]
+    with nb.NBodyEngine(1024, theta=1.0) as e:
+        e.set_state(posm, g["vel"])
+        with pytest.raises(nb.NBodyError) as err:
+            e.compute_forces()
+        assert err.value.code == nb._lib.ERR_UNSUPPORTED and "42 levels" in str(err.value)
+    # a single body: root is a leaf, no force
+    with nb.NBodyEngine(1, theta=1.0) as e:
+        e.set_state(np.array([[1, 2, 3, 4]], np.float32), np.zeros((1, 4), np.float32))
+        e.step(0.01, 1)
+        assert np.all(e.accelerations() == 0)
