@@ -185,6 +185,9 @@ NBODY_API int nbody_exchange_write_recv(nbody_ctx *ctx, const float *host);
 NBODY_API int nbody_set_theta(nbody_ctx *ctx, float theta);
 /* Nodes and levels of the last tree built, and its root CoM (= the next frame's root centre). */
 NBODY_API int nbody_bh_stats(nbody_ctx *ctx, int32_t *nodes, int32_t *levels, float root_com[3]);
+/* What DrawOctreeBoxes passes to DrawDebugBox when ShowOctree is set (OctreeSearch.cpp:39-40): for every body the box
+ * (Origin.x, Origin.y, Origin.z, Size) of the leaf that held it in the last tree; 4 floats per body, `stride` bytes apart. */
+NBODY_API int nbody_bh_leaf_boxes(nbody_ctx *ctx, float *boxes, size_t stride);
 
 /* ComputeCubeSize (OctreeSearch.cpp:47-56): max over owned bodies of max(|x|,|y|,|z|). */
 NBODY_API int nbody_get_bounds(nbody_ctx *ctx, float *size);

@@ -19,6 +19,7 @@ typedef struct nbody_actor nbody_actor;
 /* Draw callbacks: FlushPersistentDebugLines (OctreeSearch.cpp:24) and DrawDebugPoint (.cpp:41). */
 typedef void (*nbody_flush_fn)(void *user);
 typedef void (*nbody_draw_point_fn)(void *user, const float position[3], float point_size);
+typedef void (*nbody_draw_box_fn)(void *user, const float origin[3], float size);   /* DrawDebugBox, .cpp:40 */
 
 NBODY_API nbody_actor *nbody_actor_create(void);                                   /* AOctreeSearch(), .cpp:8 */
 NBODY_API void nbody_actor_destroy(nbody_actor *a);
@@ -29,6 +30,7 @@ NBODY_API void nbody_actor_create_octree(nbody_actor *a);                       
 NBODY_API void nbody_actor_tick(nbody_actor *a, float delta_seconds);              /* .cpp:21-34 */
 NBODY_API void nbody_actor_clean_particles(nbody_actor *a);                        /* .cpp:91-97 */
 NBODY_API void nbody_actor_set_draw_callbacks(nbody_actor *a, nbody_flush_fn flush, nbody_draw_point_fn point, void *user);
+NBODY_API void nbody_actor_set_box_callback(nbody_actor *a, nbody_draw_box_fn box, void *user);
 
 /* Fields (OctreeSearch.h:117-127 + the build-defined knobs of nbody_actor.hpp). */
 NBODY_API float nbody_actor_get_size(const nbody_actor *a);

@@ -41,9 +41,11 @@ class OctreeSearchActor {
   int LastStatus = NBODY_OK;            // last C-ABI return code (the reference's methods are void)
 
   // Renderer hand-off (OctreeSearch.cpp:24,40-41): FlushPersistentDebugLines, DrawDebugPoint(Position, 10.0, Black),
-  // DrawDebugBox (never called here: there is no tree at theta = 0).
+  // DrawDebugBox(Origin, (Size,Size,Size), Red) per occupied leaf when ShowOctree (only with Theta > 0: at theta = 0
+  // no tree exists).
   std::function<void()> OnFlushPersistentDebugLines;
   std::function<void(const float position[3], float point_size)> OnDrawDebugPoint;
+  std::function<void(const float origin[3], float size)> OnDrawDebugBox;
 
   OctreeSearchActor() = default;        // .cpp:8
   OctreeSearchActor(const OctreeSearchActor &) = delete;
@@ -110,6 +112,11 @@ class OctreeSearchActor {
   void DrawOctreeBoxes() {
     if (!Initialized || !forces_fresh_) return;   // the reference draws from the tree: nothing before the first force pass (.cpp:38)
     if (MirrorParticles) SyncParticles(); else SyncPositions();
+    if (ShowOctree && OnDrawDebugBox && Theta > 0.0f) {                        // .cpp:40
+      boxes_.resize(4 * Particles.size());
+      if (nbody_bh_leaf_boxes(ctx_, boxes_.data(), 16) == NBODY_OK)
+        for (size_t i = 0; i < Particles.size(); ++i) OnDrawDebugBox(&boxes_[4 * i], boxes_[4 * i + 3]);
+    }
     if (OnDrawDebugPoint)
       for (const FParticle &p : Particles) OnDrawDebugPoint(p.Position, 10.0f);
   }
@@ -160,6 +167,7 @@ class OctreeSearchActor {
   }
 
   nbody_ctx *ctx_ = nullptr;
+  std::vector<float> boxes_;
   bool forces_fresh_ = false;
   bool dirty_ = false;
 };

@@ -49,6 +49,7 @@ class Params(ctypes.Structure):
 
 FLUSH_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 DRAW_POINT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_float)
+DRAW_BOX_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_float)
 
 _lib = None
 
@@ -100,6 +101,7 @@ def lib():
     sig("nbody_exchange_write_recv", c_int, vp, fp)
     sig("nbody_set_theta", c_int, vp, c_f)
     sig("nbody_bh_stats", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), fp)
+    sig("nbody_bh_leaf_boxes", c_int, vp, fp, sz)
     sig("nbody_get_bounds", c_int, vp, fp)
     sig("nbody_get_positions", c_int, vp, fp, sz, c_i32, c_i32)
     sig("nbody_get_particles", c_int, vp, vp, sz)
@@ -129,6 +131,7 @@ def lib():
     sig("nbody_actor_tick", None, vp, c_f)
     sig("nbody_actor_clean_particles", None, vp)
     sig("nbody_actor_set_draw_callbacks", None, vp, FLUSH_FN, DRAW_POINT_FN, vp)
+    sig("nbody_actor_set_box_callback", None, vp, DRAW_BOX_FN, vp)
     sig("nbody_actor_get_size", c_f, vp)
     sig("nbody_actor_get_initialized", c_i32, vp)
     sig("nbody_actor_num_particles", c_i32, vp)

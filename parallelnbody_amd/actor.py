@@ -89,6 +89,12 @@ class OctreeSearch:
         a = np.ascontiguousarray(particles, PARTICLE_DTYPE)
         self._L.nbody_actor_set_particles(self._h, a.ctypes.data, a.shape[0])
 
+    def set_box_callback(self, on_box=None):
+        """on_box((ox,oy,oz), size) <- DrawDebugBox of an occupied leaf (ShowOctree and theta > 0)."""
+        b = _lib.DRAW_BOX_FN((lambda user, o, sz: on_box((o[0], o[1], o[2]), sz)) if on_box else 0)
+        self._cb_box = b
+        self._L.nbody_actor_set_box_callback(self._h, b, None)
+
     def set_draw_callbacks(self, on_flush=None, on_point=None):
         """on_flush() <- FlushPersistentDebugLines; on_point((x,y,z), size) <- DrawDebugPoint."""
         f = _lib.FLUSH_FN((lambda user: on_flush()) if on_flush else 0)

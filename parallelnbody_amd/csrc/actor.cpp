@@ -29,6 +29,12 @@ void nbody_actor_set_draw_callbacks(nbody_actor *a, nbody_flush_fn flush, nbody_
   else a->impl.OnDrawDebugPoint = nullptr;
 }
 
+void nbody_actor_set_box_callback(nbody_actor *a, nbody_draw_box_fn box, void *user) {
+  if (!a) return;
+  if (box) a->impl.OnDrawDebugBox = [box, user](const float *o, float sz) { box(user, o, sz); };
+  else a->impl.OnDrawDebugBox = nullptr;
+}
+
 float nbody_actor_get_size(const nbody_actor *a) { return a ? a->impl.Size : 0.0f; }
 int32_t nbody_actor_get_initialized(const nbody_actor *a) { return a && a->impl.Initialized ? 1 : 0; }
 int32_t nbody_actor_num_particles(const nbody_actor *a) { return a ? (int32_t)a->impl.Particles.size() : 0; }

@@ -865,6 +865,20 @@ int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com
   return NBODY_OK;
 }
 
+int nbody_bh_leaf_boxes(nbody_ctx *c, float *boxes, size_t stride) {
+  if (!c || !boxes || stride < 16) return c ? fail(c, NBODY_ERR_INVALID, "nbody_bh_leaf_boxes: null buffer or stride < 16") : NBODY_ERR_INVALID;
+  if (!c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_boxes: no tree has been built on this context (theta == 0?)");
+  const size_t bytes = (size_t)c->p.n_total * 16;
+  int rc = ensure_stage(c, bytes);
+  if (rc) return rc;
+  HIP_TRY(c, nbody::bh_leaf_boxes(c->bh, c->d_stage, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (stride == 16) memcpy(boxes, c->h_stage, bytes);
+  else for (int i = 0; i < c->p.n_total; ++i) memcpy((char *)boxes + (size_t)i * stride, (const char *)c->h_stage + (size_t)i * 16, 16);
+  return NBODY_OK;
+}
+
 int nbody_steps_done(nbody_ctx *c, int64_t *steps) {
   if (!c || !steps) return NBODY_ERR_INVALID;
   *steps = c->steps_done;

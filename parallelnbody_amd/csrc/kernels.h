@@ -68,6 +68,8 @@ hipError_t bh_reset_root(BhState *b, hipStream_t s);          // previous CoM :=
 hipError_t bh_forces(BhState *b, const void *posm, void *acc, const unsigned int *size_bits, float theta, double G,
                      hipStream_t s, int *status);
 void bh_stats(const BhState *b, int *nodes, int *levels);
+// out[body] = (ox, oy, oz, Size) of the leaf holding the body, for the last tree built
+hipError_t bh_leaf_boxes(BhState *b, void *out, hipStream_t s);
 hipError_t bh_get_root_com(BhState *b, float out[3], hipStream_t s);
 hipError_t bh_set_root_com(BhState *b, const float in[3], hipStream_t s);
 

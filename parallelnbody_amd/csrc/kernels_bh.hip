@@ -224,6 +224,15 @@ __global__ void bh_set_root_kernel(float *__restrict__ root, const float *__rest
   root[3] = __uint_as_float(*size_bits);
 }
 
+// What DrawOctreeBoxes hands to DrawDebugBox (OctreeSearch.cpp:39-40): the box (Origin, Size) of the leaf that
+// holds each body, written at the body's index.
+__global__ __launch_bounds__(kB) void bh_leaf_boxes_kernel(Nodes nd, int nodes, float4 *__restrict__ out) {
+  const int k = blockIdx.x * kB + threadIdx.x;
+  if (k >= nodes) return;
+  const int4 lk = nd.link[k];
+  if (lk.x < 0 && lk.y >= 0) out[lk.y] = nd.box[k];
+}
+
 __global__ void bh_save_com_kernel(Nodes nd, float *__restrict__ prev_com) {
   const float4 c = nd.com[0];
   prev_com[0] = c.x; prev_com[1] = c.y; prev_com[2] = c.z;
@@ -314,6 +323,7 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
   BH_TRY(hipStreamSynchronize(s));
   int ncur = b->h_counters[3];
+  b->last_nodes = 1;
   while (ncur > 0) {
     if (levels > kMaxLevels) { *status = 1; return hipSuccess; }
     off[levels] = cur_off; cnt[levels] = ncur; ++levels;
@@ -333,6 +343,13 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
     hipLaunchKernelGGL(bh_upsweep_kernel, dim3((cnt[l] + kB - 1) / kB), blk, 0, s, b->nd, b->frontier + off[l], cnt[l]);
   hipLaunchKernelGGL(bh_save_com_kernel, dim3(1), dim3(1), 0, s, b->nd, b->prev_com);   // next frame's root centre, .cpp:78
   hipLaunchKernelGGL(bh_walk_kernel, grd, blk, 0, s, b->nd, posm, b->idx, n, theta, G, acc);
+  return hipGetLastError();
+}
+
+hipError_t bh_leaf_boxes(BhState *b, void *out, hipStream_t s) {
+  if (b->last_nodes <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bh_leaf_boxes_kernel, dim3((b->last_nodes + kB - 1) / kB), dim3(kB), 0, s, b->nd, b->last_nodes,
+                     (float4 *)out);
   return hipGetLastError();
 }
 

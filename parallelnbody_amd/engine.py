@@ -164,6 +164,12 @@ class NBodyEngine:
         self._check(self._L.nbody_bh_stats(self._h, ctypes.byref(n), ctypes.byref(l), _fp(com)))
         return {"nodes": n.value, "levels": l.value, "root_com": com}
 
+    def bh_leaf_boxes(self):
+        """[n,4]: (Origin, Size) of the leaf holding each body in the last Barnes-Hut tree."""
+        out = np.empty((self.n_total, 4), np.float32)
+        self._check(self._L.nbody_bh_leaf_boxes(self._h, _fp(out), 16))
+        return out
+
     def synchronize(self):
         self._check(self._L.nbody_synchronize(self._h))
 

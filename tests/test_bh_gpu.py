@@ -116,3 +116,29 @@ def test_bh_limits(nb):
         e.set_state(np.array([[1, 2, 3, 4]], np.float32), np.zeros((1, 4), np.float32))
         e.step(0.01, 1)
         assert np.all(e.accelerations() == 0)
+
+
+def test_show_octree_leaf_boxes(nb):
+    # DrawOctreeBoxes with ShowOctree (OctreeSearch.cpp:39-41): one DrawDebugBox(Origin, Size) per occupied leaf.
+    g = np.load(os.path.join(GOLDEN, "refbox_n2000_seed1.npz"))
+    p = particles_from(nb, g["posm"], g["vel"])
+    a = nb.OctreeSearch()
+    a.SetParticles(p)
+    a.set_theta(REF_THETA)
+    a.ShowOctree = True
+    a.PhDeltaTime = 1e-6
+    boxes, points = [], []
+    a.set_box_callback(lambda o, s: boxes.append((o, s)))
+    a.set_draw_callbacks(on_point=lambda pos, sz: points.append(pos))
+    a.Tick(0.0)
+    assert len(boxes) == 2000 and len(points) == 2000
+    o = np.array([b[0] for b in boxes], np.float64); s = np.array([b[1] for b in boxes], np.float64)
+    pts = np.array(points, np.float64)
+    # every body lies in its leaf's box (the root may not contain everything, deeper cells do), and leaves are
+    # smaller than the root
+    inside = np.all(np.abs(pts - o) <= s[:, None] * (1 + 1e-6), axis=1)
+    assert inside.mean() > 0.95 and s.max() <= a.Size and s.min() > 0
+    a.ShowOctree = False
+    boxes.clear()
+    a.Tick(0.0)
+    assert not boxes
