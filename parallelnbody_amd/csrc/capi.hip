@@ -50,6 +50,8 @@ struct nbody_ctx {
   int sym_S = 0, sym_T = 0, sym_pad = 0, sym_pairs = 0, sym_own_tile0 = 0, sym_tiles_own = 0, sym_nsrc = 1;
   void *sym_part_i = nullptr, *sym_part_j = nullptr, *sym_pair_tab = nullptr;
   void *sym_send = nullptr, *sym_recv = nullptr;   // exchange buffers (recv == send when the context owns all bodies)
+  void *sym_dup_table = nullptr;                   // coincident-body detector (hash slots + flag)
+  int sym_dup_slots = 0;
   bool own_send = false, own_recv = false;
   bool step_open = false;      // nbody_step_begin done, nbody_step_end pending
   int64_t steps_done = 0;      // updates applied since the state was set (saved in checkpoints)
@@ -165,6 +167,7 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   L.own_tile0 = c->sym_own_tile0; L.tiles_own = c->sym_tiles_own; L.n_src = c->sym_nsrc; L.np = c->ipt / 2;
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps;
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
+  L.dup_table = c->sym_dup_table; L.dup_slots = c->sym_dup_slots;
   return L;
 }
 
@@ -454,6 +457,14 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
     if ((e = hipMalloc(&c->sym_part_i, (size_t)c->sym_T * n_own_pad * 16)) != hipSuccess) return bail(e, "hipMalloc i-side rows");
     if ((e = hipMalloc(&c->sym_part_j, (size_t)c->sym_tiles_own * c->sym_pad * 16)) != hipSuccess) return bail(e, "hipMalloc j-side rows");
     if ((e = hipMemset(c->sym_part_j, 0, (size_t)c->sym_tiles_own * c->sym_pad * 16)) != hipSuccess) return bail(e, "hipMemset j-side rows");
+    // NBODY_SYM_GUARDED=1 (A/B measurements only): always run the guarded kernel, no coincident-body detector
+    const char *guarded = getenv("NBODY_SYM_GUARDED");
+    if (p.eps == 0.0 && p.zero_mode == NBODY_ZERO_EXACT && !(guarded && guarded[0] == '1')) {
+      int slots = 1024;
+      while (slots < 2 * p.n_total) slots *= 2;
+      c->sym_dup_slots = slots;
+      if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 8)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
+    }
     if ((e = hipMalloc(&c->sym_send, (size_t)p.n_total * 16)) != hipSuccess) return bail(e, "hipMalloc send row");
     c->own_send = true;
     if (c->sym_nsrc > 1) {
@@ -499,6 +510,7 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->own_send && c->sym_send) (void)hipFree(c->sym_send);
   if (c->own_recv && c->sym_recv) (void)hipFree(c->sym_recv);
   if (c->sym_pair_tab) (void)hipFree(c->sym_pair_tab);
+  if (c->sym_dup_table) (void)hipFree(c->sym_dup_table);
   if (c->bh) nbody::bh_destroy(c->bh);
   if (c->bh_acc) (void)hipFree(c->bh_acc);
   if (c->d_stage) (void)hipFree(c->d_stage);

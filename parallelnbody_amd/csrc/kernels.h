@@ -50,6 +50,8 @@ struct SymLaunch {
   int np;               // register pairs of i-bodies per lane (1 or 2)
   double G;
   double eps2;          // > 0 softened / floor; == 0 exact d == 0 skip (clamp form)
+  void *dup_table;      // eps2 == 0 only: dup_slots x 8-byte hash slots + one flag word; nullptr = always run the guarded kernel
+  int dup_slots;        // power of two >= 2 * n_total
 };
 bool sym_pair_assigned(int a, int b, int T);   // does super tile a own the pair {a, b}?
 // forces + fold of the j-side rows into L.send

@@ -61,11 +61,23 @@ __device__ __forceinline__ f2 mul_swap(f2 a, f2 b) {
 #ifndef NBODY_SYM_WAVES
 #define NBODY_SYM_WAVES 4
 #endif
-template <int NP, int ZMODE>
+// Zero-mass padding bodies sit far outside any scene when the symmetric tiles run without a d == 0 guard (BARE):
+// a pad at the origin would coincide with a body at the origin — the reference pins body 0 there — and 0 * inf = NaN.
+// At 1e18 every pad-to-body term is |d|^-3 = 1e-55 -> 0 times a zero mass, exactly 0.
+constexpr float kPadFar = 1.0e18f;
+
+// BARE = symmetric tiles without any d == 0 handling (two packed ops per register pair cheaper than Z_CLAMP).  The
+// symmetric tiles never contain a self pair (i-set and j tile are disjoint), so d == 0 there means two DIFFERENT
+// bodies on one point.  dup_detect_kernel looks for that before every pass and leaves the verdict in *dup_flag:
+// the BARE launch runs only when there is none (run_if_dup == 0), the guarded launch only when there is one
+// (run_if_dup == 1); dup_flag == nullptr runs unconditionally.  Results are those of the guarded kernel either way.
+template <int NP, int ZMODE, bool BARE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NBODY_SYM_WAVES, NBODY_SYM_WAVES)))
 void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ part_i, float4 *__restrict__ part_j,
                           const int2 *__restrict__ pairs, int n_total, int S, int n_pad, int own_tile0, int n_own_pad,
-                          float gscale, float zp) {
+                          float gscale, float zp, const int *__restrict__ dup_flag, int run_if_dup) {
+  if (dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
+  const float4 pad = BARE ? make_float4(kPadFar, kPadFar, kPadFar, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int IPT = 2 * NP;
   constexpr int BI = kBlock * IPT;
   __shared__ float4 sh_pos[2][4][128];   // double-buffered subtile images, doubled: entries l and l+64 hold body l
@@ -97,8 +109,8 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int ia = i0 + t + (2 * p) * kBlock, ib = ia + kBlock;
-      const float4 pa = ia < n_total ? posm[ia] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 pb = ib < n_total ? posm[ib] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 pa = ia < n_total ? posm[ia] : pad;
+      const float4 pb = ib < n_total ? posm[ib] : pad;
       xi[p] = f2{pa.x, pb.x}; yi[p] = f2{pa.y, pb.y}; zi[p] = f2{pa.z, pb.z};
       nmi[p] = f2{-gscale * pa.w, -gscale * pb.w};             // -G m_i: the j side gets a_j -= G m_i s d
     }
@@ -109,7 +121,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
     const int c_begin = diag_super ? b * (BI / kJT) : 0;
     auto fetch = [&](int c) {                                   // thread t owns body j0 + t of the tile
       const int j = sj * S + c * kJT + t;
-      return (j < n_total) ? posm[j] : make_float4(0.f, 0.f, 0.f, 0.f);   // zero-mass padding
+      return (j < n_total) ? posm[j] : pad;                               // zero-mass padding
     };
     auto stage = [&](int buf, float4 q) {
       q.w *= gscale;
@@ -142,12 +154,12 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
             for (int p = 0; p < NP; ++p) { dx[p] = splat2(pj.x) - xi[p]; dy[p] = splat2(pj.y) - yi[p]; dz[p] = splat2(pj.z) - zi[p]; }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-              if (ZMODE == Z_SOFT) w[p] = fma2(dz[p], dz[p], zp2);
-              else                 w[p] = dz[p] * dz[p];
+              if (ZMODE == Z_SOFT && !BARE) w[p] = fma2(dz[p], dz[p], zp2);
+              else                          w[p] = dz[p] * dz[p];
               w[p] = fma2(dy[p], dy[p], w[p]);
               w[p] = fma2(dx[p], dx[p], w[p]);
             }
-            if (ZMODE == Z_CLAMP) {
+            if (ZMODE == Z_CLAMP && !BARE) {
 #pragma unroll
               for (int p = 0; p < NP; ++p) {
                 f2 nf;
@@ -209,6 +221,31 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
       if (ib < n_pad) Pi[ib - own0] = make_float4(a[p].x.y, a[p].y.y, a[p].z.y, 0.f);
     }
   }
+}
+
+// Do two different bodies share a position?  Every body inserts a 64-bit hash of its three coordinates into an
+// open-addressing table (pre-zeroed, >= 2n slots); meeting its own hash again sets *flag.  A hash collision between
+// different positions also sets it — that only selects the guarded kernel for this pass, never a wrong result.
+__global__ __launch_bounds__(kBlock) void dup_detect_kernel(const float4 *__restrict__ posm, int n,
+                                                            unsigned long long *__restrict__ table,
+                                                            unsigned int mask, int *__restrict__ flag) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = posm[i];
+  // +0.0f folds -0 into +0: they are the same position
+  unsigned long long h = (unsigned long long)__float_as_uint(p.x + 0.0f) * 0x9E3779B97F4A7C15ull;
+  h = (h ^ (h >> 29)) + (unsigned long long)__float_as_uint(p.y + 0.0f) * 0xBF58476D1CE4E5B9ull;
+  h = (h ^ (h >> 31)) + (unsigned long long)__float_as_uint(p.z + 0.0f) * 0x94D049BB133111EBull;
+  h ^= h >> 32;
+  if (h == 0ull) h = 1ull;                                  // 0 marks an empty slot
+  unsigned int slot = (unsigned int)(h * 0xD6E8FEB86659FD93ull >> 32) & mask;
+  for (unsigned int probe = 0; probe <= mask; ++probe) {
+    const unsigned long long old = atomicCAS(&table[slot], 0ull, h);
+    if (old == 0ull) return;                                // inserted
+    if (old == h) { atomicExch(flag, 1); return; }          // somebody with the same position (or hash) is already in
+    slot = (slot + 1) & mask;
+  }
+  atomicExch(flag, 1);                                      // table full (cannot happen at >= 2n slots): be safe
 }
 
 // send[b] = sum over the rank's own super tiles a (ascending) of the j-side row part_j[a][b], for every body b of
@@ -273,16 +310,25 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0 || L.tiles_own <= 0) return hipErrorInvalidValue;
   if (L.S % (kBlock * 2 * L.np) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
   dim3 grid(L.n_pairs), block(kBlock);
-#define NBODY_SYM(NPV, ZM, ZP)                                                                                  \
-  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)L.part_i, \
-                     (float4 *)L.part_j, (const int2 *)L.pairs, L.n_total, L.S, L.n_pad, L.own_tile0,          \
-                     L.tiles_own * L.S, (float)L.G, (float)(ZP))
-  if (L.np == 1) {
-    if (L.eps2 > 0.0) NBODY_SYM(1, Z_SOFT, L.eps2); else NBODY_SYM(1, Z_CLAMP, -0x1p126);
-  } else if (L.np == 2) {
-    if (L.eps2 > 0.0) NBODY_SYM(2, Z_SOFT, L.eps2); else NBODY_SYM(2, Z_CLAMP, -0x1p126);
+#define NBODY_SYM(NPV, ZM, BARE, ZP, FLAG, RUNIF)                                                                \
+  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE>), grid, block, 0, s, (const float4 *)L.posm,          \
+                     (float4 *)L.part_i, (float4 *)L.part_j, (const int2 *)L.pairs, L.n_total, L.S, L.n_pad,    \
+                     L.own_tile0, L.tiles_own * L.S, (float)L.G, (float)(ZP), (const int *)(FLAG), RUNIF)
+  if (L.np != 1 && L.np != 2) return hipErrorInvalidValue;
+  if (L.eps2 > 0.0) {
+    if (L.np == 1) NBODY_SYM(1, Z_SOFT, false, L.eps2, nullptr, 0); else NBODY_SYM(2, Z_SOFT, false, L.eps2, nullptr, 0);
+  } else if (L.dup_table != nullptr) {
+    // exact d == 0 semantics at the unguarded kernel's price: look for coincident bodies first, then launch both
+    // forms — exactly one of them runs (the other returns at its first instruction)
+    hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 8, s);   // table + flag word behind it
+    if (e0 != hipSuccess) return e0;
+    int *flag = (int *)((unsigned long long *)L.dup_table + L.dup_slots);
+    hipLaunchKernelGGL(dup_detect_kernel, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.posm,
+                       L.n_total, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag);
+    if (L.np == 1) { NBODY_SYM(1, Z_CLAMP, true, -0x1p126, flag, 0); NBODY_SYM(1, Z_CLAMP, false, -0x1p126, flag, 1); }
+    else           { NBODY_SYM(2, Z_CLAMP, true, -0x1p126, flag, 0); NBODY_SYM(2, Z_CLAMP, false, -0x1p126, flag, 1); }
   } else {
-    return hipErrorInvalidValue;
+    if (L.np == 1) NBODY_SYM(1, Z_CLAMP, false, -0x1p126, nullptr, 0); else NBODY_SYM(2, Z_CLAMP, false, -0x1p126, nullptr, 0);
   }
 #undef NBODY_SYM
   hipError_t e = hipGetLastError();
