@@ -165,3 +165,24 @@ def test_openmp_threads_do_not_change_results(oracle):
     pos = np.ascontiguousarray(g["posm"][:, :3]); m = np.ascontiguousarray(g["posm"][:, 3])
     a = oracle.forces_direct_f32(pos, m, nthreads=max(2, min(4, oracle.max_threads())))
     np.testing.assert_array_equal(a, g["acc_direct"])
+
+
+# Chenciner-Montgomery figure-eight: three equal masses (G = m = 1) on one closed curve, period 6.32591398
+FIG8_X = np.array([[-0.97000436, 0.24308753, 0.0], [0.97000436, -0.24308753, 0.0], [0.0, 0.0, 0.0]])
+FIG8_V = np.array([[0.4662036850, 0.4323657300, 0.0], [0.4662036850, 0.4323657300, 0.0],
+                   [-0.93240737, -0.86473146, 0.0]])
+FIG8_T = 6.32591398
+
+
+def test_three_body_figure_eight_known_answer(oracle):
+    # known answer independent of the reference: after one period the bodies are back where they started
+    n_steps = 20000
+    dt = FIG8_T / n_steps
+    pos, vel, m = FIG8_X.copy(), FIG8_V.copy(), np.ones(3)
+    a = oracle.forces_direct_f64(pos, m, g=1.0)
+    vel = vel - 0.5 * dt * a                       # the update keeps v half a step behind x (kick-drift)
+    for _ in range(n_steps):
+        a = oracle.forces_direct_f64(pos, m, g=1.0)
+        pos, vel = oracle.kick_drift_f64(pos, vel, a, dt)
+    assert np.abs(pos - FIG8_X).max() < 2e-4
+    assert np.abs(pos.sum(0)).max() < 1e-12        # centre of mass stays put

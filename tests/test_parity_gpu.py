@@ -526,3 +526,28 @@ def test_command_line_replay_of_the_shipped_scene(nb, tmp_path, capsys):
     assert lines[-1]["first_frame"] == 4 and lines[-1]["steps_done"] == 7
     pos = np.load(tmp_path / "p.npy")
     assert pos.shape == (2000, 3) and np.all(np.isfinite(pos))
+
+
+def test_three_body_figure_eight_on_the_device(nb):
+    # known-answer test independent of the oracle and the reference: the fp64 path carries the figure-eight
+    # through one period (G = m = 1; the small-N kernels: 3 bodies, one partial wave)
+    from test_oracle import FIG8_T, FIG8_V, FIG8_X
+    n_steps = 20000
+    dt = np.float32(FIG8_T / n_steps)
+    posm = np.concatenate([FIG8_X, np.ones((3, 1))], 1)
+    vel = np.concatenate([FIG8_V, np.zeros((3, 1))], 1)
+    with nb.NBodyEngine(3, precision="f64", G=1.0) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        _, _, a = e.state(np.float64)
+        vel[:, :3] -= 0.5 * float(dt) * a[:, :3]
+        e.set_state(posm, vel)
+        e.step(float(dt), n_steps)
+        p, _, _ = e.state(np.float64)
+    # dt is a float at the ABI, so n_steps * dt misses the period by ~1e-7 * T: bodies move ~1e-6 in that time
+    assert np.abs(p[:, :3] - FIG8_X).max() < 3e-4
+    # fp32 default path, same orbit, fp32 accuracy over 20000 steps
+    with nb.NBodyEngine(3, G=1.0) as e:
+        e.set_state(posm, vel)
+        e.step(float(dt), n_steps)
+        assert np.abs(e.positions() - FIG8_X).max() < 5e-2

@@ -96,6 +96,7 @@ def _worker_exchange(rank, world, port, n, out_dir):
     posm, vel = nb.ic_plummer(n, seed=9)
     sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device="cpu", engine_factory=ExchangingEngine)
     assert sim.ex_ranks == world and sim.ex_recv.shape == (world * sim.i_count, 4)
+    sim.warm_collectives()
     sim.compute_forces()
     _, _, a = sim.engine.state()
     sim.step(0.01, 2)
