@@ -128,8 +128,17 @@ void choose_algorithm(nbody_ctx *c) {
   if (!(p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4))) return;
   if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < 32768) return;
   const int BI = 256 * c->ipt;
+  // Workgroups per rank = (super tiles owned) x (about half of all super tiles).  The chip holds 1024 of them at a time
+  // (4 per CU), so a rank needs many thousands for the tail to vanish: aim at >= 16384
+  // (measured at N = 2^20: 2080 workgroups 200.8 ms, 8256 191.5, 14706 190.6, 32896 189.1).  NBODY_SYM_WORKGROUPS
+  // overrides the target (tuning only).
+  long long target = 16384;
+  if (const char *t = getenv("NBODY_SYM_WORKGROUPS")) { const long long v = atoll(t); if (v > 0) target = v; }
   if (p.i_count == p.n_total) {
-    long long S = (p.n_total + 127) / 128;           // ~128 super tiles -> ~8000 workgroups
+    // T(T+1)/2 >= target
+    long long T = 2;
+    while (T * (T + 1) / 2 < target) ++T;
+    long long S = (p.n_total + T - 1) / T;
     S = (S + BI - 1) / BI * BI;
     if (S < BI) S = BI;
     c->sym_S = (int)S;
@@ -138,13 +147,15 @@ void choose_algorithm(nbody_ctx *c) {
     c->sym_tiles_own = c->sym_T;
     c->sym_nsrc = 1;
   } else {
-    // sharded: equal slices, each a whole number k of super tiles; T = ranks * k as close to 128 as divides
+    // sharded: equal slices, each a whole number k of super tiles (T = ranks * k); k * T / 2 >= target if the slice
+    // divides finely enough
     if (p.n_total % p.i_count != 0 || p.i_begin % p.i_count != 0 || p.i_count % BI != 0) return;
     const int ranks = p.n_total / p.i_count;
-    int k = 128 / ranks;
-    if (k < 1) k = 1;
-    while (k > 1 && p.i_count % (k * BI) != 0) --k;
-    if (p.i_count % (k * BI) != 0) return;
+    const int kmax = p.i_count / BI;
+    int k = 1;
+    while (k < kmax && (long long)k * ranks * k / 2 < target) ++k;
+    while (k < kmax && p.i_count % (k * BI) != 0) ++k;
+    if (p.i_count % (k * BI) != 0) { k = kmax; }
     c->sym_S = p.i_count / k;
     c->sym_T = ranks * k;
     c->sym_own_tile0 = (p.i_begin / p.i_count) * k;
