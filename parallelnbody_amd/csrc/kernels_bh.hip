@@ -9,7 +9,7 @@
 //                                          body's path (octant = 4[x>=ox] + 2[y>=oy] + [z>=oz] per level, child
 //                                          centre = centre +- Size*0.5 evaluated as float(double + double)) is
 //                                          computed exactly as Add walks it, packed 3 bits per level into two
-//                                          64-bit keys (42 levels), sorted, and cells are split level by level.
+//                                          64-bit keys (42 levels), sorted (rocPRIM radix sort), and cells are split level by level.
 //   Octree::ComputeMass    .h:83-97    -> bh_upsweep_kernel, children 0..7 in order, fp32, /= as reciprocal multiply
 //   Octree::ComputeForces  .h:99-108   -> bh_walk_kernel: depth-first, children 0..7, `Size/d < Theta || leaf`,
 //                                          d == 0 skips (also a whole subtree whose CoM coincides with the body),
@@ -23,7 +23,9 @@
 // lines bit for bit (tests/test_bh_gpu.py).  This is latency/divergence-bound integer+fp work, not the FMA-bound
 // all-pairs path; it is the drop-in for the reference's SHIPPED configuration (theta = 1.0).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "kernels.h"
 
@@ -268,7 +270,7 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->idx, sizeof(unsigned int) * n));
   BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
   size_t bytes = 0;
-  BH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, b->klo, b->klo2, b->idx, b->idx2, n));
+  BH_TRY(rocprim::radix_sort_pairs(nullptr, bytes, b->klo, b->klo2, b->idx, b->idx2, (unsigned int)n));
   b->sort_tmp_bytes = bytes;
   BH_TRY(hipMalloc(&b->sort_tmp, bytes));
   BH_TRY(hipMalloc(&b->nd.box, sizeof(float4) * b->node_cap));
@@ -309,10 +311,10 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, posm, n, b->root, b->khi, b->klo, b->idx);
   // stable LSD sort over the 126-bit key: low word first, then the high word
   size_t tb = b->sort_tmp_bytes;
-  BH_TRY(hipcub::DeviceRadixSort::SortPairs(b->sort_tmp, tb, b->klo, b->klo2, b->idx, b->idx2, n, 0, 63, s));
+  BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->klo, b->klo2, b->idx, b->idx2, (unsigned int)n, 0u, 63u, s));
   hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->khi, b->idx2, b->khi2, n);
   tb = b->sort_tmp_bytes;
-  BH_TRY(hipcub::DeviceRadixSort::SortPairs(b->sort_tmp, tb, b->khi2, b->khi, b->idx2, b->idx, n, 0, 63, s));
+  BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->khi2, b->khi, b->idx2, b->idx, (unsigned int)n, 0u, 63u, s));
   // b->khi / b->idx are final; bring the low words (b->klo is still in body order) into the same order
   hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->klo, b->idx, b->klo2, n);
 

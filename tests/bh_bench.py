@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Barnes-Hut (theta = 1.0, the reference's shipped opening angle) on the device vs the CPU restatement of the
+"""(Lives under tests/ because it times the CPU oracle next to the device: only tests/, smoke() and bench.py's
+cpu_baseline leg may touch oracle/.)  Barnes-Hut (theta = 1.0, the reference's shipped opening angle) on the device vs the CPU restatement of the
 reference's tree (one core): time per force pass."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import numpy as np
 import parallelnbody_amd as nb
 from oracle import oracle as O
