@@ -33,11 +33,15 @@ def partition(n_total, world_size, rank):
     return rank * cnt, cnt
 
 
-def _hip_engine_factory(n_total, i_begin, i_count, posm_tensor, device_index, **kw):
-    import torch
+def _hip_engine_factory(n_total, i_begin, i_count, posm_tensor, device_index, stream=None, **kw):
     eng = NBodyEngine(n_total, i_begin=i_begin, i_count=i_count, device=device_index, **kw)
     eng.bind_device_state(posm=posm_tensor)
-    eng.set_stream(torch.cuda.current_stream(posm_tensor.device).cuda_stream)
+    if stream is not None:
+        # Kernels and collectives must be ordered on ONE stream.  torch's default stream has handle 0, which the
+        # C-ABI reads as "use the context's own stream", so the simulation owns a real side stream and issues both
+        # its kernels (through this handle) and its collectives (under torch.cuda.stream) on it.
+        assert stream.cuda_stream != 0
+        eng.set_stream(stream.cuda_stream)
     return eng
 
 
@@ -57,6 +61,9 @@ class ShardedSimulation:
         self.posm = torch.empty((self.n_total, 4), dtype=tdt, device=self.device)
         factory = engine_factory or _hip_engine_factory
         dev_index = self.device.index if self.device.type == "cuda" else -1
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        if engine_factory is None:
+            engine_kw = dict(engine_kw, stream=self.stream)
         self.engine = factory(self.n_total, self.i_begin, self.i_count, self.posm, dev_index, **engine_kw)
         self.engine.set_state(posm.astype(np.float64 if self.f64 else np.float32, copy=False),
                               np.ascontiguousarray(vel).astype(np.float64 if self.f64 else np.float32, copy=False))
@@ -69,11 +76,20 @@ class ShardedSimulation:
             self.ex_recv = torch.zeros((world_size * self.i_count, 4), dtype=torch.float32, device=self.device)
             self.engine.bind_exchange(self.ex_send, self.ex_recv)
 
+    def _on_stream(self):
+        """Context manager that makes the simulation's stream torch's current stream (no-op on CPU)."""
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def warm_collectives(self):
         """Run each collective of the step once on scratch tensors, so that RCCL's lazy communicator/channel setup
         (seconds, first call only) never lands in a timed region."""
         if self.world_size == 1:
             return
+        with self._on_stream():
+            self._warm_collectives()
+
+    def _warm_collectives(self):
         torch, dist = self.torch, self.torch.distributed
         scratch = torch.zeros((self.world_size * 8, 4), dtype=self.posm.dtype, device=self.device)
         dist.all_gather_into_tensor(scratch, scratch[self.rank * 8:(self.rank + 1) * 8], group=self.group)
@@ -92,19 +108,21 @@ class ShardedSimulation:
 
     def compute_forces(self):
         """Accelerations of the current positions (the reference's CreateOctree force loop), no update."""
-        self._forces()
-        self.engine.step_end(0.0)
+        with self._on_stream():
+            self._forces()
+            self.engine.step_end(0.0)
 
     def step(self, dt=REF_DT, nsteps=1):
         dist = self.torch.distributed
         own = self.posm[self.i_begin:self.i_begin + self.i_count]
-        for _ in range(nsteps):
-            if dt > 0:                     # OctreeSearch.cpp:25: PhDeltaTime <= 0 freezes the physics
-                self._forces()
-                self.engine.step_end(dt)
-                if self.world_size > 1:
-                    dist.all_gather_into_tensor(self.posm, own, group=self.group)
-            self.steps_done += 1
+        with self._on_stream():            # kernels and collectives in one stream order
+            for _ in range(nsteps):
+                if dt > 0:                 # OctreeSearch.cpp:25: PhDeltaTime <= 0 freezes the physics
+                    self._forces()
+                    self.engine.step_end(dt)
+                    if self.world_size > 1:
+                        dist.all_gather_into_tensor(self.posm, own, group=self.group)
+                self.steps_done += 1
 
     def gather_state(self):
         """(posm[n_total,4], vel[n_total,4]) on every rank, as numpy (for tests and checkpoints)."""
@@ -113,20 +131,22 @@ class ShardedSimulation:
         if self.world_size == 1:
             return p, v
         out = []
-        for a in (p, v):
-            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-            full = torch.empty((self.n_total, 4), dtype=t.dtype, device=self.device)
-            dist.all_gather_into_tensor(full, t, group=self.group)
-            out.append(full.cpu().numpy())
+        with self._on_stream():
+            for a in (p, v):
+                t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+                full = torch.empty((self.n_total, 4), dtype=t.dtype, device=self.device)
+                dist.all_gather_into_tensor(full, t, group=self.group)
+                out.append(full.cpu().numpy())
         return out[0], out[1]
 
     def energy(self):
         """System kinetic and potential energy (sum of the ranks' shares)."""
         ke, pe = self.engine.energy()
         if self.world_size > 1:
-            t = self.torch.tensor([ke, pe], dtype=self.torch.float64, device=self.device)
-            self.torch.distributed.all_reduce(t, group=self.group)
-            ke, pe = float(t[0]), float(t[1])
+            with self._on_stream():
+                t = self.torch.tensor([ke, pe], dtype=self.torch.float64, device=self.device)
+                self.torch.distributed.all_reduce(t, group=self.group)
+                ke, pe = float(t[0]), float(t[1])
         return ke, pe
 
     def close(self):
