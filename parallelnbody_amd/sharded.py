@@ -75,6 +75,8 @@ class ShardedSimulation:
             self.ex_send = torch.zeros((self.n_total, 4), dtype=torch.float32, device=self.device)
             self.ex_recv = torch.zeros((world_size * self.i_count, 4), dtype=torch.float32, device=self.device)
             self.engine.bind_exchange(self.ex_send, self.ex_recv)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)   # the zero-fills above ran on torch's default stream, the engine will not
 
     def _on_stream(self):
         """Context manager that makes the simulation's stream torch's current stream (no-op on CPU)."""
