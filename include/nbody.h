@@ -61,7 +61,7 @@ enum {
 /*
  * Force algorithm.  Both evaluate the same pair law over all pairs; they differ in summation order only.
  * TILED: every ordered pair (i, j), one-sided (kernels.hip).  SYMMETRIC: every unordered pair once, feeding
- * both bodies (kernels_sym.hip): fp32 non-Kahan contexts; when the bodies are sharded the slices must be equal
+ * both bodies (kernels_sym.hip, kernels_sym64.hip): fp32 non-Kahan and unsoftened fp64 contexts; when the bodies are sharded the slices must be equal
  * and the host drives nbody_step_begin / all-to-all / nbody_step_end.  The per-body summation order then depends
  * on the number of ranks (TILED's does not).
  * AUTO picks SYMMETRIC where it applies and n_total >= 32768, else TILED.
@@ -169,12 +169,13 @@ NBODY_API int nbody_step(nbody_ctx *ctx, float dt, int32_t nsteps);
 NBODY_API int nbody_step_begin(nbody_ctx *ctx);
 NBODY_API int nbody_step_end(nbody_ctx *ctx, float dt);
 NBODY_API int nbody_exchange_info(nbody_ctx *ctx, void **send, void **recv, size_t *bytes_per_rank, int32_t *n_ranks);
-/* Use caller-owned device buffers (e.g. torch tensors) for the exchange: send = n_total x float4, recv = n_ranks x i_count x float4. */
+/* Use caller-owned device buffers (e.g. torch tensors) for the exchange: send = n_total x float4, recv = n_ranks x i_count x float4
+ * (double4 on an fp64 context). */
 NBODY_API int nbody_bind_exchange(nbody_ctx *ctx, void *send, void *recv);
 /* Host-staged exchange for callers without a device-side collective: copy `send` out (n_total x 4 floats) /
- * copy `recv` in (n_ranks x i_count x 4 floats). */
-NBODY_API int nbody_exchange_read_send(nbody_ctx *ctx, float *host);
-NBODY_API int nbody_exchange_write_recv(nbody_ctx *ctx, const float *host);
+ * copy `recv` in (n_ranks x i_count x 4 floats); doubles on an fp64 context. */
+NBODY_API int nbody_exchange_read_send(nbody_ctx *ctx, void *host);
+NBODY_API int nbody_exchange_write_recv(nbody_ctx *ctx, const void *host);
 
 /*
  * Barnes-Hut mode: with theta > 0 the force pass is the reference's CreateOctree (OctreeSearch.cpp:

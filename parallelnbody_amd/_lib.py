@@ -97,8 +97,8 @@ def lib():
     sig("nbody_step_end", c_int, vp, c_f)
     sig("nbody_exchange_info", c_int, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(c_i32))
     sig("nbody_bind_exchange", c_int, vp, vp, vp)
-    sig("nbody_exchange_read_send", c_int, vp, fp)
-    sig("nbody_exchange_write_recv", c_int, vp, fp)
+    sig("nbody_exchange_read_send", c_int, vp, vp)
+    sig("nbody_exchange_write_recv", c_int, vp, vp)
     sig("nbody_set_theta", c_int, vp, c_f)
     sig("nbody_bh_stats", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), fp)
     sig("nbody_bh_leaf_boxes", c_int, vp, fp, sz)

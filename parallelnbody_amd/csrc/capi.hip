@@ -125,9 +125,11 @@ void choose_algorithm(nbody_ctx *c) {
   const nbody_params &p = c->p;
   c->sym = false;
   if (p.algorithm == NBODY_ALGO_TILED) return;
-  if (!(p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4))) return;
+  const bool f32ok = p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4);
+  const bool f64ok = p.precision == NBODY_PREC_F64 && p.eps == 0.0 && p.zero_mode == NBODY_ZERO_EXACT;   // kernels_sym64.hip
+  if (!f32ok && !f64ok) return;
   if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < 32768) return;
-  const int BI = 256 * c->ipt;
+  const int BI = f64ok ? 512 : 256 * c->ipt;
   // Workgroups per rank = (super tiles owned) x (about half of all super tiles).  The chip holds 1024 of them at a time
   // (4 per CU), so a rank needs many thousands for the tail to vanish: aim at >= 16384
   // (measured at N = 2^20: 2080 workgroups 200.8 ms, 8256 191.5, 14706 190.6, 32896 189.1).  NBODY_SYM_WORKGROUPS
@@ -175,7 +177,9 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   L.posm = c->posm; L.part_i = c->sym_part_i; L.part_j = c->sym_part_j; L.send = c->sym_send; L.recv = c->sym_recv;
   L.pairs = c->sym_pair_tab; L.n_pairs = c->sym_pairs;
   L.n_total = c->p.n_total; L.S = c->sym_S; L.T = c->sym_T; L.n_pad = c->sym_pad;
-  L.own_tile0 = c->sym_own_tile0; L.tiles_own = c->sym_tiles_own; L.n_src = c->sym_nsrc; L.np = c->ipt / 2;
+  L.own_tile0 = c->sym_own_tile0; L.tiles_own = c->sym_tiles_own; L.n_src = c->sym_nsrc;
+  L.np = c->p.precision == NBODY_PREC_F64 ? 1 : c->ipt / 2;
+  L.precision = c->p.precision;
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps;
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
   L.dup_table = c->sym_dup_table; L.dup_slots = c->sym_dup_slots;
@@ -445,8 +449,8 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if (p.algorithm == NBODY_ALGO_SYMMETRIC && !c->sym) {
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
-                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (no Kahan), i_per_thread 2 or 4, zero_mode != SELECT and, "
-                "when sharded, equal slices that are a multiple of 256*i_per_thread bodies");
+                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (no Kahan, i_per_thread 2 or 4, zero_mode != SELECT) or "
+                "unsoftened fp64 and, when sharded, equal slices that are a multiple of 256*i_per_thread (fp64: 512) bodies");
   }
 
   auto bail = [&](hipError_t he, const char *what) {
@@ -465,9 +469,9 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   c->own_acc = true;
   if (c->sym) {
     const size_t n_own_pad = (size_t)c->sym_tiles_own * c->sym_S;
-    if ((e = hipMalloc(&c->sym_part_i, (size_t)c->sym_T * n_own_pad * 16)) != hipSuccess) return bail(e, "hipMalloc i-side rows");
-    if ((e = hipMalloc(&c->sym_part_j, (size_t)c->sym_tiles_own * c->sym_pad * 16)) != hipSuccess) return bail(e, "hipMalloc j-side rows");
-    if ((e = hipMemset(c->sym_part_j, 0, (size_t)c->sym_tiles_own * c->sym_pad * 16)) != hipSuccess) return bail(e, "hipMemset j-side rows");
+    if ((e = hipMalloc(&c->sym_part_i, (size_t)c->sym_T * n_own_pad * c->elem)) != hipSuccess) return bail(e, "hipMalloc i-side rows");
+    if ((e = hipMalloc(&c->sym_part_j, (size_t)c->sym_tiles_own * c->sym_pad * c->elem)) != hipSuccess) return bail(e, "hipMalloc j-side rows");
+    if ((e = hipMemset(c->sym_part_j, 0, (size_t)c->sym_tiles_own * c->sym_pad * c->elem)) != hipSuccess) return bail(e, "hipMemset j-side rows");
     // NBODY_SYM_GUARDED=1 (A/B measurements only): always run the guarded kernel, no coincident-body detector
     const char *guarded = getenv("NBODY_SYM_GUARDED");
     if (p.eps == 0.0 && p.zero_mode == NBODY_ZERO_EXACT && !(guarded && guarded[0] == '1')) {
@@ -476,10 +480,10 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
       c->sym_dup_slots = slots;
       if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 8)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
     }
-    if ((e = hipMalloc(&c->sym_send, (size_t)p.n_total * 16)) != hipSuccess) return bail(e, "hipMalloc send row");
+    if ((e = hipMalloc(&c->sym_send, (size_t)p.n_total * c->elem)) != hipSuccess) return bail(e, "hipMalloc send row");
     c->own_send = true;
     if (c->sym_nsrc > 1) {
-      if ((e = hipMalloc(&c->sym_recv, (size_t)c->sym_nsrc * p.i_count * 16)) != hipSuccess) return bail(e, "hipMalloc recv rows");
+      if ((e = hipMalloc(&c->sym_recv, (size_t)c->sym_nsrc * p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc recv rows");
       c->own_recv = true;
     } else {
       c->sym_recv = c->sym_send;
@@ -651,24 +655,24 @@ int nbody_exchange_info(nbody_ctx *c, void **send, void **recv, size_t *bytes_pe
   const bool ex = c->sym && c->sym_nsrc > 1;
   if (send) *send = ex ? c->sym_send : nullptr;
   if (recv) *recv = ex ? c->sym_recv : nullptr;
-  if (bytes_per_rank) *bytes_per_rank = ex ? (size_t)c->p.i_count * 16 : 0;
+  if (bytes_per_rank) *bytes_per_rank = ex ? (size_t)c->p.i_count * c->elem : 0;
   if (n_ranks) *n_ranks = ex ? c->sym_nsrc : 0;
   return NBODY_OK;
 }
 
-int nbody_exchange_read_send(nbody_ctx *c, float *host) {
+int nbody_exchange_read_send(nbody_ctx *c, void *host) {
   if (!c || !host) return NBODY_ERR_INVALID;
   if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_exchange_read_send: this context has no exchange step");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(host, c->sym_send, (size_t)c->p.n_total * 16, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(host, c->sym_send, (size_t)c->p.n_total * c->elem, hipMemcpyDeviceToHost));
   return NBODY_OK;
 }
 
-int nbody_exchange_write_recv(nbody_ctx *c, const float *host) {
+int nbody_exchange_write_recv(nbody_ctx *c, const void *host) {
   if (!c || !host) return NBODY_ERR_INVALID;
   if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_exchange_write_recv: this context has no exchange step");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(c->sym_recv, host, (size_t)c->sym_nsrc * c->p.i_count * 16, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->sym_recv, host, (size_t)c->sym_nsrc * c->p.i_count * c->elem, hipMemcpyHostToDevice));
   return NBODY_OK;
 }
 

@@ -27,36 +27,11 @@
 
 #include "../../include/nbody.h"
 #include "pk_common.h"
+#include "sym_common.h"
 
 namespace nbody {
 
 namespace {
-
-constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
-
-// Does super tile a own the pair {a, b}?  (a == b, or b within the forward half of the ring of T super tiles;
-// the antipodal pair of an even ring goes to the smaller index.)
-__host__ __device__ inline bool sym_assigned(int a, int b, int T) {
-  if (a == b) return true;
-  const int d = (b - a + T) % T;
-  if (2 * d < T) return true;
-  return 2 * d == T && a < b;
-}
-
-// lane l+1 <- lane l, lane 0 <- lane 63 (v_mov_b32_dpp wave_ror:1; a half-rate VALU op on gfx950)
-__device__ __forceinline__ float wave_ror1(float v) {
-  const int i = __builtin_bit_cast(int, v);   // every lane is written, so `old` is irrelevant: pass the source (no v_mov to seed it)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x13C, 0xf, 0xf, false));
-}
-
-// (a.y*b.y, a.x*b.x): the product with its halves swapped.  The j-side scale factors are kept this way so that the
-// scalar v_fmac_f32 that adds `scale(hi body) * d(hi body)` reads an even and an odd register — a 3-source op whose
-// registers all share a parity issues at half rate on gfx950 (VALU issue model).
-__device__ __forceinline__ f2 mul_swap(f2 a, f2 b) {
-  f2 o;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(o) : "v"(a), "v"(b));
-  return o;
-}
 
 #ifndef NBODY_SYM_WAVES
 #define NBODY_SYM_WAVES 4
@@ -223,90 +198,14 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
   }
 }
 
-// Do two different bodies share a position?  Every body inserts a 64-bit hash of its three coordinates into an
-// open-addressing table (pre-zeroed, >= 2n slots); meeting its own hash again sets *flag.  A hash collision between
-// different positions also sets it — that only selects the guarded kernel for this pass, never a wrong result.
-__global__ __launch_bounds__(kBlock) void dup_detect_kernel(const float4 *__restrict__ posm, int n,
-                                                            unsigned long long *__restrict__ table,
-                                                            unsigned int mask, int *__restrict__ flag) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = posm[i];
-  // +0.0f folds -0 into +0: they are the same position
-  unsigned long long h = (unsigned long long)__float_as_uint(p.x + 0.0f) * 0x9E3779B97F4A7C15ull;
-  h = (h ^ (h >> 29)) + (unsigned long long)__float_as_uint(p.y + 0.0f) * 0xBF58476D1CE4E5B9ull;
-  h = (h ^ (h >> 31)) + (unsigned long long)__float_as_uint(p.z + 0.0f) * 0x94D049BB133111EBull;
-  h ^= h >> 32;
-  if (h == 0ull) h = 1ull;                                  // 0 marks an empty slot
-  unsigned int slot = (unsigned int)(h * 0xD6E8FEB86659FD93ull >> 32) & mask;
-  for (unsigned int probe = 0; probe <= mask; ++probe) {
-    const unsigned long long old = atomicCAS(&table[slot], 0ull, h);
-    if (old == 0ull) return;                                // inserted
-    if (old == h) { atomicExch(flag, 1); return; }          // somebody with the same position (or hash) is already in
-    slot = (slot + 1) & mask;
-  }
-  atomicExch(flag, 1);                                      // table full (cannot happen at >= 2n slots): be safe
-}
-
-// send[b] = sum over the rank's own super tiles a (ascending) of the j-side row part_j[a][b], for every body b of
-// the system: what this rank contributes to b's acceleration as the "other" body of its pairs.
-__global__ __launch_bounds__(kBlock) void reduce_j_kernel(const float4 *__restrict__ part_j, float4 *__restrict__ send,
-                                                          int n_total, int S, int T, int n_pad, int own_tile0,
-                                                          int tiles_own) {
-  const int b = blockIdx.x * kBlock + threadIdx.x;
-  if (b >= n_total) return;
-  const int tb = b / S;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int al = 0; al < tiles_own; ++al) {
-    if (!sym_assigned(own_tile0 + al, tb, T)) continue;        // that workgroup does not exist: row never written
-    const float4 p = part_j[(size_t)al * n_pad + b];
-    sx += p.x; sy += p.y; sz += p.z;
-  }
-  send[b] = make_float4(sx, sy, sz, 0.f);
-}
-
-template <typename T> __device__ __forceinline__ T mul_add_sep2(T a, T b, T c) {
-#pragma clang fp contract(off)
-  const T p = a * b;
-  return c + p;
-}
-
-// Own body bl: acc = its i-side rows (partners in ring order from its own super tile) + the rows received from
-// every rank (rank order); then optionally the reference's update (OctreeSearch.cpp:29-30), multiply and add kept apart.
-__global__ __launch_bounds__(kBlock) void update_sym_kernel(float4 *__restrict__ posm, float4 *__restrict__ vel,
-                                                            float4 *__restrict__ acc, const float4 *__restrict__ part_i,
-                                                            const float4 *__restrict__ recv, int i_begin, int i_count,
-                                                            int S, int T, int n_own_pad, int n_src, float dt,
-                                                            int integrate) {
-  const int bl = blockIdx.x * kBlock + threadIdx.x;
-  if (bl >= i_count) return;
-  const int s = (i_begin + bl) / S;
-  float ax = 0.f, ay = 0.f, az = 0.f;
-  for (int d = 0; d < T; ++d) {
-    const int sj = (s + d) % T;
-    if (!sym_assigned(s, sj, T)) continue;
-    const float4 p = part_i[(size_t)sj * n_own_pad + bl];
-    ax += p.x; ay += p.y; az += p.z;
-  }
-  for (int q = 0; q < n_src; ++q) {
-    const float4 p = recv[(size_t)q * i_count + bl];
-    ax += p.x; ay += p.y; az += p.z;
-  }
-  acc[bl] = make_float4(ax, ay, az, 0.f);
-  if (integrate) {
-    float4 v = vel[bl], x = posm[i_begin + bl];
-    v.x = mul_add_sep2(dt, ax, v.x); v.y = mul_add_sep2(dt, ay, v.y); v.z = mul_add_sep2(dt, az, v.z);
-    x.x = mul_add_sep2(dt, v.x, x.x); x.y = mul_add_sep2(dt, v.y, x.y); x.z = mul_add_sep2(dt, v.z, x.z);
-    vel[bl] = v;
-    posm[i_begin + bl] = x;
-  }
-}
-
 }  // namespace
 
 bool sym_pair_assigned(int a, int b, int T) { return sym_assigned(a, b, T); }
 
+hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s);   // kernels_sym64.hip
+
 hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
+  if (L.precision == NBODY_PREC_F64) return launch_forces_sym64(L, s);
   if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0 || L.tiles_own <= 0) return hipErrorInvalidValue;
   if (L.S % (kBlock * 2 * L.np) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
   dim3 grid(L.n_pairs), block(kBlock);
@@ -323,7 +222,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
     hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 8, s);   // table + flag word behind it
     if (e0 != hipSuccess) return e0;
     int *flag = (int *)((unsigned long long *)L.dup_table + L.dup_slots);
-    hipLaunchKernelGGL(dup_detect_kernel, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.posm,
+    hipLaunchKernelGGL(dup_detect_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.posm,
                        L.n_total, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag);
     if (L.np == 1) { NBODY_SYM(1, Z_CLAMP, true, -0x1p126, flag, 0); NBODY_SYM(1, Z_CLAMP, false, -0x1p126, flag, 1); }
     else           { NBODY_SYM(2, Z_CLAMP, true, -0x1p126, flag, 0); NBODY_SYM(2, Z_CLAMP, false, -0x1p126, flag, 1); }
@@ -333,7 +232,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
 #undef NBODY_SYM
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reduce_j_kernel, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.part_j,
+  hipLaunchKernelGGL(reduce_j_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.part_j,
                      (float4 *)L.send, L.n_total, L.S, L.T, L.n_pad, L.own_tile0, L.tiles_own);
   return hipGetLastError();
 }
@@ -342,9 +241,14 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
                              hipStream_t s) {
   if (i_count <= 0) return hipErrorInvalidValue;
   dim3 grid((i_count + kBlock - 1) / kBlock), block(kBlock);
-  hipLaunchKernelGGL(update_sym_kernel, grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
-                     (const float4 *)L.part_i, (const float4 *)L.recv, i_begin, i_count, L.S, L.T, L.tiles_own * L.S,
-                     L.n_src, dt, dt > 0.0f ? 1 : 0);
+  if (L.precision == NBODY_PREC_F64)
+    hipLaunchKernelGGL(update_sym_kernel<double>, grid, block, 0, s, (double4 *)posm, (double4 *)vel, (double4 *)acc,
+                       (const double4 *)L.part_i, (const double4 *)L.recv, i_begin, i_count, L.S, L.T, L.tiles_own * L.S,
+                       L.n_src, (double)dt, dt > 0.0f ? 1 : 0);
+  else
+    hipLaunchKernelGGL(update_sym_kernel<float>, grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
+                       (const float4 *)L.part_i, (const float4 *)L.recv, i_begin, i_count, L.S, L.T, L.tiles_own * L.S,
+                       L.n_src, dt, dt > 0.0f ? 1 : 0);
   return hipGetLastError();
 }
 

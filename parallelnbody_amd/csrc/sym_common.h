@@ -1,0 +1,142 @@
+// Shared device pieces of the symmetric force kernels (kernels_sym.hip: fp32 packed; kernels_sym64.hip: fp64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pk_common.h"
+
+namespace nbody {
+namespace {
+
+constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
+
+// Does super tile a own the pair {a, b}?  (a == b, or b within the forward half of the ring of T super tiles;
+// the antipodal pair of an even ring goes to the smaller index.)
+__host__ __device__ inline bool sym_assigned(int a, int b, int T) {
+  if (a == b) return true;
+  const int d = (b - a + T) % T;
+  if (2 * d < T) return true;
+  return 2 * d == T && a < b;
+}
+
+// lane l+1 <- lane l, lane 0 <- lane 63 (v_mov_b32_dpp wave_ror:1; a half-rate VALU op on gfx950)
+__device__ __forceinline__ float wave_ror1(float v) {
+  const int i = __builtin_bit_cast(int, v);   // every lane is written, so `old` is irrelevant: pass the source (no v_mov to seed it)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x13C, 0xf, 0xf, false));
+}
+
+// (a.y*b.y, a.x*b.x): the product with its halves swapped.  The j-side scale factors are kept this way so that the
+// scalar v_fmac_f32 that adds `scale(hi body) * d(hi body)` reads an even and an odd register — a 3-source op whose
+// registers all share a parity issues at half rate on gfx950 (VALU issue model).
+__device__ __forceinline__ f2 mul_swap(f2 a, f2 b) {
+  f2 o;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
+
+
+__device__ __forceinline__ double wave_ror1(double v) {          // a double moves as two dwords
+  const long long i = __builtin_bit_cast(long long, v);
+  const int lo = (int)(i & 0xffffffffll), hi = (int)(i >> 32);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi2 << 32) | (long long)(unsigned int)lo2);
+}
+
+template <typename T> struct SymVec;
+template <> struct SymVec<float> { using type = float4; };
+template <> struct SymVec<double> { using type = double4; };
+
+__device__ __forceinline__ unsigned long long coord_bits(float v) { return (unsigned long long)__float_as_uint(v + 0.0f); }
+__device__ __forceinline__ unsigned long long coord_bits(double v) { return (unsigned long long)__double_as_longlong(v + 0.0); }
+
+// Do two different bodies share a position?  Every body inserts a 64-bit hash of its three coordinates into an
+// open-addressing table (pre-zeroed, >= 2n slots); meeting its own hash again sets *flag.  A hash collision between
+// different positions also sets it — that only selects the guarded kernel for this pass, never a wrong result.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dup_detect_kernel(const typename SymVec<T>::type *__restrict__ posm, int n,
+                                                            unsigned long long *__restrict__ table,
+                                                            unsigned int mask, int *__restrict__ flag) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const auto p = posm[i];
+  // coord_bits adds +0 first: -0 and +0 are the same position
+  unsigned long long h = coord_bits(p.x) * 0x9E3779B97F4A7C15ull;
+  h = (h ^ (h >> 29)) + coord_bits(p.y) * 0xBF58476D1CE4E5B9ull;
+  h = (h ^ (h >> 31)) + coord_bits(p.z) * 0x94D049BB133111EBull;
+  h ^= h >> 32;
+  if (h == 0ull) h = 1ull;                                  // 0 marks an empty slot
+  unsigned int slot = (unsigned int)(h * 0xD6E8FEB86659FD93ull >> 32) & mask;
+  for (unsigned int probe = 0; probe <= mask; ++probe) {
+    const unsigned long long old = atomicCAS(&table[slot], 0ull, h);
+    if (old == 0ull) return;                                // inserted
+    if (old == h) { atomicExch(flag, 1); return; }          // somebody with the same position (or hash) is already in
+    slot = (slot + 1) & mask;
+  }
+  atomicExch(flag, 1);                                      // table full (cannot happen at >= 2n slots): be safe
+}
+
+// send[b] = sum over the rank's own super tiles a (ascending) of the j-side row part_j[a][b], for every body b of
+// the system: what this rank contributes to b's acceleration as the "other" body of its pairs.
+template <typename R>
+__global__ __launch_bounds__(kBlock) void reduce_j_kernel(const typename SymVec<R>::type *__restrict__ part_j,
+                                                          typename SymVec<R>::type *__restrict__ send, int n_total, int S,
+                                                          int T, int n_pad, int own_tile0, int tiles_own) {
+  using V = typename SymVec<R>::type;
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= n_total) return;
+  const int tb = b / S;
+  R sx = 0, sy = 0, sz = 0;
+  for (int al = 0; al < tiles_own; ++al) {
+    if (!sym_assigned(own_tile0 + al, tb, T)) continue;        // that workgroup does not exist: row never written
+    const V p = part_j[(size_t)al * n_pad + b];
+    sx += p.x; sy += p.y; sz += p.z;
+  }
+  V o; o.x = sx; o.y = sy; o.z = sz; o.w = 0;
+  send[b] = o;
+}
+
+template <typename T> __device__ __forceinline__ T mul_add_sep2(T a, T b, T c) {
+#pragma clang fp contract(off)
+  const T p = a * b;
+  return c + p;
+}
+
+// Own body bl: acc = its i-side rows (partners in ring order from its own super tile) + the rows received from
+// every rank (rank order); then optionally the reference's update (OctreeSearch.cpp:29-30), multiply and add kept apart.
+template <typename R>
+__global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::type *__restrict__ posm,
+                                                            typename SymVec<R>::type *__restrict__ vel,
+                                                            typename SymVec<R>::type *__restrict__ acc,
+                                                            const typename SymVec<R>::type *__restrict__ part_i,
+                                                            const typename SymVec<R>::type *__restrict__ recv, int i_begin,
+                                                            int i_count, int S, int T, int n_own_pad, int n_src, R dt,
+                                                            int integrate) {
+  using V = typename SymVec<R>::type;
+  const int bl = blockIdx.x * kBlock + threadIdx.x;
+  if (bl >= i_count) return;
+  const int s = (i_begin + bl) / S;
+  R ax = 0, ay = 0, az = 0;
+  for (int d = 0; d < T; ++d) {
+    const int sj = (s + d) % T;
+    if (!sym_assigned(s, sj, T)) continue;
+    const V p = part_i[(size_t)sj * n_own_pad + bl];
+    ax += p.x; ay += p.y; az += p.z;
+  }
+  for (int q = 0; q < n_src; ++q) {
+    const V p = recv[(size_t)q * i_count + bl];
+    ax += p.x; ay += p.y; az += p.z;
+  }
+  V ao; ao.x = ax; ao.y = ay; ao.z = az; ao.w = 0;
+  acc[bl] = ao;
+  if (integrate) {
+    V v = vel[bl], x = posm[i_begin + bl];
+    v.x = mul_add_sep2(dt, ax, v.x); v.y = mul_add_sep2(dt, ay, v.y); v.z = mul_add_sep2(dt, az, v.z);
+    x.x = mul_add_sep2(dt, v.x, x.x); x.y = mul_add_sep2(dt, v.y, x.y); x.z = mul_add_sep2(dt, v.z, x.z);
+    vel[bl] = v;
+    posm[i_begin + bl] = x;
+  }
+}
+
+
+}  // namespace
+}  // namespace nbody

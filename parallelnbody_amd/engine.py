@@ -145,14 +145,14 @@ class NBodyEngine:
         self._check(self._L.nbody_bind_exchange(self._h, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr())))
 
     def exchange_read_send(self):
-        out = np.empty((self.n_total, 4), np.float32)
-        self._check(self._L.nbody_exchange_read_send(self._h, _fp(out)))
+        out = np.empty((self.n_total, 4), np.float64 if self.f64 else np.float32)
+        self._check(self._L.nbody_exchange_read_send(self._h, out.ctypes.data))
         return out
 
     def exchange_write_recv(self, recv):
-        r = np.ascontiguousarray(recv, np.float32)
+        r = np.ascontiguousarray(recv, np.float64 if self.f64 else np.float32)
         assert r.shape == (self.exchange_ranks() * self.i_count, 4)
-        self._check(self._L.nbody_exchange_write_recv(self._h, _fp(r)))
+        self._check(self._L.nbody_exchange_write_recv(self._h, r.ctypes.data))
 
     def set_theta(self, theta):
         """Barnes-Hut opening angle (0 = exact all-pairs; the reference ships 1.0, OctreeSearch.cpp:85)."""

@@ -72,8 +72,8 @@ class ShardedSimulation:
         self.ex_ranks = self.engine.exchange_ranks() if hasattr(self.engine, "exchange_ranks") else 0
         if self.ex_ranks:
             assert self.ex_ranks == world_size
-            self.ex_send = torch.zeros((self.n_total, 4), dtype=torch.float32, device=self.device)
-            self.ex_recv = torch.zeros((world_size * self.i_count, 4), dtype=torch.float32, device=self.device)
+            self.ex_send = torch.zeros((self.n_total, 4), dtype=tdt, device=self.device)
+            self.ex_recv = torch.zeros((world_size * self.i_count, 4), dtype=tdt, device=self.device)
             self.engine.bind_exchange(self.ex_send, self.ex_recv)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)   # the zero-fills above ran on torch's default stream, the engine will not
@@ -96,7 +96,7 @@ class ShardedSimulation:
         scratch = torch.zeros((self.world_size * 8, 4), dtype=self.posm.dtype, device=self.device)
         dist.all_gather_into_tensor(scratch, scratch[self.rank * 8:(self.rank + 1) * 8], group=self.group)
         if self.ex_ranks:
-            a = torch.zeros((self.world_size * 8, 4), dtype=torch.float32, device=self.device)
+            a = torch.zeros((self.world_size * 8, 4), dtype=self.posm.dtype, device=self.device)
             dist.all_to_all_single(torch.empty_like(a), a, group=self.group)
         t = torch.zeros(2, dtype=torch.float64, device=self.device)
         dist.all_reduce(t, group=self.group)

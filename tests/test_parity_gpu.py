@@ -437,7 +437,7 @@ def test_symmetric_sharded_ranks_emulated_on_one_gpu(nb, oracle, ranks):
 
 
 def test_symmetric_refuses_what_it_cannot_do(nb):
-    for kw in (dict(precision="f64"), dict(precision="f32_kahan"), dict(i_begin=0, i_count=500), dict(zero_mode=1)):
+    for kw in (dict(precision="f64", eps=1.0), dict(precision="f32_kahan"), dict(i_begin=0, i_count=500), dict(zero_mode=1)):
         with pytest.raises(nb.NBodyError) as e:
             nb.NBodyEngine(1024, algorithm=2, i_per_thread=2, **kw)
         assert e.value.code == nb._lib.ERR_UNSUPPORTED
@@ -551,3 +551,52 @@ def test_three_body_figure_eight_on_the_device(nb):
         e.set_state(posm, vel)
         e.step(float(dt), n_steps)
         assert np.abs(e.positions() - FIG8_X).max() < 5e-2
+
+
+# ---- fp64 symmetric kernel (kernels_sym64.hip) -----------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1024, 2000, 5000])
+def test_symmetric_fp64_matches_the_fp64_oracle(nb, oracle, n):
+    rng = np.random.default_rng(n)
+    posm = np.concatenate([rng.normal(0, 300, (n, 3)), rng.uniform(1, 100, (n, 1))], 1)
+    posm[0, :3] = 0.0                                     # a body on the origin, like body 0 of the shipped scene
+    vel = rng.normal(0, 10, (n, 4)); vel[:, 3] = 0
+    with nb.NBodyEngine(n, precision="f64", algorithm=2) as e:
+        assert e.launch_config()["algorithm"] == "symmetric"
+        e.set_state(posm, vel)
+        e.step(0.01, 1)
+        p, v, a = e.state(np.float64)
+    ref = oracle.forces_direct_f64(posm[:, :3], posm[:, 3])
+    assert rel_err(a[:, :3], ref).max() < 1e-12
+    p1, v1 = oracle.kick_drift_f64(posm[:, :3], vel[:, :3], a[:, :3], float(np.float32(0.01)))
+    np.testing.assert_array_equal(p[:, :3], p1)
+    np.testing.assert_array_equal(v[:, :3], v1)
+    # coincident bodies take the guarded twin launch
+    posm[7, :3] = posm[n - 5, :3]
+    with nb.NBodyEngine(n, precision="f64", algorithm=2) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations(np.float64)
+    assert np.all(np.isfinite(a))
+    assert rel_err(a, oracle.forces_direct_f64(posm[:, :3], posm[:, 3])).max() < 1e-12
+
+
+def test_symmetric_fp64_sharded_emulated(nb, oracle):
+    n, ranks = 8192, 4
+    posm, vel = nb.ic_plummer(n, seed=12)
+    posm = posm.astype(np.float64); vel = vel.astype(np.float64)
+    ic = n // ranks
+    engs = [nb.NBodyEngine(n, i_begin=r * ic, i_count=ic, precision="f64", algorithm=2) for r in range(ranks)]
+    try:
+        for e in engs:
+            e.set_state(posm, vel)
+            e.step_begin()
+        sends = [e.exchange_read_send() for e in engs]
+        for r, e in enumerate(engs):
+            e.exchange_write_recv(np.concatenate([sd[r * ic:(r + 1) * ic] for sd in sends]))
+            e.step_end(0.0)
+        a = np.concatenate([e.state(np.float64)[2] for e in engs])
+    finally:
+        for e in engs:
+            e.close()
+    assert rel_err(a[:, :3], oracle.forces_direct_f64(posm[:, :3], posm[:, 3])).max() < 1e-12
