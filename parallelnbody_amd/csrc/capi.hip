@@ -136,6 +136,21 @@ void choose_algorithm(nbody_ctx *c) {
   // overrides the target (tuning only).
   long long target = 16384;
   if (const char *t = getenv("NBODY_SYM_WORKGROUPS")) { const long long v = atoll(t); if (v > 0) target = v; }
+  // The partial rows take about 2 * T * n_total elements (T super tiles ~ sqrt(2 * target)): keep them under a third
+  // of the free device memory by lowering the workgroup target for very large systems.
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+      const double elem = (p.precision == NBODY_PREC_F64) ? 32.0 : 16.0;
+      const double ranks = (double)p.n_total / (double)p.i_count;
+      while (target > 64) {
+        const double T = std::sqrt(2.0 * (double)target * (ranks > 1.0 ? ranks : 1.0));
+        const double bytes = 2.0 * T * (double)p.n_total * elem / (ranks > 1.0 ? ranks : 1.0);
+        if (bytes <= (double)free_b / 3.0) break;
+        target /= 2;
+      }
+    }
+  }
   if (p.i_count == p.n_total) {
     // T(T+1)/2 >= target
     long long T = 2;
