@@ -43,7 +43,6 @@ struct nbody_ctx {
   int j_split = 1, j_chunk = 0, ipt = 1, tile = 256;
   int wave = 0;                // small-N wave kernel: register pairs per wave (0 = tile kernels)
   bool have_state = false;
-  bool forces_valid = false;   // acc holds forces of the current positions
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
   // symmetric algorithm (kernels_sym.hip)
   bool sym = false;
@@ -353,7 +352,6 @@ int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
   HIP_TRY(c, hipMemsetAsync(c->acc, 0, (size_t)ic * c->elem, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_state = true;
-  c->forces_valid = false;
   c->floor_eps2 = -1.0;
   c->steps_done = 0;
   if (c->bh) HIP_TRY(c, nbody::bh_reset_root(c->bh, c->stream));   // a new scene: root centre starts at zero again
@@ -577,7 +575,6 @@ int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
   if (acc)  { if (c->own_acc) (void)hipFree(c->acc);   c->acc = acc;   c->own_acc = false; }
   // the caller vouches that bound buffers hold a valid state
   if (posm && vel) c->have_state = true;
-  c->forces_valid = false;
   c->floor_eps2 = -1.0;
   return NBODY_OK;
 }
@@ -660,7 +657,6 @@ int nbody_step_end(nbody_ctx *c, float dt) {
   HIP_TRY(c, hipSetDevice(c->p.device));
   c->step_open = false;
   if ((rc = run_update(c, dt > 0.0f ? dt : 0.0f))) return rc;
-  c->forces_valid = !(dt > 0.0f);
   if (dt > 0.0f) c->steps_done += 1;
   return NBODY_OK;
 }
@@ -709,7 +705,6 @@ int nbody_compute_forces(nbody_ctx *c) {
   HIP_TRY(c, hipSetDevice(c->p.device));
   if ((rc = run_forces(c))) return rc;
   if ((rc = run_update(c, 0.0f))) return rc;
-  c->forces_valid = true;
   return NBODY_OK;
 }
 
@@ -726,7 +721,6 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
     if ((rc = run_forces(c))) return rc;
     if ((rc = run_update(c, dt))) return rc;
   }
-  if (nsteps > 0) c->forces_valid = false;   // acc belongs to the pre-update positions, as in the reference
   c->steps_done += nsteps;
   return NBODY_OK;
 }
@@ -880,7 +874,6 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
   HIP_TRY(c, hipMemcpy(c->posm, posm.data(), posm.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size(), hipMemcpyHostToDevice));
-  c->have_state = true; c->forces_valid = false; c->floor_eps2 = -1.0; c->step_open = false;
   c->steps_done = h.steps_done;
   if (steps_done) *steps_done = h.steps_done;
   return NBODY_OK;
@@ -892,7 +885,6 @@ int nbody_set_theta(nbody_ctx *c, float theta) {
   if (theta > 0.0f && (c->p.precision != NBODY_PREC_F32 || c->p.i_count != c->p.n_total))
     return fail(c, NBODY_ERR_UNSUPPORTED, "nbody_set_theta: Barnes-Hut needs an fp32 context that owns all bodies");
   c->theta = theta;
-  c->forces_valid = false;
   return NBODY_OK;
 }
 
