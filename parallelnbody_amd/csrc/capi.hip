@@ -874,6 +874,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
   HIP_TRY(c, hipMemcpy(c->posm, posm.data(), posm.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size(), hipMemcpyHostToDevice));
+  c->have_state = true; c->floor_eps2 = -1.0; c->step_open = false;
   c->steps_done = h.steps_done;
   if (steps_done) *steps_done = h.steps_done;
   return NBODY_OK;
