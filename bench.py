@@ -149,9 +149,9 @@ def main():
             "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64",
                          "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, world)) if args.precision == "f32" else None,
-                         "kernel": "forces_sym_pk_kernel (+reduce_j_kernel)" if cfg["algorithm"] == "symmetric"
-                         else ("forces_tile_pk_kernel" if (args.precision != "f64" and cfg["i_per_thread"] % 2 == 0)
-                               else "forces_tile_kernel"), "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
+                         "kernel": cfg["kernel"] + (" (+dup_detect_kernel, reduce_j_kernel)"
+                                                    if cfg["algorithm"] == "symmetric" else ""),
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
                          "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs,
                          "update_kernel_avg_ms": u_ms / max(u_n, 1)},
         }

@@ -235,6 +235,9 @@ NBODY_API int nbody_kernel_time_reset(nbody_ctx *ctx);
 NBODY_API int nbody_get_launch_config(nbody_ctx *ctx, int32_t *tile, int32_t *i_per_thread, int32_t *j_split,
                                       int32_t *blocks, int32_t *threads);
 
+/* Name of the force kernel this context launches (for logs and profiles). */
+NBODY_API const char *nbody_force_kernel_name(const nbody_ctx *ctx);
+
 /* NBODY_ALGO_* actually in use, and (symmetric only) the super-tile size in bodies. */
 NBODY_API int nbody_get_algorithm(nbody_ctx *ctx, int32_t *algorithm, int32_t *super_tile);
 

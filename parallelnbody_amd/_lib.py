@@ -115,6 +115,7 @@ def lib():
     sig("nbody_kernel_time", c_int, vp, c_i32, dp, ctypes.POINTER(c_i64))
     sig("nbody_kernel_time_reset", c_int, vp)
     sig("nbody_get_launch_config", c_int, vp, *([ctypes.POINTER(c_i32)] * 5))
+    sig("nbody_force_kernel_name", ctypes.c_char_p, vp)
     sig("nbody_get_algorithm", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32))
     sig("nbody_save_checkpoint", c_int, vp, ctypes.c_char_p)
     sig("nbody_load_checkpoint", c_int, vp, ctypes.c_char_p, ctypes.POINTER(c_i64))

@@ -940,6 +940,16 @@ int nbody_kernel_time_reset(nbody_ctx *c) {
   return NBODY_OK;
 }
 
+const char *nbody_force_kernel_name(const nbody_ctx *c) {
+  if (!c) return "";
+  if (c->theta > 0.0f) return "bh_walk_kernel (+ tree build)";
+  if (c->sym) return c->p.precision == NBODY_PREC_F64 ? "forces_sym_f64_kernel" : "forces_sym_pk_kernel";
+  if (c->wave) return "forces_wave_pk_kernel";
+  if (c->p.precision != NBODY_PREC_F64 && c->ipt % 2 == 0 && (c->p.eps > 0.0 || c->p.zero_mode != NBODY_ZERO_SELECT))
+    return "forces_tile_pk_kernel";
+  return "forces_tile_kernel";
+}
+
 int nbody_get_algorithm(nbody_ctx *c, int32_t *algorithm, int32_t *super_tile) {
   if (!c) return NBODY_ERR_INVALID;
   if (algorithm) *algorithm = c->sym ? NBODY_ALGO_SYMMETRIC : NBODY_ALGO_TILED;

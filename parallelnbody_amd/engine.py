@@ -257,4 +257,5 @@ class NBodyEngine:
         self._check(self._L.nbody_get_algorithm(self._h, ctypes.byref(algo), ctypes.byref(st)))
         cfg["algorithm"] = {_lib.ALGO_TILED: "tiled", _lib.ALGO_SYMMETRIC: "symmetric"}[algo.value]
         cfg["super_tile"] = st.value
+        cfg["kernel"] = self._L.nbody_force_kernel_name(self._h).decode()
         return cfg
