@@ -84,10 +84,18 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: parallelnbody_amd has no CPU path")
+    # NBODY_DIST_BACKEND=gloo: rehearsal of this very code path on a box with fewer GPUs than ranks (ranks then share
+    # devices and the collectives go over gloo on device tensors; RCCL refuses two ranks on one device)
+    backend = os.environ.get("NBODY_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = torch.distributed
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n = args.n
     posm, vel = nb.ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
