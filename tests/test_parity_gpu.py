@@ -600,3 +600,23 @@ def test_symmetric_fp64_sharded_emulated(nb, oracle):
         for e in engs:
             e.close()
     assert rel_err(a[:, :3], oracle.forces_direct_f64(posm[:, :3], posm[:, 3])).max() < 1e-12
+
+
+def test_headline_config_runs_the_symmetric_kernel_at_speed(nb):
+    # BASELINE metric configuration: N = 2^20 fp32.  A guard against silently falling back to a slower path: the default
+    # context must select the symmetric packed kernel and sustain well over the round-1 one-sided rate (3.9e12).
+    n = 1 << 20
+    posm, vel = nb.ic_plummer(n, seed=20261003)
+    with nb.NBodyEngine(n, time_kernels=True) as e:
+        cfg = e.launch_config()
+        assert cfg["algorithm"] == "symmetric" and cfg["kernel"] == "forces_sym_pk_kernel" and cfg["i_per_thread"] == 4
+        e.set_state(posm, vel)
+        e.compute_forces(); e.synchronize(); e.kernel_time_reset()
+        e.compute_forces(); e.compute_forces()
+        ms, k = e.kernel_time(nb.KERNEL_FORCES)
+        a = e.accelerations()
+    rate = float(n) * n / (ms / k * 1e-3)
+    assert rate > 4.8e12, rate
+    assert np.all(np.isfinite(a))
+    f = (a.astype(np.float64) * posm[:, 3:4]).sum(0)             # Newton's third law at full size
+    assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * posm[:, 3]).sum() < 1e-6
