@@ -451,6 +451,8 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
                 e == hipSuccess ? "count = 0" : hipGetErrorString(e));
   if (p.device < 0 || p.device >= ndev)
     return fail(nullptr, NBODY_ERR_NO_DEVICE, "nbody_create: device %d not in [0,%d)", p.device, ndev);
+  if ((e = hipSetDevice(p.device)) != hipSuccess)      // before anything that asks the device questions (free memory)
+    return fail(nullptr, NBODY_ERR_HIP, "nbody_create: hipSetDevice(%d): %s", p.device, hipGetErrorString(e));
 
   nbody_ctx *c = new (std::nothrow) nbody_ctx();
   if (!c) return fail(nullptr, NBODY_ERR_NOMEM, "nbody_create: out of host memory");
