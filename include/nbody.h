@@ -61,7 +61,7 @@ enum {
 /*
  * Force algorithm.  Both evaluate the same pair law over all pairs; they differ in summation order only.
  * TILED: every ordered pair (i, j), one-sided (kernels.hip).  SYMMETRIC: every unordered pair once, feeding
- * both bodies (kernels_sym.hip, kernels_sym64.hip): fp32 non-Kahan and unsoftened fp64 contexts; when the bodies are sharded the slices must be equal
+ * both bodies (kernels_sym.hip, kernels_sym64.hip): fp32 non-Kahan and fp64 contexts; when the bodies are sharded the slices must be equal
  * and the host drives nbody_step_begin / all-to-all / nbody_step_end.  The per-body summation order then depends
  * on the number of ranks (TILED's does not).
  * AUTO picks SYMMETRIC where it applies and n_total >= 32768, else TILED.

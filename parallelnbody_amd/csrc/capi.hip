@@ -125,7 +125,7 @@ void choose_algorithm(nbody_ctx *c) {
   c->sym = false;
   if (p.algorithm == NBODY_ALGO_TILED) return;
   const bool f32ok = p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4);
-  const bool f64ok = p.precision == NBODY_PREC_F64 && p.eps == 0.0 && p.zero_mode == NBODY_ZERO_EXACT;   // kernels_sym64.hip
+  const bool f64ok = p.precision == NBODY_PREC_F64 && (p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT);   // kernels_sym64.hip
   if (!f32ok && !f64ok) return;
   if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < 32768) return;
   const int BI = f64ok ? 512 : 256 * c->ipt;
@@ -465,7 +465,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
                 "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (no Kahan, i_per_thread 2 or 4, zero_mode != SELECT) or "
-                "unsoftened fp64 and, when sharded, equal slices that are a multiple of 256*i_per_thread (fp64: 512) bodies");
+                "fp64 and, when sharded, equal slices that are a multiple of 256*i_per_thread (fp64: 512) bodies");
   }
 
   auto bail = [&](hipError_t he, const char *what) {

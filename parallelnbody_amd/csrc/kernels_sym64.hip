@@ -27,13 +27,15 @@ __device__ __forceinline__ double rsq64(double x) {
 }
 
 // BARE: symmetric tiles without a d == 0 guard (see kernels_sym.hip); the one-sided diagonal tiles always select.
-template <bool BARE>
+// SOFT: eps2 > 0 is added to every r^2, which keeps rsq finite everywhere: no guard at all (BARE is then irrelevant).
+template <bool BARE, bool SOFT>
 __global__ __launch_bounds__(kBlock) void forces_sym_f64_kernel(const double4 *__restrict__ posm,
                                                                 double4 *__restrict__ part_i,
                                                                 double4 *__restrict__ part_j,
                                                                 const int2 *__restrict__ pairs, int n_total, int S,
                                                                 int n_pad, int own_tile0, int n_own_pad, double gscale,
-                                                                const int *__restrict__ dup_flag, int run_if_dup) {
+                                                                double eps2, const int *__restrict__ dup_flag,
+                                                                int run_if_dup) {
   if (dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
   constexpr int IPT = 2;
   constexpr int BI = kBlock * IPT;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void forces_sym_f64_kernel(const double4 *_
   const int own0 = own_tile0 * S;
   double4 *__restrict__ Pi = part_i + (size_t)sj * n_own_pad;
   double4 *__restrict__ Pj = part_j + (size_t)(si - own_tile0) * n_pad;
-  double4 pad; pad.x = pad.y = pad.z = BARE ? kPadFar64 : 0.0; pad.w = 0.0;
+  double4 pad; pad.x = pad.y = pad.z = (BARE && !SOFT) ? kPadFar64 : 0.0; pad.w = 0.0;
   double4 zero4; zero4.x = zero4.y = zero4.z = zero4.w = 0.0;
 
   for (int e = t; e < S; e += kBlock) Pj[(size_t)sj * S + e] = zero4;   // element e: always thread e % 256
@@ -99,9 +101,9 @@ __global__ __launch_bounds__(kBlock) void forces_sym_f64_kernel(const double4 *_
 #pragma unroll
             for (int q = 0; q < IPT; ++q) {
               const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
-              const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+              const double r2 = SOFT ? fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2))) : fma(dx, dx, fma(dy, dy, dz * dz));
               double rinv = rsq64(r2);
-              if (!BARE) rinv = (r2 > 0.0) ? rinv : 0.0;
+              if (!BARE && !SOFT) rinv = (r2 > 0.0) ? rinv : 0.0;
               const double u3 = (rinv * rinv) * rinv;
               const double s_i = u3 * pj.w, s_j = u3 * nmi[q];
               ax[q] = fma(s_i, dx, ax[q]); ay[q] = fma(s_i, dy, ay[q]); az[q] = fma(s_i, dz, az[q]);
@@ -119,9 +121,9 @@ __global__ __launch_bounds__(kBlock) void forces_sym_f64_kernel(const double4 *_
 #pragma unroll
             for (int q = 0; q < IPT; ++q) {
               const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
-              const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+              const double r2 = SOFT ? fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2))) : fma(dx, dx, fma(dy, dy, dz * dz));
               double rinv = rsq64(r2);
-              rinv = (r2 > 0.0) ? rinv : 0.0;                     // self pairs live here
+              if (!SOFT) rinv = (r2 > 0.0) ? rinv : 0.0;          // self pairs live here
               const double s_i = ((rinv * rinv) * rinv) * pj.w;
               ax[q] = fma(s_i, dx, ax[q]); ay[q] = fma(s_i, dy, ay[q]); az[q] = fma(s_i, dz, az[q]);
             }
@@ -154,22 +156,23 @@ hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
   if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0 || L.tiles_own <= 0) return hipErrorInvalidValue;
   if (L.S % (kBlock * 2) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
   dim3 grid(L.n_pairs), block(kBlock);
-#define NBODY_SYM64(BARE, FLAG, RUNIF)                                                                            \
-  hipLaunchKernelGGL((forces_sym_f64_kernel<BARE>), grid, block, 0, s, (const double4 *)L.posm, (double4 *)L.part_i, \
-                     (double4 *)L.part_j, (const int2 *)L.pairs, L.n_total, L.S, L.n_pad, L.own_tile0,           \
-                     L.tiles_own * L.S, L.G, (const int *)(FLAG), RUNIF)
-  if (L.eps2 > 0.0) return hipErrorInvalidValue;       // softened fp64 stays on the one-sided kernel
-  if (L.dup_table != nullptr) {
+#define NBODY_SYM64(BARE, SOFT, FLAG, RUNIF)                                                                      \
+  hipLaunchKernelGGL((forces_sym_f64_kernel<BARE, SOFT>), grid, block, 0, s, (const double4 *)L.posm,              \
+                     (double4 *)L.part_i, (double4 *)L.part_j, (const int2 *)L.pairs, L.n_total, L.S, L.n_pad,     \
+                     L.own_tile0, L.tiles_own * L.S, L.G, L.eps2, (const int *)(FLAG), RUNIF)
+  if (L.eps2 > 0.0) {
+    NBODY_SYM64(true, true, nullptr, 0);
+  } else if (L.dup_table != nullptr) {
     hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 8, s);
     if (e0 != hipSuccess) return e0;
     int *flag = (int *)((unsigned long long *)L.dup_table + L.dup_slots);
     hipLaunchKernelGGL(dup_detect_kernel<double>, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s,
                        (const double4 *)L.posm, L.n_total, (unsigned long long *)L.dup_table,
                        (unsigned int)(L.dup_slots - 1), flag);
-    NBODY_SYM64(true, flag, 0);
-    NBODY_SYM64(false, flag, 1);
+    NBODY_SYM64(true, false, flag, 0);
+    NBODY_SYM64(false, false, flag, 1);
   } else {
-    NBODY_SYM64(false, nullptr, 0);
+    NBODY_SYM64(false, false, nullptr, 0);
   }
 #undef NBODY_SYM64
   hipError_t e = hipGetLastError();

@@ -437,7 +437,7 @@ def test_symmetric_sharded_ranks_emulated_on_one_gpu(nb, oracle, ranks):
 
 
 def test_symmetric_refuses_what_it_cannot_do(nb):
-    for kw in (dict(precision="f64", eps=1.0), dict(precision="f32_kahan"), dict(i_begin=0, i_count=500), dict(zero_mode=1)):
+    for kw in (dict(precision="f64", zero_mode=2), dict(precision="f32_kahan"), dict(i_begin=0, i_count=500), dict(zero_mode=1)):
         with pytest.raises(nb.NBodyError) as e:
             nb.NBodyEngine(1024, algorithm=2, i_per_thread=2, **kw)
         assert e.value.code == nb._lib.ERR_UNSUPPORTED
@@ -620,3 +620,14 @@ def test_headline_config_runs_the_symmetric_kernel_at_speed(nb):
     assert np.all(np.isfinite(a))
     f = (a.astype(np.float64) * posm[:, 3:4]).sum(0)             # Newton's third law at full size
     assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * posm[:, 3]).sum() < 1e-6
+
+
+def test_symmetric_fp64_softened(nb, oracle):
+    n, eps = 3000, 2.5
+    rng = np.random.default_rng(3)
+    posm = np.concatenate([rng.normal(0, 100, (n, 3)), rng.uniform(1, 10, (n, 1))], 1)
+    with nb.NBodyEngine(n, precision="f64", algorithm=2, eps=eps) as e:
+        e.set_state(posm, np.zeros((n, 4)))
+        e.compute_forces()
+        a = e.accelerations(np.float64)
+    assert rel_err(a, oracle.forces_direct_f64(posm[:, :3], posm[:, 3], eps=eps)).max() < 1e-12
