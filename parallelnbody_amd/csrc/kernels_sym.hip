@@ -219,7 +219,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   } else if (L.dup_table != nullptr) {
     // exact d == 0 semantics at the unguarded kernel's price: look for coincident bodies first, then launch both
     // forms — exactly one of them runs (the other returns at its first instruction)
-    hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 8, s);   // table + flag word behind it
+    hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 8, s);   // slots + {flag, near-origin count}
     if (e0 != hipSuccess) return e0;
     int *flag = (int *)((unsigned long long *)L.dup_table + L.dup_slots);
     hipLaunchKernelGGL(dup_detect_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.posm,

@@ -59,6 +59,11 @@ __global__ __launch_bounds__(kBlock) void dup_detect_kernel(const typename SymVe
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const auto p = posm[i];
+  // d == 0 also happens for DIFFERENT positions when every squared difference underflows: only possible if both
+  // bodies sit within ~1e-12 of the origin on all three axes (elsewhere two distinct floats differ by >= 1 ulp of
+  // their own size).  Two or more bodies in that cube -> guarded kernel.  flag[1] counts them.
+  if (fabs((double)p.x) < 1e-12 && fabs((double)p.y) < 1e-12 && fabs((double)p.z) < 1e-12)
+    if (atomicAdd(flag + 1, 1) >= 1) atomicExch(flag, 1);
   // coord_bits adds +0 first: -0 and +0 are the same position
   unsigned long long h = coord_bits(p.x) * 0x9E3779B97F4A7C15ull;
   h = (h ^ (h >> 29)) + coord_bits(p.y) * 0xBF58476D1CE4E5B9ull;

@@ -631,3 +631,20 @@ def test_symmetric_fp64_softened(nb, oracle):
         e.compute_forces()
         a = e.accelerations(np.float64)
     assert rel_err(a, oracle.forces_direct_f64(posm[:, :3], posm[:, 3], eps=eps)).max() < 1e-12
+
+
+def test_symmetric_underflowing_separations_near_the_origin(nb, oracle):
+    # two DIFFERENT positions whose squared distance underflows to 0 in fp32 (only possible within ~1e-12 of the
+    # origin): the reference's d == 0 test skips the pair; the unguarded symmetric tiles must not be used then
+    n = 2000
+    g = _golden("refbox_n2000_seed1")
+    posm = g["posm"].copy()
+    posm[0, :3] = 0.0
+    posm[1500, :3] = (1e-30, 0.0, -1e-31)
+    with nb.NBodyEngine(n, algorithm=2, i_per_thread=2) as e:
+        e.set_state(posm, g["vel"])
+        e.compute_forces()
+        a = e.accelerations()
+    assert np.all(np.isfinite(a))
+    ref = oracle.forces_direct_f32(posm[:, :3], posm[:, 3])
+    assert rel_err(a, ref).max() < TOL_ACC
