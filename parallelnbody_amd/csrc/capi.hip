@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/nbody.h"
@@ -35,6 +36,7 @@ struct nbody_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   void *posm = nullptr, *vel = nullptr, *acc = nullptr, *accp = nullptr;
+  void *posm_alt = nullptr;    // small systems: second position buffer of the one-launch step (swapped with posm)
   bool own_posm = false, own_vel = false, own_acc = false;
   void *d_stage = nullptr, *h_stage = nullptr;   // renderer hand-off staging (device repack target, pinned mirror)
   size_t stage_bytes = 0;
@@ -112,7 +114,7 @@ void choose_geometry(nbody_ctx *c) {
   c->wave = 0;
   if (p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && p.algorithm != NBODY_ALGO_SYMMETRIC &&
       p.tile == 0 && p.i_per_thread == 0 && p.j_split == 0 && p.n_total < 8192) {
-    c->wave = (p.i_count >= 4096) ? 2 : 1;
+    c->wave = 1;
     c->j_split = 1;
     c->j_chunk = (p.n_total + c->tile - 1) / c->tile * c->tile;
   }
@@ -532,6 +534,7 @@ void nbody_destroy(nbody_ctx *c) {
     for (EventPair &e : t.pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   }
   if (c->own_posm && c->posm) (void)hipFree(c->posm);
+  if (c->posm_alt) (void)hipFree(c->posm_alt);
   if (c->own_vel && c->vel) (void)hipFree(c->vel);
   if (c->own_acc && c->acc) (void)hipFree(c->acc);
   if (c->accp) (void)hipFree(c->accp);
@@ -719,7 +722,22 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
   if (nsteps > 1 && c->p.i_count != c->p.n_total)
     return fail(c, NBODY_ERR_STATE, "nbody_step: a sharded context advances one step per call (all-gather NBODY_BUF_POSM in between)");
   HIP_TRY(c, hipSetDevice(c->p.device));
+  // small single-context fp32 systems: forces + update in ONE launch per step, ping-ponging the position buffer
+  const bool one_launch = c->wave != 0 && c->theta == 0.0f && c->own_posm && c->p.i_count == c->p.n_total &&
+                          c->p.precision == NBODY_PREC_F32;
+  if (one_launch && !c->posm_alt) HIP_TRY(c, hipMalloc(&c->posm_alt, (size_t)c->p.n_total * c->elem));
   for (int s = 0; s < nsteps; ++s) {
+    if (one_launch) {
+      if ((rc = ensure_floor(c))) return rc;
+      EventPair ev;
+      const bool timed = c->p.time_kernels != 0;
+      if (timed && (rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev))) return rc;
+      HIP_TRY(c, nbody::launch_step_small(make_launch(c), c->posm_alt, c->vel, c->acc, dt, c->stream));
+      if (timed && (rc = timer_end(c, NBODY_KERNEL_FORCES, ev))) return rc;
+      if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024 && (rc = timer_drain(c, NBODY_KERNEL_FORCES))) return rc;
+      std::swap(c->posm, c->posm_alt);
+      continue;
+    }
     if ((rc = run_forces(c))) return rc;
     if ((rc = run_update(c, dt))) return rc;
   }
@@ -946,7 +964,7 @@ const char *nbody_force_kernel_name(const nbody_ctx *c) {
   if (!c) return "";
   if (c->theta > 0.0f) return "bh_walk_kernel (+ tree build)";
   if (c->sym) return c->p.precision == NBODY_PREC_F64 ? "forces_sym_f64_kernel" : "forces_sym_pk_kernel";
-  if (c->wave) return "forces_wave_pk_kernel";
+  if (c->wave) return "small_pk_kernel";
   if (c->p.precision != NBODY_PREC_F64 && c->ipt % 2 == 0 && (c->p.eps > 0.0 || c->p.zero_mode != NBODY_ZERO_SELECT))
     return "forces_tile_pk_kernel";
   return "forces_tile_kernel";

@@ -19,11 +19,14 @@ struct ForceLaunch {
   double eps2;          // > 0: softened (also the "floor" mode); == 0: exact d == 0 skip
   int zero_mode;        // for eps2 == 0: 1 = clamp trick (default), 2 = compare+select (A/B only)
   int precision;        // NBODY_PREC_*
-  int wave;             // 0: tile kernels; 1 or 2: small-N wave-per-bodies kernel with that many register pairs (j_split must be 1)
+  int wave;             // 0: tile kernels; != 0: small-N kernel, one workgroup per pair of bodies (j_split must be 1)
 };
 
 // All-pairs force partials.  Returns hipSuccess or the launch error.
 hipError_t launch_forces(const ForceLaunch &L, hipStream_t s);
+// Small single-context fp32 systems (L.wave != 0): the whole Tick body — forces, v += dt*a, x += dt*v — in one launch.
+// New positions go to posm_out (a second buffer: the old one is still being read); the caller swaps them afterwards.
+hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s);
 // Blocks / threads launch_forces will use for L (for logs).
 void forces_geometry(const ForceLaunch &L, int *blocks, int *threads);
 

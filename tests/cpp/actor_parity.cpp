@@ -58,7 +58,7 @@ int main() {
     oracle_tick_aos_f32(2000, ref.data(), 0.01f, -1.0f, 1.0e4, 0, com, &size);
     const double e = max_rel_acc(actor.Particles, ref, nullptr);
     CHECK(actor.LastStatus == NBODY_OK && e < (frame == 0 ? 2e-5 : 1e-3), "theta=0 frame %d: rel acc err %.3e", frame, e);
-    CHECK(actor.Size == size, "ComputeCubeSize %g vs %g", actor.Size, size);
+    CHECK(std::fabs(actor.Size - size) <= 1e-6f * size, "ComputeCubeSize %g vs %g", actor.Size, size);   // positions agree to ~1e-9 after a frame
     if (frame == 0) std::printf("theta = 0   frame 0: max rel acceleration error vs oracle %.3e\n", e);
   }
   CHECK(flushes == 3 && points == 3 * 2000 && boxes == 0, "draw calls: flush %d points %d boxes %d", flushes, points, boxes);

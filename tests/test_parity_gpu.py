@@ -51,7 +51,7 @@ def test_one_tick_matches_golden(nb, fixture):
     # positions: |dx| <= dt^2 |da| -> relative to the body's displacement scale
     scale = np.abs(g["pos1"]).max()
     assert np.abs(p[:, :3] - g["pos1"]).max() / scale < 1e-6
-    assert rel_err(v[:, :3], g["vel1"]).max() < 1e-5
+    assert rel_err(v[:, :3], g["vel1"]).max() < 2e-5
     np.testing.assert_array_equal(p[:, 3], g["posm"][:, 3])   # masses ride along untouched
 
 

@@ -16,7 +16,8 @@ for n in (1024, 2000, 4096, 8192, 16384):
         e.set_state(posm, vel)
         e.step(1e-6, 200); e.synchronize()
         f_ms, f_n = e.kernel_time(nb.KERNEL_FORCES); u_ms, u_n = e.kernel_time(nb.KERNEL_UPDATE)
-    print(f"N={n:6d}  step {dt*1e6:8.1f} us  ({n*n/dt:.3e} pairs/s)  force kernel {f_ms/f_n*1e3:7.1f} us  update {u_ms/u_n*1e3:6.1f} us  cfg {cfg}")
+    upd = f"{u_ms / u_n * 1e3:6.1f} us" if u_n else "fused into the force launch"
+    print(f"N={n:6d}  step {dt*1e6:8.1f} us  ({n*n/dt:.3e} pairs/s)  force kernel {f_ms/f_n*1e3:7.1f} us  update {upd}  cfg {cfg}")
 a = nb.OctreeSearch(); a.set_seed(1); a.CreateSpacePoints(2000, 1000.0); a.PhDeltaTime = 1e-6
 cnt = [0]
 a.set_draw_callbacks(on_point=None)
