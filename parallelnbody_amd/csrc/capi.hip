@@ -126,7 +126,8 @@ void choose_algorithm(nbody_ctx *c) {
   const nbody_params &p = c->p;
   c->sym = false;
   if (p.algorithm == NBODY_ALGO_TILED) return;
-  const bool f32ok = p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4);
+  const bool f32ok = (p.precision == NBODY_PREC_F32 || p.precision == NBODY_PREC_F32_KAHAN) &&
+                     p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4);
   const bool f64ok = p.precision == NBODY_PREC_F64 && (p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT);   // kernels_sym64.hip
   if (!f32ok && !f64ok) return;
   if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < 32768) return;
@@ -195,7 +196,8 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   L.n_total = c->p.n_total; L.S = c->sym_S; L.T = c->sym_T; L.n_pad = c->sym_pad;
   L.own_tile0 = c->sym_own_tile0; L.tiles_own = c->sym_tiles_own; L.n_src = c->sym_nsrc;
   L.np = c->p.precision == NBODY_PREC_F64 ? 1 : c->ipt / 2;
-  L.precision = c->p.precision;
+  L.precision = c->p.precision == NBODY_PREC_F64 ? NBODY_PREC_F64 : NBODY_PREC_F32;
+  L.kahan = c->p.precision == NBODY_PREC_F32_KAHAN ? 1 : 0;
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps;
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
   L.dup_table = c->sym_dup_table; L.dup_slots = c->sym_dup_slots;
@@ -466,7 +468,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if (p.algorithm == NBODY_ALGO_SYMMETRIC && !c->sym) {
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
-                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (no Kahan, i_per_thread 2 or 4, zero_mode != SELECT) or "
+                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (i_per_thread 2 or 4, zero_mode != SELECT) or "
                 "fp64 and, when sharded, equal slices that are a multiple of 256*i_per_thread (fp64: 512) bodies");
   }
 

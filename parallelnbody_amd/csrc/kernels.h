@@ -52,6 +52,7 @@ struct SymLaunch {
   int n_src;            // ranks sharing the bodies
   int np;               // register pairs of i-bodies per lane (1 or 2); fp64: 1 (two bodies per lane)
   int precision;        // NBODY_PREC_F32 (float4 rows) or NBODY_PREC_F64 (double4 rows)
+  int kahan;            // fp32 only: Kahan-compensated accumulation everywhere
   double G;
   double eps2;          // > 0 softened / floor; == 0 exact d == 0 skip (clamp form)
   void *dup_table;      // eps2 == 0 only: dup_slots x 8-byte hash slots + one flag word; nullptr = always run the guarded kernel

@@ -46,8 +46,11 @@ constexpr float kPadFar = 1.0e18f;
 // bodies on one point.  dup_detect_kernel looks for that before every pass and leaves the verdict in *dup_flag:
 // the BARE launch runs only when there is none (run_if_dup == 0), the guarded launch only when there is one
 // (run_if_dup == 1); dup_flag == nullptr runs unconditionally.  Results are those of the guarded kernel either way.
-template <int NP, int ZMODE, bool BARE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NBODY_SYM_WAVES, NBODY_SYM_WAVES)))
+// KAHAN: every accumulation is compensated — the i-side register pairs (Acc3pk<true>), the running j-side sums (the
+// compensation term travels with the sum: six DPP moves per step instead of three) and the diagonal one-sided tiles.
+template <int NP, int ZMODE, bool BARE, bool KAHAN>
+__global__ __launch_bounds__(kBlock)
+__attribute__((amdgpu_waves_per_eu((KAHAN && NP == 2) ? 3 : NBODY_SYM_WAVES, (KAHAN && NP == 2) ? 3 : NBODY_SYM_WAVES)))
 void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ part_i, float4 *__restrict__ part_j,
                           const int2 *__restrict__ pairs, int n_total, int S, int n_pad, int own_tile0, int n_own_pad,
                           float gscale, float zp, const int *__restrict__ dup_flag, int run_if_dup) {
@@ -80,7 +83,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
     const int i0 = si * S + b * BI;
     if (i0 >= n_total) break;
     f2 xi[NP], yi[NP], zi[NP], nmi[NP];
-    Acc3pk<false> a[NP];
+    Acc3pk<KAHAN> a[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int ia = i0 + t + (2 * p) * kBlock, ib = ia + kBlock;
@@ -120,7 +123,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
           // At step k lane l meets body (l - k) & 63 of the subtile; that body's running j-side sum sits in the
           // same lane and moves on with it (wave_ror:1: lane l+1 takes lane l's value) after every step.
           const float4 *sp = &sh_pos[buf][sub][lane + 64];
-          float jx = 0.f, jy = 0.f, jz = 0.f;
+          float jx = 0.f, jy = 0.f, jz = 0.f, kx = 0.f, ky = 0.f, kz = 0.f;   // k*: Kahan compensation of j*
 #pragma unroll 4
           for (int k = 0; k < 64; ++k) {
             const float4 pj = sp[-k];
@@ -155,10 +158,22 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
             for (int p = 0; p < NP; ++p) {
               a[p].add(w[p], dx[p], dy[p], dz[p]);
               // both of the lane's bodies act on the same j: scalar FMAs straight into its running sum
-              jx = fmaf(u[p].x, dx[p].y, jx); jy = fmaf(u[p].x, dy[p].y, jy); jz = fmaf(u[p].x, dz[p].y, jz);
-              jx = fmaf(u[p].y, dx[p].x, jx); jy = fmaf(u[p].y, dy[p].x, jy); jz = fmaf(u[p].y, dz[p].x, jz);
+              if (KAHAN) {
+                auto kadd = [](float &sum, float &c, float sc, float d) {
+                  const float yv = fmaf(sc, d, -c);
+                  const float tt = sum + yv;
+                  c = (tt - sum) - yv;
+                  sum = tt;
+                };
+                kadd(jx, kx, u[p].x, dx[p].y); kadd(jy, ky, u[p].x, dy[p].y); kadd(jz, kz, u[p].x, dz[p].y);
+                kadd(jx, kx, u[p].y, dx[p].x); kadd(jy, ky, u[p].y, dy[p].x); kadd(jz, kz, u[p].y, dz[p].x);
+              } else {
+                jx = fmaf(u[p].x, dx[p].y, jx); jy = fmaf(u[p].x, dy[p].y, jy); jz = fmaf(u[p].x, dz[p].y, jz);
+                jx = fmaf(u[p].y, dx[p].x, jx); jy = fmaf(u[p].y, dy[p].x, jy); jz = fmaf(u[p].y, dz[p].x, jz);
+              }
             }
             jx = wave_ror1(jx); jy = wave_ror1(jy); jz = wave_ror1(jz);      // the sum moves on with its body
+            if (KAHAN) { kx = wave_ror1(kx); ky = wave_ror1(ky); kz = wave_ror1(kz); }
           }
           // after 64 moves lane l holds the sum of body l of the subtile again
           sh_acc[wave][0][sub * 64 + lane] = jx; sh_acc[wave][1][sub * 64 + lane] = jy; sh_acc[wave][2][sub * 64 + lane] = jz;
@@ -172,7 +187,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
             float4 pj[JB];
 #pragma unroll
             for (int g = 0; g < JB; ++g) pj[g] = sh_pos[buf][q][k + g];
-            pair_group_pk<NP, JB, ZMODE, false>(xi, yi, zi, pj, zp2, one2, a);
+            pair_group_pk<NP, JB, ZMODE, KAHAN>(xi, yi, zi, pj, zp2, one2, a);
           }
         }
       }
@@ -209,10 +224,12 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0 || L.tiles_own <= 0) return hipErrorInvalidValue;
   if (L.S % (kBlock * 2 * L.np) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
   dim3 grid(L.n_pairs), block(kBlock);
-#define NBODY_SYM(NPV, ZM, BARE, ZP, FLAG, RUNIF)                                                                \
-  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE>), grid, block, 0, s, (const float4 *)L.posm,          \
+#define NBODY_SYM_K(NPV, ZM, BARE, KH, ZP, FLAG, RUNIF)                                                          \
+  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH>), grid, block, 0, s, (const float4 *)L.posm,      \
                      (float4 *)L.part_i, (float4 *)L.part_j, (const int2 *)L.pairs, L.n_total, L.S, L.n_pad,    \
                      L.own_tile0, L.tiles_own * L.S, (float)L.G, (float)(ZP), (const int *)(FLAG), RUNIF)
+#define NBODY_SYM(NPV, ZM, BARE, ZP, FLAG, RUNIF)                                                                \
+  do { if (L.kahan) NBODY_SYM_K(NPV, ZM, BARE, true, ZP, FLAG, RUNIF); else NBODY_SYM_K(NPV, ZM, BARE, false, ZP, FLAG, RUNIF); } while (0)
   if (L.np != 1 && L.np != 2) return hipErrorInvalidValue;
   if (L.eps2 > 0.0) {
     if (L.np == 1) NBODY_SYM(1, Z_SOFT, false, L.eps2, nullptr, 0); else NBODY_SYM(2, Z_SOFT, false, L.eps2, nullptr, 0);
@@ -230,9 +247,14 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
     if (L.np == 1) NBODY_SYM(1, Z_CLAMP, false, -0x1p126, nullptr, 0); else NBODY_SYM(2, Z_CLAMP, false, -0x1p126, nullptr, 0);
   }
 #undef NBODY_SYM
+#undef NBODY_SYM_K
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reduce_j_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.part_j,
+  if (L.kahan)
+    hipLaunchKernelGGL((reduce_j_kernel<float, true>), dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s,
+                       (const float4 *)L.part_j, (float4 *)L.send, L.n_total, L.S, L.T, L.n_pad, L.own_tile0, L.tiles_own);
+  else
+  hipLaunchKernelGGL((reduce_j_kernel<float, false>), dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.part_j,
                      (float4 *)L.send, L.n_total, L.S, L.T, L.n_pad, L.own_tile0, L.tiles_own);
   return hipGetLastError();
 }
@@ -242,11 +264,15 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
   if (i_count <= 0) return hipErrorInvalidValue;
   dim3 grid((i_count + kBlock - 1) / kBlock), block(kBlock);
   if (L.precision == NBODY_PREC_F64)
-    hipLaunchKernelGGL(update_sym_kernel<double>, grid, block, 0, s, (double4 *)posm, (double4 *)vel, (double4 *)acc,
+    hipLaunchKernelGGL((update_sym_kernel<double, false>), grid, block, 0, s, (double4 *)posm, (double4 *)vel, (double4 *)acc,
                        (const double4 *)L.part_i, (const double4 *)L.recv, i_begin, i_count, L.S, L.T, L.tiles_own * L.S,
                        L.n_src, (double)dt, dt > 0.0f ? 1 : 0);
+  else if (L.kahan)
+    hipLaunchKernelGGL((update_sym_kernel<float, true>), grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
+                       (const float4 *)L.part_i, (const float4 *)L.recv, i_begin, i_count, L.S, L.T, L.tiles_own * L.S,
+                       L.n_src, dt, dt > 0.0f ? 1 : 0);
   else
-    hipLaunchKernelGGL(update_sym_kernel<float>, grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
+    hipLaunchKernelGGL((update_sym_kernel<float, false>), grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
                        (const float4 *)L.part_i, (const float4 *)L.recv, i_begin, i_count, L.S, L.T, L.tiles_own * L.S,
                        L.n_src, dt, dt > 0.0f ? 1 : 0);
   return hipGetLastError();

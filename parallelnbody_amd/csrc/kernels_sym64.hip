@@ -177,7 +177,7 @@ hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
 #undef NBODY_SYM64
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reduce_j_kernel<double>, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s,
+  hipLaunchKernelGGL((reduce_j_kernel<double, false>), dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s,
                      (const double4 *)L.part_j, (double4 *)L.send, L.n_total, L.S, L.T, L.n_pad, L.own_tile0, L.tiles_own);
   return hipGetLastError();
 }

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(kBlock) void dup_detect_kernel(const typename SymVe
 
 // send[b] = sum over the rank's own super tiles a (ascending) of the j-side row part_j[a][b], for every body b of
 // the system: what this rank contributes to b's acceleration as the "other" body of its pairs.
-template <typename R>
+// KAHAN: rows are added with a compensated sum.
+template <typename R, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void reduce_j_kernel(const typename SymVec<R>::type *__restrict__ part_j,
                                                           typename SymVec<R>::type *__restrict__ send, int n_total, int S,
                                                           int T, int n_pad, int own_tile0, int tiles_own) {
@@ -90,11 +91,15 @@ __global__ __launch_bounds__(kBlock) void reduce_j_kernel(const typename SymVec<
   const int b = blockIdx.x * kBlock + threadIdx.x;
   if (b >= n_total) return;
   const int tb = b / S;
-  R sx = 0, sy = 0, sz = 0;
+  R sx = 0, sy = 0, sz = 0, cx = 0, cy = 0, cz = 0;
+  auto add = [](R &sum, R &c, R v) {
+    if (KAHAN) { const R yv = v - c; const R tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
+    else sum += v;
+  };
   for (int al = 0; al < tiles_own; ++al) {
     if (!sym_assigned(own_tile0 + al, tb, T)) continue;        // that workgroup does not exist: row never written
     const V p = part_j[(size_t)al * n_pad + b];
-    sx += p.x; sy += p.y; sz += p.z;
+    add(sx, cx, p.x); add(sy, cy, p.y); add(sz, cz, p.z);
   }
   V o; o.x = sx; o.y = sy; o.z = sz; o.w = 0;
   send[b] = o;
@@ -108,7 +113,7 @@ template <typename T> __device__ __forceinline__ T mul_add_sep2(T a, T b, T c) {
 
 // Own body bl: acc = its i-side rows (partners in ring order from its own super tile) + the rows received from
 // every rank (rank order); then optionally the reference's update (OctreeSearch.cpp:29-30), multiply and add kept apart.
-template <typename R>
+template <typename R, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::type *__restrict__ posm,
                                                             typename SymVec<R>::type *__restrict__ vel,
                                                             typename SymVec<R>::type *__restrict__ acc,
@@ -120,16 +125,20 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
   const int bl = blockIdx.x * kBlock + threadIdx.x;
   if (bl >= i_count) return;
   const int s = (i_begin + bl) / S;
-  R ax = 0, ay = 0, az = 0;
+  R ax = 0, ay = 0, az = 0, cx = 0, cy = 0, cz = 0;
+  auto add = [](R &sum, R &c, R v) {
+    if (KAHAN) { const R yv = v - c; const R tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
+    else sum += v;
+  };
   for (int d = 0; d < T; ++d) {
     const int sj = (s + d) % T;
     if (!sym_assigned(s, sj, T)) continue;
     const V p = part_i[(size_t)sj * n_own_pad + bl];
-    ax += p.x; ay += p.y; az += p.z;
+    add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
   }
   for (int q = 0; q < n_src; ++q) {
     const V p = recv[(size_t)q * i_count + bl];
-    ax += p.x; ay += p.y; az += p.z;
+    add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
   }
   V ao; ao.x = ax; ao.y = ay; ao.z = az; ao.w = 0;
   acc[bl] = ao;

@@ -437,7 +437,7 @@ def test_symmetric_sharded_ranks_emulated_on_one_gpu(nb, oracle, ranks):
 
 
 def test_symmetric_refuses_what_it_cannot_do(nb):
-    for kw in (dict(precision="f64", zero_mode=2), dict(precision="f32_kahan"), dict(i_begin=0, i_count=500), dict(zero_mode=1)):
+    for kw in (dict(precision="f64", zero_mode=2), dict(i_begin=0, i_count=500), dict(zero_mode=1)):
         with pytest.raises(nb.NBodyError) as e:
             nb.NBodyEngine(1024, algorithm=2, i_per_thread=2, **kw)
         assert e.value.code == nb._lib.ERR_UNSUPPORTED
@@ -648,3 +648,30 @@ def test_symmetric_underflowing_separations_near_the_origin(nb, oracle):
     assert np.all(np.isfinite(a))
     ref = oracle.forces_direct_f32(posm[:, :3], posm[:, 3])
     assert rel_err(a, ref).max() < TOL_ACC
+
+
+@pytest.mark.parametrize("ipt", [2, 4])
+def test_symmetric_kahan(nb, oracle, ipt):
+    # Kahan-compensated accumulation in the symmetric kernel: closer to fp64 than the plain symmetric sum, same parity
+    g = _golden("refbox_n2000_seed1")
+    errs = {}
+    for prec in ("f32", "f32_kahan"):
+        with nb.NBodyEngine(2000, precision=prec, algorithm=2, i_per_thread=ipt) as e:
+            assert e.launch_config()["algorithm"] == "symmetric"
+            e.set_state(g["posm"], g["vel"])
+            e.compute_forces()
+            errs[prec] = rel_err(e.accelerations(), g["acc_f64"])
+    assert errs["f32_kahan"].max() < TOL_ACC
+    assert errs["f32_kahan"].mean() <= errs["f32"].mean() * 1.05
+    n = 40000
+    rng = np.random.default_rng(1)
+    posm = np.concatenate([rng.normal(0, 300, (n, 3)), rng.uniform(1, 100, (n, 1))], 1).astype(np.float32)
+    with nb.NBodyEngine(n, precision="f32_kahan") as e:
+        assert e.launch_config()["algorithm"] == "symmetric"
+        e.set_state(posm, np.zeros((n, 4), np.float32))
+        e.compute_forces()
+        a = e.accelerations()
+    p64 = posm.astype(np.float64)
+    for i in rng.choice(n, 16, replace=False):
+        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1)
+        assert rel_err(a[i:i + 1], ref).max() < 2e-6      # compensated: an order of magnitude inside the plain tolerance
