@@ -43,6 +43,7 @@ struct nbody_ctx {
   void *scratch = nullptr;     // 64 B device scratch (bounds bits, energy sums)
   void *h_scratch = nullptr;   // pinned mirror
   int j_split = 1, j_chunk = 0, ipt = 1, tile = 256;
+  int sym_np = 1;                        // register pairs per lane of the symmetric kernel
   int wave = 0;                // small-N wave kernel: register pairs per wave (0 = tile kernels)
   bool have_state = false;
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
@@ -89,7 +90,7 @@ int floor_pow2(long long v) { int p = 1; while ((long long)p * 2 <= v) p *= 2; r
 void choose_geometry(nbody_ctx *c) {
   const nbody_params &p = c->p;
   c->tile = p.tile > 0 ? p.tile : 256;
-  if (p.i_per_thread > 0) c->ipt = p.i_per_thread;
+  if (p.i_per_thread > 0) c->ipt = p.i_per_thread > 4 ? 4 : p.i_per_thread;   // 8 exists for the symmetric kernel only
   else c->ipt = (p.precision == NBODY_PREC_F64) ? 1 : (p.n_total >= 65536 ? 4 : (p.n_total >= 8192 ? 2 : 1));
   int js;
   if (p.j_split > 0) {
@@ -128,10 +129,18 @@ void choose_algorithm(nbody_ctx *c) {
   if (p.algorithm == NBODY_ALGO_TILED) return;
   const bool f32ok = (p.precision == NBODY_PREC_F32 || p.precision == NBODY_PREC_F32_KAHAN) &&
                      p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4);
+  // bodies per lane of the symmetric kernel: 8 (four register pairs) amortises the travelling sums' dpp moves best
+  // (tools/microbench6.hip); the Kahan form has no registers for it, small systems not enough workgroups.
+  int sym_ipt = c->ipt;
+  if (p.precision == NBODY_PREC_F32 && (p.i_per_thread == 8 || (p.i_per_thread == 0 && p.n_total >= 262144)) &&
+      (p.i_count == p.n_total || p.i_count % 2048 == 0))
+    sym_ipt = 8;
+  if (p.i_per_thread == 8 && sym_ipt != 8) return;
   const bool f64ok = p.precision == NBODY_PREC_F64 && (p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT);   // kernels_sym64.hip
   if (!f32ok && !f64ok) return;
   if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < 32768) return;
-  const int BI = f64ok ? 512 : 256 * c->ipt;
+  const int BI = f64ok ? 512 : 256 * sym_ipt;
+  c->sym_np = f64ok ? 1 : sym_ipt / 2;
   // Workgroups per rank = (super tiles owned) x (about half of all super tiles).  The chip holds 1024 of them at a time
   // (4 per CU), so a rank needs many thousands for the tail to vanish: aim at >= 16384
   // (measured at N = 2^20: 2080 workgroups 200.8 ms, 8256 191.5, 14706 190.6, 32896 189.1).  NBODY_SYM_WORKGROUPS
@@ -195,7 +204,7 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   L.pairs = c->sym_pair_tab; L.n_pairs = c->sym_pairs;
   L.n_total = c->p.n_total; L.S = c->sym_S; L.T = c->sym_T; L.n_pad = c->sym_pad;
   L.own_tile0 = c->sym_own_tile0; L.tiles_own = c->sym_tiles_own; L.n_src = c->sym_nsrc;
-  L.np = c->p.precision == NBODY_PREC_F64 ? 1 : c->ipt / 2;
+  L.np = c->sym_np;
   L.precision = c->p.precision == NBODY_PREC_F64 ? NBODY_PREC_F64 : NBODY_PREC_F32;
   L.kahan = c->p.precision == NBODY_PREC_F32_KAHAN ? 1 : 0;
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps;
@@ -442,8 +451,10 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if (!(p.theta >= 0.0f)) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: theta must be >= 0");
   if (p.tile != 0 && p.tile != 64 && p.tile != 128 && p.tile != 256 && p.tile != 512)
     return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: tile must be 64, 128, 256 or 512");
-  if (p.i_per_thread != 0 && p.i_per_thread != 1 && p.i_per_thread != 2 && p.i_per_thread != 4)
-    return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: i_per_thread must be 1, 2 or 4");
+  if (p.i_per_thread != 0 && p.i_per_thread != 1 && p.i_per_thread != 2 && p.i_per_thread != 4 && p.i_per_thread != 8)
+    return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: i_per_thread must be 1, 2, 4 or 8");
+  if (p.i_per_thread == 8 && (p.algorithm == NBODY_ALGO_TILED || p.precision != NBODY_PREC_F32))
+    return fail(nullptr, NBODY_ERR_UNSUPPORTED, "nbody_create: i_per_thread 8 exists for the fp32 symmetric kernel only");
   if (p.j_split < 0) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: j_split must be >= 0");
   if (p.zero_mode < 0 || p.zero_mode > NBODY_ZERO_FLOOR) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown zero_mode %d", p.zero_mode);
   if (p.algorithm < 0 || p.algorithm > NBODY_ALGO_SYMMETRIC) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown algorithm %d", p.algorithm);
@@ -465,10 +476,16 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   c->elem = (p.precision == NBODY_PREC_F64) ? 32 : 16;
   choose_geometry(c);
   choose_algorithm(c);
+  if (p.i_per_thread == 8 && !(c->sym && c->sym_np == 4)) {
+    delete c;
+    return fail(nullptr, NBODY_ERR_UNSUPPORTED,
+                "nbody_create: i_per_thread 8 needs the fp32 symmetric kernel (N >= 32768 or NBODY_ALGO_SYMMETRIC; "
+                "sharded slices in multiples of 2048 bodies)");
+  }
   if (p.algorithm == NBODY_ALGO_SYMMETRIC && !c->sym) {
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
-                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (i_per_thread 2 or 4, zero_mode != SELECT) or "
+                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (i_per_thread 2, 4 or 8, zero_mode != SELECT) or "
                 "fp64 and, when sharded, equal slices that are a multiple of 256*i_per_thread (fp64: 512) bodies");
   }
 
@@ -986,7 +1003,7 @@ int nbody_get_launch_config(nbody_ctx *c, int32_t *tile, int32_t *i_per_thread, 
   nbody::forces_geometry(make_launch(c), &b, &t);
   if (c->sym) { b = c->sym_pairs; t = 256; }
   if (tile) *tile = c->tile;
-  if (i_per_thread) *i_per_thread = c->ipt;
+  if (i_per_thread) *i_per_thread = (c->sym && c->p.precision != NBODY_PREC_F64) ? 2 * c->sym_np : c->ipt;
   if (j_split) *j_split = c->j_split;
   if (blocks) *blocks = b;
   if (threads) *threads = t;

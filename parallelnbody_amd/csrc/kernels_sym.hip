@@ -25,6 +25,8 @@
 //     No global atomics: bit-reproducible for a given number of ranks.
 #include "kernels.h"
 
+#include <cstdlib>
+
 #include "../../include/nbody.h"
 #include "pk_common.h"
 #include "sym_common.h"
@@ -35,6 +37,12 @@ namespace {
 
 #ifndef NBODY_SYM_WAVES
 #define NBODY_SYM_WAVES 4
+#endif
+#ifndef NBODY_SYM_UNROLL
+#define NBODY_SYM_UNROLL 4
+#endif
+#ifndef NBODY_SYM_UNROLL4
+#define NBODY_SYM_UNROLL4 2   // four register pairs per lane: 128 VGPRs hold two steps in flight, not four
 #endif
 // Zero-mass padding bodies sit far outside any scene when the symmetric tiles run without a d == 0 guard (BARE):
 // a pad at the origin would coincide with a body at the origin — the reference pins body 0 there — and 0 * inf = NaN.
@@ -48,7 +56,13 @@ constexpr float kPadFar = 1.0e18f;
 // (run_if_dup == 1); dup_flag == nullptr runs unconditionally.  Results are those of the guarded kernel either way.
 // KAHAN: every accumulation is compensated — the i-side register pairs (Acc3pk<true>), the running j-side sums (the
 // compensation term travels with the sum: six DPP moves per step instead of three) and the diagonal one-sided tiles.
-template <int NP, int ZMODE, bool BARE, bool KAHAN>
+//
+// The j side of the plain (not KAHAN) kernel: each travelling sum is a register PAIR (lo: what the lanes' first bodies
+// contributed, hi: the second bodies'), fed by three v_pk_fma_f32 per register pair and folded once, after the 64 steps.
+// Six v_mov_b32_dpp per step instead of three, but no scalar FMAs: a wave64 v_fmac_f32 only issues at its 2-cycle rate
+// next to another wave's 2-cycle op — in this packed instruction stream it costs ~3.5 cycles, twelve of them per step
+// more than six packed FMAs (tools/microbench6.hip; profiles/r01_microbench_sym_inner_loop.txt).
+template <int NP, int ZMODE, bool BARE, bool KAHAN, bool JPK>
 __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu((KAHAN && NP == 2) ? 3 : NBODY_SYM_WAVES, (KAHAN && NP == 2) ? 3 : NBODY_SYM_WAVES)))
 void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ part_i, float4 *__restrict__ part_j,
@@ -58,6 +72,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
   const float4 pad = BARE ? make_float4(kPadFar, kPadFar, kPadFar, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int IPT = 2 * NP;
   constexpr int BI = kBlock * IPT;
+  constexpr int kUnroll = (NP == 4) ? NBODY_SYM_UNROLL4 : NBODY_SYM_UNROLL;
   __shared__ float4 sh_pos[2][4][128];   // double-buffered subtile images, doubled: entries l and l+64 hold body l
   __shared__ float sh_acc[4][3][kJT];    // per-WAVE j-side sums of the tile (private: no ordering between waves needed)
 
@@ -124,7 +139,9 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
           // same lane and moves on with it (wave_ror:1: lane l+1 takes lane l's value) after every step.
           const float4 *sp = &sh_pos[buf][sub][lane + 64];
           float jx = 0.f, jy = 0.f, jz = 0.f, kx = 0.f, ky = 0.f, kz = 0.f;   // k*: Kahan compensation of j*
-#pragma unroll 4
+          f2 qx = splat2(0.f), qy = splat2(0.f), qz = splat2(0.f);            // JPK: (lo, hi) partial sums
+          f2 cx = splat2(0.f), cy = splat2(0.f), cz = splat2(0.f);            // JPK && KAHAN: their compensation
+#pragma unroll kUnroll
           for (int k = 0; k < 64; ++k) {
             const float4 pj = sp[-k];
             f2 dx[NP], dy[NP], dz[NP], w[NP], u[NP];
@@ -151,14 +168,17 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
             for (int p = 0; p < NP; ++p) {
               w[p] = u[p] * u[p];
               w[p] = w[p] * u[p];                                     // |d|^-3 (ordinary ops between rsq and the asm)
-              u[p] = mul_swap(w[p], nmi[p]);                          // -G m_i |d|^-3, halves swapped
+              if (JPK) u[p] = w[p] * nmi[p];                          // -G m_i |d|^-3
+              else     u[p] = mul_swap(w[p], nmi[p]);                 // the same with its halves swapped
               w[p] = mul_bcast_hi(w[p], f2{pj.z, pj.w});              //  G m_j |d|^-3
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
               a[p].add(w[p], dx[p], dy[p], dz[p]);
-              // both of the lane's bodies act on the same j: scalar FMAs straight into its running sum
-              if (KAHAN) {
+              if (KAHAN && JPK) {
+                Acc3pk<true>::kadd(qx, cx, u[p], dx[p]); Acc3pk<true>::kadd(qy, cy, u[p], dy[p]);
+                Acc3pk<true>::kadd(qz, cz, u[p], dz[p]);
+              } else if (KAHAN) {
                 auto kadd = [](float &sum, float &c, float sc, float d) {
                   const float yv = fmaf(sc, d, -c);
                   const float tt = sum + yv;
@@ -167,20 +187,35 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
                 };
                 kadd(jx, kx, u[p].x, dx[p].y); kadd(jy, ky, u[p].x, dy[p].y); kadd(jz, kz, u[p].x, dz[p].y);
                 kadd(jx, kx, u[p].y, dx[p].x); kadd(jy, ky, u[p].y, dy[p].x); kadd(jz, kz, u[p].y, dz[p].x);
+              } else if (JPK) {
+                qx = fma2(u[p], dx[p], qx); qy = fma2(u[p], dy[p], qy); qz = fma2(u[p], dz[p], qz);
               } else {
+                // both of the lane's bodies act on the same j: scalar FMAs straight into its running sum
                 jx = fmaf(u[p].x, dx[p].y, jx); jy = fmaf(u[p].x, dy[p].y, jy); jz = fmaf(u[p].x, dz[p].y, jz);
                 jx = fmaf(u[p].y, dx[p].x, jx); jy = fmaf(u[p].y, dy[p].x, jy); jz = fmaf(u[p].y, dz[p].x, jz);
               }
             }
-            jx = wave_ror1(jx); jy = wave_ror1(jy); jz = wave_ror1(jz);      // the sum moves on with its body
-            if (KAHAN) { kx = wave_ror1(kx); ky = wave_ror1(ky); kz = wave_ror1(kz); }
+            if (!JPK) {                                                      // the sum moves on with its body
+              jx = wave_ror1(jx); jy = wave_ror1(jy); jz = wave_ror1(jz);
+              if (KAHAN) { kx = wave_ror1(kx); ky = wave_ror1(ky); kz = wave_ror1(kz); }
+            } else {
+              qx = f2{wave_ror1(qx.x), wave_ror1(qx.y)}; qy = f2{wave_ror1(qy.x), wave_ror1(qy.y)};
+              qz = f2{wave_ror1(qz.x), wave_ror1(qz.y)};
+              if (KAHAN) {
+                cx = f2{wave_ror1(cx.x), wave_ror1(cx.y)}; cy = f2{wave_ror1(cy.x), wave_ror1(cy.y)};
+                cz = f2{wave_ror1(cz.x), wave_ror1(cz.y)};
+              }
+            }
           }
+          if (JPK && KAHAN) {   // fold: (lo - its compensation) + (hi - its compensation)
+            jx = (qx.x - cx.x) + (qx.y - cx.y); jy = (qy.x - cy.x) + (qy.y - cy.y); jz = (qz.x - cz.x) + (qz.y - cz.y);
+          } else if (JPK) { jx = qx.x + qx.y; jy = qy.x + qy.y; jz = qz.x + qz.y; }
           // after 64 moves lane l holds the sum of body l of the subtile again
           sh_acc[wave][0][sub * 64 + lane] = jx; sh_acc[wave][1][sub * 64 + lane] = jy; sh_acc[wave][2][sub * 64 + lane] = jz;
         }
       } else {
         // one-sided step on the tiles that overlap the i-set: every ordered pair, self pairs dropped by ZMODE
-        constexpr int JB = (NP == 1) ? 4 : 2;
+        constexpr int JB = (NP == 1) ? 4 : (NP == 2 ? 2 : 1);
         for (int q = 0; q < 4; ++q) {
 #pragma unroll 2
           for (int k = 0; k < 64; k += JB) {
@@ -224,15 +259,30 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0 || L.tiles_own <= 0) return hipErrorInvalidValue;
   if (L.S % (kBlock * 2 * L.np) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
   dim3 grid(L.n_pairs), block(kBlock);
-#define NBODY_SYM_K(NPV, ZM, BARE, KH, ZP, FLAG, RUNIF)                                                          \
-  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH>), grid, block, 0, s, (const float4 *)L.posm,      \
+#define NBODY_SYM_K(NPV, ZM, BARE, KH, JP, ZP, FLAG, RUNIF)                                                        \
+  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, JP>), grid, block, 0, s, (const float4 *)L.posm,  \
                      (float4 *)L.part_i, (float4 *)L.part_j, (const int2 *)L.pairs, L.n_total, L.S, L.n_pad,    \
                      L.own_tile0, L.tiles_own * L.S, (float)L.G, (float)(ZP), (const int *)(FLAG), RUNIF)
 #define NBODY_SYM(NPV, ZM, BARE, ZP, FLAG, RUNIF)                                                                \
-  do { if (L.kahan) NBODY_SYM_K(NPV, ZM, BARE, true, ZP, FLAG, RUNIF); else NBODY_SYM_K(NPV, ZM, BARE, false, ZP, FLAG, RUNIF); } while (0)
-  if (L.np != 1 && L.np != 2) return hipErrorInvalidValue;
+  do {                                                                                                           \
+    if (L.kahan && jpk) NBODY_SYM_K(NPV, ZM, BARE, true, true, ZP, FLAG, RUNIF);                                 \
+    else if (L.kahan) NBODY_SYM_K(NPV, ZM, BARE, true, false, ZP, FLAG, RUNIF);                                  \
+    else if (jpk) NBODY_SYM_K(NPV, ZM, BARE, false, true, ZP, FLAG, RUNIF);                                      \
+    else NBODY_SYM_K(NPV, ZM, BARE, false, false, ZP, FLAG, RUNIF);                                              \
+  } while (0)
+#define NBODY_SYM_NP(ZM, BARE, ZP, FLAG, RUNIF)                                                                  \
+  do {                                                                                                           \
+    if (L.np == 1) NBODY_SYM(1, ZM, BARE, ZP, FLAG, RUNIF);                                                      \
+    else if (L.np == 2) NBODY_SYM(2, ZM, BARE, ZP, FLAG, RUNIF);                                                 \
+    else NBODY_SYM_K(4, ZM, BARE, false, true, ZP, FLAG, RUNIF);                                                 \
+  } while (0)
+  if (L.np != 1 && L.np != 2 && L.np != 4) return hipErrorInvalidValue;
+  if (L.np == 4 && L.kahan) return hipErrorInvalidValue;
+  // j-side sums: packed pairs (JPK) unless NBODY_SYM_JSCALAR=1 asks for the scalar form (A/B measurements, np <= 2)
+  static const bool jscalar = [] { const char *e = getenv("NBODY_SYM_JSCALAR"); return e && e[0] == '1'; }();
+  const bool jpk = !jscalar;
   if (L.eps2 > 0.0) {
-    if (L.np == 1) NBODY_SYM(1, Z_SOFT, false, L.eps2, nullptr, 0); else NBODY_SYM(2, Z_SOFT, false, L.eps2, nullptr, 0);
+    NBODY_SYM_NP(Z_SOFT, false, L.eps2, nullptr, 0);
   } else if (L.dup_table != nullptr) {
     // exact d == 0 semantics at the unguarded kernel's price: look for coincident bodies first, then launch both
     // forms — exactly one of them runs (the other returns at its first instruction)
@@ -241,11 +291,12 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
     int *flag = (int *)((unsigned long long *)L.dup_table + L.dup_slots);
     hipLaunchKernelGGL(dup_detect_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s, (const float4 *)L.posm,
                        L.n_total, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag);
-    if (L.np == 1) { NBODY_SYM(1, Z_CLAMP, true, -0x1p126, flag, 0); NBODY_SYM(1, Z_CLAMP, false, -0x1p126, flag, 1); }
-    else           { NBODY_SYM(2, Z_CLAMP, true, -0x1p126, flag, 0); NBODY_SYM(2, Z_CLAMP, false, -0x1p126, flag, 1); }
+    NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, 0);
+    NBODY_SYM_NP(Z_CLAMP, false, -0x1p126, flag, 1);
   } else {
-    if (L.np == 1) NBODY_SYM(1, Z_CLAMP, false, -0x1p126, nullptr, 0); else NBODY_SYM(2, Z_CLAMP, false, -0x1p126, nullptr, 0);
+    NBODY_SYM_NP(Z_CLAMP, false, -0x1p126, nullptr, 0);
   }
+#undef NBODY_SYM_NP
 #undef NBODY_SYM
 #undef NBODY_SYM_K
   hipError_t e = hipGetLastError();
