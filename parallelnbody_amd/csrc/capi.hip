@@ -139,8 +139,14 @@ void choose_algorithm(nbody_ctx *c) {
   const bool f64ok = p.precision == NBODY_PREC_F64 && (p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT);   // kernels_sym64.hip
   if (!f32ok && !f64ok) return;
   if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < 32768) return;
-  const int BI = f64ok ? 512 : 256 * sym_ipt;
-  c->sym_np = f64ok ? 1 : sym_ipt / 2;
+  // fp64: two bodies per lane, four (at 2 waves/SIMD — fp64 ops are 4-cycle, two waves saturate the SIMD) for large systems
+  int sym_ipt64 = 2;
+  if (f64ok && (p.i_per_thread == 4 || (p.i_per_thread == 0 && p.n_total >= 131072)) &&
+      (p.i_count == p.n_total || p.i_count % 1024 == 0))
+    sym_ipt64 = 4;
+
+  const int BI = f64ok ? 256 * sym_ipt64 : 256 * sym_ipt;
+  c->sym_np = f64ok ? sym_ipt64 / 2 : sym_ipt / 2;
   // Workgroups per rank = (super tiles owned) x (about half of all super tiles).  The chip holds 1024 of them at a time
   // (4 per CU), so a rank needs many thousands for the tail to vanish: aim at >= 16384
   // (measured at N = 2^20: 2080 workgroups 200.8 ms, 8256 191.5, 14706 190.6, 32896 189.1).  NBODY_SYM_WORKGROUPS
@@ -1003,7 +1009,7 @@ int nbody_get_launch_config(nbody_ctx *c, int32_t *tile, int32_t *i_per_thread, 
   nbody::forces_geometry(make_launch(c), &b, &t);
   if (c->sym) { b = c->sym_pairs; t = 256; }
   if (tile) *tile = c->tile;
-  if (i_per_thread) *i_per_thread = (c->sym && c->p.precision != NBODY_PREC_F64) ? 2 * c->sym_np : c->ipt;
+  if (i_per_thread) *i_per_thread = c->sym ? 2 * c->sym_np : c->ipt;
   if (j_split) *j_split = c->j_split;
   if (blocks) *blocks = b;
   if (threads) *threads = t;

@@ -4,9 +4,9 @@
 // there is no packed fp64, a lane simply carries two i-bodies.  Pair law OctreeSearch.h:101-104 in double (build-
 // defined: the reference is fp32); rsq = v_rsq_f64 + two Newton steps.
 //
-// One pair evaluation = 24 fp64 ops (3 sub, 3 for r^2, 8 for rsq, 4 scale factors, 6 accumulate FMAs) and serves two
+// One pair evaluation = 22 fp64 ops (3 sub, 3 for r^2, 6 for rsq, 4 scale factors, 6 accumulate FMAs) and serves two
 // interactions; the one-sided fp64 kernel spends ~24 per interaction.  The running sums cost six v_mov_b32_dpp per step
-// (a double moves as two dwords).
+// (a double moves as two dwords), shared by the IPT bodies of the lane.
 #include "kernels.h"
 
 #include "../../include/nbody.h"
@@ -18,18 +18,20 @@ namespace {
 
 constexpr double kPadFar64 = 1.0e18;
 
+// 1/sqrt(x): v_rsq_f64 seed (~2^-26 relative) and ONE third-order step, y (1 + e/2 + 3/8 e^2) with e = 1 - x y^2:
+// the error goes to ~e^3/3 — far below 2^-53 — in five ops where two Newton steps take seven.
 __device__ __forceinline__ double rsq64(double x) {
-  double y = __builtin_amdgcn_rsq(x);            // v_rsq_f64: ~2^-26 relative
-  const double h = 0.5 * x;
-  y = y * fma(-h * y, y, 1.5);                   // two Newton steps -> full fp64
-  y = y * fma(-h * y, y, 1.5);
-  return y;
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);
+  const double q = e * fma(e, 0.375, 0.5);
+  return fma(y, q, y);
 }
 
 // BARE: symmetric tiles without a d == 0 guard (see kernels_sym.hip); the one-sided diagonal tiles always select.
 // SOFT: eps2 > 0 is added to every r^2, which keeps rsq finite everywhere: no guard at all (BARE is then irrelevant).
-template <bool BARE, bool SOFT>
-__global__ __launch_bounds__(kBlock) void forces_sym_f64_kernel(const double4 *__restrict__ posm,
+template <bool BARE, bool SOFT, int IPT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(IPT == 4 ? 2 : 4, IPT == 4 ? 2 : 4)))
+void forces_sym_f64_kernel(const double4 *__restrict__ posm,
                                                                 double4 *__restrict__ part_i,
                                                                 double4 *__restrict__ part_j,
                                                                 const int2 *__restrict__ pairs, int n_total, int S,
@@ -37,7 +39,6 @@ __global__ __launch_bounds__(kBlock) void forces_sym_f64_kernel(const double4 *_
                                                                 double eps2, const int *__restrict__ dup_flag,
                                                                 int run_if_dup) {
   if (dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
-  constexpr int IPT = 2;
   constexpr int BI = kBlock * IPT;
   __shared__ double4 sh_pos[4][128];       // subtile images, doubled: entries l and l+64 hold body l (16 KB)
   __shared__ double sh_acc[4][3][kJT];     // per-wave j-side sums of the tile (24 KB)
@@ -154,12 +155,14 @@ __global__ __launch_bounds__(kBlock) void forces_sym_f64_kernel(const double4 *_
 
 hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
   if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0 || L.tiles_own <= 0) return hipErrorInvalidValue;
-  if (L.S % (kBlock * 2) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
+  if ((L.np != 1 && L.np != 2) || L.S % (kBlock * 2 * L.np) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
   dim3 grid(L.n_pairs), block(kBlock);
-#define NBODY_SYM64(BARE, SOFT, FLAG, RUNIF)                                                                      \
-  hipLaunchKernelGGL((forces_sym_f64_kernel<BARE, SOFT>), grid, block, 0, s, (const double4 *)L.posm,              \
+#define NBODY_SYM64_I(BARE, SOFT, IPTV, FLAG, RUNIF)                                                              \
+  hipLaunchKernelGGL((forces_sym_f64_kernel<BARE, SOFT, IPTV>), grid, block, 0, s, (const double4 *)L.posm,        \
                      (double4 *)L.part_i, (double4 *)L.part_j, (const int2 *)L.pairs, L.n_total, L.S, L.n_pad,     \
                      L.own_tile0, L.tiles_own * L.S, L.G, L.eps2, (const int *)(FLAG), RUNIF)
+#define NBODY_SYM64(BARE, SOFT, FLAG, RUNIF)                                                                      \
+  do { if (L.np == 2) NBODY_SYM64_I(BARE, SOFT, 4, FLAG, RUNIF); else NBODY_SYM64_I(BARE, SOFT, 2, FLAG, RUNIF); } while (0)
   if (L.eps2 > 0.0) {
     NBODY_SYM64(true, true, nullptr, 0);
   } else if (L.dup_table != nullptr) {
@@ -175,6 +178,7 @@ hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
     NBODY_SYM64(false, false, nullptr, 0);
   }
 #undef NBODY_SYM64
+#undef NBODY_SYM64_I
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((reduce_j_kernel<double, false>), dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s,

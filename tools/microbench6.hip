@@ -19,13 +19,15 @@ enum { V_NODPP = 1, V_NOJ = 2, V_NORSQ = 4, V_NOLDS = 8, V_NOI = 16,
        J_ASM12 = 64,   // all twelve of the step (NP = 2) as one block, after the i-side
        J_SIX = 128,    // six running sums (one set per register pair), folded before the dpp moves
        J_PK = 256,
-       J_PK6 = 512 };  // packed partial sums that travel as they are (six dpp moves per step), folded after the 64 steps   // packed j-side: 3 v_pk_fma_f32 per pair into (lo, hi) partial sums, folded before the dpp moves
+       J_PK6 = 512,
+       J_LDS = 1024 }; // with J_PK6: the sums travel through a wave-private LDS row (ds_write_b64 + ds_read_b64, no VALU op)  // packed partial sums that travel as they are (six dpp moves per step), folded after the 64 steps   // packed j-side: 3 v_pk_fma_f32 per pair into (lo, hi) partial sums, folded before the dpp moves
 
 template <int NP, int UNROLL, int V, int WAVES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void loop_kernel(const float4 *__restrict__ posm, float4 *__restrict__ out, long long *__restrict__ cyc, int rounds) {
   __shared__ float4 sh_pos[2][4][128];
   __shared__ float sh_acc[4][3][256];
+  __shared__ f2 exch[4][3][64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   {
     const float4 q = posm[(blockIdx.x * 256 + t) & 65535];
@@ -113,7 +115,14 @@ void loop_kernel(const float4 *__restrict__ posm, float4 *__restrict__ out, long
       } else if (V & J_PK6) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) { qx = fma2(u[p], dx[p], qx); qy = fma2(u[p], dy[p], qy); qz = fma2(u[p], dz[p], qz); }
-        qx = f2{wave_ror1(qx.x), wave_ror1(qx.y)}; qy = f2{wave_ror1(qy.x), wave_ror1(qy.y)}; qz = f2{wave_ror1(qz.x), wave_ror1(qz.y)};
+        if (V & V_NODPP) {
+        } else if (V & J_LDS) {
+          exch[wave][0][lane] = qx; exch[wave][1][lane] = qy; exch[wave][2][lane] = qz;
+          const int from = (lane + 63) & 63;
+          qx = exch[wave][0][from]; qy = exch[wave][1][from]; qz = exch[wave][2][from];
+        } else {
+          qx = f2{wave_ror1(qx.x), wave_ror1(qx.y)}; qy = f2{wave_ror1(qy.x), wave_ror1(qy.y)}; qz = f2{wave_ror1(qz.x), wave_ror1(qz.y)};
+        }
       } else if (V & J_PK) {
         // u was made with mul_swap: halves swapped; use a plain product instead
         f2 px = f2{jx, 0.f}, py = f2{jy, 0.f}, pz = f2{jz, 0.f};
@@ -224,13 +233,11 @@ int main() {
   hipMalloc(&posm, n * 16); hipMalloc(&out, 1024 * 256 * 16); hipMalloc(&cyc, 4 * 4096 * 8);
   hipMemcpy(posm, h.data(), n * 16, hipMemcpyHostToDevice);
   run<2, 4, 0>("warm-up", posm, out, cyc);
-  run<2, 4, 0, 3>("full step", posm, out, cyc);
-  run<2, 4, 0, 2>("full step", posm, out, cyc);
-  run<4, 4, J_PK6, 3>("j-side: packed travelling sums (6 dpp)", posm, out, cyc);
-  run<4, 2, J_PK6, 3>("j-side: packed travelling sums (6 dpp)", posm, out, cyc);
-  run<4, 8, J_PK6, 3>("j-side: packed travelling sums (6 dpp)", posm, out, cyc);
-  run<6, 2, J_PK6, 3>("j-side: packed travelling sums (6 dpp)", posm, out, cyc);
-  run<4, 4, 0, 3>("full step", posm, out, cyc);
+  run<4, 2, J_PK6>("packed travelling sums (6 dpp)", posm, out, cyc);
+  run<4, 2, J_PK6 | J_LDS>("packed sums travelling through LDS", posm, out, cyc);
+  run<4, 4, J_PK6 | J_LDS>("packed sums travelling through LDS", posm, out, cyc);
+  run<2, 4, J_PK6 | J_LDS>("packed sums travelling through LDS", posm, out, cyc);
+  run<4, 2, J_PK6 | V_NODPP>("packed sums, not travelling (floor)", posm, out, cyc);
   calib<0>("v_pk_fma_f32", out); calib<1>("v_fmac_f32", out); calib<2>("v_rsq_f32", out); calib<3>("v_mov_b32_dpp", out);
   run<2, 4, 0>("full step", posm, out, cyc);
   run<2, 2, 0>("full step", posm, out, cyc);
