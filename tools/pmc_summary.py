@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Summarise the PMC passes of tools/profile_bench.sh: per-launch counter means of the dominant kernel (the launches
+that ran: the twin launch that returns at once is dropped by duration) and the derived figures DESIGN.md quotes."""
+import csv
+import glob
+import os
+import sys
+
+out, kernel = sys.argv[1], sys.argv[2]
+N = 1 << 20
+vals, dur = {}, []
+for d in sorted(glob.glob(os.path.join(out, "pmc[0-9]"))):
+    tag = os.path.basename(d)
+    trace = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                trace[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    long_ids = {k for k, v in trace.items() if v > 1.0}            # ms: the launch that did the work
+    if tag == "pmc3":
+        dur = sorted(trace[k] for k in long_ids)
+    acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"] and (not long_ids or r["Dispatch_Id"] in long_ids):
+                acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+                acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    for name, per in acc.items():
+        vals[(tag, name)] = sum(per.values()) / len(per)
+print(f"# rocprofv3 --pmc passes, MI355X, command: python3 tools/sweep.py --n 1048576 --iters 1 --ipts 8 --zeros 0 --algos 2")
+print(f"# kernel: {kernel} (the launch that ran; its guarded twin returns at its first instruction); per-launch means")
+for (tag, name), v in sorted(vals.items()):
+    print(f"{tag},{name},{v:.6g}")
+if dur:
+    print("kernel_duration_ms_in_pmc3_run," + str([round(x, 3) for x in dur]))
+g = lambda n: next((v for (t, k), v in vals.items() if k == n), None)
+steps = N * (N - 1) / 2 / 512.0          # wave-steps: 64 lanes x 4 register pairs x 2 bodies meet one j
+if g("SQ_INSTS_VALU"):
+    print(f"# derived: wave-steps = N(N-1)/2/512 = {steps:.4g}; SQ_INSTS_VALU per wave-step = {g('SQ_INSTS_VALU') / steps:.1f}"
+          " (64 packed + 8 v_rsq_f32 + 6 v_mov_b32_dpp = 78 in the symmetric tiles)")
+if g("GRBM_GUI_ACTIVE") and dur:
+    t = sum(dur) / len(dur) * 1e-3
+    clk = g("GRBM_GUI_ACTIVE") / 8 / t
+    print(f"# clock = GRBM_GUI_ACTIVE/8/duration = {clk / 1e9:.3f} GHz; SIMD cycles per wave-step = {1024 * t * clk / steps:.1f}"
+          f" (16 interactions per lane) = {1024 * t * clk / steps / 16:.2f} per interaction-lane")
+if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None and dur:
+    t = sum(dur) / len(dur) * 1e-3
+    rd, wr = g("FETCH_SIZE") * 1024 * 2, g("WRITE_SIZE") * 1024     # KB; gfx950: FETCH_SIZE counts 128-B requests at 64 B
+    print(f"# HBM: FETCH_SIZE {g('FETCH_SIZE'):.6g} KB x2 (gfx950 correction) = {rd / 1e9:.2f} GB; WRITE_SIZE {g('WRITE_SIZE'):.6g} KB = {wr / 1e9:.2f} GB"
+          f" per launch; {(rd + wr) / 1e9:.1f} GB / {t:.4f} s = {(rd + wr) / t / 1e9:.0f} GB/s = {(rd + wr) / t / 8e12 * 100:.1f} % of HBM bandwidth")
