@@ -59,7 +59,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 20, help="bodies (default 2^20 = BASELINE metric)")
+    ap.add_argument("--n", "--bodies", dest="n", type=int, default=1 << 20,
+                    help="bodies (default 2^20 = BASELINE metric); use --bodies under torch.distributed.run, whose own parser claims --n")
     ap.add_argument("--precision", default="f32", choices=["f32", "f32_kahan", "f64"])
     ap.add_argument("--eps", type=float, default=0.0)
     ap.add_argument("--dt", type=float, default=0.01)
@@ -100,20 +101,44 @@ def main():
 
     n = args.n
     posm, vel = nb.ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
-    sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device=f"cuda:{local_rank}",
-                               precision=args.precision, eps=args.eps, tile=args.tile, i_per_thread=args.ipt,
-                               j_split=args.jsplit, time_kernels=True,
-                               algorithm={"auto": 0, "tiled": 1, "symmetric": 2}[args.algorithm],
-                               zero_mode={"exact": 0, "floor": 2}[args.zero_mode])
-    cfg = sim.engine.launch_config()
-    sim.warm_collectives()
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    sim.step(args.dt, args.warmup)
+    def build(algorithm):
+        sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device=f"cuda:{local_rank}",
+                                   precision=args.precision, eps=args.eps, tile=args.tile, i_per_thread=args.ipt,
+                                   j_split=args.jsplit, time_kernels=True,
+                                   algorithm={"auto": 0, "tiled": 1, "symmetric": 2}[algorithm],
+                                   zero_mode={"exact": 0, "floor": 2}[args.zero_mode])
+        sim.warm_collectives()
+        sim.step(args.dt, args.warmup)
+        if os.environ.get("NBODY_BENCH_FAIL_FIRST") == "1" and algorithm == "auto":   # rehearsal of the retry below
+            raise RuntimeError("NBODY_BENCH_FAIL_FIRST")
+        return sim
+
+    # Multi-GPU only: the symmetric algorithm adds an all-to-all to the step.  If any rank cannot bring that path up,
+    # every rank falls back — loudly, and named in config.algorithm — to the one-sided HIP kernel, whose step needs the
+    # all-gather alone.  (Still the HIP path: there is no CPU fallback anywhere.)
+    sim, failure, fallback = None, None, None
+    try:
+        sim = build(args.algorithm)
+    except Exception as e:  # noqa: BLE001
+        if world == 1 or args.algorithm != "auto":
+            raise
+        failure = f"{type(e).__name__}: {e}"
+    if world > 1 and args.algorithm == "auto":
+        ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0:
+            print(f"[bench rank {rank}] symmetric multi-GPU path failed ({failure or 'on another rank'}); "
+                  "falling back to the one-sided kernel", file=sys.stderr, flush=True)
+            if sim is not None:
+                sim.close()
+            sim = build("tiled")
+            fallback = "tiled after symmetric path failed"
+    cfg = sim.engine.launch_config()
     fence()
     sim.engine.kernel_time_reset()
     t0 = time.perf_counter()
@@ -154,7 +179,8 @@ def main():
                        "lds_tile_bodies": cfg["tile"], "i_per_lane": cfg["i_per_thread"],
                        "j_split": cfg["j_split"] if cfg["algorithm"] == "tiled" else None,
                        "super_tile_bodies": cfg["super_tile"] or None,
-                       "workgroups": cfg["blocks"], "accumulate": args.precision, "finite": finite},
+                       "workgroups": cfg["blocks"], "accumulate": args.precision, "finite": finite,
+                       **({"fallback": fallback} if fallback else {})},
             "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64",
                          "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, world)) if args.precision == "f32" else None,
