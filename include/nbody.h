@@ -202,6 +202,14 @@ NBODY_API int nbody_get_positions(nbody_ctx *ctx, float *xyz, size_t stride, int
 /* Owned records [i_begin, i_begin+i_count) into aos[0..i_count): Mass, Position, Velocity, Acceleration. */
 NBODY_API int nbody_get_particles(nbody_ctx *ctx, void *aos, size_t stride);
 
+/* Renderer hand-off straight into the caller's buffer (what OctreeSearch.cpp:41 reads every frame):
+ * page-lock `bytes` of caller memory at `host` for this context.  nbody_get_positions (stride 12) and
+ * nbody_get_particles (stride 40) whose destination lies inside a pinned range then DMA into it directly — one copy,
+ * device to destination — instead of going through the context's own staging buffer and a host memcpy.  The memory
+ * stays the caller's; unpin it (or destroy the context) before freeing it.  Results are identical either way. */
+NBODY_API int nbody_pin_host_buffer(nbody_ctx *ctx, void *host, size_t bytes);
+NBODY_API int nbody_unpin_host_buffer(nbody_ctx *ctx, void *host);
+
 /* Owned bodies, native layout (fp32; converted down from fp64 contexts).  Either pointer may be NULL. */
 NBODY_API int nbody_get_state_soa(nbody_ctx *ctx, float *posm4, float *vel4, float *acc4);
 NBODY_API int nbody_get_state_soa_f64(nbody_ctx *ctx, double *posm4, double *vel4, double *acc4);

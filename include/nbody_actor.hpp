@@ -61,6 +61,7 @@ class OctreeSearchActor {
     std::vector<float> posm(4 * (size_t)N), vel(4 * (size_t)N);
     LastStatus = nbody_ic_reference_box(N, SizeArg, ActorLocation, Seed, posm.data(), vel.data());
     if (LastStatus) return;
+    Release();                          // before `Particles` gives up its (pinned) storage
     Particles.assign((size_t)N, FParticle{});
     for (int32_t i = 0; i < N; ++i) {
       FParticle &p = Particles[(size_t)i];
@@ -73,7 +74,14 @@ class OctreeSearchActor {
   // Build-defined: explicit initial state instead of the random one (same post-conditions as CreateSpacePoints).
   void SetParticles(const FParticle *p, int32_t N) {
     if (!p || N <= 0) { LastStatus = NBODY_ERR_INVALID; return; }
-    Particles.assign(p, p + N);
+    if (p >= Particles.data() && p < Particles.data() + Particles.size()) {   // re-upload of (part of) the own array
+      std::vector<FParticle> copy(p, p + N);
+      Release();
+      Particles.swap(copy);
+    } else {
+      Release();
+      Particles.assign(p, p + N);
+    }
     Upload();
   }
 
@@ -146,10 +154,14 @@ class OctreeSearchActor {
     LastStatus = nbody_get_positions(ctx_, Particles.data()->Position, sizeof(FParticle), 0, (int32_t)Particles.size());
   }
 
-  void Upload() {
-    nbody_destroy(ctx_);
+  void Release() {
+    nbody_destroy(ctx_);                // also unpins `Particles`
     ctx_ = nullptr;
     Initialized = false;
+  }
+
+  void Upload() {
+    Release();
     nbody_params p;
     nbody_default_params(&p);
     p.n_total = (int32_t)Particles.size();
@@ -161,6 +173,10 @@ class OctreeSearchActor {
     if (LastStatus) return;
     LastStatus = nbody_set_particles(ctx_, Particles.data(), sizeof(FParticle), (int32_t)Particles.size());
     if (LastStatus) return;
+    // the per-frame mirror lands in `Particles` by one DMA (an optimisation only: unpinned memory works the same).
+    // `Particles` must keep its storage while the actor is initialised, as the reference's TArray does between
+    // CreateSpacePoints and CleanParticles.
+    (void)nbody_pin_host_buffer(ctx_, Particles.data(), Particles.size() * sizeof(FParticle));
     Initialized = true;                                                        // .cpp:71
     forces_fresh_ = false;
     dirty_ = false;

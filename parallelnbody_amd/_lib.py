@@ -105,6 +105,8 @@ def lib():
     sig("nbody_get_bounds", c_int, vp, fp)
     sig("nbody_get_positions", c_int, vp, fp, sz, c_i32, c_i32)
     sig("nbody_get_particles", c_int, vp, vp, sz)
+    sig("nbody_pin_host_buffer", c_int, vp, vp, sz)
+    sig("nbody_unpin_host_buffer", c_int, vp, vp)
     sig("nbody_get_state_soa", c_int, vp, fp, fp, fp)
     sig("nbody_get_state_soa_f64", c_int, vp, dp, dp, dp)
     sig("nbody_energy", c_int, vp, dp, dp)

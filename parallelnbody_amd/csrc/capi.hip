@@ -44,6 +44,7 @@ struct nbody_ctx {
   void *h_scratch = nullptr;   // pinned mirror
   int j_split = 1, j_chunk = 0, ipt = 1, tile = 256;
   int sym_np = 1;                        // register pairs per lane of the symmetric kernel
+  std::vector<std::pair<char *, size_t>> pinned;   // caller memory page-locked by nbody_pin_host_buffer
   int wave = 0;                // small-N wave kernel: register pairs per wave (0 = tile kernels)
   bool have_state = false;
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
@@ -409,6 +410,14 @@ int ensure_stage(nbody_ctx *c, size_t bytes) {
   return NBODY_OK;
 }
 
+// Is [dst, dst + bytes) inside memory the caller pinned for this context?
+bool in_pinned(const nbody_ctx *c, const void *dst, size_t bytes) {
+  const char *d = (const char *)dst;
+  for (const auto &r : c->pinned)
+    if (d >= r.first && d + bytes <= r.first + r.second) return true;
+  return false;
+}
+
 int check_ready(nbody_ctx *c) {
   if (!c) return NBODY_ERR_INVALID;
   if (!c->have_state) return fail(c, NBODY_ERR_STATE, "no particles set (call nbody_set_particles / nbody_set_state_soa first)");
@@ -575,6 +584,7 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+  for (const auto &r : c->pinned) (void)hipHostUnregister(r.first);   // the memory itself stays the caller's
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -807,8 +817,10 @@ int nbody_get_positions(nbody_ctx *c, float *xyz, size_t stride, int32_t first, 
   const size_t bytes = (size_t)count * 12;
   if ((rc = ensure_stage(c, bytes))) return rc;
   HIP_TRY(c, nbody::launch_pack_positions(c->p.precision, c->posm, (float *)c->d_stage, first, count, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  const bool direct = stride == 12 && in_pinned(c, xyz, bytes);     // caller's pinned buffer: DMA straight into it
+  HIP_TRY(c, hipMemcpyAsync(direct ? (void *)xyz : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (direct) return NBODY_OK;
   if (stride == 12) {
     memcpy(xyz, c->h_stage, bytes);
   } else {
@@ -846,8 +858,10 @@ int nbody_get_particles(nbody_ctx *c, void *aos, size_t stride) {
   if ((rc = ensure_stage(c, bytes))) return rc;
   HIP_TRY(c, nbody::launch_pack_particles(c->p.precision, c->posm, c->vel, c->acc, (float *)c->d_stage, c->p.i_begin,
                                           c->p.i_count, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  const bool direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
+  HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (direct) return NBODY_OK;
   if (stride == sizeof(nbody_particle)) {
     memcpy(aos, c->h_stage, bytes);
   } else {
@@ -856,6 +870,30 @@ int nbody_get_particles(nbody_ctx *c, void *aos, size_t stride) {
     for (size_t i = 0; i < ic; ++i) memcpy(base + i * stride, src + i * sizeof(nbody_particle), sizeof(nbody_particle));
   }
   return NBODY_OK;
+}
+
+int nbody_pin_host_buffer(nbody_ctx *c, void *host, size_t bytes) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (!host || bytes == 0) return fail(c, NBODY_ERR_INVALID, "nbody_pin_host_buffer: null buffer or zero size");
+  for (const auto &r : c->pinned)
+    if ((char *)host < r.first + r.second && r.first < (char *)host + bytes)
+      return fail(c, NBODY_ERR_INVALID, "nbody_pin_host_buffer: overlaps a range that is already pinned");
+  HIP_TRY(c, hipSetDevice(c->p.device));
+  HIP_TRY(c, hipHostRegister(host, bytes, hipHostRegisterDefault));
+  c->pinned.emplace_back((char *)host, bytes);
+  return NBODY_OK;
+}
+
+int nbody_unpin_host_buffer(nbody_ctx *c, void *host) {
+  if (!c) return NBODY_ERR_INVALID;
+  for (size_t k = 0; k < c->pinned.size(); ++k)
+    if (c->pinned[k].first == (char *)host) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      c->pinned.erase(c->pinned.begin() + (long)k);
+      HIP_TRY(c, hipHostUnregister(host));
+      return NBODY_OK;
+    }
+  return fail(c, NBODY_ERR_INVALID, "nbody_unpin_host_buffer: not a buffer pinned through this context");
 }
 
 // ---- checkpoint / resume (nothing in the reference to mirror: its state is not even a UPROPERTY) ----

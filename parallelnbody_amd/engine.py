@@ -184,16 +184,36 @@ class NBodyEngine:
         return ke.value, pe.value
 
     # -- state out --
-    def positions(self, first=0, count=None):
+    def positions(self, first=0, count=None, out=None):
+        """Positions [count,3] (what the renderer reads each frame).  `out`: a C-contiguous float32 array to fill — if it
+        was handed to `pin()` the copy is one DMA from the device into it."""
         count = self.n_total - first if count is None else count
-        out = np.empty((count, 3), np.float32)
+        if out is None:
+            out = np.empty((count, 3), np.float32)
+        elif out.dtype != np.float32 or out.shape != (count, 3) or not out.flags.c_contiguous:
+            raise ValueError("positions: out must be a C-contiguous float32 [count,3] array")
         self._check(self._L.nbody_get_positions(self._h, _fp(out), 12, first, count))
         return out
 
-    def particles(self):
-        out = np.zeros(self.i_count, PARTICLE_DTYPE)
+    def particles(self, out=None):
+        if out is None:
+            out = np.zeros(self.i_count, PARTICLE_DTYPE)
+        elif out.dtype != PARTICLE_DTYPE or out.shape != (self.i_count,) or not out.flags.c_contiguous:
+            raise ValueError("particles: out must be a C-contiguous PARTICLE_DTYPE [i_count] array")
         self._check(self._L.nbody_get_particles(self._h, out.ctypes.data, PARTICLE_DTYPE.itemsize))
         return out
+
+    def pin(self, array):
+        """Page-lock a caller-owned numpy array for this context (nbody_pin_host_buffer): `positions(out=array)` /
+        `particles(out=array)` then land in it with a single device-to-destination copy.  Keep the array alive until
+        `unpin(array)` or `close()`."""
+        self._check(self._L.nbody_pin_host_buffer(self._h, array.ctypes.data, array.nbytes))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(array)
+
+    def unpin(self, array):
+        self._check(self._L.nbody_unpin_host_buffer(self._h, array.ctypes.data))
+        self._pinned = [a for a in getattr(self, "_pinned", []) if a is not array]
 
     def state(self, dtype=np.float32):
         """(posm, vel, acc) of the owned bodies, [i_count,4] each."""

@@ -167,6 +167,35 @@ def test_aos_round_trip_and_reference_layout(nb, oracle):
     np.testing.assert_array_equal(sub, out["Position"][100:150])
 
 
+def test_hand_off_into_a_pinned_caller_buffer(nb):
+    # the per-frame hand-off lands in the caller's own (page-locked) memory by one DMA; same bytes as
+    # the staged path, partial ranges and foreign strides still go through staging, misuse is refused
+    g = _golden("refbox_n2000_seed1")
+    n = 2000
+    with nb.NBodyEngine(n) as e:
+        e.set_state(g["posm"], g["vel"])
+        e.step(0.01, 2)
+        ref_p, ref_x = e.particles(), e.positions()
+        mine_p = np.zeros(n, nb.PARTICLE_DTYPE)
+        mine_x = np.full((n, 3), np.nan, np.float32)
+        e.pin(mine_p); e.pin(mine_x)
+        with pytest.raises(nb.NBodyError):
+            e.pin(mine_x[10:20])                                  # overlaps a pinned range
+        assert e.particles(out=mine_p) is mine_p and mine_p.tobytes() == ref_p.tobytes()
+        e.positions(out=mine_x)
+        np.testing.assert_array_equal(mine_x, ref_x)
+        part = e.positions(first=5, count=7, out=mine_x[100:107])  # inside the pinned array: direct as well
+        np.testing.assert_array_equal(part, ref_x[5:12])
+        e.step(0.01, 1)
+        np.testing.assert_array_equal(e.positions(out=mine_x), e.positions())
+        e.unpin(mine_x)
+        with pytest.raises(nb.NBodyError):
+            e.unpin(mine_x)                                       # not pinned any more
+        np.testing.assert_array_equal(e.positions(out=mine_x), e.positions())   # staged path again
+    # the context is gone: the arrays are ordinary memory again and still hold the last frame
+    assert np.all(np.isfinite(mine_x)) and mine_p["Mass"].min() > 0
+
+
 def test_pause_and_argument_errors(nb):
     g = _golden("plummer_n1024_seed1")
     with nb.NBodyEngine(1024) as e:
