@@ -344,6 +344,40 @@ def _sync_energy(e, dt):
     return 0.5 * (m * (vs ** 2).sum(1)).sum() + pe
 
 
+def _drift(nb, n, precision, steps, chunk, dt=0.002):
+    a_pl, M, G = 100.0, 1000.0, 1.0e4           # crossing time a / sqrt(GM/a) = 0.32 -> 160 steps per crossing
+    posm, vel = nb.ic_plummer(n, M, a_pl, G, seed=5)
+    with nb.NBodyEngine(n, precision=precision, eps=0.05 * a_pl) as e:
+        kernel = e.launch_config()["kernel"]
+        e.set_state(posm, vel)
+        e.compute_forces()
+        p0, v0, a0 = e.state(np.float64)
+        v_half = v0.copy(); v_half[:, :3] -= 0.5 * dt * a0[:, :3]
+        e.set_state(p0 if precision == "f64" else p0.astype(np.float32),
+                    v_half if precision == "f64" else v_half.astype(np.float32))
+        e0 = _sync_energy(e, -dt)
+        worst = 0.0
+        for _ in range(steps // chunk):
+            e.step(dt, chunk)
+            worst = max(worst, abs(_sync_energy(e, -dt) - e0) / abs(e0))
+    return worst, kernel
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32_kahan", "f64"])
+def test_energy_drift_1k_steps_symmetric_kernels(nb, precision):
+    # the same acceptance bound on the kernels the headline configurations run (each pair once), N = 32768
+    worst, kernel = _drift(nb, 32768, precision, 1000, 250)
+    assert kernel.startswith("forces_sym_")
+    assert worst < 1e-4, worst
+
+
+def test_config3_fp64_energy_drift_at_full_size(nb):
+    # BASELINE configs[3]: N = 262144 fp64, energy-drift check over 100 steps (6.9e12 pair evaluations)
+    worst, kernel = _drift(nb, 262144, "f64", 100, 50)
+    assert kernel == "forces_sym_f64_kernel"
+    assert worst < 1e-6, worst
+
+
 @pytest.mark.parametrize("precision", ["f32", "f32_kahan", "f64"])
 def test_energy_drift_1k_steps(nb, precision):
     # north-star acceptance: total-energy drift < 1e-4 over 1000 steps on a softened Plummer sphere.
