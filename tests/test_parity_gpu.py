@@ -625,14 +625,15 @@ def test_three_body_figure_eight_on_the_device(nb):
 
 # ---- fp64 symmetric kernel (kernels_sym64.hip) -----------------------------------------------------------------------
 
+@pytest.mark.parametrize("ipt", [2, 4])
 @pytest.mark.parametrize("n", [1024, 2000, 5000])
-def test_symmetric_fp64_matches_the_fp64_oracle(nb, oracle, n):
+def test_symmetric_fp64_matches_the_fp64_oracle(nb, oracle, n, ipt):
     rng = np.random.default_rng(n)
     posm = np.concatenate([rng.normal(0, 300, (n, 3)), rng.uniform(1, 100, (n, 1))], 1)
     posm[0, :3] = 0.0                                     # a body on the origin, like body 0 of the shipped scene
     vel = rng.normal(0, 10, (n, 4)); vel[:, 3] = 0
-    with nb.NBodyEngine(n, precision="f64", algorithm=2) as e:
-        assert e.launch_config()["algorithm"] == "symmetric"
+    with nb.NBodyEngine(n, precision="f64", algorithm=2, i_per_thread=ipt) as e:
+        assert e.launch_config()["algorithm"] == "symmetric" and e.launch_config()["i_per_thread"] == ipt
         e.set_state(posm, vel)
         e.step(0.01, 1)
         p, v, a = e.state(np.float64)
@@ -643,7 +644,7 @@ def test_symmetric_fp64_matches_the_fp64_oracle(nb, oracle, n):
     np.testing.assert_array_equal(v[:, :3], v1)
     # coincident bodies take the guarded twin launch
     posm[7, :3] = posm[n - 5, :3]
-    with nb.NBodyEngine(n, precision="f64", algorithm=2) as e:
+    with nb.NBodyEngine(n, precision="f64", algorithm=2, i_per_thread=ipt) as e:
         e.set_state(posm, vel)
         e.compute_forces()
         a = e.accelerations(np.float64)
@@ -651,12 +652,13 @@ def test_symmetric_fp64_matches_the_fp64_oracle(nb, oracle, n):
     assert rel_err(a, oracle.forces_direct_f64(posm[:, :3], posm[:, 3])).max() < 1e-12
 
 
-def test_symmetric_fp64_sharded_emulated(nb, oracle):
+@pytest.mark.parametrize("ipt", [2, 4])
+def test_symmetric_fp64_sharded_emulated(nb, oracle, ipt):
     n, ranks = 8192, 4
     posm, vel = nb.ic_plummer(n, seed=12)
     posm = posm.astype(np.float64); vel = vel.astype(np.float64)
     ic = n // ranks
-    engs = [nb.NBodyEngine(n, i_begin=r * ic, i_count=ic, precision="f64", algorithm=2) for r in range(ranks)]
+    engs = [nb.NBodyEngine(n, i_begin=r * ic, i_count=ic, precision="f64", algorithm=2, i_per_thread=ipt) for r in range(ranks)]
     try:
         for e in engs:
             e.set_state(posm, vel)
@@ -670,6 +672,29 @@ def test_symmetric_fp64_sharded_emulated(nb, oracle):
         for e in engs:
             e.close()
     assert rel_err(a[:, :3], oracle.forces_direct_f64(posm[:, :3], posm[:, 3])).max() < 1e-12
+
+
+def test_config4_kahan_softened_at_full_size(nb, oracle):
+    # BASELINE configs[4]: N = 2097152 softened Plummer, Kahan accumulation (there: 10k steps on 8 GPUs; here one force
+    # pass of the whole system on one GPU — 4.4e12 interactions — checked on a sample against the fp64 direct sum, and
+    # through Newton's third law over all bodies)
+    n = 1 << 21
+    posm, vel = nb.ic_plummer(n, seed=21)
+    eps = 0.5
+    with nb.NBodyEngine(n, precision="f32_kahan", eps=eps) as e:
+        cfg = e.launch_config()
+        assert cfg["algorithm"] == "symmetric" and cfg["kernel"] == "forces_sym_pk_kernel"
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+    assert np.all(np.isfinite(a))
+    p64 = posm.astype(np.float64)
+    rng = np.random.default_rng(4)
+    for i in rng.choice(n, 6, replace=False):
+        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], eps=eps, i0=int(i), i1=int(i) + 1)
+        assert rel_err(a[i:i + 1], ref).max() < 2e-6
+    f = (a.astype(np.float64) * p64[:, 3:4]).sum(0)
+    assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * p64[:, 3]).sum() < 1e-7
 
 
 def test_headline_config_runs_the_symmetric_kernel_at_speed(nb):
