@@ -97,12 +97,13 @@ void choose_geometry(nbody_ctx *c) {
   if (p.j_split > 0) {
     js = p.j_split;
   } else {
-    // aim at >= 2048 workgroups (8 per CU) down to an 8-way body partition, keep >= 4 tiles per chunk
+    // aim at >= 2048 workgroups (8 per CU) down to an 8-way body partition; a chunk may be a single tile — small
+    // systems are short of workgroups, not of work per workgroup (N = 8192: 52 us with 8 chunks, 29 us with 32)
     const long long per_block = 256LL * c->ipt;
     long long iblocks8 = (p.n_total / 8 + per_block - 1) / per_block;
     if (iblocks8 < 1) iblocks8 = 1;
     js = floor_pow2((2048 + iblocks8 - 1) / iblocks8);
-    const int max_js = p.n_total / (4 * c->tile);
+    const int max_js = p.n_total / c->tile;
     if (js > max_js) js = max_js;
     if (js < 1) js = 1;
   }
