@@ -132,9 +132,9 @@ void choose_algorithm(nbody_ctx *c) {
   const bool f32ok = (p.precision == NBODY_PREC_F32 || p.precision == NBODY_PREC_F32_KAHAN) &&
                      p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4);
   // bodies per lane of the symmetric kernel: 8 (four register pairs) amortises the travelling sums' dpp moves best
-  // (tools/microbench6.hip); the Kahan form has no registers for it, small systems not enough workgroups.
+  // (tools/microbench6.hip; the Kahan form then runs 2 waves/SIMD at 240 VGPRs); small systems have too few workgroups for it.
   int sym_ipt = c->ipt;
-  if (p.precision == NBODY_PREC_F32 && (p.i_per_thread == 8 || (p.i_per_thread == 0 && p.n_total >= 262144)) &&
+  if (p.precision != NBODY_PREC_F64 && (p.i_per_thread == 8 || (p.i_per_thread == 0 && p.n_total >= 262144)) &&
       (p.i_count == p.n_total || p.i_count % 2048 == 0))
     sym_ipt = 8;
   if (p.i_per_thread == 8 && sym_ipt != 8) return;
@@ -469,8 +469,8 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
     return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: tile must be 64, 128, 256 or 512");
   if (p.i_per_thread != 0 && p.i_per_thread != 1 && p.i_per_thread != 2 && p.i_per_thread != 4 && p.i_per_thread != 8)
     return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: i_per_thread must be 1, 2, 4 or 8");
-  if (p.i_per_thread == 8 && (p.algorithm == NBODY_ALGO_TILED || p.precision != NBODY_PREC_F32))
-    return fail(nullptr, NBODY_ERR_UNSUPPORTED, "nbody_create: i_per_thread 8 exists for the fp32 symmetric kernel only");
+  if (p.i_per_thread == 8 && (p.algorithm == NBODY_ALGO_TILED || p.precision == NBODY_PREC_F64))
+    return fail(nullptr, NBODY_ERR_UNSUPPORTED, "nbody_create: i_per_thread 8 exists for the fp32 symmetric kernels only");
   if (p.j_split < 0) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: j_split must be >= 0");
   if (p.zero_mode < 0 || p.zero_mode > NBODY_ZERO_FLOOR) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown zero_mode %d", p.zero_mode);
   if (p.algorithm < 0 || p.algorithm > NBODY_ALGO_SYMMETRIC) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown algorithm %d", p.algorithm);

@@ -62,9 +62,13 @@ constexpr float kPadFar = 1.0e18f;
 // Six v_mov_b32_dpp per step instead of three, but no scalar FMAs: a wave64 v_fmac_f32 only issues at its 2-cycle rate
 // next to another wave's 2-cycle op — in this packed instruction stream it costs ~3.5 cycles, twelve of them per step
 // more than six packed FMAs (tools/microbench6.hip; profiles/r01_microbench_sym_inner_loop.txt).
+// waves per SIMD: 4 (128 VGPRs); the Kahan form needs 164 VGPRs with two register pairs per lane (3 waves) and ~230
+// with four (2 waves — packed ops are 4-cycle, two waves keep the SIMD within 2 % of four)
+constexpr int sym_waves(int np, bool kahan) { return !kahan ? NBODY_SYM_WAVES : (np == 4 ? 2 : (np == 2 ? 3 : NBODY_SYM_WAVES)); }
+
 template <int NP, int ZMODE, bool BARE, bool KAHAN, bool JPK>
 __global__ __launch_bounds__(kBlock)
-__attribute__((amdgpu_waves_per_eu((KAHAN && NP == 2) ? 3 : NBODY_SYM_WAVES, (KAHAN && NP == 2) ? 3 : NBODY_SYM_WAVES)))
+__attribute__((amdgpu_waves_per_eu(sym_waves(NP, KAHAN), sym_waves(NP, KAHAN))))
 void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ part_i, float4 *__restrict__ part_j,
                           const int2 *__restrict__ pairs, int n_total, int S, int n_pad, int own_tile0, int n_own_pad,
                           float gscale, float zp, const int *__restrict__ dup_flag, int run_if_dup) {
@@ -274,10 +278,10 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   do {                                                                                                           \
     if (L.np == 1) NBODY_SYM(1, ZM, BARE, ZP, FLAG, RUNIF);                                                      \
     else if (L.np == 2) NBODY_SYM(2, ZM, BARE, ZP, FLAG, RUNIF);                                                 \
+    else if (L.kahan) NBODY_SYM_K(4, ZM, BARE, true, true, ZP, FLAG, RUNIF);                                     \
     else NBODY_SYM_K(4, ZM, BARE, false, true, ZP, FLAG, RUNIF);                                                 \
   } while (0)
   if (L.np != 1 && L.np != 2 && L.np != 4) return hipErrorInvalidValue;
-  if (L.np == 4 && L.kahan) return hipErrorInvalidValue;
   // j-side sums: packed pairs (JPK) unless NBODY_SYM_JSCALAR=1 asks for the scalar form (A/B measurements, np <= 2)
   static const bool jscalar = [] { const char *e = getenv("NBODY_SYM_JSCALAR"); return e && e[0] == '1'; }();
   const bool jpk = !jscalar;

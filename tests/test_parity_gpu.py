@@ -506,8 +506,8 @@ def test_symmetric_refuses_what_it_cannot_do(nb):
         with pytest.raises(nb.NBodyError) as e:
             nb.NBodyEngine(1024, algorithm=2, i_per_thread=2, **kw)
         assert e.value.code == nb._lib.ERR_UNSUPPORTED
-    # eight bodies per lane: the plain fp32 symmetric kernel only, and sharded slices must be multiples of 2048
-    for kw in (dict(precision="f32_kahan"), dict(algorithm=1), dict(algorithm=2, i_begin=0, i_count=1024)):
+    # eight bodies per lane: the fp32 symmetric kernels only, and sharded slices must be multiples of 2048
+    for kw in (dict(precision="f64"), dict(algorithm=1), dict(algorithm=2, i_begin=0, i_count=1024)):
         with pytest.raises(nb.NBodyError) as e:
             nb.NBodyEngine(4096, i_per_thread=8, **{"algorithm": 2, **kw})
         assert e.value.code == nb._lib.ERR_UNSUPPORTED
@@ -745,7 +745,7 @@ def test_symmetric_underflowing_separations_near_the_origin(nb, oracle):
     assert rel_err(a, ref).max() < TOL_ACC
 
 
-@pytest.mark.parametrize("ipt", [2, 4])
+@pytest.mark.parametrize("ipt", [2, 4, 8])
 def test_symmetric_kahan(nb, oracle, ipt):
     # Kahan-compensated accumulation in the symmetric kernel: closer to fp64 than the plain symmetric sum, same parity
     g = _golden("refbox_n2000_seed1")
