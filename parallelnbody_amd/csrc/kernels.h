@@ -20,6 +20,8 @@ struct ForceLaunch {
   int zero_mode;        // for eps2 == 0: 1 = clamp trick (default), 2 = compare+select (A/B only)
   int precision;        // NBODY_PREC_*
   int wave;             // 0: tile kernels; != 0: small-N kernel, one workgroup per pair of bodies (j_split must be 1)
+  void *dup_table = nullptr;   // packed fp32 kernel, exact mode: coincident-body detector's table [dup_slots] + {flag, count};
+  int dup_slots = 0;           // with it, tiles that hold no self pair run without the d == 0 guard when no two bodies coincide
 };
 
 // All-pairs force partials.  Returns hipSuccess or the launch error.

@@ -10,6 +10,7 @@
 
 #include "../../include/nbody.h"
 #include "pk_common.h"
+#include "sym_common.h"
 
 namespace nbody {
 
@@ -206,10 +207,14 @@ __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T
 // law runs on packed instructions with every constant in VGPRs: 12 packed ops + 2 v_rsq_f32 per two pairs.
 // ---------------------------------------------------------------------------------------------------------
 // NP register pairs of i-bodies per lane (IPT = 2*NP); JB j-bodies per staged group.
+// dup_flag (Z_CLAMP only): verdict of dup_detect_kernel on this pass's positions.  With no two bodies on one point
+// (*dup_flag == 0) d == 0 can only be a self pair, so full tiles that do not overlap the workgroup's own i-range run
+// the pair law bare — 5 packed ops + 1 v_rsq_f32 per pair-lane instead of 7 + 1.  The results are the guarded ones.
 template <int NP, int TILE, int ZMODE, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__restrict__ posm,
                                                                 float4 *__restrict__ accp, int n_total, int i_begin,
-                                                                int i_count, int j_chunk, float gscale, float zp) {
+                                                                int i_count, int j_chunk, float gscale, float zp,
+                                                                const int *__restrict__ dup_flag) {
   constexpr int IPT = 2 * NP;
   constexpr int LPT = (TILE + kBlock - 1) / kBlock;
   __shared__ float4 sh[2][TILE];
@@ -255,6 +260,8 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
     }
   };
 
+  const bool bare_ok = ZMODE == Z_CLAMP && dup_flag != nullptr && *dup_flag == 0;
+  const int own_lo = i_begin + ibase, own_hi = own_lo + kBlock * IPT;       // this workgroup's i-bodies (global indices)
   if (ntiles > 0) { load_tile(0); store_tile(0); }
   __syncthreads();
   for (int tile = 0; tile < ntiles; ++tile) {
@@ -262,12 +269,24 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
     const bool more = tile + 1 < ntiles;
     if (more) load_tile(tile + 1);
     constexpr int JB = (NP == 1) ? 4 : 2;
+    const int t_lo = j0 + tile * TILE, t_hi = t_lo + TILE;
+    // no self pair in the tile and no zero-mass padding (pads sit on the origin, where a body may be)
+    if (ZMODE == Z_CLAMP && bare_ok && t_hi <= j1 && (t_hi <= own_lo || t_lo >= own_hi)) {
 #pragma unroll 2
-    for (int jj = 0; jj < TILE; jj += JB) {
-      float4 pj[JB];
+      for (int jj = 0; jj < TILE; jj += JB) {
+        float4 pj[JB];
 #pragma unroll
-      for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
-      pair_group_pk<NP, JB, ZMODE, KAHAN>(xi, yi, zi, pj, zp2, one2, a);
+        for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
+        pair_group_pk<NP, JB, Z_BARE, KAHAN>(xi, yi, zi, pj, zp2, one2, a);
+      }
+    } else {
+#pragma unroll 2
+      for (int jj = 0; jj < TILE; jj += JB) {
+        float4 pj[JB];
+#pragma unroll
+        for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
+        pair_group_pk<NP, JB, ZMODE, KAHAN>(xi, yi, zi, pj, zp2, one2, a);
+      }
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
@@ -481,11 +500,23 @@ hipError_t launch_forces_t(const ForceLaunch &L, hipStream_t s) {
   if constexpr (sizeof(T) == 4 && IPT % 2 == 0) {
     // production fp32 path: packed kernel (compare+select only exists in the scalar kernel, for A/B)
     if (L.eps2 > 0.0 || L.zero_mode != Z_SELECT) {
-#define NBODY_LAUNCH_PK(ZM, ZP)                                                                                  \
+#define NBODY_LAUNCH_PK(ZM, ZP, FLAG)                                                                            \
   hipLaunchKernelGGL((forces_tile_pk_kernel<IPT / 2, TILE, ZM, KAHAN>), grid, block, 0, s, (const float4 *)L.posm, \
-                     (float4 *)L.accp, L.n_total, L.i_begin, L.i_count, L.j_chunk, (float)L.G, (float)(ZP))
-      if (L.eps2 > 0.0) NBODY_LAUNCH_PK(Z_SOFT, L.eps2);
-      else NBODY_LAUNCH_PK(Z_CLAMP, -0x1p126);
+                     (float4 *)L.accp, L.n_total, L.i_begin, L.i_count, L.j_chunk, (float)L.G, (float)(ZP),        \
+                     (const int *)(FLAG))
+      if (L.eps2 > 0.0) {
+        NBODY_LAUNCH_PK(Z_SOFT, L.eps2, nullptr);
+      } else if (L.dup_table != nullptr) {
+        hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 8, s);   // slots + {flag, near-origin count}
+        if (e0 != hipSuccess) return e0;
+        int *flag = (int *)((unsigned long long *)L.dup_table + L.dup_slots);
+        hipLaunchKernelGGL(dup_detect_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                           (const float4 *)L.posm, L.n_total, (unsigned long long *)L.dup_table,
+                           (unsigned int)(L.dup_slots - 1), flag);
+        NBODY_LAUNCH_PK(Z_CLAMP, -0x1p126, flag);
+      } else {
+        NBODY_LAUNCH_PK(Z_CLAMP, -0x1p126, nullptr);
+      }
 #undef NBODY_LAUNCH_PK
       return hipGetLastError();
     }

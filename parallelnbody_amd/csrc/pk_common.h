@@ -13,7 +13,9 @@ constexpr int kBlock = 256;   // 4 waves of 64 lanes: one per SIMD of a CU
 //   Z_CLAMP  : r2' = r2 + clamp01(1 - r2*2^126): exactly r2 for every normal r2 > 0, exactly 1 for r2 == 0
 //              (then s = G*m is finite and s*0 = 0).  Two full-rate VALU ops (v_fma ... clamp, v_add).
 //   Z_SELECT : rinv = r2 > 0 ? rsq(r2) : 0 — v_cmp + v_cndmask, both half-rate on gfx950; kept for A/B.
-enum { Z_SOFT = 0, Z_CLAMP = 1, Z_SELECT = 2 };
+//   Z_BARE   : no handling at all — only for tiles that hold no self pair, on inputs proven free of coincident
+//              bodies (dup_detect_kernel, sym_common.h).
+enum { Z_SOFT = 0, Z_CLAMP = 1, Z_SELECT = 2, Z_BARE = 3 };
 
 __device__ __forceinline__ float rsq_dev(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
 
