@@ -398,6 +398,8 @@ __global__ __launch_bounds__(kBlock) void update_kernel(typename V4<T>::type *__
   const int il = blockIdx.x * kBlock + threadIdx.x;
   if (il >= i_count) return;
   T ax = 0, ay = 0, az = 0, cx = 0, cy = 0, cz = 0;
+  // rows are added in chunk order (deterministic); eight loads in flight: small systems have few threads and many rows
+#pragma unroll 8
   for (int c = 0; c < j_split; ++c) {
     const V p = accp[(size_t)c * i_count + il];
     if (KAHAN) {
