@@ -11,9 +11,10 @@ constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
 
 // Does super tile a own the pair {a, b}?  (a == b, or b within the forward half of the ring of T super tiles;
 // the antipodal pair of an even ring goes to the smaller index.)
-__host__ __device__ inline bool sym_assigned(int a, int b, int T) {
+__host__ __device__ inline bool sym_assigned(int a, int b, int T) {      // 0 <= a, b < T
   if (a == b) return true;
-  const int d = (b - a + T) % T;
+  int d = b - a;
+  if (d < 0) d += T;
   if (2 * d < T) return true;
   return 2 * d == T && a < b;
 }
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(kBlock) void reduce_j_kernel(const typename SymVec<
     if (KAHAN) { const R yv = v - c; const R tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
     else sum += v;
   };
+#pragma unroll 4
   for (int al = 0; al < tiles_own; ++al) {
     if (!sym_assigned(own_tile0 + al, tb, T)) continue;        // that workgroup does not exist: row never written
     const V p = part_j[(size_t)al * n_pad + b];
@@ -130,12 +132,17 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
     if (KAHAN) { const R yv = v - c; const R tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
     else sum += v;
   };
-  for (int d = 0; d < T; ++d) {
-    const int sj = (s + d) % T;
-    if (!sym_assigned(s, sj, T)) continue;
+  // partners of s in ring order: itself, the forward half of the ring, and the antipode of an even ring if s is the
+  // smaller index (exactly sym_assigned(s, sj, T), without a test per row)
+  const int d_end = (T - 1) / 2 + ((T % 2 == 0 && s < T / 2) ? 1 : 0);
+#pragma unroll 4
+  for (int d = 0; d <= d_end; ++d) {
+    int sj = s + d;
+    if (sj >= T) sj -= T;
     const V p = part_i[(size_t)sj * n_own_pad + bl];
     add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
   }
+#pragma unroll 4
   for (int q = 0; q < n_src; ++q) {
     const V p = recv[(size_t)q * i_count + bl];
     add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
