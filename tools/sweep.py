@@ -30,13 +30,25 @@ def main():
     print(f"{'algo':>9} {'prec':>9} {'tile':>5} {'ipt':>4} {'jsplit':>6} {'zero':>5} {'blocks':>7} {'ms':>10} {'pairs/s':>12} {'%peak':>7}")
     for algo, prec, tile, ipt, js, zm in itertools.product(ints(a.algos), a.precisions.split(","), ints(a.tiles),
                                                            ints(a.ipts), ints(a.jsplits), ints(a.zeros)):
-        with nb.NBodyEngine(a.n, precision=prec, tile=tile, i_per_thread=ipt, j_split=js, zero_mode=zm, eps=a.eps,
-                            time_kernels=True, algorithm=algo) as e:
+        try:
+            eng = nb.NBodyEngine(a.n, precision=prec, tile=tile, i_per_thread=ipt, j_split=js, zero_mode=zm, eps=a.eps,
+                                 time_kernels=True, algorithm=algo)
+        except nb.NBodyError:
+            continue                     # a combination the library refuses (e.g. 8 bodies per lane, one-sided kernel)
+        with eng as e:
             e.set_state(posm, vel)
+            # warm-up: ~0.25 s of passes first — the clock needs sustained load to settle (N = 65536: 0.955 ms per
+            # pass in a 5-pass run, 0.796 ms in a 500-pass run), then time at least as much again
+            e.kernel_time_reset()
             e.compute_forces()
             e.synchronize()
+            t1, _ = e.kernel_time(nb.KERNEL_FORCES)
+            reps = min(5000, max(1, int(250.0 / max(t1, 1e-3))))
+            for _ in range(reps):
+                e.compute_forces()
+            e.synchronize()
             e.kernel_time_reset()
-            for _ in range(a.iters):
+            for _ in range(max(a.iters, reps)):
                 e.compute_forces()
             ms, n = e.kernel_time(nb.KERNEL_FORCES)
             cfg = e.launch_config()
