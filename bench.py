@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--zero-mode", default="exact", choices=["exact", "floor"],
                     help="exact = the reference's d == 0 skip for every distance; floor = ~1e-20 eps^2 floor")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length; 0 = skip")
+    ap.add_argument("--settle-seconds", type=float, default=0.3,
+                    help="untimed force passes before the warm-up steps (state unchanged): lets the GPU clock settle")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,6 +115,7 @@ def main():
                                    algorithm={"auto": 0, "tiled": 1, "symmetric": 2}[algorithm],
                                    zero_mode={"exact": 0, "floor": 2}[args.zero_mode])
         sim.warm_collectives()
+        sim.settle(args.settle_seconds)     # untimed force passes: the clock needs sustained load to settle
         sim.step(args.dt, args.warmup)
         if os.environ.get("NBODY_BENCH_FAIL_FIRST") == "1" and algorithm == "auto":   # rehearsal of the retry below
             raise RuntimeError("NBODY_BENCH_FAIL_FIRST")

@@ -126,6 +126,26 @@ class ShardedSimulation:
                         dist.all_gather_into_tensor(self.posm, own, group=self.group)
                 self.steps_done += 1
 
+    def settle(self, seconds=0.3):
+        """Untimed force passes (state unchanged: nothing is integrated) for about `seconds`, the same number on every
+        rank: the GPU clock needs sustained load to settle (a run of a few ms-long passes measures the ramp, not the
+        kernel).  Returns the number of passes."""
+        import time
+        torch, dist = self.torch, self.torch.distributed
+        with self._on_stream():
+            sync = self.stream.synchronize if self.stream is not None else (lambda: None)
+            t0 = time.perf_counter()
+            self._forces(); self.engine.step_end(0.0)      # dt = 0: accelerations only, nothing is integrated
+            sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.device)
+            if self.world_size > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            reps = int(min(2000, max(1, seconds / max(float(t[0]), 1e-5))))
+            for _ in range(reps):
+                self._forces(); self.engine.step_end(0.0)
+            sync()
+        return reps + 1
+
     def gather_state(self):
         """(posm[n_total,4], vel[n_total,4]) on every rank, as numpy (for tests and checkpoints)."""
         torch, dist = self.torch, self.torch.distributed

@@ -97,6 +97,7 @@ def _worker_exchange(rank, world, port, n, out_dir):
     sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device="cpu", engine_factory=ExchangingEngine)
     assert sim.ex_ranks == world and sim.ex_recv.shape == (world * sim.i_count, 4)
     sim.warm_collectives()
+    assert sim.settle(0.0) == 2            # untimed force passes (with their exchange), same count on both ranks, state untouched
     sim.compute_forces()
     _, _, a = sim.engine.state()
     sim.step(0.01, 2)
