@@ -100,7 +100,7 @@ typedef struct nbody_params {
   double G;               /* gravitational constant; reference 1e4 */
   double eps;             /* Plummer softening length; reference 0 (d == 0 pairs are skipped) */
   int32_t tile;           /* bodies per LDS tile: 64, 128, 256 (default), 512 */
-  int32_t i_per_thread;   /* i-bodies per lane: 1, 2, 4 (8: fp32 symmetric kernels only); 0 = auto */
+  int32_t i_per_thread;   /* i-bodies per lane: 1, 2, 4 (8: fp32 symmetric kernels, 16: the plain one only); 0 = auto */
   int32_t j_split;        /* j-range chunks summed separately then combined in order; 0 = auto (a function of n_total only) */
   int32_t time_kernels;   /* nonzero: bracket kernels with HIP events for nbody_kernel_time */
   int32_t zero_mode;      /* how d == 0 pairs are dropped when eps == 0 (NBODY_ZERO_*); 0 = default */

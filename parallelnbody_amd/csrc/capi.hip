@@ -91,7 +91,7 @@ int floor_pow2(long long v) { int p = 1; while ((long long)p * 2 <= v) p *= 2; r
 void choose_geometry(nbody_ctx *c) {
   const nbody_params &p = c->p;
   c->tile = p.tile > 0 ? p.tile : 256;
-  if (p.i_per_thread > 0) c->ipt = p.i_per_thread > 4 ? 4 : p.i_per_thread;   // 8 exists for the symmetric kernel only
+  if (p.i_per_thread > 0) c->ipt = p.i_per_thread > 4 ? 4 : p.i_per_thread;   // 8 and 16 exist for the symmetric kernel only
   else c->ipt = (p.precision == NBODY_PREC_F64) ? 1 : (p.n_total >= 65536 ? 4 : (p.n_total >= 8192 ? 2 : 1));
   int js;
   if (p.j_split > 0) {
@@ -138,6 +138,14 @@ void choose_algorithm(nbody_ctx *c) {
       (p.i_count == p.n_total || p.i_count % 2048 == 0))
     sym_ipt = 8;
   if (p.i_per_thread == 8 && sym_ipt != 8) return;
+  // sixteen (eight register pairs, ~230 VGPRs, 2 waves/SIMD): the dpp moves' share halves again
+  // (N = 2^20: 164.5 ms against 170.1 ms with eight; smaller systems — and slices below 2^18 bodies: 22.5 against
+  // 22.2 ms for one of eight ranks — have too few workgroups for it)
+  if (p.precision == NBODY_PREC_F32 &&
+      (p.i_per_thread == 16 || (p.i_per_thread == 0 && p.n_total >= (1 << 20) && p.i_count >= (1 << 18))) &&
+      (p.i_count == p.n_total || p.i_count % 4096 == 0))
+    sym_ipt = 16;
+  if (p.i_per_thread == 16 && sym_ipt != 16) return;
   const bool f64ok = p.precision == NBODY_PREC_F64 && (p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT);   // kernels_sym64.hip
   if (!f32ok && !f64ok) return;
   if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < 32768) return;
@@ -153,7 +161,7 @@ void choose_algorithm(nbody_ctx *c) {
   // (4 per CU), so a rank needs many thousands for the tail to vanish: aim at >= 16384
   // (measured at N = 2^20: 2080 workgroups 200.8 ms, 8256 191.5, 14706 190.6, 32896 189.1).  NBODY_SYM_WORKGROUPS
   // overrides the target (tuning only).
-  long long target = 16384;
+  long long target = sym_ipt == 16 ? 32768 : 16384;    // 2 waves/SIMD hold 512 workgroups at a time: 32896 measured best
   if (const char *t = getenv("NBODY_SYM_WORKGROUPS")) { const long long v = atoll(t); if (v > 0) target = v; }
   // The partial rows take about 2 * T * n_total elements (T super tiles ~ sqrt(2 * target)): keep them under a third
   // of the free device memory by lowering the workgroup target for very large systems.
@@ -468,8 +476,11 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if (!(p.theta >= 0.0f)) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: theta must be >= 0");
   if (p.tile != 0 && p.tile != 64 && p.tile != 128 && p.tile != 256 && p.tile != 512)
     return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: tile must be 64, 128, 256 or 512");
-  if (p.i_per_thread != 0 && p.i_per_thread != 1 && p.i_per_thread != 2 && p.i_per_thread != 4 && p.i_per_thread != 8)
-    return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: i_per_thread must be 1, 2, 4 or 8");
+  if (p.i_per_thread != 0 && p.i_per_thread != 1 && p.i_per_thread != 2 && p.i_per_thread != 4 && p.i_per_thread != 8 &&
+      p.i_per_thread != 16)
+    return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: i_per_thread must be 1, 2, 4, 8 or 16");
+  if (p.i_per_thread == 16 && (p.algorithm == NBODY_ALGO_TILED || p.precision != NBODY_PREC_F32))
+    return fail(nullptr, NBODY_ERR_UNSUPPORTED, "nbody_create: i_per_thread 16 exists for the plain fp32 symmetric kernel only");
   if (p.i_per_thread == 8 && (p.algorithm == NBODY_ALGO_TILED || p.precision == NBODY_PREC_F64))
     return fail(nullptr, NBODY_ERR_UNSUPPORTED, "nbody_create: i_per_thread 8 exists for the fp32 symmetric kernels only");
   if (p.j_split < 0) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: j_split must be >= 0");
@@ -493,7 +504,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   c->elem = (p.precision == NBODY_PREC_F64) ? 32 : 16;
   choose_geometry(c);
   choose_algorithm(c);
-  if (p.i_per_thread == 8 && !(c->sym && c->sym_np == 4)) {
+  if ((p.i_per_thread == 8 && !(c->sym && c->sym_np == 4)) || (p.i_per_thread == 16 && !(c->sym && c->sym_np == 8))) {
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
                 "nbody_create: i_per_thread 8 needs the fp32 symmetric kernel (N >= 32768 or NBODY_ALGO_SYMMETRIC; "

@@ -64,7 +64,9 @@ constexpr float kPadFar = 1.0e18f;
 // more than six packed FMAs (tools/microbench6.hip; profiles/r01_microbench_sym_inner_loop.txt).
 // waves per SIMD: 4 (128 VGPRs); the Kahan form needs 164 VGPRs with two register pairs per lane (3 waves) and ~230
 // with four (2 waves — packed ops are 4-cycle, two waves keep the SIMD within 2 % of four)
-constexpr int sym_waves(int np, bool kahan) { return !kahan ? NBODY_SYM_WAVES : (np == 4 ? 2 : (np == 2 ? 3 : NBODY_SYM_WAVES)); }
+constexpr int sym_waves(int np, bool kahan) {
+  return np == 8 ? 2 : (!kahan ? NBODY_SYM_WAVES : (np == 4 ? 2 : (np == 2 ? 3 : NBODY_SYM_WAVES)));
+}
 
 template <int NP, int ZMODE, bool BARE, bool KAHAN, bool JPK>
 __global__ __launch_bounds__(kBlock)
@@ -76,7 +78,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
   const float4 pad = BARE ? make_float4(kPadFar, kPadFar, kPadFar, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int IPT = 2 * NP;
   constexpr int BI = kBlock * IPT;
-  constexpr int kUnroll = (NP == 4) ? NBODY_SYM_UNROLL4 : NBODY_SYM_UNROLL;
+  constexpr int kUnroll = (NP >= 4) ? NBODY_SYM_UNROLL4 : NBODY_SYM_UNROLL;
   __shared__ float4 sh_pos[2][4][128];   // double-buffered subtile images, doubled: entries l and l+64 hold body l
   __shared__ float sh_acc[4][3][kJT];    // per-WAVE j-side sums of the tile (private: no ordering between waves needed)
 
@@ -219,7 +221,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
         }
       } else {
         // one-sided step on the tiles that overlap the i-set: every ordered pair, self pairs dropped by ZMODE
-        constexpr int JB = (NP == 1) ? 4 : (NP == 2 ? 2 : 1);
+        constexpr int JB = (NP == 1) ? 4 : (NP == 2 ? 2 : 1);   // j-bodies in flight in the one-sided tiles
         for (int q = 0; q < 4; ++q) {
 #pragma unroll 2
           for (int k = 0; k < 64; k += JB) {
@@ -278,10 +280,12 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   do {                                                                                                           \
     if (L.np == 1) NBODY_SYM(1, ZM, BARE, ZP, FLAG, RUNIF);                                                      \
     else if (L.np == 2) NBODY_SYM(2, ZM, BARE, ZP, FLAG, RUNIF);                                                 \
+    else if (L.np == 8) NBODY_SYM_K(8, ZM, BARE, false, true, ZP, FLAG, RUNIF);                                  \
     else if (L.kahan) NBODY_SYM_K(4, ZM, BARE, true, true, ZP, FLAG, RUNIF);                                     \
     else NBODY_SYM_K(4, ZM, BARE, false, true, ZP, FLAG, RUNIF);                                                 \
   } while (0)
-  if (L.np != 1 && L.np != 2 && L.np != 4) return hipErrorInvalidValue;
+  if (L.np != 1 && L.np != 2 && L.np != 4 && L.np != 8) return hipErrorInvalidValue;
+  if (L.np == 8 && L.kahan) return hipErrorInvalidValue;
   // j-side sums: packed pairs (JPK) unless NBODY_SYM_JSCALAR=1 asks for the scalar form (A/B measurements, np <= 2)
   static const bool jscalar = [] { const char *e = getenv("NBODY_SYM_JSCALAR"); return e && e[0] == '1'; }();
   const bool jpk = !jscalar;

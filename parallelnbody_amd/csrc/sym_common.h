@@ -9,14 +9,17 @@ namespace {
 
 constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
 
-// Does super tile a own the pair {a, b}?  (a == b, or b within the forward half of the ring of T super tiles;
-// the antipodal pair of an even ring goes to the smaller index.)
+// Does super tile a own the pair {a, b}?  (a == b, or b within the forward half of the ring of T super tiles; the
+// antipodal pair of an even ring goes to its smaller index if that is even, to the larger one if it is odd — so that
+// every rank, which owns a run of consecutive super tiles, gets the same number of them.)
 __host__ __device__ inline bool sym_assigned(int a, int b, int T) {      // 0 <= a, b < T
   if (a == b) return true;
   int d = b - a;
   if (d < 0) d += T;
   if (2 * d < T) return true;
-  return 2 * d == T && a < b;
+  if (2 * d != T) return false;
+  const int lo = a < b ? a : b;
+  return ((lo & 1) == 0) == (a == lo);
 }
 
 // lane l+1 <- lane l, lane 0 <- lane 63 (v_mov_b32_dpp wave_ror:1; a half-rate VALU op on gfx950)
@@ -132,9 +135,10 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
     if (KAHAN) { const R yv = v - c; const R tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
     else sum += v;
   };
-  // partners of s in ring order: itself, the forward half of the ring, and the antipode of an even ring if s is the
-  // smaller index (exactly sym_assigned(s, sj, T), without a test per row)
-  const int d_end = (T - 1) / 2 + ((T % 2 == 0 && s < T / 2) ? 1 : 0);
+  // partners of s in ring order: itself, the forward half of the ring, and the antipode of an even ring if s owns that
+  // pair (exactly sym_assigned(s, sj, T), without a test per row)
+  const int anti = s + T / 2 < T ? s + T / 2 : s - T / 2;
+  const int d_end = (T - 1) / 2 + ((T % 2 == 0 && sym_assigned(s, anti, T)) ? 1 : 0);
 #pragma unroll 4
   for (int d = 0; d <= d_end; ++d) {
     int sj = s + d;

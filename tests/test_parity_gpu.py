@@ -420,7 +420,7 @@ def test_config3_fp64_size_properties(nb, oracle):
 
 # ---- symmetric algorithm (each unordered pair once, kernels_sym.hip) -----------------------------------------
 
-@pytest.mark.parametrize("ipt", [2, 4, 8])
+@pytest.mark.parametrize("ipt", [2, 4, 8, 16])
 @pytest.mark.parametrize("zero_mode", [0, 2])
 @pytest.mark.parametrize("fixture", ["plummer_n1024_seed1", "refbox_n2000_seed1"])
 def test_symmetric_forces_match_oracle(nb, fixture, ipt, zero_mode):
@@ -456,7 +456,7 @@ def test_symmetric_step_and_duplicates(nb, oracle):
     np.testing.assert_array_equal(p[:, :3], p1)
 
 
-@pytest.mark.parametrize("ipt", [2, 8])
+@pytest.mark.parametrize("ipt", [2, 8, 16])
 @pytest.mark.parametrize("n", [257, 1000, 4096, 5000])
 def test_symmetric_ragged_sizes(nb, oracle, n, ipt):
     rng = np.random.default_rng(n)
@@ -468,7 +468,7 @@ def test_symmetric_ragged_sizes(nb, oracle, n, ipt):
     assert rel_err(a, oracle.forces_direct_f32(posm[:, :3], posm[:, 3])).max() < TOL_ACC
 
 
-@pytest.mark.parametrize("ranks,ipt", [(2, 2), (4, 2), (8, 2), (2, 8), (4, 8)])
+@pytest.mark.parametrize("ranks,ipt", [(2, 2), (4, 2), (8, 2), (2, 8), (4, 8), (2, 16)])
 def test_symmetric_sharded_ranks_emulated_on_one_gpu(nb, oracle, ranks, ipt):
     # The multi-GPU symmetric path: every rank evaluates its share of the body PAIRS once, the j-side halves
     # travel through one all-to-all.  Emulated here with `ranks` contexts on one device and the exchange staged
@@ -510,6 +510,11 @@ def test_symmetric_refuses_what_it_cannot_do(nb):
     for kw in (dict(precision="f64"), dict(algorithm=1), dict(algorithm=2, i_begin=0, i_count=1024)):
         with pytest.raises(nb.NBodyError) as e:
             nb.NBodyEngine(4096, i_per_thread=8, **{"algorithm": 2, **kw})
+        assert e.value.code == nb._lib.ERR_UNSUPPORTED
+    # sixteen: the plain fp32 symmetric kernel only, slices in multiples of 4096
+    for kw in (dict(precision="f32_kahan"), dict(algorithm=1), dict(algorithm=2, i_begin=0, i_count=2048)):
+        with pytest.raises(nb.NBodyError) as e:
+            nb.NBodyEngine(8192, i_per_thread=16, **{"algorithm": 2, **kw})
         assert e.value.code == nb._lib.ERR_UNSUPPORTED
 
 
@@ -704,7 +709,7 @@ def test_headline_config_runs_the_symmetric_kernel_at_speed(nb):
     posm, vel = nb.ic_plummer(n, seed=20261003)
     with nb.NBodyEngine(n, time_kernels=True) as e:
         cfg = e.launch_config()
-        assert cfg["algorithm"] == "symmetric" and cfg["kernel"] == "forces_sym_pk_kernel" and cfg["i_per_thread"] == 8
+        assert cfg["algorithm"] == "symmetric" and cfg["kernel"] == "forces_sym_pk_kernel" and cfg["i_per_thread"] == 16
         e.set_state(posm, vel)
         e.compute_forces(); e.synchronize(); e.kernel_time_reset()
         e.compute_forces(); e.compute_forces()

@@ -238,6 +238,10 @@ int main() {
   run<4, 4, J_PK6 | J_LDS>("packed sums travelling through LDS", posm, out, cyc);
   run<2, 4, J_PK6 | J_LDS>("packed sums travelling through LDS", posm, out, cyc);
   run<4, 2, J_PK6 | V_NODPP>("packed sums, not travelling (floor)", posm, out, cyc);
+  run<8, 1, J_PK6, 2>("packed travelling sums (6 dpp)", posm, out, cyc);
+  run<8, 2, J_PK6, 2>("packed travelling sums (6 dpp)", posm, out, cyc);
+  run<4, 4, J_PK6, 2>("packed travelling sums (6 dpp)", posm, out, cyc);
+  run<6, 2, J_PK6, 2>("packed travelling sums (6 dpp)", posm, out, cyc);
   calib<0>("v_pk_fma_f32", out); calib<1>("v_fmac_f32", out); calib<2>("v_rsq_f32", out); calib<3>("v_mov_b32_dpp", out);
   run<2, 4, 0>("full step", posm, out, cyc);
   run<2, 2, 0>("full step", posm, out, cyc);
