@@ -24,10 +24,10 @@ if ROOT not in sys.path:
 PEAK_FP32_TFLOPS = 157.3      # MI355X vector fp32 peak, MI355X_MICROARCH.md "Chip-level parameters"
 FLOP_PER_PAIR = 20            # 3 sub + 6 (dot) + 4 (rsqrt cubed) + 1 (mass) + 6 (3 FMA)
 # HBM bytes per force launch from the PMC passes in profiles/r01_pmc_forces_tile_kernel.txt and
-# profiles/r01_pmc_forces_sym_kernel_ipt8.txt (tools/profile_bench.sh), keyed by (algorithm, n, gpus):
+# profiles/r01_pmc_forces_sym_kernel_ipt16.txt (tools/profile_bench.sh), keyed by (algorithm, n, gpus):
 # FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE.  None for configurations not profiled.
 TRAFFIC_BYTES_PER_LAUNCH = {("tiled", 1 << 20, 1): 2 * 173606 * 1024 + 262144 * 1024,
-                            ("symmetric", 1 << 20, 1): 2 * 3879990 * 1024 + 8178140 * 1024}
+                            ("symmetric", 1 << 20, 1): 2 * 2290740 * 1024 + 6528970 * 1024}
 
 
 def cpu_baseline(posm, target_seconds):

@@ -7,6 +7,7 @@ import os
 import sys
 
 out, kernel = sys.argv[1], sys.argv[2]
+BPL = int(sys.argv[3]) if len(sys.argv) > 3 else 16        # bodies per lane of the profiled launch
 N = 1 << 20
 vals, dur = {}, []
 for d in sorted(glob.glob(os.path.join(out, "pmc[0-9]"))):
@@ -27,22 +28,22 @@ for d in sorted(glob.glob(os.path.join(out, "pmc[0-9]"))):
                 acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for name, per in acc.items():
         vals[(tag, name)] = sum(per.values()) / len(per)
-print(f"# rocprofv3 --pmc passes, MI355X, command: python3 tools/sweep.py --n 1048576 --iters 1 --ipts 8 --zeros 0 --algos 2")
+print(f"# rocprofv3 --pmc passes, MI355X, command: python3 tools/sweep.py --n 1048576 --iters 1 --ipts {BPL} --zeros 0 --algos 2")
 print(f"# kernel: {kernel} (the launch that ran; its guarded twin returns at its first instruction); per-launch means")
 for (tag, name), v in sorted(vals.items()):
     print(f"{tag},{name},{v:.6g}")
 if dur:
     print("kernel_duration_ms_in_pmc3_run," + str([round(x, 3) for x in dur]))
 g = lambda n: next((v for (t, k), v in vals.items() if k == n), None)
-steps = N * (N - 1) / 2 / 512.0          # wave-steps: 64 lanes x 4 register pairs x 2 bodies meet one j
+steps = N * (N - 1) / 2 / (64.0 * BPL)   # wave-steps: 64 lanes x BPL bodies meet one j
 if g("SQ_INSTS_VALU"):
-    print(f"# derived: wave-steps = N(N-1)/2/512 = {steps:.4g}; SQ_INSTS_VALU per wave-step = {g('SQ_INSTS_VALU') / steps:.1f}"
-          " (64 packed + 8 v_rsq_f32 + 6 v_mov_b32_dpp = 78 in the symmetric tiles)")
+    print(f"# derived: wave-steps = N(N-1)/2/{64 * BPL} = {steps:.4g}; SQ_INSTS_VALU per wave-step = {g('SQ_INSTS_VALU') / steps:.1f}"
+          f" ({8 * BPL} packed + {BPL} v_rsq_f32 + 6 v_mov_b32_dpp = {9 * BPL + 6} in the symmetric tiles)")
 if g("GRBM_GUI_ACTIVE") and dur:
     t = sum(dur) / len(dur) * 1e-3
     clk = g("GRBM_GUI_ACTIVE") / 8 / t
     print(f"# clock = GRBM_GUI_ACTIVE/8/duration = {clk / 1e9:.3f} GHz; SIMD cycles per wave-step = {1024 * t * clk / steps:.1f}"
-          f" (16 interactions per lane) = {1024 * t * clk / steps / 16:.2f} per interaction-lane")
+          f" ({2 * BPL} interactions per lane) = {1024 * t * clk / steps / (2 * BPL):.2f} per interaction-lane")
 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None and dur:
     t = sum(dur) / len(dur) * 1e-3
     rd, wr = g("FETCH_SIZE") * 1024 * 2, g("WRITE_SIZE") * 1024     # KB; gfx950: FETCH_SIZE counts 128-B requests at 64 B
