@@ -37,12 +37,6 @@ constexpr int kB = 256;
 constexpr int kLevelsPerKey = 21;
 constexpr int kMaxLevels = 2 * kLevelsPerKey;   // 42
 
-__device__ __forceinline__ int key_digit(unsigned long long hi, unsigned long long lo, int level) {
-  const unsigned long long k = level < kLevelsPerKey ? hi : lo;
-  const int l = level < kLevelsPerKey ? level : level - kLevelsPerKey;
-  return (int)((k >> (3 * (kLevelsPerKey - 1 - l))) & 7ull);
-}
-
 // child centre and size exactly as Octree::Add computes them (.h:71-74)
 __device__ __forceinline__ void child_box(const float o[3], float size, int c, float out[3], float *csize) {
   out[0] = (float)((double)o[0] + (double)size * ((c & 4) ? 0.5 : -0.5));
@@ -111,61 +105,121 @@ __global__ void bh_root_kernel(Nodes nd, const float *__restrict__ root, const f
   }
 }
 
-// One thread per cell of the current level that holds >= 2 bodies: create its 8 children (.h:68-75).
-__global__ __launch_bounds__(kB) void bh_split_kernel(Nodes nd, const unsigned long long *__restrict__ khi,
-                                                      const unsigned long long *__restrict__ klo,
-                                                      const unsigned int *__restrict__ sidx,
-                                                      const float4 *__restrict__ posm, const int *__restrict__ cur,
-                                                      int ncur, int *__restrict__ nxt, int *__restrict__ counters,
-                                                      int node_cap) {
-  const int f = blockIdx.x * kB + threadIdx.x;
-  if (f >= ncur) return;
-  const int me = cur[f];
+// Create the 8 children of cell `me`, which holds >= 2 bodies (.h:68-75) — EIGHT consecutive lanes per cell, lane c
+// makes child c: the eight binary searches (where does key digit > c start?) run side by side instead of one after
+// the other (88 dependent loads for the root of a 2000-body tree), the lower bound comes from the neighbour lane.
+// All eight lanes of a group must call this together.  node_counter / next_counter / err: global memory or LDS.
+__device__ __forceinline__ void split_cell8(const Nodes &nd, const unsigned long long *khi,
+                                            const unsigned long long *__restrict__ klo,
+                                            const unsigned int *__restrict__ sidx, const float4 *__restrict__ posm, int me,
+                                            int c, int *__restrict__ nxt, int *node_counter, int *next_counter, int *err,
+                                            int node_cap) {
   const int4 lk = nd.link[me];
   const int level = lk.w;
   const int2 rg = nd.range[me];
-  if (level >= kMaxLevels) { atomicExch(&counters[2], 1); return; }     // bodies closer than Size/2^42: the reference would recurse on
-  const int base = atomicAdd(&counters[0], 8);
-  if (base + 8 > node_cap) { atomicExch(&counters[2], 2); return; }
+  if (level >= kMaxLevels) { if (c == 0) atomicExch(err, 1); return; }  // bodies closer than Size/2^42: the reference would recurse on
+  const unsigned long long *kw = level < kLevelsPerKey ? khi : klo;      // only the word that holds this level's digit
+  const int ksh = 3 * (kLevelsPerKey - 1 - (level < kLevelsPerKey ? level : level - kLevelsPerKey));
+  int base = 0;
+  if (c == 0) base = atomicAdd(node_counter, 8);
+  base = __shfl(base, 0, 8);
+  if (base + 8 > node_cap) { if (c == 0) atomicExch(err, 2); return; }
+  const float4 bx = nd.box[me];
+  // bodies of this cell are sorted by key, so those of child c are contiguous: find where digit > c starts
+  int a = rg.x, b = rg.y;
+  while (a < b) {
+    const int m = (a + b) >> 1;
+    if ((int)((kw[m] >> ksh) & 7ull) <= c) a = m + 1; else b = m;
+  }
+  const int hi = a;
+  int lo = __shfl_up(hi, 1, 8);
+  if (c == 0) lo = rg.x;
+  if (c == 0) nd.link[me] = make_int4(base, -1, lk.z, level);
+  const int cnt = hi - lo, id = base + c;
+  const float o[3] = {bx.x, bx.y, bx.z};
+  float co[3], cs;
+  child_box(o, bx.w, c, co, &cs);
+  nd.box[id] = make_float4(co[0], co[1], co[2], cs);
+  nd.range[id] = make_int2(lo, hi);
+  const int skip = (c < 7) ? id + 1 : lk.z;              // next node of a depth-first walk that does not descend
+  if (cnt >= 2) {
+    nd.link[id] = make_int4(-1, -1, skip, level + 1);
+    nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+    nxt[atomicAdd(next_counter, 1)] = id;
+  } else if (cnt == 1) {
+    const unsigned int body = sidx[lo];
+    nd.link[id] = make_int4(-1, (int)body, skip, level + 1);
+    nd.com[id] = posm[body];
+  } else {
+    nd.link[id] = make_int4(-1, -1, skip, level + 1);
+    nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);        // empty leaf: TotalMass 0, CoM ZeroVector
+  }
+}
+
+// Create the 8 children of cell `me` by ONE lane (levels with many cells: bandwidth- rather than latency-bound).
+__device__ __forceinline__ void split_cell1(const Nodes &nd, const unsigned long long *__restrict__ khi,
+                                            const unsigned long long *__restrict__ klo,
+                                            const unsigned int *__restrict__ sidx, const float4 *__restrict__ posm, int me,
+                                            int *__restrict__ nxt, int *node_counter, int *next_counter, int *err,
+                                            int node_cap) {
+  const int4 lk = nd.link[me];
+  const int level = lk.w;
+  const int2 rg = nd.range[me];
+  if (level >= kMaxLevels) { atomicExch(err, 1); return; }
+  const unsigned long long *kw = level < kLevelsPerKey ? khi : klo;
+  const int ksh = 3 * (kLevelsPerKey - 1 - (level < kLevelsPerKey ? level : level - kLevelsPerKey));
+  const int base = atomicAdd(node_counter, 8);
+  if (base + 8 > node_cap) { atomicExch(err, 2); return; }
   nd.link[me] = make_int4(base, -1, lk.z, level);
   const float4 bx = nd.box[me];
   const float o[3] = {bx.x, bx.y, bx.z};
   int lo = rg.x;
   for (int c = 0; c < 8; ++c) {
-    // bodies of this cell are sorted by key, so those of child c are contiguous: find where digit > c starts
     int a = lo, b = rg.y;
     while (a < b) {
       const int m = (a + b) >> 1;
-      if (key_digit(khi[m], klo[m], level) <= c) a = m + 1; else b = m;
+      if ((int)((kw[m] >> ksh) & 7ull) <= c) a = m + 1; else b = m;
     }
     const int hi = a, cnt = hi - lo, id = base + c;
     float co[3], cs;
     child_box(o, bx.w, c, co, &cs);
     nd.box[id] = make_float4(co[0], co[1], co[2], cs);
     nd.range[id] = make_int2(lo, hi);
-    const int skip = (c < 7) ? id + 1 : lk.z;              // next node of a depth-first walk that does not descend
+    const int skip = (c < 7) ? id + 1 : lk.z;
     if (cnt >= 2) {
       nd.link[id] = make_int4(-1, -1, skip, level + 1);
       nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-      nxt[atomicAdd(&counters[1], 1)] = id;
+      nxt[atomicAdd(next_counter, 1)] = id;
     } else if (cnt == 1) {
       const unsigned int body = sidx[lo];
       nd.link[id] = make_int4(-1, (int)body, skip, level + 1);
       nd.com[id] = posm[body];
     } else {
       nd.link[id] = make_int4(-1, -1, skip, level + 1);
-      nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);        // empty leaf: TotalMass 0, CoM ZeroVector
+      nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     lo = hi;
   }
 }
 
-// Octree::ComputeMass of the cells of one level (deepest level first), .h:89-95.
-__global__ __launch_bounds__(kB) void bh_upsweep_kernel(Nodes nd, const int *__restrict__ cells, int ncells) {
+// Eight threads per cell of the current level that holds >= 2 bodies (LANES = 8), or one (LANES = 1).
+template <int LANES>
+__global__ __launch_bounds__(kB) void bh_split_kernel(Nodes nd, const unsigned long long *__restrict__ khi,
+                                                      const unsigned long long *__restrict__ klo,
+                                                      const unsigned int *__restrict__ sidx,
+                                                      const float4 *__restrict__ posm, const int *__restrict__ cur,
+                                                      int ncur, int *__restrict__ nxt, int *__restrict__ counters,
+                                                      int node_cap) {
+  const int g = blockIdx.x * kB + threadIdx.x;
+  const int f = LANES == 8 ? g >> 3 : g;
+  if (f >= ncur) return;
+  if (LANES == 8) split_cell8(nd, khi, klo, sidx, posm, cur[f], g & 7, nxt, &counters[0], &counters[1], &counters[2], node_cap);
+  else            split_cell1(nd, khi, klo, sidx, posm, cur[f], nxt, &counters[0], &counters[1], &counters[2], node_cap);
+}
+
+// Octree::ComputeMass of one cell whose children are done, .h:89-95.
+__device__ __forceinline__ void upsweep_cell(const Nodes &nd, int me) {
 #pragma clang fp contract(off)
-  const int f = blockIdx.x * kB + threadIdx.x;
-  if (f >= ncells) return;
-  const int me = cells[f];
   const int base = nd.link[me].x;
   float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
   for (int c = 0; c < 8; ++c) {
@@ -181,6 +235,84 @@ __global__ __launch_bounds__(kB) void bh_upsweep_kernel(Nodes nd, const int *__r
     cx = bx.x; cy = bx.y; cz = bx.z;
   }
   nd.com[me] = make_float4(cx, cy, cz, M);
+}
+
+// The cells of one level (deepest level first).
+__global__ __launch_bounds__(kB) void bh_upsweep_kernel(Nodes nd, const int *__restrict__ cells, int ncells) {
+  const int f = blockIdx.x * kB + threadIdx.x;
+  if (f >= ncells) return;
+  upsweep_cell(nd, cells[f]);
+}
+
+// Small systems (the reference ships N = 2000): the whole Add + ComputeMass — root, every level's splits, the upsweep
+// from the deepest level, the next frame's root centre — by ONE workgroup in one launch, levels separated by
+// barriers instead of a launch and a host round trip each (N = 2000: 12 levels).
+// counters out: [0] nodes, [1] levels, [2] error (0 ok, 1 depth limit, 2 node pool full).
+constexpr int kSmallThreads = 1024;
+constexpr int kLdsKeys = 8192;
+__global__ __launch_bounds__(kSmallThreads) void bh_build_small_kernel(Nodes nd, const float *__restrict__ root,
+                                                                       const float4 *__restrict__ posm,
+                                                                       const unsigned long long *khi,
+                                                                       const unsigned long long *__restrict__ klo,
+                                                                       const unsigned int *__restrict__ sidx, int n,
+                                                                       int *__restrict__ frontier, int *__restrict__ counters,
+                                                                       int node_cap, float *__restrict__ prev_com) {
+  __shared__ int s_off[kMaxLevels + 2], s_cnt[kMaxLevels + 2];
+  __shared__ int s_nodes, s_next, s_err;
+  __shared__ unsigned long long s_khi[kLdsKeys];          // the first 21 levels' digits: binary searches at LDS latency
+  const int t = threadIdx.x;
+  if (n <= kLdsKeys) {
+    for (int i = t; i < n; i += kSmallThreads) s_khi[i] = khi[i];
+    khi = s_khi;                                            // generic pointer: flat loads resolve to LDS
+  }
+  if (t == 0) {
+    nd.box[0] = make_float4(root[0], root[1], root[2], root[3]);
+    nd.range[0] = make_int2(0, n);
+    s_nodes = 1; s_next = 0; s_err = 0;
+    if (n >= 2) {
+      nd.link[0] = make_int4(-1, -1, -1, 0);
+      nd.com[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      frontier[0] = 0;
+      s_cnt[0] = 1;
+    } else {
+      const unsigned int b = sidx[0];
+      nd.link[0] = make_int4(-1, (int)b, -1, 0);
+      nd.com[0] = posm[b];
+      s_cnt[0] = 0;
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  int levels = 0, cur_off = 0, ncur = s_cnt[0];
+  bool failed = false;
+  while (ncur > 0) {
+    if (levels > kMaxLevels) { failed = true; if (t == 0) s_err = 1; break; }
+    int *cur = frontier + cur_off, *nxt = cur + ncur;
+    for (int g = t; g < 8 * ncur; g += kSmallThreads)      // eight lanes per cell
+      split_cell8(nd, khi, klo, sidx, posm, cur[g >> 3], g & 7, nxt, &s_nodes, &s_next, &s_err, node_cap);
+    __threadfence();
+    __syncthreads();
+    if (s_err != 0) { failed = true; break; }
+    if (t == 0) { s_off[levels] = cur_off; s_cnt[levels] = ncur; }
+    ++levels;
+    cur_off += ncur;
+    ncur = s_next;
+    __syncthreads();
+    if (t == 0) s_next = 0;
+    __syncthreads();
+  }
+  if (!failed) {
+    for (int l = levels - 1; l >= 0; --l) {                  // ComputeMass: children before parents
+      const int off = s_off[l], cnt = s_cnt[l];
+      for (int f = t; f < cnt; f += kSmallThreads) upsweep_cell(nd, frontier[off + f]);
+      __threadfence();
+      __syncthreads();
+    }
+  }
+  if (t == 0) {
+    if (!failed) { const float4 c = nd.com[0]; prev_com[0] = c.x; prev_com[1] = c.y; prev_com[2] = c.z; }   // .cpp:78
+    counters[0] = s_nodes; counters[1] = levels; counters[2] = s_err; counters[3] = 0;
+  }
 }
 
 // Octree::ComputeForces for every body (.h:99-108), bodies taken in key order for coherence.
@@ -241,6 +373,9 @@ __global__ void bh_save_com_kernel(Nodes nd, float *__restrict__ prev_com) {
 }
 
 }  // namespace
+
+constexpr int kCoopCells = 32768;     // levels with fewer cells than this split with eight lanes per cell
+constexpr int kSmallBodies = 16384;   // up to here one workgroup builds the whole tree (bh_build_small_kernel)
 
 struct BhState {
   int n = 0, node_cap = 0;
@@ -318,6 +453,19 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   // b->khi / b->idx are final; bring the low words (b->klo is still in body order) into the same order
   hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->klo, b->idx, b->klo2, n);
 
+  if (n <= kSmallBodies) {
+    // one launch builds and sweeps the tree; the walk follows at once, the verdict is read after it (a refused tree
+    // is still walkable: unsplit cells look like empty leaves)
+    hipLaunchKernelGGL(bh_build_small_kernel, dim3(1), dim3(kSmallThreads), 0, s, b->nd, b->root, posm, b->khi, b->klo2,
+                       b->idx, n, b->frontier, b->counters, b->node_cap, b->prev_com);
+    hipLaunchKernelGGL(bh_walk_kernel, grd, blk, 0, s, b->nd, posm, b->idx, n, theta, G, acc);
+    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    BH_TRY(hipStreamSynchronize(s));
+    b->last_nodes = b->h_counters[0];
+    b->last_levels = b->h_counters[1];
+    *status = b->h_counters[2];
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(bh_root_kernel, dim3(1), dim3(1), 0, s, b->nd, b->root, posm, b->idx, n, b->counters, b->frontier);
   // level by level; the frontier of level l sits at frontier[off[l] .. off[l] + cnt[l])
   int off[kMaxLevels + 2], cnt[kMaxLevels + 2];
@@ -330,8 +478,12 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
     if (levels > kMaxLevels) { *status = 1; return hipSuccess; }
     off[levels] = cur_off; cnt[levels] = ncur; ++levels;
     int *cur = b->frontier + cur_off, *nxt = cur + ncur;
-    hipLaunchKernelGGL(bh_split_kernel, dim3((ncur + kB - 1) / kB), blk, 0, s, b->nd, b->khi, b->klo2, b->idx, posm, cur,
-                       ncur, nxt, b->counters, b->node_cap);
+    if (ncur < kCoopCells)     // few cells: latency-bound, eight lanes per cell; many: one lane each
+      hipLaunchKernelGGL(bh_split_kernel<8>, dim3((8 * ncur + kB - 1) / kB), blk, 0, s, b->nd, b->khi, b->klo2, b->idx, posm,
+                         cur, ncur, nxt, b->counters, b->node_cap);
+    else
+      hipLaunchKernelGGL(bh_split_kernel<1>, dim3((ncur + kB - 1) / kB), blk, 0, s, b->nd, b->khi, b->klo2, b->idx, posm,
+                         cur, ncur, nxt, b->counters, b->node_cap);
     BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
     BH_TRY(hipMemsetAsync(b->counters + 1, 0, sizeof(int), s));
     BH_TRY(hipStreamSynchronize(s));
