@@ -4,6 +4,10 @@
     python -m parallelnbody_amd --n 2000 --size 1000 --dt 0.01 --steps 600          # the shipped scene
     python -m parallelnbody_amd --plummer --n 65536 --eps 1 --steps 100 --energy-every 20
     python -m parallelnbody_amd --n 2000 --steps 300 --checkpoint run.ckpt ; python -m parallelnbody_amd --n 2000 --resume run.ckpt --steps 300
+    python -m parallelnbody_amd --n 2000 --theta 1.0 --steps 600 --trajectory run.trj --trajectory-every 10   # as shipped: Barnes-Hut, theta = 1
+
+Trajectory file (nothing in the reference to mirror): header `NBDYTRJ1`, int32 n, int32 reserved, then per
+dumped frame int64 frame number + n x 3 float32 positions — `read_trajectory(path)` returns (frames, positions[k, n, 3]).
 """
 import argparse
 import json
@@ -12,6 +16,20 @@ import time
 import numpy as np
 
 from . import NBodyEngine, ic_plummer, ic_reference_box
+
+
+TRJ_MAGIC = b"NBDYTRJ1"
+
+
+def read_trajectory(path):
+    """(frame numbers [k], positions [k, n, 3] float32) of a file written by --trajectory."""
+    with open(path, "rb") as f:
+        if f.read(8) != TRJ_MAGIC:
+            raise ValueError(f"{path}: not a trajectory file")
+        n = int(np.frombuffer(f.read(8), np.int32)[0])
+        rec = np.dtype([("frame", "<i8"), ("pos", "<f4", (n, 3))])
+        data = np.frombuffer(f.read(), rec)
+    return data["frame"].copy(), data["pos"].copy()
 
 
 def main(argv=None):
@@ -30,23 +48,42 @@ def main(argv=None):
     ap.add_argument("--checkpoint", help="write the final state here")
     ap.add_argument("--resume", help="start from this checkpoint instead of fresh initial conditions")
     ap.add_argument("--dump-positions", help="write the final positions (n x 3 float32, .npy)")
+    ap.add_argument("--theta", type=float, default=0.0,
+                    help="opening angle: 0 = exact all-pairs (default); 1.0 = the reference's shipped Barnes-Hut walk")
+    ap.add_argument("--trajectory", help="write positions every --trajectory-every frames to this file (read_trajectory reads it back)")
+    ap.add_argument("--trajectory-every", type=int, default=1)
     a = ap.parse_args(argv)
 
     posm, vel = (ic_plummer(a.n, G=a.G, seed=a.seed) if a.plummer else ic_reference_box(a.n, a.size, seed=a.seed))
-    with NBodyEngine(a.n, device=a.device, precision=a.precision, G=a.G, eps=a.eps) as e:
+    if a.trajectory_every < 1:
+        ap.error("--trajectory-every must be >= 1")
+    with NBodyEngine(a.n, device=a.device, precision=a.precision, G=a.G, eps=a.eps, theta=a.theta) as e:
         e.set_state(posm, vel)
         start = e.load_checkpoint(a.resume) if a.resume else 0
-        chunk = a.energy_every if a.energy_every > 0 else a.steps
+        trj = None
+        if a.trajectory:
+            trj = open(a.trajectory, "wb")
+            trj.write(TRJ_MAGIC + np.array([a.n, 0], np.int32).tobytes())
+            frame_buf = np.empty((a.n, 3), np.float32)
+            e.pin(frame_buf)                                     # frames land in it by one DMA
+        # advance in chunks that end on every frame somebody wants to see
+        marks = [m for m in (a.energy_every, a.trajectory_every if trj else 0) if m > 0]
         t0 = time.perf_counter()
         done = 0
         while done < a.steps:
-            k = min(chunk, a.steps - done)
+            k = min([a.steps - done] + [m - (start + done) % m for m in marks])
             e.step(a.dt, k)
             done += k
-            if a.energy_every > 0:
+            frame = start + done
+            if a.energy_every > 0 and frame % a.energy_every == 0:
                 ke, pe = e.energy()
-                print(json.dumps({"frame": start + done, "kinetic": ke, "potential": pe, "total": ke + pe}))
+                print(json.dumps({"frame": frame, "kinetic": ke, "potential": pe, "total": ke + pe}))
+            if trj and frame % a.trajectory_every == 0:
+                e.positions(out=frame_buf)
+                trj.write(np.int64(frame).tobytes() + frame_buf.tobytes())
         e.synchronize()
+        if trj:
+            trj.close()
         wall = time.perf_counter() - t0
         size = e.bounds()
         if a.checkpoint:

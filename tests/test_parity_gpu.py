@@ -601,6 +601,15 @@ def test_command_line_replay_of_the_shipped_scene(nb, tmp_path, capsys):
     assert lines[-1]["first_frame"] == 4 and lines[-1]["steps_done"] == 7
     pos = np.load(tmp_path / "p.npy")
     assert pos.shape == (2000, 3) and np.all(np.isfinite(pos))
+    # trajectory dump, with the reference's shipped opening angle: frames 3, 6, 9 of a 10-frame run; the last dumped
+    # frame equals a straight run to frame 9
+    from parallelnbody_amd.__main__ import read_trajectory
+    trj = str(tmp_path / "t.trj")
+    main(["--n", "2000", "--theta", "1.0", "--steps", "10", "--trajectory", trj, "--trajectory-every", "3"])
+    main(["--n", "2000", "--theta", "1.0", "--steps", "9", "--dump-positions", str(tmp_path / "p9.npy")])
+    frames, xyz = read_trajectory(trj)
+    assert frames.tolist() == [3, 6, 9] and xyz.shape == (3, 2000, 3)
+    np.testing.assert_array_equal(xyz[2], np.load(tmp_path / "p9.npy"))
 
 
 def test_three_body_figure_eight_on_the_device(nb):
