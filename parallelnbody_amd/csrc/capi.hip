@@ -309,6 +309,7 @@ int run_forces_bh(nbody_ctx *c) {
   HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, 0, c->p.n_total, (unsigned int *)c->scratch, c->stream));
   int status = 0;
   HIP_TRY(c, nbody::bh_forces(c->bh, c->posm, c->bh_acc, (const unsigned int *)c->scratch, c->theta, c->p.G, c->stream, &status));
+  if (status != 0 && timed) c->timers[NBODY_KERNEL_FORCES].pool.push_back(ev);   // the pair goes back unused
   if (status == 1) return fail(c, NBODY_ERR_UNSUPPORTED, "Barnes-Hut tree deeper than 42 levels: two bodies closer than Size/2^42 (the reference's Add would recurse without bound on coincident bodies)");
   if (status == 2) return fail(c, NBODY_ERR_NOMEM, "Barnes-Hut node pool exhausted");
   if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
