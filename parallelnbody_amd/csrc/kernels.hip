@@ -436,7 +436,15 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const typename V4<T>::ty
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order as uints
+  // one atomic per workgroup (8192 same-address atomics — one per wave of a 2048-block grid — cost 80 us at N = 2^20)
+  __shared__ float wave_max[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, wave_max[w]);
+    atomicMax(out_bits, __float_as_uint(m));                              // non-negative floats order as uints
+  }
 }
 
 // fp64 energy diagnostic.  out[0] += sum_i 1/2 m_i v_i^2 (only by blockIdx.y == 0),
@@ -635,7 +643,7 @@ hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_cou
                          hipStream_t s) {
   if (i_count <= 0) return hipErrorInvalidValue;
   int blocks = (i_count + kBlock - 1) / kBlock;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;
   if (precision == NBODY_PREC_F64)
     hipLaunchKernelGGL((bounds_kernel<double, false>), dim3(blocks), dim3(kBlock), 0, s, (const double4 *)posm, i_begin,
                        i_count, out_bits);
@@ -648,7 +656,7 @@ hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_cou
 hipError_t launch_massmax(int precision, const void *posm, int n_total, unsigned int *out_bits, hipStream_t s) {
   if (n_total <= 0) return hipErrorInvalidValue;
   int blocks = (n_total + kBlock - 1) / kBlock;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;
   if (precision == NBODY_PREC_F64)
     hipLaunchKernelGGL((bounds_kernel<double, true>), dim3(blocks), dim3(kBlock), 0, s, (const double4 *)posm, 0, n_total,
                        out_bits);

@@ -156,6 +156,34 @@ __device__ __forceinline__ void split_cell8(const Nodes &nd, const unsigned long
   }
 }
 
+// Reserve `v` slots for every active lane of the wave with ONE atomicAdd on *counter (hundreds of thousands of cells
+// per level would otherwise queue on a single address); returns this lane's first slot.
+__device__ __forceinline__ int wave_reserve(int *counter, int v) {
+  const unsigned long long active = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  int before = 0, total = 0;
+  for (unsigned long long m = active; m != 0ull; m &= m - 1ull) {      // lanes in ascending order
+    const int l = __ffsll((long long)m) - 1;
+    const int vl = __shfl(v, l, 64);
+    if (l < lane) before += vl;
+    total += vl;
+  }
+  const int leader = __ffsll((long long)active) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, total);
+  return __shfl(base, leader, 64) + before;
+}
+
+// The same for a constant `v` per lane: no scan needed.
+__device__ __forceinline__ int wave_reserve_const(int *counter, int v) {
+  const unsigned long long active = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)active) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, v * __popcll(active));
+  return __shfl(base, leader, 64) + v * __popcll(active & ((1ull << lane) - 1ull));
+}
+
 // Create the 8 children of cell `me` by ONE lane (levels with many cells: bandwidth- rather than latency-bound).
 __device__ __forceinline__ void split_cell1(const Nodes &nd, const unsigned long long *__restrict__ khi,
                                             const unsigned long long *__restrict__ klo,
@@ -168,19 +196,28 @@ __device__ __forceinline__ void split_cell1(const Nodes &nd, const unsigned long
   if (level >= kMaxLevels) { atomicExch(err, 1); return; }
   const unsigned long long *kw = level < kLevelsPerKey ? khi : klo;
   const int ksh = 3 * (kLevelsPerKey - 1 - (level < kLevelsPerKey ? level : level - kLevelsPerKey));
-  const int base = atomicAdd(node_counter, 8);
+  const int base = wave_reserve_const(node_counter, 8);
   if (base + 8 > node_cap) { atomicExch(err, 2); return; }
   nd.link[me] = make_int4(base, -1, lk.z, level);
   const float4 bx = nd.box[me];
   const float o[3] = {bx.x, bx.y, bx.z};
-  int lo = rg.x;
+  int bound[9];
+  bound[0] = rg.x;
+  int splitting = 0;
+#pragma unroll
   for (int c = 0; c < 8; ++c) {
-    int a = lo, b = rg.y;
+    int a = bound[c], b = rg.y;
     while (a < b) {
       const int m = (a + b) >> 1;
       if ((int)((kw[m] >> ksh) & 7ull) <= c) a = m + 1; else b = m;
     }
-    const int hi = a, cnt = hi - lo, id = base + c;
+    bound[c + 1] = a;
+    splitting += (a - bound[c] >= 2) ? 1 : 0;
+  }
+  int slot = wave_reserve(next_counter, splitting);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int lo = bound[c], hi = bound[c + 1], cnt = hi - lo, id = base + c;
     float co[3], cs;
     child_box(o, bx.w, c, co, &cs);
     nd.box[id] = make_float4(co[0], co[1], co[2], cs);
@@ -189,7 +226,7 @@ __device__ __forceinline__ void split_cell1(const Nodes &nd, const unsigned long
     if (cnt >= 2) {
       nd.link[id] = make_int4(-1, -1, skip, level + 1);
       nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-      nxt[atomicAdd(next_counter, 1)] = id;
+      nxt[slot++] = id;
     } else if (cnt == 1) {
       const unsigned int body = sidx[lo];
       nd.link[id] = make_int4(-1, (int)body, skip, level + 1);
@@ -198,7 +235,6 @@ __device__ __forceinline__ void split_cell1(const Nodes &nd, const unsigned long
       nd.link[id] = make_int4(-1, -1, skip, level + 1);
       nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    lo = hi;
   }
 }
 
