@@ -784,3 +784,85 @@ def test_symmetric_kahan(nb, oracle, ipt):
     for i in rng.choice(n, 16, replace=False):
         ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1)
         assert rel_err(a[i:i + 1], ref).max() < 2e-6      # compensated: an order of magnitude inside the plain tolerance
+
+
+def _forces_over_ranks(nb, n, ranks, posm, vel, **kw):
+    """Accelerations of all bodies from `ranks` contexts on one device (exchange staged through the host when the
+    contexts use the symmetric algorithm), plus the set of kernels that ran."""
+    bounds = [(n * r) // ranks for r in range(ranks + 1)]
+    engs = []
+    try:
+        for r in range(ranks):
+            engs.append(nb.NBodyEngine(n, i_begin=bounds[r], i_count=bounds[r + 1] - bounds[r], **kw))
+    except nb.NBodyError as e:           # a combination the library refuses: it must refuse cleanly, for a stated reason
+        for x in engs:
+            x.close()
+        assert e.code in (nb._lib.ERR_UNSUPPORTED, nb._lib.ERR_INVALID), e
+        return None, set()
+    try:
+        kernels = {e.launch_config()["kernel"] for e in engs}
+        for e in engs:
+            e.set_state(posm, vel)
+            e.step_begin()
+        if engs[0].exchange_ranks():
+            assert all(e.exchange_ranks() == ranks for e in engs)
+            ic = n // ranks
+            sends = [e.exchange_read_send() for e in engs]
+            for r, e in enumerate(engs):
+                e.exchange_write_recv(np.concatenate([sd[r * ic:(r + 1) * ic] for sd in sends]))
+        for e in engs:
+            e.step_end(0.0)
+        a = np.concatenate([e.state(np.float64)[2] for e in engs])[:, :3]
+    finally:
+        for e in engs:
+            e.close()
+    return a, kernels
+
+
+def test_geometry_fuzz_sizes_ranks_and_precisions(nb, oracle):
+    # Whatever geometry the library picks for a size / slicing / precision — kernel, bodies per lane, super tiles,
+    # j chunks, padding — or whatever the caller forces (algorithm, bodies per lane, zero-distance mode) and the library
+    # accepts, the accelerations are the pair law's: 160 random configurations, sampled against the fp64 sum.
+    rng = np.random.default_rng(20261004)
+    seen, ran = set(), 0
+    for trial in range(160):
+        ranks = int(rng.choice([1, 1, 2, 4, 8]))
+        prec = str(rng.choice(["f32", "f32", "f32_kahan", "f64"]))
+        u = rng.random()
+        if u < 0.45:
+            n = int(rng.integers(1, 9000))                       # small and ragged
+        elif u < 0.95:
+            n = int(rng.integers(9000, 70000))
+            if rng.random() < 0.6:
+                n = (n // (ranks * 4096)) * ranks * 4096 or ranks * 4096   # sliceable for every symmetric form
+        else:
+            n = int(rng.integers(70000, 300000)) // (ranks * 4096) * ranks * 4096
+        n = max(n, ranks)
+        eps = float(rng.choice([0.0, 0.0, 0.7]))
+        forced = {}
+        if rng.random() < 0.5:
+            forced = dict(algorithm=int(rng.choice([0, 1, 2])), i_per_thread=int(rng.choice([0, 1, 2, 4, 8, 16])),
+                          zero_mode=int(rng.choice([0, 0, 2])))
+        posm = np.concatenate([rng.normal(0, 300, (n, 3)), rng.uniform(1, 100, (n, 1))], 1)
+        if n > 3:
+            posm[0, :3] = 0.0                                    # the shipped scene pins body 0 at the origin
+        vel = np.zeros((n, 4))
+        if prec != "f64":
+            posm = posm.astype(np.float32); vel = vel.astype(np.float32)
+        a, kernels = _forces_over_ranks(nb, n, ranks, posm, vel, precision=prec, eps=eps, **forced)
+        if a is None:
+            continue
+        ran += 1
+        seen |= kernels
+        assert np.all(np.isfinite(a)), (trial, n, ranks, prec, eps, forced, kernels)
+        p64 = posm.astype(np.float64)
+        tol = 1e-11 if prec == "f64" else 2e-5
+        for i in rng.choice(n, min(n, 5), replace=False):
+            ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], eps=eps, i0=int(i), i1=int(i) + 1)[0]
+            scale = np.linalg.norm(ref)
+            if scale == 0.0:
+                assert np.linalg.norm(a[i]) == 0.0
+            else:
+                assert np.linalg.norm(a[i] - ref) / scale < tol, (trial, n, ranks, prec, eps, forced, kernels, int(i))
+    assert ran >= 100, ran
+    assert {"forces_sym_pk_kernel", "forces_tile_pk_kernel", "small_pk_kernel", "forces_sym_f64_kernel"} <= seen, seen
