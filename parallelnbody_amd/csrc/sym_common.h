@@ -68,6 +68,8 @@ __global__ __launch_bounds__(kBlock) void dup_detect_kernel(const typename SymVe
   // their own size).  Two or more bodies in that cube -> guarded kernel.  flag[1] counts them.
   if (fabs((double)p.x) < 1e-12 && fabs((double)p.y) < 1e-12 && fabs((double)p.z) < 1e-12)
     if (atomicAdd(flag + 1, 1) >= 1) atomicExch(flag, 1);
+  // the unguarded kernels park their zero-mass padding at (1e18, 1e18, 1e18): a body exactly there would meet it at d == 0
+  if (p.x == (T)1.0e18 && p.y == (T)1.0e18 && p.z == (T)1.0e18) atomicExch(flag, 1);
   // coord_bits adds +0 first: -0 and +0 are the same position
   unsigned long long h = coord_bits(p.x) * 0x9E3779B97F4A7C15ull;
   h = (h ^ (h >> 29)) + coord_bits(p.y) * 0xBF58476D1CE4E5B9ull;

@@ -759,6 +759,24 @@ def test_symmetric_underflowing_separations_near_the_origin(nb, oracle):
     assert rel_err(a, ref).max() < TOL_ACC
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_symmetric_body_on_the_padding_point(nb, oracle, prec):
+    # the unguarded symmetric tiles park their zero-mass padding at (1e18, 1e18, 1e18); a body exactly there must not
+    # meet it at d == 0 (inf * 0): the detector sends such a pass to the guarded kernel
+    n = 2000                                                   # ragged: the last super tile is padded
+    g = _golden("refbox_n2000_seed1")
+    dt = np.float64 if prec == "f64" else np.float32
+    posm = g["posm"].astype(dt)
+    posm[1999, :3] = dt(1.0e18)
+    with nb.NBodyEngine(n, algorithm=2, i_per_thread=2, precision=prec) as e:
+        e.set_state(posm, g["vel"].astype(dt))
+        e.compute_forces()
+        a = e.accelerations(np.float64)
+    assert np.all(np.isfinite(a))
+    ref = oracle.forces_direct_f64(posm[:, :3].astype(np.float64), posm[:, 3].astype(np.float64))
+    assert rel_err(a[:1999], ref[:1999]).max() < (1e-11 if prec == "f64" else TOL_ACC)
+
+
 @pytest.mark.parametrize("ipt", [2, 4, 8])
 def test_symmetric_kahan(nb, oracle, ipt):
     # Kahan-compensated accumulation in the symmetric kernel: closer to fp64 than the plain symmetric sum, same parity
