@@ -202,6 +202,12 @@ NBODY_API int nbody_get_positions(nbody_ctx *ctx, float *xyz, size_t stride, int
 /* Owned records [i_begin, i_begin+i_count) into aos[0..i_count): Mass, Position, Velocity, Acceleration. */
 NBODY_API int nbody_get_particles(nbody_ctx *ctx, void *aos, size_t stride);
 
+/* One frame of AOctreeSearch::Tick (OctreeSearch.cpp:21-34) with a single host synchronisation: if dt > 0, *size =
+ * ComputeCubeSize of the current positions (.cpp:26) and one Tick body (.cpp:27-31); then the owned FParticle records
+ * as nbody_get_particles delivers them (what .cpp:33,41 draws).  size and aos may each be NULL.  Same results as
+ * nbody_get_bounds + nbody_step(dt, 1) + nbody_get_particles; not for sharded symmetric contexts (phased step). */
+NBODY_API int nbody_tick(nbody_ctx *ctx, float dt, float *size, void *aos, size_t stride);
+
 /* Renderer hand-off straight into the caller's buffer (what OctreeSearch.cpp:41 reads every frame):
  * page-lock `bytes` of caller memory at `host` for this context.  nbody_get_positions (stride 12) and
  * nbody_get_particles (stride 40) whose destination lies inside a pinned range then DMA into it directly — one copy,

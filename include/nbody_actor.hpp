@@ -107,7 +107,12 @@ class OctreeSearchActor {
     if (OnFlushPersistentDebugLines) OnFlushPersistentDebugLines();            // .cpp:24
     if (PhDeltaTime > 0 && Initialized) {                                      // .cpp:25 (+ guards .cpp:49,76)
       LastStatus = nbody_set_theta(ctx_, Theta);
-      if (LastStatus == NBODY_OK) {
+      if (LastStatus == NBODY_OK && MirrorParticles) {
+        // .cpp:26-31 and the mirror DrawOctreeBoxes reads, in one call with one host synchronisation
+        float s = Size;
+        LastStatus = nbody_tick(ctx_, PhDeltaTime, &s, Particles.data(), sizeof(FParticle));
+        if (LastStatus == NBODY_OK) { Size = s; dirty_ = false; forces_fresh_ = true; }
+      } else if (LastStatus == NBODY_OK) {
         ComputeCubeSize();                                                     // .cpp:26
         LastStatus = nbody_step(ctx_, PhDeltaTime, 1);                         // .cpp:27-31
         if (LastStatus == NBODY_OK) { dirty_ = true; forces_fresh_ = true; }

@@ -105,6 +105,7 @@ def lib():
     sig("nbody_get_bounds", c_int, vp, fp)
     sig("nbody_get_positions", c_int, vp, fp, sz, c_i32, c_i32)
     sig("nbody_get_particles", c_int, vp, vp, sz)
+    sig("nbody_tick", c_int, vp, c_f, fp, vp, sz)
     sig("nbody_pin_host_buffer", c_int, vp, vp, sz)
     sig("nbody_unpin_host_buffer", c_int, vp, vp)
     sig("nbody_get_state_soa", c_int, vp, fp, fp, fp)

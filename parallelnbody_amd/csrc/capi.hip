@@ -898,6 +898,44 @@ int nbody_get_particles(nbody_ctx *c, void *aos, size_t stride) {
   return NBODY_OK;
 }
 
+// One whole frame of the actor with ONE host synchronisation: ComputeCubeSize of the current positions, the Tick body,
+// the FParticle mirror.
+int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (aos && stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "nbody_tick: stride < 40");
+  if ((rc = needs_phases(c, "nbody_tick"))) return rc;
+  HIP_TRY(c, hipSetDevice(c->p.device));
+  const bool live = dt > 0.0f;                                   // OctreeSearch.cpp:25
+  if (live && size) {                                            // .cpp:26, 47-56: bounds of the positions BEFORE the step
+    HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
+    HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, c->p.i_begin, c->p.i_count, (unsigned int *)c->scratch, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->scratch, 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (live && (rc = nbody_step(c, dt, 1))) return rc;            // .cpp:27-31
+  const size_t ic = (size_t)c->p.i_count, bytes = ic * sizeof(nbody_particle);
+  bool direct = false;
+  if (aos) {                                                     // .cpp:33,41: what the frame draws
+    if ((rc = ensure_stage(c, bytes))) return rc;
+    HIP_TRY(c, nbody::launch_pack_particles(c->p.precision, c->posm, c->vel, c->acc, (float *)c->d_stage, c->p.i_begin,
+                                            c->p.i_count, c->stream));
+    direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
+    HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (live && size) memcpy(size, c->h_scratch, 4);
+  if (aos && !direct) {
+    if (stride == sizeof(nbody_particle)) {
+      memcpy(aos, c->h_stage, bytes);
+    } else {
+      char *base = (char *)aos;
+      const char *src = (const char *)c->h_stage;
+      for (size_t i = 0; i < ic; ++i) memcpy(base + i * stride, src + i * sizeof(nbody_particle), sizeof(nbody_particle));
+    }
+  }
+  return NBODY_OK;
+}
+
 int nbody_pin_host_buffer(nbody_ctx *c, void *host, size_t bytes) {
   if (!c) return NBODY_ERR_INVALID;
   if (!host || bytes == 0) return fail(c, NBODY_ERR_INVALID, "nbody_pin_host_buffer: null buffer or zero size");

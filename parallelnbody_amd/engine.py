@@ -203,6 +203,17 @@ class NBodyEngine:
         self._check(self._L.nbody_get_particles(self._h, out.ctypes.data, PARTICLE_DTYPE.itemsize))
         return out
 
+    def tick(self, dt=REF_DT, out=None):
+        """One frame of AOctreeSearch::Tick with a single host synchronisation (nbody_tick): returns (Size of the
+        positions before the step — None when dt <= 0 —, the owned FParticle records after it)."""
+        if out is None:
+            out = np.zeros(self.i_count, PARTICLE_DTYPE)
+        elif out.dtype != PARTICLE_DTYPE or out.shape != (self.i_count,) or not out.flags.c_contiguous:
+            raise ValueError("tick: out must be a C-contiguous PARTICLE_DTYPE [i_count] array")
+        size = ctypes.c_float(0.0)
+        self._check(self._L.nbody_tick(self._h, dt, ctypes.byref(size), out.ctypes.data, PARTICLE_DTYPE.itemsize))
+        return (size.value if dt > 0 else None), out
+
     def pin(self, array):
         """Page-lock a caller-owned numpy array for this context (nbody_pin_host_buffer): `positions(out=array)` /
         `particles(out=array)` then land in it with a single device-to-destination copy.  Keep the array alive until

@@ -196,6 +196,22 @@ def test_hand_off_into_a_pinned_caller_buffer(nb):
     assert np.all(np.isfinite(mine_x)) and mine_p["Mass"].min() > 0
 
 
+@pytest.mark.parametrize("theta", [0.0, 1.0])
+def test_tick_is_bounds_plus_step_plus_mirror(nb, theta):
+    # nbody_tick = nbody_get_bounds + nbody_step(dt, 1) + nbody_get_particles with one host synchronisation: same bytes
+    g = _golden("refbox_n2000_seed1")
+    with nb.NBodyEngine(2000, theta=theta) as a, nb.NBodyEngine(2000, theta=theta) as b:
+        a.set_state(g["posm"], g["vel"]); b.set_state(g["posm"], g["vel"])
+        mine = np.zeros(2000, nb.PARTICLE_DTYPE)
+        b.pin(mine)
+        for _ in range(3):
+            size_a = a.bounds(); a.step(0.01, 1); pa = a.particles()
+            size_b, pb = b.tick(0.01, out=mine)
+            assert size_b == size_a and pb is mine and pb.tobytes() == pa.tobytes()
+        size_b, pb = b.tick(0.0)                                  # paused: no bounds, no step, the mirror only
+        assert size_b is None and pb.tobytes() == pa.tobytes() and b.steps_done() == 3
+
+
 def test_pause_and_argument_errors(nb):
     g = _golden("plummer_n1024_seed1")
     with nb.NBodyEngine(1024) as e:
