@@ -173,7 +173,10 @@ void choose_algorithm(nbody_ctx *c) {
       while (target > 64) {
         const double T = std::sqrt(2.0 * (double)target * (ranks > 1.0 ? ranks : 1.0));
         const double bytes = 2.0 * T * (double)p.n_total * elem / (ranks > 1.0 ? ranks : 1.0);
-        if (bytes <= (double)free_b / 3.0) break;
+        // sharded: every rank must arrive at the same super tiles (the pair assignment depends on T), so the cap
+        // comes from the card's total memory — equal on equal GPUs — not from what happens to be free on this one
+        const double budget = ranks > 1.0 ? (double)total_b / 4.0 : (double)free_b / 3.0;
+        if (bytes <= budget) break;
         target /= 2;
       }
     }
