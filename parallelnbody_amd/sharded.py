@@ -100,8 +100,25 @@ class ShardedSimulation:
             dist.all_to_all_single(torch.empty_like(a), a, group=self.group)
         t = torch.zeros(2, dtype=torch.float64, device=self.device)
         dist.all_reduce(t, group=self.group)
+        self._check_same_geometry()
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+
+    def _check_same_geometry(self):
+        """Every rank must have arrived at the same algorithm and super tiles: which rank evaluates which body pair
+        depends on them, and a disagreement would double-count or drop pairs silently."""
+        if not hasattr(self.engine, "launch_config"):
+            return
+        torch, dist = self.torch, self.torch.distributed
+        cfg = self.engine.launch_config()
+        mine = [1 if cfg.get("algorithm") == "symmetric" else 0, int(cfg.get("super_tile") or 0), int(self.ex_ranks)]
+        lo = torch.tensor(mine, dtype=torch.int64, device=self.device)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if lo.tolist() != hi.tolist():
+            raise RuntimeError(f"ranks disagree on the force-pass geometry (algorithm, super tile, exchange ranks): "
+                               f"this rank {mine}, minimum {lo.tolist()}, maximum {hi.tolist()}")
 
     def _forces(self):
         self.engine.step_begin()
