@@ -77,6 +77,9 @@ class ShardedSimulation:
             self.engine.bind_exchange(self.ex_send, self.ex_recv)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)   # the zero-fills above ran on torch's default stream, the engine will not
+        if world_size > 1:
+            with self._on_stream():
+                self._check_same_geometry()
 
     def _on_stream(self):
         """Context manager that makes the simulation's stream torch's current stream (no-op on CPU)."""
@@ -100,7 +103,6 @@ class ShardedSimulation:
             dist.all_to_all_single(torch.empty_like(a), a, group=self.group)
         t = torch.zeros(2, dtype=torch.float64, device=self.device)
         dist.all_reduce(t, group=self.group)
-        self._check_same_geometry()
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
