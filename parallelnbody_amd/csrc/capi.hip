@@ -432,6 +432,17 @@ bool in_pinned(const nbody_ctx *c, const void *dst, size_t bytes) {
   return false;
 }
 
+// The staged, packed FParticle records -> the caller's array (records `stride` bytes apart).
+void unstage_particles(const nbody_ctx *c, void *aos, size_t stride, size_t count) {
+  if (stride == sizeof(nbody_particle)) {
+    memcpy(aos, c->h_stage, count * sizeof(nbody_particle));
+    return;
+  }
+  char *base = (char *)aos;
+  const char *src = (const char *)c->h_stage;
+  for (size_t i = 0; i < count; ++i) memcpy(base + i * stride, src + i * sizeof(nbody_particle), sizeof(nbody_particle));
+}
+
 int check_ready(nbody_ctx *c) {
   if (!c) return NBODY_ERR_INVALID;
   if (!c->have_state) return fail(c, NBODY_ERR_STATE, "no particles set (call nbody_set_particles / nbody_set_state_soa first)");
@@ -890,14 +901,7 @@ int nbody_get_particles(nbody_ctx *c, void *aos, size_t stride) {
   const bool direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
   HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (direct) return NBODY_OK;
-  if (stride == sizeof(nbody_particle)) {
-    memcpy(aos, c->h_stage, bytes);
-  } else {
-    char *base = (char *)aos;
-    const char *src = (const char *)c->h_stage;
-    for (size_t i = 0; i < ic; ++i) memcpy(base + i * stride, src + i * sizeof(nbody_particle), sizeof(nbody_particle));
-  }
+  if (!direct) unstage_particles(c, aos, stride, ic);
   return NBODY_OK;
 }
 
@@ -927,15 +931,7 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (live && size) memcpy(size, c->h_scratch, 4);
-  if (aos && !direct) {
-    if (stride == sizeof(nbody_particle)) {
-      memcpy(aos, c->h_stage, bytes);
-    } else {
-      char *base = (char *)aos;
-      const char *src = (const char *)c->h_stage;
-      for (size_t i = 0; i < ic; ++i) memcpy(base + i * stride, src + i * sizeof(nbody_particle), sizeof(nbody_particle));
-    }
-  }
+  if (aos && !direct) unstage_particles(c, aos, stride, ic);
   return NBODY_OK;
 }
 
