@@ -186,3 +186,107 @@ def test_three_body_figure_eight_known_answer(oracle):
         pos, vel = oracle.kick_drift_f64(pos, vel, a, dt)
     assert np.abs(pos - FIG8_X).max() < 2e-4
     assert np.abs(pos.sum(0)).max() < 1e-12        # centre of mass stays put
+
+
+# ---- a second, independent restatement of the reference's octree (pure Python, numpy scalars) --------------------------
+# Written from OctreeSearch.h:20-109 on its own, in a different language and a different shape (recursive objects, as the
+# reference; the C oracle is iterative over arrays): two readings of the same lines that agree bit for bit are less
+# likely to share a transcription error.  Small cases only (pure-Python loops).
+
+_f = np.float32
+_d = np.float64
+
+
+class _PyCell:
+    def __init__(self, origin, size):                      # .h:31-33
+        self.origin, self.size = origin, _f(size)
+        self.body = None
+        self.mass = _f(0)
+        self.com = np.zeros(3, np.float32)
+        self.kids = None
+
+    def octant(self, p):                                   # .h:50-56
+        return (4 if p[0] >= self.origin[0] else 0) | (2 if p[1] >= self.origin[1] else 0) | (1 if p[2] >= self.origin[2] else 0)
+
+    def add(self, idx, pos):                               # .h:60-81
+        if self.kids is None:
+            if self.body is None:
+                self.body = idx
+                return
+            old, self.body = self.body, None
+            self.kids = []
+            for i in range(8):
+                c = self.origin.copy()
+                # `center.X += Size * (i & 4 ? 0.5 : -0.5)`: float * double in double, added to the float in double, rounded once
+                c[0] = _f(_d(c[0]) + _d(self.size) * (0.5 if i & 4 else -0.5))
+                c[1] = _f(_d(c[1]) + _d(self.size) * (0.5 if i & 2 else -0.5))
+                c[2] = _f(_d(c[2]) + _d(self.size) * (0.5 if i & 1 else -0.5))
+                self.kids.append(_PyCell(c, _f(0.5 * _d(self.size))))
+            self.kids[self.octant(pos[old])].add(old, pos)
+            self.kids[self.octant(pos[idx])].add(idx, pos)
+        else:
+            self.kids[self.octant(pos[idx])].add(idx, pos)
+
+    def compute_mass(self, pos, mass):                     # .h:83-97
+        if self.kids is None:
+            if self.body is not None:
+                self.com = pos[self.body].copy()
+                self.mass = mass[self.body]
+            return
+        for k in self.kids:
+            k.compute_mass(pos, mass)
+            self.mass = _f(self.mass + k.mass)
+            for a in range(3):
+                self.com[a] = _f(self.com[a] + _f(k.mass * k.com[a]))
+        if self.mass != 0:
+            rv = _f(_f(1.0) / self.mass)                   # FVector::operator/=(float): scale by the reciprocal [UE4 4.9]
+            for a in range(3):
+                self.com[a] = _f(self.com[a] * rv)
+        else:
+            self.com = self.origin.copy()
+
+    def forces(self, p, theta, acc):                       # .h:99-108
+        if self.kids is None and self.body is None:
+            return
+        dx = _f(self.com[0] - p[0]); dy = _f(self.com[1] - p[1]); dz = _f(self.com[2] - p[2])
+        d = np.sqrt(_f(_f(_f(dx * dx) + _f(dy * dy)) + _f(dz * dz)))      # FVector::Dist: fp32 throughout
+        if d == 0:
+            return
+        if _f(self.size / d) < theta or self.body is not None:
+            s = _f(1e4 * _d(self.mass) / _d(d) ** 3)        # double expression, then scalar * FVector takes a float
+            acc[0] = _f(acc[0] + _f(s * dx)); acc[1] = _f(acc[1] + _f(s * dy)); acc[2] = _f(acc[2] + _f(s * dz))
+        elif self.kids is not None:
+            for k in self.kids:
+                k.forces(p, theta, acc)
+
+
+def _py_create_octree(pos, mass, theta, root_origin, root_size):
+    root = _PyCell(np.asarray(root_origin, np.float32).copy(), root_size)       # OctreeSearch.cpp:77-79
+    for i in range(len(pos)):
+        root.add(i, pos)                                                         # .cpp:80
+    root.compute_mass(pos, mass)                                                 # .cpp:81
+    acc = np.zeros((len(pos), 3), np.float32)
+    for i in range(len(pos)):
+        root.forces(pos[i], _f(theta), acc[i])                                   # .cpp:83-86
+    return acc, root.com
+
+
+@pytest.mark.parametrize("theta", [0.0, 0.5, 1.0])
+@pytest.mark.parametrize("n,seed", [(2, 0), (9, 1), (64, 2), (200, 3)])
+def test_c_octree_agrees_with_an_independent_python_restatement(oracle, n, seed, theta):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-500, 500, (n, 3)).astype(np.float32)
+    mass = rng.uniform(1, 5000, n).astype(np.float32)
+    if n > 2:
+        pos[0] = 0.0                                       # the shipped scene pins body 0 at the origin
+    origin = np.array([3.5, -1.25, 0.75], np.float32)      # a previous frame's centre of mass, say
+    size = oracle.bounds_f32(pos)
+    with np.errstate(over="ignore"):
+        want, want_com = _py_create_octree(pos, mass, theta, origin, size)
+    got, got_com, _ = oracle.octree_forces_f32(pos, mass, theta, root_origin=origin, root_size=size, pow_mode=0)
+    # pow_mode 0 = the C library's pow(double, 3), which is also what numpy's float64 `** 3` calls: bit for bit
+    np.testing.assert_array_equal(got_com, want_com)
+    np.testing.assert_array_equal(got, want)
+    # the d*(d*d) reading of pow (pow_mode 2) differs in the last bit of the double on a few pairs: 1 ulp of the float
+    got2, _, _ = oracle.octree_forces_f32(pos, mass, theta, root_origin=origin, root_size=size, pow_mode=2)
+    assert np.abs(got2 - want).max() <= np.abs(want).max() * 2.0 ** -22
