@@ -287,6 +287,6 @@ def test_c_octree_agrees_with_an_independent_python_restatement(oracle, n, seed,
     # pow_mode 0 = the C library's pow(double, 3), which is also what numpy's float64 `** 3` calls: bit for bit
     np.testing.assert_array_equal(got_com, want_com)
     np.testing.assert_array_equal(got, want)
-    # the d*(d*d) reading of pow (pow_mode 2) differs in the last bit of the double on a few pairs: 1 ulp of the float
+    # the float-overload reading of pow (pow_mode 2: d*(d*d) in fp32, a pre-C++11 <cmath>) stays within an ulp or two
     got2, _, _ = oracle.octree_forces_f32(pos, mass, theta, root_origin=origin, root_size=size, pow_mode=2)
     assert np.abs(got2 - want).max() <= np.abs(want).max() * 2.0 ** -22
