@@ -22,7 +22,9 @@
  * GetAbsMax = max(max(|X|,|Y|),|Z|)) and the C runtime's pow.  The .sln names Visual Studio
  * 2013, whose <cmath> may resolve pow(float,int) to a float overload rather than C++11's
  * double promotion; `pow_mode` selects the reading (0 = double pow, the C++11 rule and the
- * default; 1 = powf; 2 = float d*(d*d)).  The three differ by a few fp32 ulp per pair.
+ * default; 1 = powf; 2 = float d*(d*d); 3 = the correctly rounded cube in double, (d*d)*d — d*d is
+ * exact for a float d — which a correctly rounded pow would return and glibc's returns for all but a
+ * few arguments in a thousand).  The readings differ by a few fp32 ulp per pair at most.
  */
 #include <math.h>
 #include <stdint.h>
@@ -54,6 +56,7 @@ ORACLE_API int oracle_sizeof_particle(void) { return (int)sizeof(oracle_particle
  * ---------------------------------------------------------------------------------------- */
 static inline float cube_of(float d, int pow_mode, double *as_double) {
   if (pow_mode == 0) { *as_double = pow((double)d, 3.0); return 0.0f; }
+  if (pow_mode == 3) { const double dd = (double)d; *as_double = (dd * dd) * dd; return 0.0f; }
   float p = (pow_mode == 1) ? powf(d, 3.0f) : d * (d * d);
   *as_double = (double)p;
   return p;

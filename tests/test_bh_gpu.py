@@ -37,6 +37,10 @@ def test_bh_forces_match_the_oracle_tree(nb, oracle, fixture, theta):
     _check_same(a, ref)
     assert st["nodes"] == nodes
     np.testing.assert_array_equal(st["root_com"], com)
+    # with the cube taken as the correctly rounded (d*d)*d in double (pow_mode 3: what a correctly rounded pow returns,
+    # and what the device computes) instead of glibc's pow(d, 3.0), every body agrees in every bit
+    ref3, _, _ = oracle.octree_forces_f32(pos, m, theta, pow_mode=3)
+    np.testing.assert_array_equal(a, ref3)
     # and it really is an approximation of the all-pairs answer, not the all-pairs kernel
     assert 0.001 < rel_err(a, g["acc_direct"]).mean() < 1.5
 
