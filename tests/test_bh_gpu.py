@@ -45,6 +45,26 @@ def test_bh_forces_match_the_oracle_tree(nb, oracle, fixture, theta):
     assert 0.001 < rel_err(a, g["acc_direct"]).mean() < 1.5
 
 
+def test_vanishing_theta_is_all_pairs_in_the_reference_order(nb, oracle):
+    # theta -> 0+ never accepts a cell, so the walk visits every leaf in the reference's depth-first order: the exact
+    # all-pairs sum, added up in the order the reference adds it.  Bit for bit the oracle's tree at the same theta; and
+    # the all-pairs kernels (their own summation order) agree with it within the stated tolerance.
+    g = np.load(os.path.join(GOLDEN, "refbox_n2000_seed1.npz"))
+    pos = np.ascontiguousarray(g["posm"][:, :3]); m = np.ascontiguousarray(g["posm"][:, 3])
+    tiny = 1e-30
+    ref3, _, _ = oracle.octree_forces_f32(pos, m, tiny, pow_mode=3)
+    with nb.NBodyEngine(2000, theta=tiny) as e:
+        e.set_state(g["posm"], g["vel"])
+        e.compute_forces()
+        a_tree = e.accelerations()
+        e.set_theta(0.0)
+        e.compute_forces()
+        a_pairs = e.accelerations()
+    np.testing.assert_array_equal(a_tree, ref3)
+    assert rel_err(a_pairs, a_tree).max() < 2e-5
+    assert rel_err(a_tree, g["acc_f64"]).max() < 2e-5
+
+
 def test_bh_ticks_follow_the_reference_frame_loop(nb, oracle):
     # Tick (OctreeSearch.cpp:25-32) with theta = 1.0: bounds -> tree rooted at the PREVIOUS tree's CoM -> walk -> kick-drift
     g = np.load(os.path.join(GOLDEN, "refbox_n2000_seed1.npz"))
