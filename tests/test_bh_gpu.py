@@ -87,6 +87,22 @@ def test_bh_ticks_follow_the_reference_frame_loop(nb, oracle):
     assert rel_err(a0, ref).max() < 2e-5
 
 
+def test_bh_frames_equal_the_oracle_in_every_bit(nb, oracle):
+    # twenty whole Ticks of the shipped scene at the shipped opening angle: positions, velocities, accelerations, Size and
+    # the root centre of every frame equal the oracle's (cube correctly rounded, pow_mode 3) in every bit
+    g = np.load(os.path.join(GOLDEN, "refbox_n2000_seed1.npz"))
+    q = particles_from(nb, g["posm"], g["vel"])
+    com, size = None, 0.0
+    with nb.NBodyEngine(2000, theta=REF_THETA) as e:
+        e.set_state(g["posm"], g["vel"])
+        for frame in range(20):
+            size_dev, out = e.tick(0.01)
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+            assert size_dev == size, frame
+            np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
+            assert out.tobytes() == q.tobytes(), frame
+
+
 def test_bh_actor_with_the_shipped_opening_angle(nb, oracle):
     g = np.load(os.path.join(GOLDEN, "refbox_n2000_seed1.npz"))
     p = particles_from(nb, g["posm"], g["vel"])
