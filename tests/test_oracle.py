@@ -290,3 +290,31 @@ def test_c_octree_agrees_with_an_independent_python_restatement(oracle, n, seed,
     # the float-overload reading of pow (pow_mode 2: d*(d*d) in fp32, a pre-C++11 <cmath>) stays within an ulp or two
     got2, _, _ = oracle.octree_forces_f32(pos, mass, theta, root_origin=origin, root_size=size, pow_mode=2)
     assert np.abs(got2 - want).max() <= np.abs(want).max() * 2.0 ** -22
+
+
+def test_c_tick_agrees_with_the_python_restatement_over_frames(nb, oracle):
+    # whole frames (OctreeSearch.cpp:24-32, 47-56, 74-89): Size, tree rooted at the previous frame's centre of mass, walk
+    # at the shipped theta, kick-drift — the Python restatement above against oracle_tick_aos_f32, every bit, 3 frames
+    rng = np.random.default_rng(11)
+    n, dt = 48, _f(0.01)
+    pos = rng.uniform(-300, 300, (n, 3)).astype(np.float32)
+    vel = rng.normal(0, 20, (n, 3)).astype(np.float32)
+    mass = rng.uniform(1, 5000, n).astype(np.float32)
+    q = np.zeros(n, nb.PARTICLE_DTYPE)
+    q["Mass"], q["Position"], q["Velocity"] = mass, pos, vel
+    com_c, size_c = None, 0.0
+    com_py = np.zeros(3, np.float32)                       # FVector t = ZeroVector before the first tree, .cpp:77
+    for frame in range(3):
+        size_py = max(float(np.abs(p).max()) for p in pos)                      # ComputeCubeSize, .cpp:47-56
+        with np.errstate(over="ignore"):
+            acc, com_py = _py_create_octree(pos, mass, 1.0, com_py, size_py)     # CreateOctree, .cpp:74-89
+        for i in range(n):                                                       # .cpp:28-31
+            for a in range(3):
+                vel[i, a] = _f(vel[i, a] + _f(dt * acc[i, a]))
+                pos[i, a] = _f(pos[i, a] + _f(dt * vel[i, a]))
+        com_c, size_c = oracle.tick_aos_f32(q, float(dt), theta=1.0, root_com=com_c, size=size_c, pow_mode=0)
+        assert size_c == size_py, frame
+        np.testing.assert_array_equal(com_c, com_py)
+        np.testing.assert_array_equal(q["Acceleration"], acc)
+        np.testing.assert_array_equal(q["Velocity"], vel)
+        np.testing.assert_array_equal(q["Position"], pos)
