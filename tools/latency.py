@@ -2,7 +2,6 @@
 """Step latency at small N (the reference's shipped scene is N = 2000): wall time per nbody_step and per actor Tick."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import parallelnbody_amd as nb
 
 for n in (1024, 2000, 4096, 8192, 16384):

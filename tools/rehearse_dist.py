@@ -2,7 +2,7 @@
 """Rehearsal of the multi-GPU plumbing on ONE GPU: torchrun with a single rank, backend nccl (= RCCL).
 Exercises init_process_group(device_id), barrier, all_reduce, the in-place all_gather_into_tensor of a slice of the
 replicated tensor and all_to_all_single on device tensors, then a ShardedSimulation step loop and bench.py's timing code."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
