@@ -139,10 +139,10 @@ void choose_algorithm(nbody_ctx *c) {
     sym_ipt = 8;
   if (p.i_per_thread == 8 && sym_ipt != 8) return;
   // sixteen (eight register pairs, ~230 VGPRs, 2 waves/SIMD): the dpp moves' share halves again
-  // (N = 2^20: 164.5 ms against 170.1 ms with eight; smaller systems — and slices below 2^18 bodies: 22.5 against
-  // 22.2 ms for one of eight ranks — have too few workgroups for it)
+  // (N = 2^20: 164.5 ms against 170.1 ms with eight, N = 2^19: 42.9 against 44.2; smaller systems — N = 2^18: 12.1
+  // against 11.3 — and slices below 2^18 bodies — 22.5 against 22.2 ms for one of eight ranks — have too few workgroups for it)
   if (p.precision == NBODY_PREC_F32 &&
-      (p.i_per_thread == 16 || (p.i_per_thread == 0 && p.n_total >= (1 << 20) && p.i_count >= (1 << 18))) &&
+      (p.i_per_thread == 16 || (p.i_per_thread == 0 && p.n_total >= (1 << 19) && p.i_count >= (1 << 18))) &&
       (p.i_count == p.n_total || p.i_count % 4096 == 0))
     sym_ipt = 16;
   if (p.i_per_thread == 16 && sym_ipt != 16) return;
