@@ -1,0 +1,36 @@
+"""bench.py's one-line JSON contract (the driver parses it): run it small and check every field the contract names."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--n", "65536", "--cpu-seconds", "0.5", "--settle-seconds", "0.05"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["dtype"] == "f32" and r["data"] == "synthetic" and r["vs_baseline"] is None and r["scaling"] == "strong"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    assert r["value"] == pytest.approx(65536.0 ** 2 * 3 / (r["ms_per_step"] * 3e-3), rel=1e-6)
+    rf = r["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
+    assert 0.2 < rf["frac"] < 1.0, rf           # a real measurement of the HIP kernel (N = 65536: about two thirds of peak)
+    cb = r["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == r["unit"]
