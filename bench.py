@@ -161,6 +161,12 @@ def main():
     # kernel evaluates each unordered pair once and credits both bodies: same interaction count, fewer instructions)
     launch_pairs = float(sim.i_count) * float(n)
     avg_launch_s = (f_ms / max(f_n, 1)) * 1e-3
+    # slowest and fastest rank's force pass (the step waits for the slowest): where scaling is lost, if it is
+    launch_ms_minmax = [avg_launch_s * 1e3, avg_launch_s * 1e3]
+    if world > 1:
+        t = torch.tensor([-avg_launch_s * 1e3, avg_launch_s * 1e3], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        launch_ms_minmax = [-float(t[0]), float(t[1])]
     achieved_tflops = launch_pairs * FLOP_PER_PAIR / avg_launch_s * 1e-12
     peak = PEAK_FP32_TFLOPS if args.precision != "f64" else PEAK_FP32_TFLOPS / 2
     p_end, _ = sim.gather_state()
@@ -190,6 +196,7 @@ def main():
                          "kernel": cfg["kernel"] + (" (+dup_detect_kernel, reduce_j_kernel)"
                                                     if cfg["algorithm"] == "symmetric" else ""),
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
+                         "launch_ms_min_max_over_ranks": launch_ms_minmax,
                          "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs,
                          "update_kernel_avg_ms": u_ms / max(u_n, 1)},
         }
