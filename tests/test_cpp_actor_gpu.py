@@ -33,3 +33,17 @@ def test_cpp_actor_parity_program(nb, oracle, tmp_path):
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "actor parity: ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_host_program(nb, tmp_path):
+    # the C shim (nbody_actor.h) from a C11 program: the host INTEGRATION.md sketches, sixty frames at theta = 1 and at 0
+    exe = str(tmp_path / "actor_demo")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "actor_demo.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "parallelnbody_amd"), "-lnbody_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "parallelnbody_amd")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "actor demo: ok" in out.stdout
