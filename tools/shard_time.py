@@ -13,10 +13,10 @@ for P in (1, 2, 4, 8):
         with nb.NBodyEngine(n, i_begin=r * ic, i_count=ic, time_kernels=True) as e:
             e.set_state(posm, vel)
             cfg = e.launch_config()
-            for _ in range(3):
+            for _ in range(3 * P):                      # ~0.5 s of passes first: the clock needs sustained load to settle
                 e.step_begin(); e.step_end(0.0)
             e.synchronize(); e.kernel_time_reset()
-            for _ in range(3):
+            for _ in range(3 * P):
                 e.step_begin(); e.step_end(0.0)
             f_ms, k = e.kernel_time(nb.KERNEL_FORCES); u_ms, ku = e.kernel_time(nb.KERNEL_UPDATE)
         t = f_ms / k
