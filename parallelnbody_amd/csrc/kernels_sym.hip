@@ -107,9 +107,12 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
     Acc3pk<KAHAN> a[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+      // one 16-byte load from a clamped index, then a select: `ia < n_total ? posm[ia] : pad` compiles to four
+      // predicated dword loads and keeps ia alive for the epilogue
       const int ia = i0 + t + (2 * p) * kBlock, ib = ia + kBlock;
-      const float4 pa = ia < n_total ? posm[ia] : pad;
-      const float4 pb = ib < n_total ? posm[ib] : pad;
+      float4 pa = posm[min(ia, n_total - 1)], pb = posm[min(ib, n_total - 1)];
+      if (ia >= n_total) pa = pad;
+      if (ib >= n_total) pb = pad;
       xi[p] = f2{pa.x, pb.x}; yi[p] = f2{pa.y, pb.y}; zi[p] = f2{pa.z, pb.z};
       nmi[p] = f2{-gscale * pa.w, -gscale * pb.w};             // -G m_i: the j side gets a_j -= G m_i s d
     }
@@ -245,9 +248,13 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ 
       }
     }
 
+    // the body indices are recomputed from the thread id here (opaque to the optimiser) instead of staying alive in
+    // VGPRs across the whole i-set: they were what the compiler spilled to scratch
+    int te = threadIdx.x;
+    asm volatile("" : "+v"(te));
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const int ia = i0 + t + (2 * p) * kBlock, ib = ia + kBlock;
+      const int ia = i0 + te + (2 * p) * kBlock, ib = ia + kBlock;
       if (ia < n_pad) Pi[ia - own0] = make_float4(a[p].x.x, a[p].y.x, a[p].z.x, 0.f);
       if (ib < n_pad) Pi[ib - own0] = make_float4(a[p].x.y, a[p].y.y, a[p].z.y, 0.f);
     }

@@ -434,6 +434,26 @@ def test_config3_fp64_size_properties(nb, oracle):
     assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * p64[:, 3]).sum() < 1e-13
 
 
+def test_config3_fp64_at_full_size_against_the_oracle(nb, oracle):
+    # BASELINE configs[3] at its own size: N = 262144 fp64, the instantiation that runs there (four bodies per lane),
+    # sampled bodies (random, super-tile ends, an i-set boundary) against the fp64 oracle at 1e-12
+    import bench
+    n = 262144
+    posm, vel = nb.ic_plummer(n, seed=3)
+    p64 = posm.astype(np.float64)
+    with nb.NBodyEngine(n, precision="f64") as e:
+        cfg = e.launch_config()
+        assert cfg["kernel"] == "forces_sym_f64_kernel" and cfg["i_per_thread"] == 4
+        e.set_state(p64, vel.astype(np.float64))
+        e.compute_forces()
+        a = e.accelerations(np.float64)
+    bodies = bench.sample_bodies(0, n, cfg["super_tile"], cfg["i_per_thread"], seed=3)
+    assert len(bodies) >= 24
+    for i in bodies:
+        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1)
+        assert rel_err(a[i:i + 1], ref).max() < 1e-12, i
+
+
 # ---- symmetric algorithm (each unordered pair once, kernels_sym.hip) -----------------------------------------
 
 @pytest.mark.parametrize("ipt", [2, 4, 8, 16])
@@ -718,16 +738,20 @@ def test_config4_kahan_softened_at_full_size(nb, oracle):
         e.compute_forces()
         a = e.accelerations()
     assert np.all(np.isfinite(a))
+    # sampled bodies (random, super-tile ends, an i-set boundary) against the fp64 direct sum — sum(m a) = 0 alone cannot
+    # fail for a kernel that feeds +s d and -s d from the same s
+    import bench
+    bodies = bench.sample_bodies(0, n, cfg["super_tile"], cfg["i_per_thread"], seed=4)
+    assert len(bodies) >= 24
     p64 = posm.astype(np.float64)
-    rng = np.random.default_rng(4)
-    for i in rng.choice(n, 6, replace=False):
-        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], eps=eps, i0=int(i), i1=int(i) + 1)
-        assert rel_err(a[i:i + 1], ref).max() < 2e-6
+    for i in bodies:
+        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], eps=eps, i0=int(i), i1=int(i) + 1, nthreads=8)
+        assert rel_err(a[i:i + 1], ref).max() < 2e-6, i
     f = (a.astype(np.float64) * p64[:, 3:4]).sum(0)
     assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * p64[:, 3]).sum() < 1e-7
 
 
-def test_headline_config_runs_the_symmetric_kernel_at_speed(nb):
+def test_headline_config_runs_the_symmetric_kernel_at_speed(nb, oracle):
     # BASELINE metric configuration: N = 2^20 fp32.  A guard against silently falling back to a slower path: the default
     # context must select the symmetric packed kernel and sustain well over the round-1 one-sided rate (3.9e12).
     n = 1 << 20
@@ -743,6 +767,16 @@ def test_headline_config_runs_the_symmetric_kernel_at_speed(nb):
     rate = float(n) * n / (ms / k * 1e-3)
     assert rate > 4.8e12, rate
     assert np.all(np.isfinite(a))
+    # the benched instantiation at the benched size against the oracle's fp64 direct sum (OctreeSearch.h:101-104 over all
+    # j), on random bodies, the ends of the first / middle / last super tile and both sides of an i-set boundary
+    import bench
+    bodies = bench.sample_bodies(0, n, cfg["super_tile"], cfg["i_per_thread"], seed=20)
+    assert len(bodies) >= 24
+    p64 = posm.astype(np.float64)
+    for i in bodies:
+        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1, nthreads=8)
+        assert rel_err(a[i:i + 1], ref).max() < TOL_ACC, i
+    assert bench.sampled_force_error(posm, a, 0, bodies[:4], 1.0e4, 0.0) < TOL_ACC     # bench.py's own checker agrees
     f = (a.astype(np.float64) * posm[:, 3:4]).sum(0)             # Newton's third law at full size
     assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * posm[:, 3]).sum() < 1e-6
 
