@@ -61,10 +61,10 @@ enum {
 /*
  * Force algorithm.  Both evaluate the same pair law over all pairs; they differ in summation order only.
  * TILED: every ordered pair (i, j), one-sided (kernels.hip).  SYMMETRIC: every unordered pair once, feeding
- * both bodies (kernels_sym.hip, kernels_sym64.hip): fp32 non-Kahan and fp64 contexts; when the bodies are sharded the slices must be equal
- * and the host drives nbody_step_begin / all-to-all / nbody_step_end.  The per-body summation order then depends
- * on the number of ranks (TILED's does not).
- * AUTO picks SYMMETRIC where it applies and n_total >= 32768, else TILED.
+ * both bodies (kernels_sym.hip, kernels_sym64.hip; work plan csrc/sym_plan.h): fp32, Kahan fp32 and fp64 contexts;
+ * when the bodies are sharded the slices must be equal multiples of 256 * i_per_thread bodies and the host drives
+ * nbody_step_begin / all-to-all / nbody_step_end.  The per-body summation order then depends on the number of ranks
+ * (TILED's does not).  AUTO picks SYMMETRIC where it applies and n_total >= 32768, else TILED.
  */
 enum { NBODY_ALGO_AUTO = 0, NBODY_ALGO_TILED = 1, NBODY_ALGO_SYMMETRIC = 2 };
 
@@ -256,6 +256,16 @@ NBODY_API const char *nbody_force_kernel_name(const nbody_ctx *ctx);
 
 /* NBODY_ALGO_* actually in use, and (symmetric only) the super-tile size in bodies. */
 NBODY_API int nbody_get_algorithm(nbody_ctx *ctx, int32_t *algorithm, int32_t *super_tile);
+
+/* Host only (no device needed): the work plan of the symmetric force pass for a context owning [i_begin, i_begin +
+ * i_count) of n_total bodies — i-sets of `bodies_per_iset` bodies (256 x i_per_thread) against strips of 64-body
+ * subtiles, strip lengths by guided self-scheduling over `slots` resident workgroups (csrc/sym_plan.h).  items, when
+ * not NULL, receives 8 int32 per work item: i0, j0, n_sub, flags (1 = one-sided strip inside the i-set's own block),
+ * slot_i, slot_j (element offsets of its partial-sum segments), 0, 0.  Build-defined diagnostics; the CPU tests use it
+ * to check that every body pair is evaluated exactly once. */
+NBODY_API int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
+                                      int32_t slots, int32_t k_guided, int32_t min_sub, int32_t *n_items,
+                                      uint64_t *pool_elems, int32_t *items, int32_t items_cap);
 
 /* ---- checkpoint / resume (build-defined: the reference keeps its state in a non-serialised TArray) ---------- */
 

@@ -14,6 +14,7 @@
 
 #include "../../include/nbody.h"
 #include "kernels.h"
+#include "sym_plan.h"
 
 namespace {
 
@@ -48,10 +49,13 @@ struct nbody_ctx {
   int wave = 0;                // small-N wave kernel: register pairs per wave (0 = tile kernels)
   bool have_state = false;
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
-  // symmetric algorithm (kernels_sym.hip)
+  // symmetric algorithm (kernels_sym.hip, kernels_sym64.hip; plan: sym_plan.h)
   bool sym = false;
-  int sym_S = 0, sym_T = 0, sym_pad = 0, sym_pairs = 0, sym_own_tile0 = 0, sym_tiles_own = 0, sym_nsrc = 1;
-  void *sym_part_i = nullptr, *sym_part_j = nullptr, *sym_pair_tab = nullptr;
+  int sym_bi = 0, sym_pad = 0, sym_items_n = 0, sym_nsrc = 1, sym_slots = 0, sym_k = 0, sym_min_sub = 0;
+  size_t sym_pool_elems = 0;
+  nbody::SymPlan *plan = nullptr;                  // host copy, dropped once uploaded
+  void *sym_pool = nullptr, *sym_items = nullptr, *sym_iptr = nullptr, *sym_ioff = nullptr, *sym_jptr = nullptr,
+       *sym_joff = nullptr, *sym_posg = nullptr;
   void *sym_send = nullptr, *sym_recv = nullptr;   // exchange buffers (recv == send when the context owns all bodies)
   void *sym_dup_table = nullptr;                   // coincident-body detector (hash slots + flag)
   int sym_dup_slots = 0;
@@ -123,106 +127,87 @@ void choose_geometry(nbody_ctx *c) {
   }
 }
 
-// Symmetric algorithm: applicability and super-tile geometry.  The bodies of the system are cut into T super tiles
-// of S bodies; a context owns a whole number of them.
+// Symmetric algorithm: applicability, bodies per lane, and the work plan (sym_plan.h).  Everything here is a function
+// of the parameters and of the device's CU count and total memory — never of what happens to be free — so that equal
+// GPUs arrive at equal plans (the ranks of a sharded job must) and results are reproducible from box to box.
+int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  if (!e || !*e) return dflt;
+  const int v = atoi(e);
+  return v > 0 ? v : dflt;
+}
+
 void choose_algorithm(nbody_ctx *c) {
   const nbody_params &p = c->p;
   c->sym = false;
   if (p.algorithm == NBODY_ALGO_TILED) return;
-  const bool f32ok = (p.precision == NBODY_PREC_F32 || p.precision == NBODY_PREC_F32_KAHAN) &&
-                     p.zero_mode != NBODY_ZERO_SELECT && (c->ipt == 2 || c->ipt == 4);
-  // bodies per lane of the symmetric kernel: 8 (four register pairs) amortises the travelling sums' dpp moves best
-  // (tools/microbench6.hip; the Kahan form then runs 2 waves/SIMD at 240 VGPRs); small systems have too few workgroups for it.
-  int sym_ipt = c->ipt;
-  if (p.precision != NBODY_PREC_F64 && (p.i_per_thread == 8 || (p.i_per_thread == 0 && p.n_total >= 262144)) &&
-      (p.i_count == p.n_total || p.i_count % 2048 == 0))
-    sym_ipt = 8;
-  if (p.i_per_thread == 8 && sym_ipt != 8) return;
-  // sixteen (eight register pairs, ~230 VGPRs, 2 waves/SIMD): the dpp moves' share halves again
-  // (N = 2^20: 164.5 ms against 170.1 ms with eight, N = 2^19: 42.9 against 44.2; smaller systems — N = 2^18: 12.1
-  // against 11.3 — and slices below 2^18 bodies — 22.5 against 22.2 ms for one of eight ranks — have too few workgroups for it)
-  if (p.precision == NBODY_PREC_F32 &&
-      (p.i_per_thread == 16 || (p.i_per_thread == 0 && p.n_total >= (1 << 19) && p.i_count >= (1 << 18))) &&
-      (p.i_count == p.n_total || p.i_count % 4096 == 0))
-    sym_ipt = 16;
-  if (p.i_per_thread == 16 && sym_ipt != 16) return;
-  const bool f64ok = p.precision == NBODY_PREC_F64 && (p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT);   // kernels_sym64.hip
-  if (!f32ok && !f64ok) return;
-  if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < 32768) return;
-  // fp64: two bodies per lane, four (at 2 waves/SIMD — fp64 ops are 4-cycle, two waves saturate the SIMD) for large systems
-  int sym_ipt64 = 2;
-  if (f64ok && (p.i_per_thread == 4 || (p.i_per_thread == 0 && p.n_total >= 131072)) &&
-      (p.i_count == p.n_total || p.i_count % 1024 == 0))
-    sym_ipt64 = 4;
-
-  const int BI = f64ok ? 256 * sym_ipt64 : 256 * sym_ipt;
-  c->sym_np = f64ok ? sym_ipt64 / 2 : sym_ipt / 2;
-  // Workgroups per rank = (super tiles owned) x (about half of all super tiles).  The chip holds 1024 of them at a time
-  // (4 per CU), so a rank needs many thousands for the tail to vanish: aim at >= 16384
-  // (measured at N = 2^20: 2080 workgroups 200.8 ms, 8256 191.5, 14706 190.6, 32896 189.1).  NBODY_SYM_WORKGROUPS
-  // overrides the target (tuning only).
-  long long target = sym_ipt == 16 ? 32768 : 16384;    // 2 waves/SIMD hold 512 workgroups at a time: 32896 measured best
-  if (const char *t = getenv("NBODY_SYM_WORKGROUPS")) { const long long v = atoll(t); if (v > 0) target = v; }
-  // The partial rows take about 2 * T * n_total elements (T super tiles ~ sqrt(2 * target)): keep them under a third
-  // of the free device memory by lowering the workgroup target for very large systems.
-  {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
-      const double elem = (p.precision == NBODY_PREC_F64) ? 32.0 : 16.0;
-      const double ranks = (double)p.n_total / (double)p.i_count;
-      while (target > 64) {
-        const double T = std::sqrt(2.0 * (double)target * (ranks > 1.0 ? ranks : 1.0));
-        const double bytes = 2.0 * T * (double)p.n_total * elem / (ranks > 1.0 ? ranks : 1.0);
-        // sharded: every rank must arrive at the same super tiles (the pair assignment depends on T), so the cap
-        // comes from the card's total memory — equal on equal GPUs — not from what happens to be free on this one
-        const double budget = ranks > 1.0 ? (double)total_b / 4.0 : (double)free_b / 3.0;
-        if (bytes <= budget) break;
-        target /= 2;
-      }
-    }
-  }
-  if (p.i_count == p.n_total) {
-    // T(T+1)/2 >= target
-    long long T = 2;
-    while (T * (T + 1) / 2 < target) ++T;
-    long long S = (p.n_total + T - 1) / T;
-    S = (S + BI - 1) / BI * BI;
-    if (S < BI) S = BI;
-    c->sym_S = (int)S;
-    c->sym_T = (int)((p.n_total + S - 1) / S);
-    c->sym_own_tile0 = 0;
-    c->sym_tiles_own = c->sym_T;
-    c->sym_nsrc = 1;
+  if (p.zero_mode == NBODY_ZERO_SELECT) return;                         // compare+select lives in the one-sided kernel only
+  if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < env_int("NBODY_SYM_MIN_N", 32768)) return;
+  const bool f64 = p.precision == NBODY_PREC_F64, kahan = p.precision == NBODY_PREC_F32_KAHAN;
+  if (f64 && !(p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT)) return;
+  // bodies per lane.  fp32: 2 * register pairs; more of them amortise the travelling sums' dpp moves over more
+  // arithmetic (tools/microbench6.hip) but make the i-set — the quantum of work — larger.  fp64: 2, or 4 at 2 waves/SIMD.
+  int ipt = p.i_per_thread;
+  if (f64) {
+    if (ipt == 0) ipt = p.n_total >= 65536 ? 4 : 2;
+    if (ipt != 2 && ipt != 4) return;
   } else {
-    // sharded: equal slices, each a whole number k of super tiles (T = ranks * k); k * T / 2 >= target if the slice
-    // divides finely enough
-    if (p.n_total % p.i_count != 0 || p.i_begin % p.i_count != 0 || p.i_count % BI != 0) return;
-    const int ranks = p.n_total / p.i_count;
-    const int kmax = p.i_count / BI;
-    int k = 1;
-    while (k < kmax && (long long)k * ranks * k / 2 < target) ++k;
-    while (k < kmax && p.i_count % (k * BI) != 0) ++k;
-    if (p.i_count % (k * BI) != 0) { k = kmax; }
-    c->sym_S = p.i_count / k;
-    c->sym_T = ranks * k;
-    c->sym_own_tile0 = (p.i_begin / p.i_count) * k;
-    c->sym_tiles_own = k;
-    c->sym_nsrc = ranks;
+    if (ipt == 0) {
+      // measured on one box, sustained load (profiles/r02_sweep_symmetric_by_n.txt): sixteen bodies per lane win from
+      // N = 131072 up (2.71 vs 2.75 ms there, 164 vs 172 ms at N = 2^20), eight at N = 32768 and 65536 (0.722 vs 0.757 ms
+      // with four at N = 65536), four below; the Kahan form has no sixteen (its i-side compensation doubles the accumulators)
+      if (!kahan && p.n_total >= 131072) ipt = 16;
+      else if (p.n_total >= 32768) ipt = 8;
+      else ipt = 4;
+      ipt = env_int("NBODY_SYM_IPT", ipt);
+      if (kahan && ipt == 16) ipt = 8;
+      // sharded slices must be whole i-sets
+      while (ipt > 2 && p.i_count != p.n_total && p.i_count % (256 * ipt) != 0) ipt /= 2;
+    }
+    if (ipt != 2 && ipt != 4 && ipt != 8 && ipt != 16) return;
+    if (ipt == 16 && kahan) return;
   }
-  c->sym_pad = c->sym_T * c->sym_S;
-  int pairs = 0;
-  for (int a = c->sym_own_tile0; a < c->sym_own_tile0 + c->sym_tiles_own; ++a)
-    for (int b = 0; b < c->sym_T; ++b) pairs += nbody::sym_pair_assigned(a, b, c->sym_T) ? 1 : 0;
-  c->sym_pairs = pairs;
+  const int bi = 256 * ipt;
+  // workgroups the chip holds at a time: one wave of each per SIMD -> (waves per SIMD) per CU
+  int cus = 256;
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
+  const int np = ipt / 2;
+  const int wps = f64 ? (ipt == 4 ? 2 : 4) : (np == 8 ? 2 : (np == 4 ? (kahan ? 2 : 3) : (kahan && np == 2 ? 3 : 4)));
+  c->sym_slots = cus * wps;
+  // a strip = 1/(K * slots) of the work still to hand out.  K = 3 leaves the first strips too long for slots of unequal
+  // speed to even out (N = 2^20: 170.1 ms; fp64 464 ms); 6: 164.1 / 400; 24: 163.3 / 397 at three times the segments.
+  c->sym_k = env_int("NBODY_SYM_K", 6);
+  // shortest strip, in 64-body subtiles: small systems need the finest grain to fill 1024 SIMDs evenly (N = 32768:
+  // 0.211 ms with 1, 0.230 with 4), large ones save segments with whole 256-body tiles
+  c->sym_min_sub = env_int("NBODY_SYM_MIN_SUB", p.n_total < 65536 ? 1 : (p.n_total < 262144 ? 2 : 4));
+  nbody::SymPlan *plan = new (std::nothrow) nbody::SymPlan();
+  if (!plan) return;
+  std::string why;
+  if (!nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, plan, &why)) {
+    g_create_error = "symmetric plan: " + why;
+    delete plan;
+    return;
+  }
+  // the partial-sum pool must fit comfortably: at most a third of the card's TOTAL memory
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0 &&
+      (double)plan->pool_elems * (f64 ? 32.0 : 16.0) > (double)total_b / 3.0) {
+    g_create_error = "symmetric plan: the partial-sum pool would exceed a third of the device memory";
+    delete plan;
+    return;
+  }
+  c->plan = plan;
+  c->sym_bi = bi; c->sym_np = f64 ? ipt / 2 : np; c->sym_pad = plan->n_pad; c->sym_items_n = (int)plan->items.size();
+  c->sym_nsrc = plan->n_src; c->sym_pool_elems = (size_t)plan->pool_elems;
   c->sym = true;
 }
 
 nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   nbody::SymLaunch L;
-  L.posm = c->posm; L.part_i = c->sym_part_i; L.part_j = c->sym_part_j; L.send = c->sym_send; L.recv = c->sym_recv;
-  L.pairs = c->sym_pair_tab; L.n_pairs = c->sym_pairs;
-  L.n_total = c->p.n_total; L.S = c->sym_S; L.T = c->sym_T; L.n_pad = c->sym_pad;
-  L.own_tile0 = c->sym_own_tile0; L.tiles_own = c->sym_tiles_own; L.n_src = c->sym_nsrc;
+  L.posm = c->posm; L.posg = c->sym_posg; L.pool = c->sym_pool; L.items = c->sym_items; L.n_items = c->sym_items_n;
+  L.i_ptr = c->sym_iptr; L.i_off = c->sym_ioff; L.j_ptr = c->sym_jptr; L.j_off = c->sym_joff;
+  L.send = c->sym_send; L.recv = c->sym_recv;
+  L.n_total = c->p.n_total; L.n_pad = c->sym_pad; L.n_src = c->sym_nsrc;
   L.np = c->sym_np;
   L.precision = c->p.precision == NBODY_PREC_F64 ? NBODY_PREC_F64 : NBODY_PREC_F32;
   L.kahan = c->p.precision == NBODY_PREC_F32_KAHAN ? 1 : 0;
@@ -519,17 +504,19 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   c->elem = (p.precision == NBODY_PREC_F64) ? 32 : 16;
   choose_geometry(c);
   choose_algorithm(c);
-  if ((p.i_per_thread == 8 && !(c->sym && c->sym_np == 4)) || (p.i_per_thread == 16 && !(c->sym && c->sym_np == 8))) {
+  if ((p.i_per_thread == 8 || p.i_per_thread == 16) && !(c->sym && c->sym_bi == 256 * p.i_per_thread)) {
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
-                "nbody_create: i_per_thread 8 needs the fp32 symmetric kernel (N >= 32768 or NBODY_ALGO_SYMMETRIC; "
-                "sharded slices in multiples of 2048 bodies)");
+                "nbody_create: i_per_thread %d needs the fp32 symmetric kernel (N >= 32768 or NBODY_ALGO_SYMMETRIC; "
+                "sharded slices in multiples of %d bodies)", p.i_per_thread, 256 * p.i_per_thread);
   }
   if (p.algorithm == NBODY_ALGO_SYMMETRIC && !c->sym) {
+    const std::string why = g_create_error;
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
-                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (i_per_thread 2, 4 or 8, zero_mode != SELECT) or "
-                "fp64 and, when sharded, equal slices that are a multiple of 256*i_per_thread (fp64: 512) bodies");
+                "nbody_create: NBODY_ALGO_SYMMETRIC needs fp32 (i_per_thread 2, 4, 8 or 16, zero_mode != SELECT) or "
+                "fp64 (i_per_thread 2 or 4) and, when sharded, equal slices that are a multiple of 256*i_per_thread bodies%s%s",
+                why.empty() ? "" : " — ", why.c_str());
   }
 
   auto bail = [&](hipError_t he, const char *what) {
@@ -547,10 +534,22 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if ((e = hipMalloc(&c->acc, (size_t)p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc acc");
   c->own_acc = true;
   if (c->sym) {
-    const size_t n_own_pad = (size_t)c->sym_tiles_own * c->sym_S;
-    if ((e = hipMalloc(&c->sym_part_i, (size_t)c->sym_T * n_own_pad * c->elem)) != hipSuccess) return bail(e, "hipMalloc i-side rows");
-    if ((e = hipMalloc(&c->sym_part_j, (size_t)c->sym_tiles_own * c->sym_pad * c->elem)) != hipSuccess) return bail(e, "hipMalloc j-side rows");
-    if ((e = hipMemset(c->sym_part_j, 0, (size_t)c->sym_tiles_own * c->sym_pad * c->elem)) != hipSuccess) return bail(e, "hipMemset j-side rows");
+    const nbody::SymPlan &P = *c->plan;
+    auto up = [&](void **dst, const void *src, size_t bytes, const char *what) -> hipError_t {
+      hipError_t he = hipMalloc(dst, bytes ? bytes : 4);
+      if (he != hipSuccess) { fail(nullptr, NBODY_ERR_HIP, "nbody_create: hipMalloc %s: %s", what, hipGetErrorString(he)); return he; }
+      if (bytes) he = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+      return he;
+    };
+    if ((e = hipMalloc(&c->sym_pool, c->sym_pool_elems * c->elem)) != hipSuccess) return bail(e, "hipMalloc partial-sum pool");
+    if ((e = up(&c->sym_items, P.items.data(), P.items.size() * sizeof(nbody::SymItem), "work items")) != hipSuccess) return bail(e, "work items");
+    if ((e = up(&c->sym_iptr, P.i_ptr.data(), P.i_ptr.size() * 4, "i-side list")) != hipSuccess) return bail(e, "i-side list");
+    if ((e = up(&c->sym_ioff, P.i_off.data(), P.i_off.size() * 4, "i-side list")) != hipSuccess) return bail(e, "i-side list");
+    if ((e = up(&c->sym_jptr, P.j_ptr.data(), P.j_ptr.size() * 4, "j-side list")) != hipSuccess) return bail(e, "j-side list");
+    if ((e = up(&c->sym_joff, P.j_off.data(), P.j_off.size() * 4, "j-side list")) != hipSuccess) return bail(e, "j-side list");
+    delete c->plan; c->plan = nullptr;
+    if (p.precision != NBODY_PREC_F64 &&
+        (e = hipMalloc(&c->sym_posg, (size_t)c->sym_pad * 16)) != hipSuccess) return bail(e, "hipMalloc scaled positions");
     // NBODY_SYM_GUARDED=1 (A/B measurements only): always run the guarded kernel, no coincident-body detector
     const char *guarded = getenv("NBODY_SYM_GUARDED");
     if (p.eps == 0.0 && p.zero_mode == NBODY_ZERO_EXACT && !(guarded && guarded[0] == '1')) {
@@ -567,18 +566,6 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
     } else {
       c->sym_recv = c->sym_send;
     }
-    std::vector<int> tab;
-    tab.reserve((size_t)c->sym_pairs * 2);
-    const int a0 = c->sym_own_tile0, a1 = a0 + c->sym_tiles_own;
-    for (int a = a0; a < a1; ++a)                            // full super-tile pairs first, the half-size diagonal ones last
-      for (int d = 1; d < c->sym_T; ++d) {
-        const int b = (a + d) % c->sym_T;
-        if (nbody::sym_pair_assigned(a, b, c->sym_T)) { tab.push_back(a); tab.push_back(b); }
-      }
-    for (int a = a0; a < a1; ++a) { tab.push_back(a); tab.push_back(a); }
-    if ((int)tab.size() != 2 * c->sym_pairs) return bail(hipErrorUnknown, "pair table size");
-    if ((e = hipMalloc(&c->sym_pair_tab, tab.size() * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc pair table");
-    if ((e = hipMemcpy(c->sym_pair_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy pair table");
   } else {
     if ((e = hipMalloc(&c->accp, (size_t)c->j_split * p.i_count * c->elem)) != hipSuccess) return bail(e, "hipMalloc accp");
     // packed one-sided kernel, exact d == 0: the same detector lets the tiles that hold no self pair run unguarded
@@ -612,11 +599,11 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->own_vel && c->vel) (void)hipFree(c->vel);
   if (c->own_acc && c->acc) (void)hipFree(c->acc);
   if (c->accp) (void)hipFree(c->accp);
-  if (c->sym_part_i) (void)hipFree(c->sym_part_i);
-  if (c->sym_part_j) (void)hipFree(c->sym_part_j);
+  for (void *q : {c->sym_pool, c->sym_items, c->sym_iptr, c->sym_ioff, c->sym_jptr, c->sym_joff, c->sym_posg})
+    if (q) (void)hipFree(q);
+  delete c->plan;
   if (c->own_send && c->sym_send) (void)hipFree(c->sym_send);
   if (c->own_recv && c->sym_recv) (void)hipFree(c->sym_recv);
-  if (c->sym_pair_tab) (void)hipFree(c->sym_pair_tab);
   if (c->sym_dup_table) (void)hipFree(c->sym_dup_table);
   if (c->bh) nbody::bh_destroy(c->bh);
   if (c->bh_acc) (void)hipFree(c->bh_acc);
@@ -1099,7 +1086,7 @@ const char *nbody_force_kernel_name(const nbody_ctx *c) {
 int nbody_get_algorithm(nbody_ctx *c, int32_t *algorithm, int32_t *super_tile) {
   if (!c) return NBODY_ERR_INVALID;
   if (algorithm) *algorithm = c->sym ? NBODY_ALGO_SYMMETRIC : NBODY_ALGO_TILED;
-  if (super_tile) *super_tile = c->sym ? c->sym_S : 0;
+  if (super_tile) *super_tile = c->sym ? c->sym_bi : 0;
   return NBODY_OK;
 }
 
@@ -1108,9 +1095,9 @@ int nbody_get_launch_config(nbody_ctx *c, int32_t *tile, int32_t *i_per_thread, 
   if (!c) return NBODY_ERR_INVALID;
   int b = 0, t = 0;
   nbody::forces_geometry(make_launch(c), &b, &t);
-  if (c->sym) { b = c->sym_pairs; t = 256; }
+  if (c->sym) { b = c->sym_items_n; t = 256; }
   if (tile) *tile = c->tile;
-  if (i_per_thread) *i_per_thread = c->sym ? 2 * c->sym_np : c->ipt;
+  if (i_per_thread) *i_per_thread = c->sym ? c->sym_bi / 256 : c->ipt;
   if (j_split) *j_split = c->j_split;
   if (blocks) *blocks = b;
   if (threads) *threads = t;

@@ -36,31 +36,29 @@ void forces_geometry(const ForceLaunch &L, int *blocks, int *threads);
 hipError_t launch_update(int precision, void *posm, void *vel, void *acc, const void *accp, int i_begin,
                          int i_count, int j_split, float dt, hipStream_t s);
 
-// Symmetric (each unordered pair once) fp32 force pass — kernels_sym.hip.  The context owns the contiguous run of
-// super tiles [own_tile0, own_tile0 + tiles_own) of the T = n_pad / S super tiles of the system.
+// Symmetric (each unordered pair once) force pass — kernels_sym.hip (fp32), kernels_sym64.hip (fp64).  Who evaluates
+// which pairs, where the partial sums go and in which order they are added is the plan of sym_plan.h, uploaded once.
 struct SymLaunch {
-  const void *posm;     // [n_total] float4, all bodies
-  void *part_i;         // [T][tiles_own*S] float4: i-side sums of own bodies, row = partner super tile
-  void *part_j;         // [tiles_own][n_pad] float4: j-side sums of any body, row = own super tile (zeroed once at creation)
+  const void *posm;     // [n_total] float4 / double4, all bodies
+  void *posg;           // fp32 only: [n_pad] float4 (x, y, z, G m) + zero-mass padding, rewritten every pass
+  void *pool;           // [pool_elems] float4 / double4: the items' partial-sum segments
+  const void *items;    // [n_items] SymItem: one workgroup each
+  int n_items;
+  const void *i_ptr, *i_off;   // CSR over own 64-body granules: i-side segments
+  const void *j_ptr, *j_off;   // CSR over all granules: j-side segments
   void *send;           // [n_total] float4: this rank's j-side contribution to every body (n_src segments of i_count)
   const void *recv;     // [n_src][i_count] float4: what every rank contributed to the own bodies (== send when n_src == 1)
-  const void *pairs;    // [n_pairs] int2 (si, sj): one workgroup each
-  int n_pairs;
   int n_total;
-  int S;                // bodies per super tile (multiple of 256*2*np)
-  int T;                // super tiles in the system = ceil(n_total / S)
-  int n_pad;            // T * S
-  int own_tile0, tiles_own;
+  int n_pad;            // blocks * bodies per i-set
   int n_src;            // ranks sharing the bodies
-  int np;               // register pairs of i-bodies per lane (1 or 2); fp64: 1 (two bodies per lane)
+  int np;               // fp32: register pairs of i-bodies per lane (1, 2, 4, 8); fp64: bodies per lane / 2 (1, 2)
   int precision;        // NBODY_PREC_F32 (float4 rows) or NBODY_PREC_F64 (double4 rows)
-  int kahan;            // fp32 only: Kahan-compensated accumulation everywhere
+  int kahan;            // fp32 only: Kahan-compensated accumulation
   double G;
   double eps2;          // > 0 softened / floor; == 0 exact d == 0 skip (clamp form)
   void *dup_table;      // eps2 == 0 only: dup_slots x 8-byte hash slots + one flag word; nullptr = always run the guarded kernel
   int dup_slots;        // power of two >= 2 * n_total
 };
-bool sym_pair_assigned(int a, int b, int T);   // does super tile a own the pair {a, b}?
 // forces + fold of the j-side rows into L.send
 hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);
 // acc = own i-side rows + L.recv segments; dt > 0: kick-drift of the owned slice

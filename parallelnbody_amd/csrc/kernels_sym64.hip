@@ -1,6 +1,6 @@
 // fp64 form of the symmetric (each unordered pair once) force kernel — same structure as kernels_sym.hip
-// (super tiles, circulant pair assignment, i-sets in registers, 256-body j tiles in LDS, the running j-side sum moving
-// from lane to lane with its body, workgroup-private partial rows), with double state and plain v_*_f64 arithmetic:
+// (work items = an i-set in registers against a strip of 64-body subtiles, 256-body j tiles in LDS, the running j-side
+// sum moving from lane to lane with its body, item-private partial-sum segments), with double state and plain v_*_f64 arithmetic:
 // there is no packed fp64, a lane simply carries two i-bodies.  Pair law OctreeSearch.h:101-104 in double (build-
 // defined: the reference is fp32); rsq = v_rsq_f64 + two Newton steps.
 //
@@ -27,140 +27,125 @@ __device__ __forceinline__ double rsq64(double x) {
   return fma(y, q, y);
 }
 
-// BARE: symmetric tiles without a d == 0 guard (see kernels_sym.hip); the one-sided diagonal tiles always select.
+// BARE: symmetric strips without a d == 0 guard (see kernels_sym.hip); the one-sided strips always select.
 // SOFT: eps2 > 0 is added to every r^2, which keeps rsq finite everywhere: no guard at all (BARE is then irrelevant).
+// Work items, segments and their summation order: sym_plan.h.  State is read from posm itself (double4 is 32 bytes —
+// two LDS-DMA pieces per body — so tiles are staged through registers here, and nothing spills).
 template <bool BARE, bool SOFT, int IPT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(IPT == 4 ? 2 : 4, IPT == 4 ? 2 : 4)))
-void forces_sym_f64_kernel(const double4 *__restrict__ posm,
-                                                                double4 *__restrict__ part_i,
-                                                                double4 *__restrict__ part_j,
-                                                                const int2 *__restrict__ pairs, int n_total, int S,
-                                                                int n_pad, int own_tile0, int n_own_pad, double gscale,
-                                                                double eps2, const int *__restrict__ dup_flag,
-                                                                int run_if_dup) {
+void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict__ pool,
+                           const SymItem *__restrict__ items, int n_total, double gscale, double eps2,
+                           const int *__restrict__ dup_flag, int run_if_dup) {
   if (dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
-  constexpr int BI = kBlock * IPT;
   __shared__ double4 sh_pos[4][128];       // subtile images, doubled: entries l and l+64 hold body l (16 KB)
   __shared__ double sh_acc[4][3][kJT];     // per-wave j-side sums of the tile (24 KB)
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int2 pr = pairs[blockIdx.x];
-  const int si = pr.x, sj = pr.y;
-  const bool diag_super = si == sj;
-  const int own0 = own_tile0 * S;
-  double4 *__restrict__ Pi = part_i + (size_t)sj * n_own_pad;
-  double4 *__restrict__ Pj = part_j + (size_t)(si - own_tile0) * n_pad;
-  double4 pad; pad.x = pad.y = pad.z = (BARE && !SOFT) ? kPadFar64 : 0.0; pad.w = 0.0;
-  double4 zero4; zero4.x = zero4.y = zero4.z = zero4.w = 0.0;
+  const SymItem *__restrict__ itp = items + blockIdx.x;          // wave-uniform: scalar loads
+  const int i0 = itp->i0, j0 = itp->j0, n_sub = itp->n_sub;
+  const unsigned int slot_i = itp->slot_i, slot_j = itp->slot_j;
+  const bool one_sided = (itp->flags & kSymOneSided) != 0;
+  const int n_tiles = (n_sub + 3) >> 2;
+  const double padc = (BARE && !SOFT) ? kPadFar64 : 0.0;     // zero-mass padding: (padc, padc, padc, 0)
 
-  for (int e = t; e < S; e += kBlock) Pj[(size_t)sj * S + e] = zero4;   // element e: always thread e % 256
-
-  const int tiles_in_super = S / kJT;
-  int c_end = (n_total - sj * S + kJT - 1) / kJT;
-  if (c_end > tiles_in_super) c_end = tiles_in_super;
-
-  for (int b = 0; b < S / BI; ++b) {
-    const int i0 = si * S + b * BI;
-    if (i0 >= n_total) break;
-    double xi[IPT], yi[IPT], zi[IPT], nmi[IPT], ax[IPT], ay[IPT], az[IPT];
+  double xi[IPT], yi[IPT], zi[IPT], nmi[IPT], ax[IPT], ay[IPT], az[IPT];
 #pragma unroll
-    for (int q = 0; q < IPT; ++q) {
-      const int i = i0 + t + q * kBlock;
-      const double4 p = i < n_total ? posm[i] : pad;
-      xi[q] = p.x; yi[q] = p.y; zi[q] = p.z; nmi[q] = -gscale * p.w;
-      ax[q] = ay[q] = az[q] = 0.0;
-    }
-
-    const int c_begin = diag_super ? b * (BI / kJT) : 0;
-    auto fetch = [&](int c) {
-      const int j = sj * S + c * kJT + t;
-      return (j < n_total) ? posm[j] : pad;
-    };
-    auto stage = [&](double4 q) {
-      q.w *= gscale;
-      sh_pos[wave][lane] = q;
-      sh_pos[wave][lane + 64] = q;
-    };
-    if (c_begin < c_end) stage(fetch(c_begin));
-    __syncthreads();
-
-    for (int c = c_begin; c < c_end; ++c) {
-      const int j0 = sj * S + c * kJT;
-      const bool sym = !diag_super || j0 >= i0 + BI;
-      const bool more = c + 1 < c_end;
-      double4 nxt;
-      if (more) nxt = fetch(c + 1);
-
-      if (sym) {
-        for (int r = 0; r < 4; ++r) {
-          const int sub = (r + wave) & 3;
-          const double4 *sp = &sh_pos[sub][lane + 64];
-          double jx = 0.0, jy = 0.0, jz = 0.0;
-#pragma unroll 2
-          for (int k = 0; k < 64; ++k) {
-            const double4 pj = sp[-k];
-#pragma unroll
-            for (int q = 0; q < IPT; ++q) {
-              const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
-              const double r2 = SOFT ? fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2))) : fma(dx, dx, fma(dy, dy, dz * dz));
-              double rinv = rsq64(r2);
-              if (!BARE && !SOFT) rinv = (r2 > 0.0) ? rinv : 0.0;
-              const double u3 = (rinv * rinv) * rinv;
-              const double s_i = u3 * pj.w, s_j = u3 * nmi[q];
-              ax[q] = fma(s_i, dx, ax[q]); ay[q] = fma(s_i, dy, ay[q]); az[q] = fma(s_i, dz, az[q]);
-              jx = fma(s_j, dx, jx); jy = fma(s_j, dy, jy); jz = fma(s_j, dz, jz);
-            }
-            jx = wave_ror1(jx); jy = wave_ror1(jy); jz = wave_ror1(jz);
-          }
-          sh_acc[wave][0][sub * 64 + lane] = jx; sh_acc[wave][1][sub * 64 + lane] = jy; sh_acc[wave][2][sub * 64 + lane] = jz;
-        }
-      } else {
-        for (int q4 = 0; q4 < 4; ++q4) {
-#pragma unroll 2
-          for (int k = 0; k < 64; ++k) {
-            const double4 pj = sh_pos[q4][k];
-#pragma unroll
-            for (int q = 0; q < IPT; ++q) {
-              const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
-              const double r2 = SOFT ? fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2))) : fma(dx, dx, fma(dy, dy, dz * dz));
-              double rinv = rsq64(r2);
-              if (!SOFT) rinv = (r2 > 0.0) ? rinv : 0.0;          // self pairs live here
-              const double s_i = ((rinv * rinv) * rinv) * pj.w;
-              ax[q] = fma(s_i, dx, ax[q]); ay[q] = fma(s_i, dy, ay[q]); az[q] = fma(s_i, dz, az[q]);
-            }
-          }
-        }
-      }
-      __syncthreads();   // every wave is done with sh_pos; the tile's j-side sums are complete
-      if (sym) {
-        double4 *dst = &Pj[j0 + t];
-        double4 o = *dst;
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) { o.x += sh_acc[wv][0][t]; o.y += sh_acc[wv][1][t]; o.z += sh_acc[wv][2][t]; }
-        *dst = o;
-      }
-      if (more) stage(nxt);
-      __syncthreads();   // next tile staged; sh_acc may be rewritten
-    }
-
-#pragma unroll
-    for (int q = 0; q < IPT; ++q) {
-      const int i = i0 + t + q * kBlock;
-      if (i < n_pad) { double4 o; o.x = ax[q]; o.y = ay[q]; o.z = az[q]; o.w = 0.0; Pi[i - own0] = o; }
-    }
+  for (int q = 0; q < IPT; ++q) {
+    const int i = i0 + t + q * kBlock;
+    // clamped index, then a select per component: `i < n ? posm[i] : pad` on structs becomes a select of POINTERS with
+    // the pad parked in scratch and a flat load
+    double4 p = posm[min(i, n_total - 1)];
+    if (i >= n_total) { p.x = padc; p.y = padc; p.z = padc; p.w = 0.0; }
+    xi[q] = p.x; yi[q] = p.y; zi[q] = p.z; nmi[q] = -gscale * p.w;
+    ax[q] = ay[q] = az[q] = 0.0;
   }
+
+  auto fetch = [&](int c) {                                  // thread t owns body j0 + 256 c + t of the strip
+    const int j = j0 + c * kJT + t;
+    double4 q = posm[min(j, n_total - 1)];
+    if (j >= n_total || 4 * c + wave >= n_sub) { q.x = padc; q.y = padc; q.z = padc; q.w = 0.0; }
+    return q;
+  };
+  auto stage = [&](double4 q) {
+    q.w *= gscale;
+    sh_pos[wave][lane] = q;
+    sh_pos[wave][lane + 64] = q;
+  };
+  stage(fetch(0));
+  __syncthreads();
+
+  for (int c = 0; c < n_tiles; ++c) {
+    const int nsub = min(4, n_sub - 4 * c);
+    const bool more = c + 1 < n_tiles;
+    double4 nxt;
+    if (more) nxt = fetch(c + 1);
+
+    if (!one_sided) {
+      for (int sub = 0; sub < nsub; ++sub) {
+        const double4 *sp = &sh_pos[sub][lane + 64];
+        double jx = 0.0, jy = 0.0, jz = 0.0;
+#pragma unroll 2
+        for (int k = 0; k < 64; ++k) {
+          const double4 pj = sp[-k];
+#pragma unroll
+          for (int q = 0; q < IPT; ++q) {
+            const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
+            const double r2 = SOFT ? fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2))) : fma(dx, dx, fma(dy, dy, dz * dz));
+            double rinv = rsq64(r2);
+            if (!BARE && !SOFT) rinv = (r2 > 0.0) ? rinv : 0.0;
+            const double u3 = (rinv * rinv) * rinv;
+            const double s_i = u3 * pj.w, s_j = u3 * nmi[q];
+            ax[q] = fma(s_i, dx, ax[q]); ay[q] = fma(s_i, dy, ay[q]); az[q] = fma(s_i, dz, az[q]);
+            jx = fma(s_j, dx, jx); jy = fma(s_j, dy, jy); jz = fma(s_j, dz, jz);
+          }
+          jx = wave_ror1(jx); jy = wave_ror1(jy); jz = wave_ror1(jz);
+        }
+        sh_acc[wave][0][sub * 64 + lane] = jx; sh_acc[wave][1][sub * 64 + lane] = jy; sh_acc[wave][2][sub * 64 + lane] = jz;
+      }
+    } else {
+      for (int q4 = 0; q4 < nsub; ++q4) {
+#pragma unroll 2
+        for (int k = 0; k < 64; ++k) {
+          const double4 pj = sh_pos[q4][k];
+#pragma unroll
+          for (int q = 0; q < IPT; ++q) {
+            const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
+            const double r2 = SOFT ? fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2))) : fma(dx, dx, fma(dy, dy, dz * dz));
+            double rinv = rsq64(r2);
+            if (!SOFT) rinv = (r2 > 0.0) ? rinv : 0.0;          // self pairs live here
+            const double s_i = ((rinv * rinv) * rinv) * pj.w;
+            ax[q] = fma(s_i, dx, ax[q]); ay[q] = fma(s_i, dy, ay[q]); az[q] = fma(s_i, dz, az[q]);
+          }
+        }
+      }
+    }
+    __syncthreads();   // every wave is done with sh_pos; the tile's j-side sums are complete
+    if (!one_sided && t < nsub * 64) {
+      double4 o;
+      o.x = ((sh_acc[0][0][t] + sh_acc[1][0][t]) + sh_acc[2][0][t]) + sh_acc[3][0][t];
+      o.y = ((sh_acc[0][1][t] + sh_acc[1][1][t]) + sh_acc[2][1][t]) + sh_acc[3][1][t];
+      o.z = ((sh_acc[0][2][t] + sh_acc[1][2][t]) + sh_acc[2][2][t]) + sh_acc[3][2][t];
+      o.w = 0.0;
+      pool[(size_t)slot_j + (size_t)c * kJT + t] = o;
+    }
+    if (more) stage(nxt);
+    __syncthreads();   // next tile staged; sh_acc may be rewritten
+  }
+
+  double4 *__restrict__ Pi = pool + (size_t)slot_i + t;
+#pragma unroll
+  for (int q = 0; q < IPT; ++q) { double4 o; o.x = ax[q]; o.y = ay[q]; o.z = az[q]; o.w = 0.0; Pi[q * kBlock] = o; }
 }
 
 }  // namespace
 
 hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
-  if (L.n_total <= 0 || L.n_pairs <= 0 || L.S <= 0 || L.T <= 0 || L.tiles_own <= 0) return hipErrorInvalidValue;
-  if ((L.np != 1 && L.np != 2) || L.S % (kBlock * 2 * L.np) != 0 || L.S % kJT != 0) return hipErrorInvalidValue;
-  dim3 grid(L.n_pairs), block(kBlock);
+  if (L.n_total <= 0 || L.n_items <= 0 || !L.pool || !L.items) return hipErrorInvalidValue;
+  if (L.np != 1 && L.np != 2) return hipErrorInvalidValue;
+  dim3 grid(L.n_items), block(kBlock);
 #define NBODY_SYM64_I(BARE, SOFT, IPTV, FLAG, RUNIF)                                                              \
   hipLaunchKernelGGL((forces_sym_f64_kernel<BARE, SOFT, IPTV>), grid, block, 0, s, (const double4 *)L.posm,        \
-                     (double4 *)L.part_i, (double4 *)L.part_j, (const int2 *)L.pairs, L.n_total, L.S, L.n_pad,     \
-                     L.own_tile0, L.tiles_own * L.S, L.G, L.eps2, (const int *)(FLAG), RUNIF)
+                     (double4 *)L.pool, (const SymItem *)L.items, L.n_total, L.G, L.eps2, (const int *)(FLAG), RUNIF)
 #define NBODY_SYM64(BARE, SOFT, FLAG, RUNIF)                                                                      \
   do { if (L.np == 2) NBODY_SYM64_I(BARE, SOFT, 4, FLAG, RUNIF); else NBODY_SYM64_I(BARE, SOFT, 2, FLAG, RUNIF); } while (0)
   if (L.eps2 > 0.0) {
@@ -182,7 +167,8 @@ hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((reduce_j_kernel<double, false>), dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s,
-                     (const double4 *)L.part_j, (double4 *)L.send, L.n_total, L.S, L.T, L.n_pad, L.own_tile0, L.tiles_own);
+                     (const double4 *)L.pool, (double4 *)L.send, (const unsigned int *)L.j_ptr,
+                     (const unsigned int *)L.j_off, L.n_total);
   return hipGetLastError();
 }
 

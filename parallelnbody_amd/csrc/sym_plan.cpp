@@ -1,0 +1,169 @@
+// Host-side planner of the symmetric force pass (see sym_plan.h).  No device code.
+#include "sym_plan.h"
+
+#include "../../include/nbody.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace nbody {
+
+namespace {
+
+// Does block a own the block pair {a, b}?  b within the forward half of the ring of T blocks; the antipodal pair of an
+// even ring goes to its smaller index if that is even, to the larger one if it is odd — so that every run of
+// consecutive rows gets the same number of pairs.
+bool ring_assigned(int a, int b, int T) {
+  if (a == b) return false;
+  int d = b - a;
+  if (d < 0) d += T;
+  if (2 * d < T) return true;
+  if (2 * d != T) return false;
+  const int lo = a < b ? a : b;
+  return ((lo & 1) == 0) == (a == lo);
+}
+
+struct Range { int row, j_sub0, n_sub, one_sided; };
+
+bool fail(std::string *err, const char *msg) {
+  if (err) *err = msg;
+  return false;
+}
+
+}  // namespace
+
+bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, int k_guided, int min_sub, SymPlan *out,
+                    std::string *err) {
+  if (n_total <= 0 || i_count <= 0 || i_begin < 0 || i_begin + i_count > n_total) return fail(err, "bad body range");
+  if (bi < 64 || bi % 64 != 0) return fail(err, "bodies per i-set must be a multiple of 64");
+  if (slots < 1 || k_guided < 1 || min_sub < 1) return fail(err, "bad scheduling parameters");
+  SymPlan P;
+  P.bi = bi;
+  P.T = (n_total + bi - 1) / bi;
+  P.n_pad = P.T * bi;
+  P.n_gran = (n_total + 63) / 64;
+  const bool all = i_count == n_total;
+  if (all) {
+    P.own_block0 = 0; P.own_blocks = P.T; P.n_src = 1;
+  } else {
+    // sharded: equal slices, each a whole number of blocks (every rank must cut the ring the same way)
+    if (n_total % i_count != 0 || i_begin % i_count != 0 || i_count % bi != 0)
+      return fail(err, "sharded symmetric contexts need equal slices that are a multiple of the i-set size");
+    P.own_block0 = i_begin / bi; P.own_blocks = i_count / bi; P.n_src = n_total / i_count;
+  }
+  P.own_gran0 = i_begin / 64;
+  P.own_grans = (i_count + 63) / 64;
+  const int sub_per_block = bi / 64;
+
+  // the rows' ranges, in 64-body subtiles, clipped to the bodies that exist
+  std::vector<Range> ranges;
+  long long total_cost = 0;
+  for (int a = P.own_block0; a < P.own_block0 + P.own_blocks; ++a) {
+    const int d0 = a * sub_per_block;
+    if (d0 >= P.n_gran) continue;                                    // (cannot happen: the last block holds a body)
+    const int dn = std::min(sub_per_block, P.n_gran - d0);
+    ranges.push_back({a, d0, dn, 1});
+    total_cost += 2LL * dn;                                          // a one-sided subtile costs about two symmetric ones
+    int h = 0;
+    while (h + 1 < P.T && ring_assigned(a, (a + h + 1) % P.T, P.T)) ++h;
+    for (int d = h + 1; d < P.T; ++d)
+      if (ring_assigned(a, (a + d) % P.T, P.T)) return fail(err, "internal: forward blocks not contiguous");
+    if (h == 0) continue;
+    const long long ring = (long long)P.T * sub_per_block;
+    const long long s = (long long)((a + 1) % P.T) * sub_per_block, len = (long long)h * sub_per_block;
+    const long long piece[2][2] = {{s, std::min(s + len, ring)}, {0, std::max(0LL, s + len - ring)}};
+    for (const auto &pc : piece) {
+      const long long lo = pc[0], hi = std::min<long long>(pc[1], P.n_gran);
+      if (hi <= lo) continue;
+      ranges.push_back({a, (int)lo, (int)(hi - lo), 0});
+      total_cost += hi - lo;
+    }
+  }
+
+  // guided self-scheduling: each strip takes 1/(k * slots) of the cost still to hand out
+  long long remaining = total_cost;
+  uint64_t pool = 0;
+  const long long kp = (long long)k_guided * slots;
+  for (const Range &r : ranges) {
+    const int unit = r.one_sided ? 2 : 1;
+    int pos = 0;
+    while (pos < r.n_sub) {
+      long long n = (remaining / kp) / unit;
+      if (n < min_sub) n = min_sub;
+      if (n >= 4) n -= n % 4;                                       // whole 256-body tiles except at a range's end
+      if (n > r.n_sub - pos) n = r.n_sub - pos;
+      if (r.n_sub - pos - n < min_sub) n = r.n_sub - pos;           // no slivers
+      SymItem it{};
+      it.i0 = r.row * bi;
+      it.j0 = (r.j_sub0 + pos) * 64;
+      it.n_sub = (int)n;
+      it.flags = r.one_sided ? kSymOneSided : 0;
+      if (pool + (uint64_t)bi + (uint64_t)n * 64 >= (1ull << 32)) return fail(err, "partial-sum pool exceeds 2^32 elements");
+      it.slot_i = (uint32_t)pool; pool += (uint64_t)bi;
+      if (!r.one_sided) { it.slot_j = (uint32_t)pool; pool += (uint64_t)n * 64; }
+      P.items.push_back(it);
+      pos += (int)n;
+      remaining -= n * unit;
+    }
+  }
+  P.pool_elems = pool;
+
+  // CSR over the own granules: i-side segments, in item order (a row's items are contiguous)
+  P.i_ptr.assign((size_t)P.own_grans + 1, 0);
+  for (const SymItem &it : P.items) {
+    const int g0 = it.i0 / 64 - P.own_gran0;
+    for (int g = g0; g < g0 + sub_per_block && g < P.own_grans; ++g) P.i_ptr[(size_t)g + 1] += 1;
+  }
+  for (int g = 0; g < P.own_grans; ++g) P.i_ptr[(size_t)g + 1] += P.i_ptr[(size_t)g];
+  P.i_off.assign(P.i_ptr.back(), 0);
+  {
+    std::vector<uint32_t> fill(P.i_ptr.begin(), P.i_ptr.end() - 1);
+    for (const SymItem &it : P.items) {
+      const int g0 = it.i0 / 64 - P.own_gran0;
+      for (int g = g0; g < g0 + sub_per_block && g < P.own_grans; ++g)
+        P.i_off[fill[(size_t)g]++] = it.slot_i + (uint32_t)(g - g0) * 64u;
+    }
+  }
+  // CSR over all granules: j-side segments
+  P.j_ptr.assign((size_t)P.n_gran + 1, 0);
+  for (const SymItem &it : P.items)
+    if (!(it.flags & kSymOneSided))
+      for (int k = 0; k < it.n_sub; ++k) P.j_ptr[(size_t)(it.j0 / 64 + k) + 1] += 1;
+  for (int g = 0; g < P.n_gran; ++g) P.j_ptr[(size_t)g + 1] += P.j_ptr[(size_t)g];
+  P.j_off.assign(P.j_ptr.back(), 0);
+  {
+    std::vector<uint32_t> fill(P.j_ptr.begin(), P.j_ptr.end() - 1);
+    for (const SymItem &it : P.items)
+      if (!(it.flags & kSymOneSided))
+        for (int k = 0; k < it.n_sub; ++k) P.j_off[fill[(size_t)(it.j0 / 64 + k)]++] = it.slot_j + (uint32_t)k * 64u;
+  }
+  *out = std::move(P);
+  return true;
+}
+
+}  // namespace nbody
+
+// C-ABI view of the planner (host only, no device): lets the CPU test suite check that a plan covers every body pair
+// exactly once and that its segments do not overlap.
+extern "C" int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
+                                       int32_t slots, int32_t k_guided, int32_t min_sub, int32_t *n_items,
+                                       uint64_t *pool_elems, int32_t *items, int32_t items_cap) {
+  nbody::SymPlan P;
+  std::string why;
+  if (i_count == 0) i_count = n_total - i_begin;
+  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided, min_sub, &P, &why))
+    return NBODY_ERR_UNSUPPORTED;
+  if (n_items) *n_items = (int32_t)P.items.size();
+  if (pool_elems) *pool_elems = P.pool_elems;
+  if (items) {
+    if (items_cap < (int32_t)P.items.size()) return NBODY_ERR_INVALID;
+    static_assert(sizeof(nbody::SymItem) == 32, "SymItem is eight 32-bit words");
+    for (size_t k = 0; k < P.items.size(); ++k) {
+      const nbody::SymItem &it = P.items[k];
+      int32_t *o = items + 8 * k;
+      o[0] = it.i0; o[1] = it.j0; o[2] = it.n_sub; o[3] = it.flags;
+      o[4] = (int32_t)it.slot_i; o[5] = (int32_t)it.slot_j; o[6] = 0; o[7] = 0;
+    }
+  }
+  return NBODY_OK;
+}

@@ -1,0 +1,81 @@
+"""Host logic of the symmetric force pass: the work plan (parallelnbody_amd/csrc/sym_plan.{h,cpp}) through its C-ABI
+view nbody_sym_plan_describe.  CPU only — no kernel runs here.
+
+A plan is correct when, over all ranks of a job, every unordered pair of different bodies is evaluated exactly once
+(symmetric strips) or, inside an i-set's own block, every ordered pair once (one-sided strips), and when no two partial-sum
+segments overlap.  The GPU parity tests then check the arithmetic; this file checks the bookkeeping for the sizes
+BASELINE.json names and for ragged / sharded ones."""
+import numpy as np
+import pytest
+
+
+def _coverage(nb, n, ranks, bi, slots, k, min_sub):
+    """sym[a, g] / one[a, g]: how many items pair block a's i-set with 64-body subtile g, over all ranks."""
+    T, G = -(-n // bi), -(-n // 64)
+    sym = np.zeros((T, G), np.int32)
+    one = np.zeros((T, G), np.int32)
+    pools = []
+    for r in range(ranks):
+        ib, ic = (r * (n // ranks), n // ranks) if ranks > 1 else (0, 0)
+        items, pool = nb.sym_plan(n, ib, ic, bi, slots, k, min_sub)
+        assert len(items) > 0
+        segs = []
+        for i0, j0, n_sub, flags, slot_i, slot_j, _, _ in items:
+            assert i0 % bi == 0 and j0 % 64 == 0 and n_sub >= 1 and j0 // 64 + n_sub <= G
+            if ranks > 1:
+                assert ib <= i0 < ib + ic
+            tgt = one if flags & 1 else sym
+            tgt[i0 // bi, j0 // 64:j0 // 64 + n_sub] += 1
+            segs.append((np.uint32(slot_i), bi))
+            if not flags & 1:
+                segs.append((np.uint32(slot_j), 64 * n_sub))
+        segs.sort()
+        end = 0
+        for s, ln in segs:                      # segments are disjoint and inside the pool
+            assert int(s) >= end
+            end = int(s) + ln
+        assert end <= pool
+        pools.append(pool)
+    return sym, one, pools
+
+
+@pytest.mark.parametrize("n,ranks,bi,slots", [
+    (1024, 1, 512, 1024), (2000, 1, 512, 1024), (5000, 1, 1024, 1024), (40000, 1, 2048, 768), (65536, 1, 4096, 512),
+    (65536, 1, 1024, 1024), (100003, 1, 2048, 768), (65536, 2, 2048, 768), (65536, 8, 4096, 512), (49152, 3, 1024, 1024),
+    (32768, 4, 512, 1024)])
+def test_every_pair_exactly_once(nb, n, ranks, bi, slots):
+    sym, one, _ = _coverage(nb, n, ranks, bi, slots, 3, 4)
+    T, G = sym.shape
+    blk = np.arange(G) * 64 // bi                       # block of each subtile
+    # inside its own block an i-set meets every subtile one-sided, exactly once, and never symmetrically
+    own = blk[None, :] == np.arange(T)[:, None]
+    assert np.array_equal(one, own.astype(np.int32))
+    assert not sym[own].any()
+    # two subtiles of different blocks: the pair is evaluated by exactly one of the two rows
+    E = sym[blk, :]                                      # E[gi, gj] = does gi's row take subtile gj
+    off = blk[:, None] != blk[None, :]
+    assert np.array_equal((E + E.T)[off], np.ones(off.sum(), np.int32))
+
+
+def test_headline_plan_shape(nb):
+    # N = 2^20, sixteen bodies per lane, 512 resident workgroups: long strips first, 256-body strips last, a pool of a
+    # few GB (the round-1 layout needed 8.6 GB of private rows here)
+    items, pool = nb.sym_plan(1 << 20, 0, 0, 4096, 512, 3, 4)
+    sym = items[items[:, 3] == 0]
+    assert sym[0, 2] > 1000 and sym[-1, 2] == 4
+    assert sym[0, 2] == sym[:, 2].max() and sym[-len(sym) // 10:, 2].max() <= 16   # long strips first, short ones last
+    assert 8000 < len(items) < 20000
+    assert pool * 16 < 3.5e9
+    # every rank of an 8-GPU job gets the same amount of work
+    work = []
+    for r in range(8):
+        it, _ = nb.sym_plan(1 << 20, r << 17, 1 << 17, 4096, 512, 3, 4)
+        work.append(int(it[it[:, 3] == 0][:, 2].sum()))
+    assert max(work) - min(work) <= 4096 // 64
+
+
+def test_unplannable_ranges_are_refused(nb):
+    with pytest.raises(nb.NBodyError):
+        nb.sym_plan(65536, 1000, 3000, 1024, 512, 3, 4)          # slices must be equal multiples of the i-set
+    with pytest.raises(nb.NBodyError):
+        nb.sym_plan(65536, 0, 32768, 1000, 512, 3, 4)            # i-sets are multiples of 64 bodies
