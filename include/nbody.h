@@ -118,6 +118,19 @@ NBODY_API int nbody_default_params(nbody_params *p);
 /* AOctreeSearch ctor + CreateSpacePoints' allocation (OctreeSearch.cpp:8,62). */
 NBODY_API int nbody_create(const nbody_params *p, nbody_ctx **out);
 
+/*
+ * The same context over several GPUs of one node, driven by ONE caller thread — the reference's only caller is the game
+ * thread (OctreeSearch.cpp:21-34).  Bodies are range-partitioned in equal slices over `devices` (n_total a multiple of
+ * n_dev); every device keeps all positions.  Per step each device runs the force pass of its slice, [symmetric
+ * algorithm] the j-side sums change hands by grouped ncclSend/ncclRecv, the slices are integrated, and ONE in-place
+ * ncclAllGather of the positions (RCCL over xGMI; communicators from ncclCommInitAll, librccl loaded at this call)
+ * brings every device up to date.  p->i_begin / i_count / device are ignored (the context owns all bodies); theta must
+ * be 0.  Every entry point of this header works on the result except the device-plumbing ones (nbody_set_stream,
+ * nbody_device_ptr, nbody_bind_*, nbody_step_begin/_end, nbody_exchange_*) and the Barnes-Hut ones, which report
+ * NBODY_ERR_UNSUPPORTED / NBODY_ERR_STATE.  With n_dev = 1 results equal nbody_create's bit for bit.
+ */
+NBODY_API int nbody_create_multi(const nbody_params *p, const int32_t *devices, int32_t n_dev, nbody_ctx **out);
+
 /* CleanParticles (OctreeSearch.cpp:91-97).  NULL is allowed, like `delete NULL` there. */
 NBODY_API void nbody_destroy(nbody_ctx *ctx);
 
@@ -269,10 +282,15 @@ NBODY_API int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t 
 
 /* ---- checkpoint / resume (build-defined: the reference keeps its state in a non-serialised TArray) ---------- */
 
-/* Raw little-endian dump of the context's state: header, all positions+masses, owned velocities and accelerations.
- * Resuming from it continues the trajectory bit for bit.  A sharded job writes one file per rank. */
+/* Raw little-endian dump of the context's state: header (format NBDYCKP2: sizes, steps, G, eps, theta and — Barnes-Hut —
+ * the previous tree's centre of mass, where the reference roots the next tree, OctreeSearch.cpp:77-79), all
+ * positions+masses, owned velocities and accelerations.  Resuming from it continues the trajectory bit for bit, at
+ * theta = 0 and at theta > 0.  A sharded job writes one file per rank; a multi-device context writes the single file a
+ * one-device context of the whole system would. */
 NBODY_API int nbody_save_checkpoint(nbody_ctx *ctx, const char *path);
-/* The context must have the same n_total / owned range / precision as the one that saved the file. */
+/* The context must have the same n_total, precision, G and eps as the one that saved the file, and an owned range inside
+ * the file's (so a whole-system file also feeds every slice of a sharded or multi-device job).  An fp32 context that
+ * owns all bodies also takes over theta and the tree root. */
 NBODY_API int nbody_load_checkpoint(nbody_ctx *ctx, const char *path, int64_t *steps_done);
 /* Updates applied since the state was set or loaded. */
 NBODY_API int nbody_steps_done(nbody_ctx *ctx, int64_t *steps);

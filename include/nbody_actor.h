@@ -43,6 +43,8 @@ NBODY_API void nbody_actor_set_show_octree(nbody_actor *a, int32_t show);
 NBODY_API void nbody_actor_set_theta(nbody_actor *a, float theta);
 NBODY_API void nbody_actor_set_seed(nbody_actor *a, uint64_t seed);
 NBODY_API void nbody_actor_set_engine(nbody_actor *a, int32_t device, int32_t precision, double G, double eps);
+/* Share the bodies over several GPUs from the next CreateSpacePoints / SetParticles on (nbody_create_multi); n = 0: one GPU again. */
+NBODY_API void nbody_actor_set_devices(nbody_actor *a, const int32_t *devices, int32_t n);
 NBODY_API int32_t nbody_actor_last_status(const nbody_actor *a);
 /* Copy the (synchronised) Particles array out; returns the number of records written. */
 NBODY_API int32_t nbody_actor_get_particles(nbody_actor *a, nbody_particle *out, int32_t capacity);

@@ -35,6 +35,7 @@ class OctreeSearchActor {
   float ActorLocation[3] = {0, 0, 0};   // GetActorLocation(), .cpp:64
   bool MirrorParticles = true;          // refresh `Particles` after every Tick, as the reference's TArray is live
   int Device = 0;
+  std::vector<int32_t> Devices;         // non-empty: share the bodies over these GPUs (nbody_create_multi; Theta must be 0)
   int Precision = NBODY_PREC_F32;
   double G = 1.0e4;                     // .h:104
   double Eps = 0.0;
@@ -174,7 +175,8 @@ class OctreeSearchActor {
     p.precision = Precision;
     p.G = G;
     p.eps = Eps;
-    LastStatus = nbody_create(&p, &ctx_);
+    LastStatus = Devices.empty() ? nbody_create(&p, &ctx_)
+                                 : nbody_create_multi(&p, Devices.data(), (int32_t)Devices.size(), &ctx_);
     if (LastStatus) return;
     LastStatus = nbody_set_particles(ctx_, Particles.data(), sizeof(FParticle), (int32_t)Particles.size());
     if (LastStatus) return;

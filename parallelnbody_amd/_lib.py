@@ -86,6 +86,7 @@ def lib():
     sig("nbody_device_count", c_int)
     sig("nbody_default_params", c_int, ctypes.POINTER(Params))
     sig("nbody_create", c_int, ctypes.POINTER(Params), ctypes.POINTER(vp))
+    sig("nbody_create_multi", c_int, ctypes.POINTER(Params), ctypes.POINTER(c_i32), c_i32, ctypes.POINTER(vp))
     sig("nbody_destroy", None, vp)
     sig("nbody_last_error", ctypes.c_char_p, vp)
     sig("nbody_set_particles", c_int, vp, vp, sz, c_i32)
@@ -148,6 +149,7 @@ def lib():
     sig("nbody_actor_set_theta", None, vp, c_f)
     sig("nbody_actor_set_seed", None, vp, ctypes.c_uint64)
     sig("nbody_actor_set_engine", None, vp, c_i32, c_i32, c_d, c_d)
+    sig("nbody_actor_set_devices", None, vp, ctypes.POINTER(c_i32), c_i32)
     sig("nbody_actor_last_status", c_i32, vp)
     sig("nbody_actor_get_particles", c_i32, vp, vp, c_i32)
     _lib = L

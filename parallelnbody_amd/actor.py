@@ -63,6 +63,11 @@ class OctreeSearch:
     def set_theta(self, theta):
         self._L.nbody_actor_set_theta(self._h, theta)
 
+    def set_devices(self, devices):
+        """Share the bodies over several GPUs (nbody_create_multi) from the next CreateSpacePoints / SetParticles on."""
+        devs = (ctypes.c_int32 * len(devices))(*devices) if devices else None
+        self._L.nbody_actor_set_devices(self._h, devs, len(devices) if devices else 0)
+
     def set_seed(self, seed):
         self._L.nbody_actor_set_seed(self._h, seed)
 

@@ -48,6 +48,11 @@ void nbody_actor_set_engine(nbody_actor *a, int32_t device, int32_t precision, d
   if (!a) return;
   a->impl.Device = device; a->impl.Precision = precision; a->impl.G = G; a->impl.Eps = eps;
 }
+void nbody_actor_set_devices(nbody_actor *a, const int32_t *devices, int32_t n) {
+  if (!a) return;
+  if (devices && n > 0) a->impl.Devices.assign(devices, devices + n);
+  else a->impl.Devices.clear();
+}
 int32_t nbody_actor_last_status(const nbody_actor *a) { return a ? a->impl.LastStatus : NBODY_ERR_INVALID; }
 
 int32_t nbody_actor_get_particles(nbody_actor *a, nbody_particle *out, int32_t capacity) {

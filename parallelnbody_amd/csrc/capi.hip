@@ -14,6 +14,7 @@
 
 #include "../../include/nbody.h"
 #include "kernels.h"
+#include "multi.h"
 #include "sym_plan.h"
 
 namespace {
@@ -32,6 +33,7 @@ struct KernelTimer {
 }  // namespace
 
 struct nbody_ctx {
+  nbody::Multi *multi = nullptr;   // nbody_create_multi: this context is a front for one context per device (multi.h)
   nbody_params p;
   size_t elem;                 // bytes per float4/double4 element
   hipStream_t own_stream = nullptr;
@@ -80,6 +82,15 @@ int fail(nbody_ctx *c, int code, const char *fmt, ...) {
   va_end(ap);
   if (c) c->err = buf; else g_create_error = buf;
   return code;
+}
+
+// A call on a multi-device context is answered by its Multi; its message becomes the context's.
+int multi_rc(nbody_ctx *c, int rc) {
+  if (rc) c->err = nbody::multi_error(c->multi);
+  return rc;
+}
+int multi_unsupported(nbody_ctx *c, const char *who) {
+  return fail(c, NBODY_ERR_UNSUPPORTED, "%s: not available on a multi-device context (nbody_create_multi); use one context per device", who);
 }
 
 #define HIP_TRY(c, expr)                                                                         \
@@ -587,7 +598,24 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   return NBODY_OK;
 }
 
+int nbody_create_multi(const nbody_params *pin, const int32_t *devices, int32_t n_dev, nbody_ctx **out) {
+  if (!pin || !devices || !out) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create_multi: null argument");
+  *out = nullptr;
+  nbody_ctx *c = new (std::nothrow) nbody_ctx();
+  if (!c) return fail(nullptr, NBODY_ERR_NOMEM, "nbody_create_multi: out of host memory");
+  std::string why;
+  const int rc = nbody::multi_create(pin, devices, n_dev, &c->multi, &why);
+  if (rc) { delete c; return fail(nullptr, rc, "%s", why.c_str()); }
+  c->p = *pin;
+  c->p.i_begin = 0; c->p.i_count = pin->n_total; c->p.device = devices[0];
+  c->theta = 0.0f;
+  c->elem = (pin->precision == NBODY_PREC_F64) ? 32 : 16;
+  *out = c;
+  return NBODY_OK;
+}
+
 void nbody_destroy(nbody_ctx *c) {
+  if (c && c->multi) { nbody::multi_destroy(c->multi); delete c; return; }
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (KernelTimer &t : c->timers) {
@@ -617,6 +645,7 @@ void nbody_destroy(nbody_ctx *c) {
 }
 
 int nbody_set_stream(nbody_ctx *c, void *hip_stream) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_set_stream");
   if (!c) return NBODY_ERR_INVALID;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -624,6 +653,7 @@ int nbody_set_stream(nbody_ctx *c, void *hip_stream) {
 }
 
 int nbody_device_ptr(nbody_ctx *c, int32_t which, void **ptr, size_t *bytes) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_device_ptr");
   if (!c || !ptr) return NBODY_ERR_INVALID;
   switch (which) {
     case NBODY_BUF_POSM: *ptr = c->posm; if (bytes) *bytes = (size_t)c->p.n_total * c->elem; break;
@@ -635,6 +665,7 @@ int nbody_device_ptr(nbody_ctx *c, int32_t which, void **ptr, size_t *bytes) {
 }
 
 int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_bind_device_state");
   if (!c) return NBODY_ERR_INVALID;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (posm) { if (c->own_posm) (void)hipFree(c->posm); c->posm = posm; c->own_posm = false; }
@@ -647,6 +678,7 @@ int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
 }
 
 int nbody_synchronize(nbody_ctx *c) {
+  if (c && c->multi) return multi_rc(c, nbody::multi_synchronize(c->multi));
   if (!c) return NBODY_ERR_INVALID;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NBODY_OK;
@@ -655,12 +687,14 @@ int nbody_synchronize(nbody_ctx *c) {
 int nbody_set_state_soa(nbody_ctx *c, const float *posm4, const float *vel4, int32_t n) {
   if (!c || !posm4 || !vel4) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa: null buffer") : NBODY_ERR_INVALID;
   if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa: n = %d but the context holds %d bodies", n, c->p.n_total);
+  if (c->multi) { const int rc = multi_rc(c, nbody::multi_set_state_soa(c->multi, posm4, vel4, n)); if (!rc) { c->have_state = true; c->steps_done = 0; } return rc; }
   return upload_soa<float>(c, posm4, vel4);
 }
 
 int nbody_set_state_soa_f64(nbody_ctx *c, const double *posm4, const double *vel4, int32_t n) {
   if (!c || !posm4 || !vel4) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa_f64: null buffer") : NBODY_ERR_INVALID;
   if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa_f64: n = %d but the context holds %d bodies", n, c->p.n_total);
+  if (c->multi) { const int rc = multi_rc(c, nbody::multi_set_state_soa_f64(c->multi, posm4, vel4, n)); if (!rc) { c->have_state = true; c->steps_done = 0; } return rc; }
   return upload_soa<double>(c, posm4, vel4);
 }
 
@@ -668,6 +702,7 @@ int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n)
   if (!c || !aos) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_particles: null buffer") : NBODY_ERR_INVALID;
   if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_particles: n = %d but the context holds %d bodies", n, c->p.n_total);
   if (stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "nbody_set_particles: stride %zu < %zu", stride, sizeof(nbody_particle));
+  if (c->multi) { const int rc = multi_rc(c, nbody::multi_set_particles(c->multi, aos, stride, n)); if (!rc) { c->have_state = true; c->steps_done = 0; } return rc; }
   std::vector<float> posm((size_t)n * 4), vel((size_t)n * 4);
   const char *base = (const char *)aos;
   for (int i = 0; i < n; ++i) {
@@ -708,6 +743,7 @@ static int needs_phases(nbody_ctx *c, const char *who) {
 }
 
 int nbody_step_begin(nbody_ctx *c) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_step_begin");
   int rc = check_ready(c);
   if (rc) return rc;
   if (c->step_open) return fail(c, NBODY_ERR_STATE, "nbody_step_begin: previous step not ended");
@@ -718,6 +754,7 @@ int nbody_step_begin(nbody_ctx *c) {
 }
 
 int nbody_step_end(nbody_ctx *c, float dt) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_step_end");
   int rc = check_ready(c);
   if (rc) return rc;
   if (!c->step_open) return fail(c, NBODY_ERR_STATE, "nbody_step_end: no step begun");
@@ -729,6 +766,7 @@ int nbody_step_end(nbody_ctx *c, float dt) {
 }
 
 int nbody_exchange_info(nbody_ctx *c, void **send, void **recv, size_t *bytes_per_rank, int32_t *n_ranks) {
+  if (c && c->multi) { if (send) *send = nullptr; if (recv) *recv = nullptr; if (bytes_per_rank) *bytes_per_rank = 0; if (n_ranks) *n_ranks = 0; return NBODY_OK; }
   if (!c) return NBODY_ERR_INVALID;
   const bool ex = c->sym && c->sym_nsrc > 1;
   if (send) *send = ex ? c->sym_send : nullptr;
@@ -739,6 +777,7 @@ int nbody_exchange_info(nbody_ctx *c, void **send, void **recv, size_t *bytes_pe
 }
 
 int nbody_exchange_read_send(nbody_ctx *c, void *host) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_exchange_read_send");
   if (!c || !host) return NBODY_ERR_INVALID;
   if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_exchange_read_send: this context has no exchange step");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -747,6 +786,7 @@ int nbody_exchange_read_send(nbody_ctx *c, void *host) {
 }
 
 int nbody_exchange_write_recv(nbody_ctx *c, const void *host) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_exchange_write_recv");
   if (!c || !host) return NBODY_ERR_INVALID;
   if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_exchange_write_recv: this context has no exchange step");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -755,6 +795,7 @@ int nbody_exchange_write_recv(nbody_ctx *c, const void *host) {
 }
 
 int nbody_bind_exchange(nbody_ctx *c, void *send, void *recv) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_bind_exchange");
   if (!c) return NBODY_ERR_INVALID;
   if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_bind_exchange: this context has no exchange step");
   if (!send || !recv) return fail(c, NBODY_ERR_INVALID, "nbody_bind_exchange: null buffer");
@@ -768,6 +809,7 @@ int nbody_bind_exchange(nbody_ctx *c, void *send, void *recv) {
 int nbody_compute_forces(nbody_ctx *c) {
   int rc = check_ready(c);
   if (rc) return rc;
+  if (c->multi) return multi_rc(c, nbody::multi_forces(c->multi, 0.0f));
   if ((rc = needs_phases(c, "nbody_compute_forces"))) return rc;
   HIP_TRY(c, hipSetDevice(c->p.device));
   if ((rc = run_forces(c))) return rc;
@@ -780,6 +822,13 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
   if (rc) return rc;
   if (nsteps < 0) return fail(c, NBODY_ERR_INVALID, "nbody_step: nsteps < 0");
   if (!(dt > 0.0f)) return NBODY_OK;   // OctreeSearch.cpp:25: PhDeltaTime <= 0 freezes the physics
+  if (c->multi) {
+    for (int s = 0; s < nsteps; ++s) {
+      if ((rc = multi_rc(c, nbody::multi_forces(c->multi, dt)))) return rc;
+      c->steps_done += 1;
+    }
+    return NBODY_OK;
+  }
   if ((rc = needs_phases(c, "nbody_step"))) return rc;
   if (nsteps > 1 && c->p.i_count != c->p.n_total)
     return fail(c, NBODY_ERR_STATE, "nbody_step: a sharded context advances one step per call (all-gather NBODY_BUF_POSM in between)");
@@ -811,6 +860,7 @@ int nbody_get_bounds(nbody_ctx *c, float *size) {
   int rc = check_ready(c);
   if (rc) return rc;
   if (!size) return fail(c, NBODY_ERR_INVALID, "nbody_get_bounds: null output");
+  if (c->multi) return multi_rc(c, nbody::multi_get_bounds(c->multi, size));
   HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
   HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, c->p.i_begin, c->p.i_count, (unsigned int *)c->scratch, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->scratch, 4, hipMemcpyDeviceToHost, c->stream));
@@ -822,6 +872,7 @@ int nbody_get_bounds(nbody_ctx *c, float *size) {
 int nbody_energy(nbody_ctx *c, double *ke, double *pe) {
   int rc = check_ready(c);
   if (rc) return rc;
+  if (c->multi) return multi_rc(c, nbody::multi_energy(c->multi, ke, pe));
   HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 16, c->stream));
   HIP_TRY(c, nbody::launch_energy(c->p.precision, c->posm, c->vel, c->p.n_total, c->p.i_begin, c->p.i_count, c->p.G,
                                   c->p.eps * c->p.eps, (double *)c->scratch, c->stream));
@@ -840,6 +891,7 @@ int nbody_get_positions(nbody_ctx *c, float *xyz, size_t stride, int32_t first, 
   if (!xyz || stride < 12) return fail(c, NBODY_ERR_INVALID, "nbody_get_positions: null buffer or stride < 12");
   if (first < 0 || count < 0 || first + count > c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_get_positions: range out of bounds");
   if (count == 0) return NBODY_OK;
+  if (c->multi) return multi_rc(c, nbody::multi_get_positions(c->multi, xyz, stride, first, count));
   // one repack kernel + one pinned D2H copy (OctreeSearch.cpp:41 reads Position of every body each frame)
   const size_t bytes = (size_t)count * 12;
   if ((rc = ensure_stage(c, bytes))) return rc;
@@ -861,6 +913,7 @@ int nbody_get_positions(nbody_ctx *c, float *xyz, size_t stride, int32_t first, 
 int nbody_get_state_soa(nbody_ctx *c, float *posm4, float *vel4, float *acc4) {
   int rc = check_ready(c);
   if (rc) return rc;
+  if (c->multi) return multi_rc(c, nbody::multi_get_state_soa(c->multi, posm4, vel4, acc4));
   if (posm4 && (rc = download4<float>(c, c->posm, (size_t)c->p.i_begin, (size_t)c->p.i_count, posm4))) return rc;
   if (vel4 && (rc = download4<float>(c, c->vel, 0, (size_t)c->p.i_count, vel4))) return rc;
   if (acc4 && (rc = download4<float>(c, c->acc, 0, (size_t)c->p.i_count, acc4))) return rc;
@@ -870,6 +923,7 @@ int nbody_get_state_soa(nbody_ctx *c, float *posm4, float *vel4, float *acc4) {
 int nbody_get_state_soa_f64(nbody_ctx *c, double *posm4, double *vel4, double *acc4) {
   int rc = check_ready(c);
   if (rc) return rc;
+  if (c->multi) return multi_rc(c, nbody::multi_get_state_soa_f64(c->multi, posm4, vel4, acc4));
   if (posm4 && (rc = download4<double>(c, c->posm, (size_t)c->p.i_begin, (size_t)c->p.i_count, posm4))) return rc;
   if (vel4 && (rc = download4<double>(c, c->vel, 0, (size_t)c->p.i_count, vel4))) return rc;
   if (acc4 && (rc = download4<double>(c, c->acc, 0, (size_t)c->p.i_count, acc4))) return rc;
@@ -880,6 +934,7 @@ int nbody_get_particles(nbody_ctx *c, void *aos, size_t stride) {
   int rc = check_ready(c);
   if (rc) return rc;
   if (!aos || stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "nbody_get_particles: null buffer or stride < 40");
+  if (c->multi) return multi_rc(c, nbody::multi_get_particles(c->multi, aos, stride));
   const size_t ic = (size_t)c->p.i_count;
   const size_t bytes = ic * sizeof(nbody_particle);
   if ((rc = ensure_stage(c, bytes))) return rc;
@@ -898,9 +953,17 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
   int rc = check_ready(c);
   if (rc) return rc;
   if (aos && stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "nbody_tick: stride < 40");
+  if (c->multi) {                                                // the same frame as three calls: every device has its own stream to wait for
+    if (dt > 0.0f && size && (rc = nbody_get_bounds(c, size))) return rc;
+    if (dt > 0.0f && (rc = nbody_step(c, dt, 1))) return rc;
+    return aos ? nbody_get_particles(c, aos, stride) : nbody_synchronize(c);
+  }
   if ((rc = needs_phases(c, "nbody_tick"))) return rc;
   HIP_TRY(c, hipSetDevice(c->p.device));
   const bool live = dt > 0.0f;                                   // OctreeSearch.cpp:25
+  // the eps floor of NBODY_ZERO_FLOOR is computed through the same 64-byte scratch the bounds travel in: settle it
+  // before the bounds are queued, or the first frame would return the largest mass as Size
+  if (live && c->theta == 0.0f && (rc = ensure_floor(c))) return rc;
   if (live && size) {                                            // .cpp:26, 47-56: bounds of the positions BEFORE the step
     HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
     HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, c->p.i_begin, c->p.i_count, (unsigned int *)c->scratch, c->stream));
@@ -925,6 +988,7 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
 int nbody_pin_host_buffer(nbody_ctx *c, void *host, size_t bytes) {
   if (!c) return NBODY_ERR_INVALID;
   if (!host || bytes == 0) return fail(c, NBODY_ERR_INVALID, "nbody_pin_host_buffer: null buffer or zero size");
+  if (c->multi) return NBODY_OK;   // an optimisation only: a multi-device context delivers through each device's staging buffer
   for (const auto &r : c->pinned)
     if ((char *)host < r.first + r.second && r.first < (char *)host + bytes)
       return fail(c, NBODY_ERR_INVALID, "nbody_pin_host_buffer: overlaps a range that is already pinned");
@@ -936,6 +1000,7 @@ int nbody_pin_host_buffer(nbody_ctx *c, void *host, size_t bytes) {
 
 int nbody_unpin_host_buffer(nbody_ctx *c, void *host) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return NBODY_OK;
   for (size_t k = 0; k < c->pinned.size(); ++k)
     if (c->pinned[k].first == (char *)host) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -949,13 +1014,15 @@ int nbody_unpin_host_buffer(nbody_ctx *c, void *host) {
 // ---- checkpoint / resume (nothing in the reference to mirror: its state is not even a UPROPERTY) ----
 namespace {
 struct CkptHeader {
-  char magic[8];          // "NBDYCKP1"
+  char magic[8];          // "NBDYCKP2"
   uint32_t header_bytes;
   int32_t n_total, i_begin, i_count;
   int32_t elem_bytes;     // 4 (fp32 state) or 8 (fp64 state)
-  int32_t reserved;
+  int32_t has_root;       // Barnes-Hut cross-frame state present: root_com is the next tree's root centre
   int64_t steps_done;
   double G, eps;
+  float theta;            // opening angle in force when the file was written (the reference ships 1.0, OctreeSearch.cpp:85)
+  float root_com[3];      // previous tree's centre of mass (OctreeSearch.cpp:77-79)
 };
 }  // namespace
 
@@ -966,16 +1033,27 @@ int nbody_save_checkpoint(nbody_ctx *c, const char *path) {
   const bool f64 = c->p.precision == NBODY_PREC_F64;
   const size_t eb = f64 ? 8 : 4, n = (size_t)c->p.n_total, ic = (size_t)c->p.i_count;
   std::vector<char> posm(n * 4 * eb), vel(ic * 4 * eb), acc(ic * 4 * eb);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(posm.data(), c->posm, posm.size(), hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(vel.data(), c->vel, vel.size(), hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(acc.data(), c->acc, acc.size(), hipMemcpyDeviceToHost));
   CkptHeader h;
   memset(&h, 0, sizeof h);
-  memcpy(h.magic, "NBDYCKP1", 8);
+  if (c->multi) {
+    // a multi-device context writes the file a single context of the whole system would write
+    rc = f64 ? nbody_get_state_soa_f64(c, (double *)posm.data(), (double *)vel.data(), (double *)acc.data())
+             : nbody_get_state_soa(c, (float *)posm.data(), (float *)vel.data(), (float *)acc.data());
+    if (rc) return rc;
+  } else {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(posm.data(), c->posm, posm.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(vel.data(), c->vel, vel.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(acc.data(), c->acc, acc.size(), hipMemcpyDeviceToHost));
+    if (c->bh) {                                                   // the next frame's tree is rooted at this frame's CoM
+      HIP_TRY(c, nbody::bh_get_root_com(c->bh, h.root_com, c->stream));
+      h.has_root = 1;
+    }
+  }
+  memcpy(h.magic, "NBDYCKP2", 8);
   h.header_bytes = (uint32_t)sizeof h;
   h.n_total = c->p.n_total; h.i_begin = c->p.i_begin; h.i_count = c->p.i_count;
-  h.elem_bytes = (int32_t)eb; h.steps_done = c->steps_done; h.G = c->p.G; h.eps = c->p.eps;
+  h.elem_bytes = (int32_t)eb; h.steps_done = c->steps_done; h.G = c->p.G; h.eps = c->p.eps; h.theta = c->theta;
   FILE *f = fopen(path, "wb");
   if (!f) return fail(c, NBODY_ERR_INVALID, "nbody_save_checkpoint: cannot open %s for writing", path);
   const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(posm.data(), 1, posm.size(), f) == posm.size() &&
@@ -986,6 +1064,14 @@ int nbody_save_checkpoint(nbody_ctx *c, const char *path) {
 
 int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
   if (!c || !path) return c ? fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: null path") : NBODY_ERR_INVALID;
+  if (c->multi) {                                                  // every device reads its slice of the same file
+    int64_t n = 0;
+    const int rc = multi_rc(c, nbody::multi_load_checkpoint(c->multi, path, &n));
+    if (rc) return rc;
+    c->have_state = true; c->steps_done = n;
+    if (steps_done) *steps_done = n;
+    return NBODY_OK;
+  }
   FILE *f = fopen(path, "rb");
   if (!f) return fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: cannot open %s", path);
   CkptHeader h;
@@ -993,22 +1079,47 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
   const size_t eb = f64 ? 8 : 4, n = (size_t)c->p.n_total, ic = (size_t)c->p.i_count;
   int rc = NBODY_OK;
   std::vector<char> posm(n * 4 * eb), vel(ic * 4 * eb), acc(ic * 4 * eb);
-  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "NBDYCKP1", 8) != 0 || h.header_bytes != sizeof h)
-    rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: %s is not a checkpoint of this engine", path);
-  else if (h.n_total != c->p.n_total || h.i_begin != c->p.i_begin || h.i_count != c->p.i_count || h.elem_bytes != (int32_t)eb)
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "NBDYCKP2", 8) != 0 || h.header_bytes != sizeof h)
+    rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: %s is not a checkpoint of this engine (format NBDYCKP2)", path);
+  // the file's owned range must contain the context's: a whole-system file also feeds the slices of a sharded job
+  else if (h.n_total != c->p.n_total || h.elem_bytes != (int32_t)eb || h.i_begin > c->p.i_begin ||
+           h.i_begin + h.i_count < c->p.i_begin + c->p.i_count)
     rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: layout mismatch (file n=%d [%d,+%d) %d-byte, context n=%d [%d,+%d) %zu-byte)",
               h.n_total, h.i_begin, h.i_count, h.elem_bytes, c->p.n_total, c->p.i_begin, c->p.i_count, eb);
-  else if (fread(posm.data(), 1, posm.size(), f) != posm.size() || fread(vel.data(), 1, vel.size(), f) != vel.size() ||
-           fread(acc.data(), 1, acc.size(), f) != acc.size())
-    rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: %s is truncated", path);
+  else if (h.G != c->p.G || h.eps != c->p.eps)
+    rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: the file was written with G = %.17g, eps = %.17g but the context has G = %.17g, "
+              "eps = %.17g: resuming would not continue the same trajectory", h.G, h.eps, c->p.G, c->p.eps);
+  else {
+    const long skip = (long)((size_t)(c->p.i_begin - h.i_begin) * 4 * eb), rest = (long)(((size_t)h.i_count - ic) * 4 * eb) - skip;
+    if (fread(posm.data(), 1, posm.size(), f) != posm.size() || fseek(f, skip, SEEK_CUR) != 0 ||
+        fread(vel.data(), 1, vel.size(), f) != vel.size() || fseek(f, rest + skip, SEEK_CUR) != 0 ||
+        fread(acc.data(), 1, acc.size(), f) != acc.size())
+      rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: %s is truncated", path);
+  }
   fclose(f);
   if (rc) return rc;
+  HIP_TRY(c, hipSetDevice(c->p.device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(c->posm, posm.data(), posm.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size(), hipMemcpyHostToDevice));
   c->have_state = true; c->floor_eps2 = -1.0; c->step_open = false;
   c->steps_done = h.steps_done;
+  // Barnes-Hut: the opening angle and the root of the next tree (the previous tree's CoM, OctreeSearch.cpp:77-79) are
+  // part of the trajectory.  Only contexts that can run the walk take them over.
+  if (c->p.precision == NBODY_PREC_F32 && c->p.i_count == c->p.n_total) {
+    c->theta = h.theta;
+    if (h.has_root || c->bh) {
+      if (!c->bh) {
+        hipError_t e = nbody::bh_create(&c->bh, c->p.n_total);
+        if (e != hipSuccess) return fail(c, NBODY_ERR_HIP, "bh_create: %s", hipGetErrorString(e));
+        HIP_TRY(c, hipMalloc(&c->bh_acc, (size_t)c->p.n_total * 16));
+      }
+      const float zero[3] = {0.f, 0.f, 0.f};
+      HIP_TRY(c, nbody::bh_set_root_com(c->bh, h.has_root ? h.root_com : zero, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+  }
   if (steps_done) *steps_done = h.steps_done;
   return NBODY_OK;
 }
@@ -1016,6 +1127,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
 int nbody_set_theta(nbody_ctx *c, float theta) {
   if (!c) return NBODY_ERR_INVALID;
   if (!(theta >= 0.0f)) return fail(c, NBODY_ERR_INVALID, "nbody_set_theta: theta must be >= 0");
+  if (c->multi) return theta > 0.0f ? multi_unsupported(c, "nbody_set_theta(theta > 0)") : NBODY_OK;
   if (theta > 0.0f && (c->p.precision != NBODY_PREC_F32 || c->p.i_count != c->p.n_total))
     return fail(c, NBODY_ERR_UNSUPPORTED, "nbody_set_theta: Barnes-Hut needs an fp32 context that owns all bodies");
   c->theta = theta;
@@ -1024,6 +1136,7 @@ int nbody_set_theta(nbody_ctx *c, float theta) {
 
 int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com[3]) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return fail(c, NBODY_ERR_STATE, "nbody_bh_stats: no tree has been built on this context");
   if (!c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_stats: no tree has been built on this context");
   int n = 0, l = 0;
   nbody::bh_stats(c->bh, &n, &l);
@@ -1035,7 +1148,7 @@ int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com
 
 int nbody_bh_leaf_boxes(nbody_ctx *c, float *boxes, size_t stride) {
   if (!c || !boxes || stride < 16) return c ? fail(c, NBODY_ERR_INVALID, "nbody_bh_leaf_boxes: null buffer or stride < 16") : NBODY_ERR_INVALID;
-  if (!c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_boxes: no tree has been built on this context (theta == 0?)");
+  if (c->multi || !c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_boxes: no tree has been built on this context (theta == 0?)");
   const size_t bytes = (size_t)c->p.n_total * 16;
   int rc = ensure_stage(c, bytes);
   if (rc) return rc;
@@ -1055,6 +1168,7 @@ int nbody_steps_done(nbody_ctx *c, int64_t *steps) {
 
 int nbody_kernel_time(nbody_ctx *c, int32_t which, double *total_ms, int64_t *launches) {
   if (!c || which < 0 || which > 1) return NBODY_ERR_INVALID;
+  if (c->multi) return multi_rc(c, nbody::multi_kernel_time(c->multi, which, total_ms, launches));
   int rc = timer_drain(c, which);
   if (rc) return rc;
   if (total_ms) *total_ms = c->timers[which].total_ms;
@@ -1064,6 +1178,7 @@ int nbody_kernel_time(nbody_ctx *c, int32_t which, double *total_ms, int64_t *la
 
 int nbody_kernel_time_reset(nbody_ctx *c) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return multi_rc(c, nbody::multi_kernel_time_reset(c->multi));
   for (int w = 0; w < 2; ++w) {
     int rc = timer_drain(c, w);
     if (rc) return rc;
@@ -1075,6 +1190,7 @@ int nbody_kernel_time_reset(nbody_ctx *c) {
 
 const char *nbody_force_kernel_name(const nbody_ctx *c) {
   if (!c) return "";
+  if (c->multi) return nbody_force_kernel_name(nbody::multi_part(c->multi, 0));
   if (c->theta > 0.0f) return "bh_walk_kernel (+ tree build)";
   if (c->sym) return c->p.precision == NBODY_PREC_F64 ? "forces_sym_f64_kernel" : "forces_sym_pk_kernel";
   if (c->wave) return "small_pk_kernel";
@@ -1085,6 +1201,7 @@ const char *nbody_force_kernel_name(const nbody_ctx *c) {
 
 int nbody_get_algorithm(nbody_ctx *c, int32_t *algorithm, int32_t *super_tile) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return nbody_get_algorithm(nbody::multi_part(c->multi, 0), algorithm, super_tile);
   if (algorithm) *algorithm = c->sym ? NBODY_ALGO_SYMMETRIC : NBODY_ALGO_TILED;
   if (super_tile) *super_tile = c->sym ? c->sym_bi : 0;
   return NBODY_OK;
@@ -1093,6 +1210,7 @@ int nbody_get_algorithm(nbody_ctx *c, int32_t *algorithm, int32_t *super_tile) {
 int nbody_get_launch_config(nbody_ctx *c, int32_t *tile, int32_t *i_per_thread, int32_t *j_split, int32_t *blocks,
                             int32_t *threads) {
   if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return nbody_get_launch_config(nbody::multi_part(c->multi, 0), tile, i_per_thread, j_split, blocks, threads);   // per device
   int b = 0, t = 0;
   nbody::forces_geometry(make_launch(c), &b, &t);
   if (c->sym) { b = c->sym_items_n; t = 256; }

@@ -72,7 +72,7 @@ class NBodyEngine:
     """One context = one GPU's share [i_begin, i_begin+i_count) of an n_total-body system."""
 
     def __init__(self, n_total, *, i_begin=0, i_count=0, device=0, precision="f32", G=REF_G, eps=0.0, tile=0,
-                 i_per_thread=0, j_split=0, time_kernels=False, zero_mode=0, algorithm=0, theta=0.0):
+                 i_per_thread=0, j_split=0, time_kernels=False, zero_mode=0, algorithm=0, theta=0.0, devices=None):
         L = _lib.lib()
         p = Params()
         L.nbody_default_params(ctypes.byref(p))
@@ -85,7 +85,12 @@ class NBodyEngine:
         p.algorithm = algorithm
         p.theta = theta
         h = ctypes.c_void_p()
-        rc = L.nbody_create(ctypes.byref(p), ctypes.byref(h))
+        if devices is not None:
+            # one context over several GPUs, driven from this thread (nbody_create_multi: RCCL between the devices)
+            devs = (ctypes.c_int32 * len(devices))(*devices)
+            rc = L.nbody_create_multi(ctypes.byref(p), devs, len(devices), ctypes.byref(h))
+        else:
+            rc = L.nbody_create(ctypes.byref(p), ctypes.byref(h))
         if rc:
             raise NBodyError(rc, L.nbody_last_error(None).decode())
         self._L, self._h = L, h

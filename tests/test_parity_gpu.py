@@ -626,6 +626,46 @@ def test_checkpoint_resume_continues_bit_for_bit(nb, tmp_path):
             e.load_checkpoint(str(bad))
 
 
+def test_checkpoint_resume_at_the_shipped_opening_angle(nb, tmp_path):
+    # theta = 1.0 is what the reference ships (OctreeSearch.cpp:85); each tree is rooted at the previous tree's centre of
+    # mass (.cpp:77-79), so that CoM and theta are part of the state a checkpoint must carry
+    g = _golden("refbox_n2000_seed1")
+    path = str(tmp_path / "bh.ckpt")
+    with nb.NBodyEngine(2000, theta=1.0) as e:
+        e.set_state(g["posm"], g["vel"])
+        e.step(0.01, 6)
+        e.save_checkpoint(path)
+        e.step(0.01, 6)
+        want, com = e.particles(), e.bh_stats()["root_com"]
+    with nb.NBodyEngine(2000) as e:                        # a fresh context created with the default theta = 0 ...
+        assert e.load_checkpoint(path) == 6                # ... takes the opening angle and the tree root from the file
+        e.step(0.01, 6)
+        assert e.particles().tobytes() == want.tobytes()
+        np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
+    with nb.NBodyEngine(2000, theta=1.0) as e:             # a context that has already built trees of another scene
+        e.set_state(g["posm"][::-1].copy(), g["vel"])
+        e.step(0.01, 2)
+        assert e.load_checkpoint(path) == 6
+        e.step(0.01, 6)
+        assert e.particles().tobytes() == want.tobytes()
+    with nb.NBodyEngine(2000, G=2.0e4) as e:               # another G: not the same trajectory, refused
+        with pytest.raises(nb.NBodyError) as err:
+            e.load_checkpoint(path)
+        assert "G =" in str(err.value)
+
+
+def test_tick_returns_the_bounds_on_the_first_floor_mode_frame(nb):
+    # NBODY_ZERO_FLOOR computes its eps floor through the same scratch words the bounds travel in: the first frame used to
+    # return the largest mass as Size
+    posm, vel = nb.ic_reference_box(3000, 1000.0, seed=2)
+    with nb.NBodyEngine(3000, zero_mode=2) as a, nb.NBodyEngine(3000, zero_mode=2) as b:
+        a.set_state(posm, vel); b.set_state(posm, vel)
+        size, rec = a.tick(0.01)
+        want = b.bounds()
+        b.step(0.01, 1)
+        assert size == want and rec.tobytes() == b.particles().tobytes()
+
+
 def test_command_line_replay_of_the_shipped_scene(nb, tmp_path, capsys):
     from parallelnbody_amd.__main__ import main
     ck = str(tmp_path / "a.ckpt")
