@@ -23,11 +23,14 @@ if ROOT not in sys.path:
 
 PEAK_FP32_TFLOPS = 157.3      # MI355X vector fp32 peak, MI355X_MICROARCH.md "Chip-level parameters"
 FLOP_PER_PAIR = 20            # 3 sub + 6 (dot) + 4 (rsqrt cubed) + 1 (mass) + 6 (3 FMA)
-# HBM bytes per force launch from the PMC passes in profiles/r01_pmc_forces_tile_kernel.txt and
-# profiles/r01_pmc_forces_sym_kernel_ipt16.txt (tools/profile_bench.sh), keyed by (algorithm, n, gpus):
-# FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE.  None for configurations not profiled.
-TRAFFIC_BYTES_PER_LAUNCH = {("tiled", 1 << 20, 1): 2 * 173606 * 1024 + 262144 * 1024,
-                            ("symmetric", 1 << 20, 1): 2 * 2290740 * 1024 + 6528970 * 1024}
+FLOP_PER_EVAL_SYM = 25        # what the symmetric kernel executes per UNORDERED pair: 3 sub + 5 (r^2) + 1 rsq + 2 (cube)
+                              # + 2 (the two mass factors) + 12 (six FMAs); matches the PMC count (profiles/r02_pmc_*.txt)
+# HBM bytes per force launch, measured by PMC passes (tools/profile_kernel.sh: FETCH_SIZE x2 — the gfx950 correction of
+# MI355X_MICROARCH.md — + WRITE_SIZE, separate passes), keyed by (algorithm, n, gpus, bodies per lane, precision) with the
+# file the number comes from.  Configurations that were not profiled report null.
+TRAFFIC_BYTES_PER_LAUNCH = {
+    ("tiled", 1 << 20, 1, 4, "f32"): (2 * 173606 * 1024 + 262144 * 1024, "profiles/r01_pmc_forces_tile_kernel.txt"),
+}
 
 
 def sample_bodies(i_begin, i_count, super_tile, i_per_lane, seed=7):
@@ -69,10 +72,15 @@ def sampled_force_error(posm_all, acc_own, i_begin, bodies, G, eps):
 
 
 def cpu_baseline(posm, target_seconds):
-    """The oracle's direct sum (reference arithmetic) on the host cores, on a bounded i-slice of the same
-    workload.  Test/bench infrastructure only — never part of the measured GPU path."""
+    """CPU numbers reported next to the GPU's (never the thing measured or shipped), on the host cores of this box:
+      port : the oracle's direct sum in the reference's own arithmetic (fp32 Dist, double pow per pair — OctreeSearch.h:
+             101-104), OpenMP over i, on a bounded i-slice of the SAME workload;
+      simd : SURVEY 8(d)(A)'s baseline — the build's own plain fp32 direct sum, OpenMP over i and SIMD over j
+             (oracle/cpu_baseline.c), at N = 1024 (configs[0]) and N = 65536 (configs[1]), whole passes, best of several.
+    `value` is the port's (the reference's arithmetic on the benched workload)."""
     import numpy as np
     from oracle import oracle as O
+    import parallelnbody_amd as nb
     O.build()
     n = posm.shape[0]
     pos = np.ascontiguousarray(posm[:, :3]); mass = np.ascontiguousarray(posm[:, 3])
@@ -87,9 +95,27 @@ def cpu_baseline(posm, target_seconds):
     t0 = time.perf_counter()
     O.forces_direct_f32(pos, mass, i0=0, i1=ni, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": ni * n / dt, "unit": "pair-interactions/s", "cores": cores, "kind": "port",
+    port = {"value": ni * n / dt, "unit": "pair-interactions/s", "cores": cores, "kind": "port",
             "sample": f"oracle direct sum (reference fp32/double-pow arithmetic), bodies 0..{ni - 1} vs all {n} "
                       f"of the same Plummer input, {dt:.1f} s, OpenMP over i"}
+    simd = {}
+    for m in (1024, 65536):
+        pm, _ = nb.ic_plummer(m, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
+        p3 = np.ascontiguousarray(pm[:, :3]); ms = np.ascontiguousarray(pm[:, 3])
+        O.forces_simd_f32(p3, ms, nthreads=cores)                       # builds the library, spins the threads up
+        best, spent, reps = 1e30, 0.0, 0
+        while spent < 2.0 and reps < 200:
+            t0 = time.perf_counter()
+            O.forces_simd_f32(p3, ms, nthreads=cores)
+            d = time.perf_counter() - t0
+            best = min(best, d); spent += d; reps += 1
+        simd[f"n{m}"] = {"value": m * float(m) / best, "unit": "pair-interactions/s", "cores": cores,
+                         "sample": f"whole force pass at N={m}, best of {reps}, {best * 1e3:.3f} ms"}
+    out = dict(port)
+    out["port"] = port
+    out["simd"] = {"kind": "build's own fp32 direct sum, OpenMP over i, omp simd over j, 1/sqrtf cubed (oracle/cpu_baseline.c, "
+                           "-O3 -march=native -ffast-math); not the reference's arithmetic", **simd}
+    return out
 
 
 def main():
@@ -155,30 +181,23 @@ def main():
         sim.warm_collectives()
         sim.settle(args.settle_seconds)     # untimed force passes: the clock needs sustained load to settle
         sim.step(args.dt, args.warmup)
-        if os.environ.get("NBODY_BENCH_FAIL_FIRST") == "1" and algorithm == "auto":   # rehearsal of the retry below
-            raise RuntimeError("NBODY_BENCH_FAIL_FIRST")
         return sim
 
-    # Multi-GPU only: the symmetric algorithm adds an all-to-all to the step.  If any rank cannot bring that path up,
-    # every rank falls back — loudly, and named in config.algorithm — to the one-sided HIP kernel, whose step needs the
-    # all-gather alone.  (Still the HIP path: there is no CPU fallback anywhere.)
-    sim, failure, fallback = None, None, None
+    # Multi-GPU only: the symmetric algorithm needs equal slices of whole i-sets and room for its partial sums.  Engine
+    # creation is the one stage whose outcome the ranks agree on with a matched collective (ShardedSimulation raises
+    # EngineCreationFailed on EVERY rank), so that is the one failure answered by a rebuild — loudly, and named in
+    # config.fallback — on the one-sided HIP kernel, whose step needs the all-gather alone.  Any later failure ends the
+    # job with a non-zero exit code: ranks cannot agree on it without risking mismatched collectives.
+    fallback = None
     try:
         sim = build(args.algorithm)
-    except Exception as e:  # noqa: BLE001
-        if world == 1 or args.algorithm != "auto":
+    except nb.EngineCreationFailed as e:
+        if args.algorithm != "auto":
             raise
-        failure = f"{type(e).__name__}: {e}"
-    if world > 1 and args.algorithm == "auto":
-        ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok[0]) == 0:
-            print(f"[bench rank {rank}] symmetric multi-GPU path failed ({failure or 'on another rank'}); "
-                  "falling back to the one-sided kernel", file=sys.stderr, flush=True)
-            if sim is not None:
-                sim.close()
-            sim = build("tiled")
-            fallback = "tiled after symmetric path failed"
+        print(f"[bench rank {rank}] symmetric multi-GPU engines could not be created ({e}); "
+              "every rank rebuilds on the one-sided kernel", file=sys.stderr, flush=True)
+        sim = build("tiled")
+        fallback = f"tiled: symmetric engines could not be created ({e})"
     cfg = sim.engine.launch_config()
     fence()
     sim.engine.kernel_time_reset()
@@ -206,7 +225,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         launch_ms_minmax = [-float(t[0]), float(t[1])]
     achieved_tflops = launch_pairs * FLOP_PER_PAIR / avg_launch_s * 1e-12
+    # what the hardware executed: the symmetric kernel evaluates each unordered pair once (25 flop) and credits both
+    # bodies; the one-sided kernel evaluates every ordered pair (20 flop)
+    executed_tflops = (launch_pairs / 2 * FLOP_PER_EVAL_SYM if cfg["algorithm"] == "symmetric"
+                       else launch_pairs * FLOP_PER_PAIR) / avg_launch_s * 1e-12
     peak = PEAK_FP32_TFLOPS if args.precision != "f64" else PEAK_FP32_TFLOPS / 2
+    traffic = TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, world, cfg["i_per_thread"], args.precision), (None, None))
     p_end, _ = sim.gather_state()
     finite = bool(np.isfinite(p_end).all())
     # parity of the benched instantiation at the benched size, after the timed region: one more force pass of the
@@ -247,8 +271,12 @@ def main():
                        **({"fallback": fallback} if fallback else {})},
             "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64",
                          "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
-                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, world)) if args.precision == "f32" else None,
-                         "kernel": cfg["kernel"] + (" (+dup_detect_kernel, reduce_j_kernel)"
+                         "achieved_is": "algorithmic: N_i x N ordered interactions x 20 flop (SURVEY 8d) / launch time",
+                         "executed": executed_tflops, "executed_frac": executed_tflops / peak,
+                         "executed_is": ("VALU flops issued: each unordered pair evaluated once, 25 flop"
+                                         if cfg["algorithm"] == "symmetric" else "every ordered pair evaluated, 20 flop"),
+                         "traffic": traffic[0], "traffic_source": traffic[1],
+                         "kernel": cfg["kernel"] + (" (+sym_prep_kernel, reduce_j_kernel)"
                                                     if cfg["algorithm"] == "symmetric" else ""),
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
                          "launch_ms_min_max_over_ranks": launch_ms_minmax,

@@ -30,6 +30,42 @@ def build(force=False):
     return _LIB_PATH
 
 
+_BASE_PATH = os.path.join(_HERE, "libnbody_cpubase.so")
+_base = None
+
+
+def cpubase():
+    """The SIMD fp32 direct sum of oracle/cpu_baseline.c (a throughput baseline, not the oracle).  Built here with
+    -march=native, so always for the host that runs it."""
+    global _base
+    if _base is None:
+        src = os.path.join(_HERE, "cpu_baseline.c")
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libnbody_cpubase.so"], stdout=subprocess.DEVNULL)
+        assert os.path.getmtime(_BASE_PATH) >= os.path.getmtime(src)
+        B = ctypes.CDLL(_BASE_PATH)
+        fp = ctypes.POINTER(ctypes.c_float)
+        B.cpubase_max_threads.restype = ctypes.c_int
+        B.cpubase_forces_f32.argtypes = [ctypes.c_int, fp, fp, fp, fp, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                         ctypes.c_int, fp, ctypes.c_int]
+        B.cpubase_forces_f32.restype = ctypes.c_int
+        _base = B
+    return _base
+
+
+def forces_simd_f32(pos, mass, g=REF_G, eps=0.0, i0=0, i1=None, nthreads=1):
+    """The build's own fp32 direct sum (OpenMP over i, SIMD over j).  Returns acc[i0:i1]."""
+    pos = _f32(pos); mass = _f32(mass)
+    n = pos.shape[0]
+    i1 = n if i1 is None else i1
+    x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
+    acc = np.zeros((n, 3), np.float32)
+    rc = cpubase().cpubase_forces_f32(n, _fp(x), _fp(y), _fp(z), _fp(mass), np.float32(g), np.float32(eps * eps), i0, i1,
+                                      _fp(acc), nthreads)
+    if rc:
+        raise RuntimeError(f"cpubase_forces_f32 rc={rc}")
+    return acc[i0:i1]
+
+
 def lib():
     global _lib
     if _lib is None:

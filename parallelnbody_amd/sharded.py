@@ -45,6 +45,12 @@ def _hip_engine_factory(n_total, i_begin, i_count, posm_tensor, device_index, st
     return eng
 
 
+class EngineCreationFailed(RuntimeError):
+    """Some rank could not create its engine.  Raised on EVERY rank at the same point — right after the one collective
+    that follows engine creation — so a caller may tear down and rebuild (e.g. with another algorithm) without any rank
+    being left inside a collective the others never enter."""
+
+
 class ShardedSimulation:
     def __init__(self, posm, vel, *, rank=0, world_size=1, device=None, group=None, engine_factory=None,
                  **engine_kw):
@@ -64,7 +70,25 @@ class ShardedSimulation:
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         if engine_factory is None:
             engine_kw = dict(engine_kw, stream=self.stream)
-        self.engine = factory(self.n_total, self.i_begin, self.i_count, self.posm, dev_index, **engine_kw)
+        # Engine creation can fail on one rank only (memory, an unsupported geometry).  The ranks agree on the outcome
+        # with ONE matched collective, the first this object issues, before anything else can diverge.
+        self.engine, failure = None, None
+        try:
+            import os
+            if os.environ.get("NBODY_REHEARSE_CREATE_FAILURE") == str(rank) and engine_kw.get("algorithm", 0) == 0:
+                raise RuntimeError("NBODY_REHEARSE_CREATE_FAILURE")      # rehearsal of the path below (tests, tools)
+            self.engine = factory(self.n_total, self.i_begin, self.i_count, self.posm, dev_index, **engine_kw)
+        except Exception as e:  # noqa: BLE001
+            if world_size == 1:
+                raise
+            failure = f"{type(e).__name__}: {e}"
+        if world_size > 1:
+            ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=self.device)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=group)
+            if int(ok[0]) == 0:
+                if self.engine is not None:
+                    self.engine.close()
+                raise EngineCreationFailed(failure or "engine creation failed on another rank")
         self.engine.set_state(posm.astype(np.float64 if self.f64 else np.float32, copy=False),
                               np.ascontiguousarray(vel).astype(np.float64 if self.f64 else np.float32, copy=False))
         self.steps_done = 0

@@ -318,3 +318,21 @@ def test_c_tick_agrees_with_the_python_restatement_over_frames(nb, oracle):
         np.testing.assert_array_equal(q["Acceleration"], acc)
         np.testing.assert_array_equal(q["Velocity"], vel)
         np.testing.assert_array_equal(q["Position"], pos)
+
+
+def test_simd_cpu_baseline_is_the_same_pair_law(oracle):
+    # oracle/cpu_baseline.c (bench.py's cpu_baseline.simd leg): plain fp32, SIMD over j — a throughput
+    # baseline, not the oracle; it must still be the pair law of OctreeSearch.h:101-104 to fp32 rounding, self pair and
+    # coincident bodies included
+    rng = np.random.default_rng(12)
+    n = 777
+    pos = rng.normal(0, 50, (n, 3)).astype(np.float32)
+    pos[5] = pos[9]                                          # two bodies on one point: d == 0, skipped (.h:102)
+    mass = rng.uniform(1, 100, n).astype(np.float32)
+    a = oracle.forces_simd_f32(pos, mass, nthreads=2)
+    ref = oracle.forces_direct_f64(pos.astype(np.float64), mass.astype(np.float64))
+    assert np.all(np.isfinite(a))
+    assert (np.linalg.norm(a - ref, axis=1) / np.linalg.norm(ref, axis=1)).max() < 2e-5
+    soft = oracle.forces_simd_f32(pos, mass, eps=2.0, i0=100, i1=200, nthreads=2)
+    ref = oracle.forces_direct_f64(pos.astype(np.float64), mass.astype(np.float64), eps=2.0, i0=100, i1=200)
+    assert (np.linalg.norm(soft - ref, axis=1) / np.linalg.norm(ref, axis=1)).max() < 2e-5

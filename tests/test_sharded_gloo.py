@@ -176,3 +176,42 @@ def test_two_ranks_reproduce_one_rank(nb, oracle, tmp_path):
     ke, pe = oracle.energy_f64(pos, v, posm[:, 3])
     assert float(r0["ke"]) == pytest.approx(ke, rel=1e-6) and float(r0["pe"]) == pytest.approx(pe, rel=1e-6)
     assert float(r1["ke"]) == pytest.approx(ke, rel=1e-6)
+
+
+def _worker_creation_failure(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import parallelnbody_amd as nb
+    posm, vel = nb.ic_plummer(128, seed=9)
+
+    def picky(n_total, i_begin, i_count, posm_tensor, device_index, **kw):
+        if kw.get("algorithm", 0) == 0 and i_begin > 0:       # only rank 1 cannot build the "auto" engine
+            raise MemoryError("no room for the partial sums on this rank")
+        return OracleEngine(n_total, i_begin, i_count, posm_tensor, device_index, **kw)
+
+    outcome = "created"
+    try:
+        nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device="cpu", engine_factory=picky)
+    except nb.EngineCreationFailed as e:
+        outcome = f"failed together: {e}"
+    # both ranks are at the same point: the rebuild's collectives match
+    sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device="cpu", engine_factory=picky, algorithm=1)
+    sim.step(0.01, 1)
+    p, _ = sim.gather_state()
+    with open(os.path.join(out_dir, f"o{rank}.txt"), "w") as f:
+        f.write(outcome + "\n" + repr(float(p[:, :3].sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_engine_creation_failure_on_one_rank_is_seen_by_all(nb, tmp_path):
+    # one rank failing to create its engine must not leave the other inside collectives nobody else enters: both raise
+    # EngineCreationFailed after the same all-reduce, and a rebuild (bench.py falls back to the one-sided kernel) works
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_creation_failure, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    o0 = (tmp_path / "o0.txt").read_text().splitlines(); o1 = (tmp_path / "o1.txt").read_text().splitlines()
+    assert o0[0].startswith("failed together") and o1[0].startswith("failed together")
+    assert "another rank" in o0[0] and "MemoryError" in o1[0]
+    assert o0[1] == o1[1]
