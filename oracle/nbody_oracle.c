@@ -120,6 +120,8 @@ typedef struct {
   int count, cap;
   const float *pos, *mass;
   int overflow;
+  int div_mode;          /* reading of FVector::operator/=(float) in ComputeMass, .h:95: 0 = multiply by the fp32 reciprocal
+                            (UE4's implementation as remembered — [external], the engine is not vendored), 1 = divide */
 } otree;
 
 #define ORACLE_MAX_DEPTH 200
@@ -201,8 +203,12 @@ static void node_compute_mass(otree *t, int k) {                      /* Compute
     }
     onode *nd = &t->nodes[k];
     if (nd->total_mass != 0.0f) {
-      float rv = 1.0f / nd->total_mass;            /* UE4 FVector::operator/=(float): reciprocal multiply */
-      nd->com[0] *= rv; nd->com[1] *= rv; nd->com[2] *= rv;
+      if (t->div_mode == 0) {
+        float rv = 1.0f / nd->total_mass;          /* UE4 FVector::operator/=(float): reciprocal multiply */
+        nd->com[0] *= rv; nd->com[1] *= rv; nd->com[2] *= rv;
+      } else {                                     /* the other reading: three divisions */
+        nd->com[0] = nd->com[0] / nd->total_mass; nd->com[1] = nd->com[1] / nd->total_mass; nd->com[2] = nd->com[2] / nd->total_mass;
+      }
     } else {
       memcpy(nd->com, nd->origin, sizeof(float) * 3);
     }
@@ -231,37 +237,61 @@ static void node_forces(const otree *t, int k, const float pi[3], float theta, d
   }
 }
 
+/* DrawOctreeBoxes — OctreeSearch.cpp:36-45: depth first, children 0..7; at every occupied leaf the reference draws
+ * DrawDebugBox(Origin, (Size, Size, Size)) when ShowOctree and DrawDebugPoint(Particle->Position).  Recorded here: the
+ * leaf's (Origin, Size) and its particle, in that order of visit. */
+static void node_draw(const otree *t, int k, float *boxes, int *order, int *count) {
+  if (k < 0) return;                                                        /* .cpp:38 */
+  const onode *nd = &t->nodes[k];
+  if (node_is_leaf(t, k) && nd->particle != -1) {                           /* .cpp:39 */
+    if (boxes) { memcpy(&boxes[4 * *count], nd->origin, 12); boxes[4 * *count + 3] = nd->size; }   /* .cpp:40 */
+    if (order) order[*count] = nd->particle;                                /* .cpp:41 */
+    *count += 1;
+  } else {
+    for (int i = 0; i < 8; ++i) node_draw(t, nd->child[i], boxes, order, count);   /* .cpp:43 */
+  }
+}
+
 /*
  * CreateOctree — OctreeSearch.cpp:74-89: root = Octree(root_origin, root_size); Add every
  * particle in index order; ComputeMass; then for each i: Acceleration = 0; ComputeForces(i, theta)
  * (the reference passes theta = 1.0; theta = 0 is exact all-pairs in DFS order).
  * root_com_out receives the root's CenterOfMass, which the next frame's CreateOctree uses as its
  * root origin (.cpp:78-79).  node_count_out (optional) receives the number of nodes.
+ * leaf_boxes ([n][4], optional) / leaf_order ([n], optional): what DrawOctreeBoxes (.cpp:36-45) would draw on this
+ * tree — (Origin, Size) of every occupied leaf and the particle it holds, in depth-first order.
+ * div_mode: see otree.  acc may be NULL (tree only).
  * Returns 0, or 1 if insertion exceeded ORACLE_MAX_DEPTH (duplicate positions: the reference
- * would recurse without bound), 2 on allocation failure, 3 if a body lies outside the root box
- * (allowed by the reference — reported for information only through *outside_out).
+ * would recurse without bound), 2 on allocation failure.
  */
-ORACLE_API int oracle_octree_forces_f32(int n, const float *pos, const float *mass,
-                                        const float root_origin[3], float root_size, float theta,
-                                        double g, int pow_mode, float *acc, float root_com_out[3],
-                                        int *node_count_out) {
+ORACLE_API int oracle_octree_f32(int n, const float *pos, const float *mass, const float root_origin[3], float root_size,
+                                 float theta, double g, int pow_mode, int div_mode, float *acc, float root_com_out[3],
+                                 int *node_count_out, float *leaf_boxes, int *leaf_order) {
   otree t;
   memset(&t, 0, sizeof(t));
-  t.pos = pos; t.mass = mass;
+  t.pos = pos; t.mass = mass; t.div_mode = div_mode;
   int root = node_new(&t, root_origin, root_size);
   if (root < 0) return 2;
   for (int i = 0; i < n && !t.overflow; ++i) node_add(&t, root, i, 0);      /* .cpp:80 */
   if (t.overflow) { int e = t.overflow; free(t.nodes); return e; }
   node_compute_mass(&t, root);                                              /* .cpp:81 */
-  for (int i = 0; i < n; ++i) {                                             /* .cpp:83-86 */
+  for (int i = 0; acc && i < n; ++i) {                                      /* .cpp:83-86 */
     float a[3] = {0.0f, 0.0f, 0.0f};
     node_forces(&t, root, &pos[3 * i], theta, g, pow_mode, a);
     acc[3 * i + 0] = a[0]; acc[3 * i + 1] = a[1]; acc[3 * i + 2] = a[2];
   }
+  if (leaf_boxes || leaf_order) { int cnt = 0; node_draw(&t, root, leaf_boxes, leaf_order, &cnt); }
   if (root_com_out) memcpy(root_com_out, t.nodes[root].com, sizeof(float) * 3);
   if (node_count_out) *node_count_out = t.count;
   free(t.nodes);
   return 0;
+}
+
+ORACLE_API int oracle_octree_forces_f32(int n, const float *pos, const float *mass,
+                                        const float root_origin[3], float root_size, float theta,
+                                        double g, int pow_mode, float *acc, float root_com_out[3],
+                                        int *node_count_out) {
+  return oracle_octree_f32(n, pos, mass, root_origin, root_size, theta, g, pow_mode, 0, acc, root_com_out, node_count_out, 0, 0);
 }
 
 /* Integration loop — OctreeSearch.cpp:28-31:  Velocity += dt*Acceleration; Position += dt*Velocity. */
@@ -290,8 +320,18 @@ ORACLE_API float oracle_bounds_f32(int n, const float *pos) {
  * actor's persistent "previous tree CoM" (zero before the first frame, .cpp:77-78), updated in place.
  * `size_io` mirrors the actor's Size field.
  */
+static int tick_aos(int n, oracle_particle *p, float dt, float theta, double g, int pow_mode, int div_mode, float root_com[3],
+                    float *size_io);
 ORACLE_API int oracle_tick_aos_f32(int n, oracle_particle *p, float dt, float theta, double g,
                                    int pow_mode, float root_com[3], float *size_io) {
+  return tick_aos(n, p, dt, theta, g, pow_mode, 0, root_com, size_io);
+}
+ORACLE_API int oracle_tick_aos2_f32(int n, oracle_particle *p, float dt, float theta, double g, int pow_mode, int div_mode,
+                                    float root_com[3], float *size_io) {
+  return tick_aos(n, p, dt, theta, g, pow_mode, div_mode, root_com, size_io);
+}
+static int tick_aos(int n, oracle_particle *p, float dt, float theta, double g, int pow_mode, int div_mode, float root_com[3],
+                    float *size_io) {
   if (!(dt > 0.0f)) return 0;                                               /* .cpp:25 */
   if (n <= 0) return 0;
   float *pos = (float *)malloc(sizeof(float) * 3 * (size_t)n);
@@ -305,7 +345,7 @@ ORACLE_API int oracle_tick_aos_f32(int n, oracle_particle *p, float dt, float th
     rc = oracle_forces_direct_f32(n, pos, mass, g, 0.0f, pow_mode, 0, n, acc, 1);
   } else {
     float com[3];
-    rc = oracle_octree_forces_f32(n, pos, mass, root_com, *size_io, theta, g, pow_mode, acc, com, 0);
+    rc = oracle_octree_f32(n, pos, mass, root_com, *size_io, theta, g, pow_mode, div_mode, acc, com, 0, 0, 0);
     if (rc == 0) memcpy(root_com, com, sizeof(com));
   }
   if (rc == 0) {

@@ -82,6 +82,12 @@ def lib():
         L.oracle_octree_forces_f32.argtypes = [ctypes.c_int, fp, fp, fp, ctypes.c_float, ctypes.c_float,
                                                ctypes.c_double, ctypes.c_int, fp, fp, ip]
         L.oracle_octree_forces_f32.restype = ctypes.c_int
+        L.oracle_octree_f32.argtypes = [ctypes.c_int, fp, fp, fp, ctypes.c_float, ctypes.c_float, ctypes.c_double, ctypes.c_int,
+                                        ctypes.c_int, fp, fp, ip, fp, ip]
+        L.oracle_octree_f32.restype = ctypes.c_int
+        L.oracle_tick_aos2_f32.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_double,
+                                           ctypes.c_int, ctypes.c_int, fp, fp]
+        L.oracle_tick_aos2_f32.restype = ctypes.c_int
         L.oracle_kick_drift_f32.argtypes = [ctypes.c_int, fp, fp, fp, ctypes.c_float]
         L.oracle_kick_drift_f32.restype = None
         L.oracle_bounds_f32.argtypes = [ctypes.c_int, fp]
@@ -137,10 +143,11 @@ def forces_direct_f32(pos, mass, g=REF_G, eps=0.0, pow_mode=0, i0=0, i1=None, nt
     return acc[i0:i1]
 
 
-def octree_forces_f32(pos, mass, theta, root_origin=(0.0, 0.0, 0.0), root_size=None, g=REF_G, pow_mode=0):
+def octree_forces_f32(pos, mass, theta, root_origin=(0.0, 0.0, 0.0), root_size=None, g=REF_G, pow_mode=0, div_mode=0):
     """The reference's CreateOctree (OctreeSearch.cpp:74-89): tree build, upsweep, walk per body.
 
-    Returns (acc, root_com, node_count).  root_size defaults to ComputeCubeSize's value."""
+    Returns (acc, root_com, node_count).  root_size defaults to ComputeCubeSize's value.  div_mode: the reading of
+    FVector::operator/= in ComputeMass (0 = reciprocal multiply, 1 = divide)."""
     pos = _f32(pos); mass = _f32(mass)
     n = pos.shape[0]
     if root_size is None:
@@ -149,11 +156,28 @@ def octree_forces_f32(pos, mass, theta, root_origin=(0.0, 0.0, 0.0), root_size=N
     acc = np.zeros((n, 3), np.float32)
     com = np.zeros(3, np.float32)
     cnt = ctypes.c_int(0)
-    rc = lib().oracle_octree_forces_f32(n, _fp(pos), _fp(mass), _fp(origin), np.float32(root_size),
-                                        np.float32(theta), float(g), pow_mode, _fp(acc), _fp(com), ctypes.byref(cnt))
+    rc = lib().oracle_octree_f32(n, _fp(pos), _fp(mass), _fp(origin), np.float32(root_size), np.float32(theta), float(g),
+                                 pow_mode, div_mode, _fp(acc), _fp(com), ctypes.byref(cnt), None, None)
     if rc:
-        raise RuntimeError(f"oracle_octree_forces_f32 rc={rc} (1 = duplicate positions)")
+        raise RuntimeError(f"oracle_octree_f32 rc={rc} (1 = duplicate positions)")
     return acc, com, cnt.value
+
+
+def octree_leaves_f32(pos, mass, root_origin=(0.0, 0.0, 0.0), root_size=None):
+    """What DrawOctreeBoxes (OctreeSearch.cpp:36-45) draws on the tree of these bodies: (boxes[n,4] = Origin, Size of
+    every occupied leaf; order[n] = the particle in it), both in the reference's depth-first order."""
+    pos = _f32(pos); mass = _f32(mass)
+    n = pos.shape[0]
+    if root_size is None:
+        root_size = bounds_f32(pos)
+    origin = _f32(np.asarray(root_origin, np.float32))
+    boxes = np.zeros((n, 4), np.float32)
+    order = np.zeros(n, np.int32)
+    rc = lib().oracle_octree_f32(n, _fp(pos), _fp(mass), _fp(origin), np.float32(root_size), np.float32(1.0), REF_G, 0, 0,
+                                 None, None, None, _fp(boxes), order.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if rc:
+        raise RuntimeError(f"oracle_octree_f32 rc={rc} (1 = duplicate positions)")
+    return boxes, order
 
 
 def kick_drift_f32(pos, vel, acc, dt):
@@ -169,15 +193,15 @@ def bounds_f32(pos):
     return float(lib().oracle_bounds_f32(pos.shape[0], _fp(pos)))
 
 
-def tick_aos_f32(particles, dt, theta=REF_THETA, g=REF_G, pow_mode=0, root_com=None, size=0.0):
+def tick_aos_f32(particles, dt, theta=REF_THETA, g=REF_G, pow_mode=0, root_com=None, size=0.0, div_mode=0):
     """AOctreeSearch::Tick physics (OctreeSearch.cpp:25-32) on FParticle records, in place.
 
     theta < 0 → index-order direct sum.  Returns (root_com, size)."""
     assert particles.dtype == PARTICLE_DTYPE and particles.flags.c_contiguous
     com = np.zeros(3, np.float32) if root_com is None else _f32(root_com).copy()
     sz = ctypes.c_float(size)
-    rc = lib().oracle_tick_aos_f32(particles.shape[0], particles.ctypes.data, np.float32(dt), np.float32(theta),
-                                   float(g), pow_mode, _fp(com), ctypes.byref(sz))
+    rc = lib().oracle_tick_aos2_f32(particles.shape[0], particles.ctypes.data, np.float32(dt), np.float32(theta),
+                                    float(g), pow_mode, div_mode, _fp(com), ctypes.byref(sz))
     if rc:
         raise RuntimeError(f"oracle_tick_aos_f32 rc={rc}")
     return com, sz.value

@@ -34,3 +34,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == r["unit"]
+    # the two CPU legs VERDICT r1 asked for: the reference-arithmetic port and the SIMD direct sum at N = 1024 and 65536
+    assert cb["port"]["value"] == cb["value"]
+    assert cb["simd"]["n1024"]["value"] > 0 and cb["simd"]["n65536"]["value"] > cb["port"]["value"]
+    # parity of the benched pass inside the bench run itself, and the executed-flop figure next to the credited one
+    cf = r["config"]
+    assert cf["bodies_sampled"] >= 24 and cf["max_rel_err_sampled"] < cf["rel_err_tolerance"] == 2e-5
+    assert rf["executed"] == pytest.approx(rf["achieved"] * 25 / 40) and "traffic_source" in rf

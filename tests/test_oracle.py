@@ -198,6 +198,8 @@ _d = np.float64
 
 
 class _PyCell:
+    divide = False                                         # reading of `CenterOfMass /= TotalMass` (.h:95)
+
     def __init__(self, origin, size):                      # .h:31-33
         self.origin, self.size = origin, _f(size)
         self.body = None
@@ -239,9 +241,13 @@ class _PyCell:
             for a in range(3):
                 self.com[a] = _f(self.com[a] + _f(k.mass * k.com[a]))
         if self.mass != 0:
-            rv = _f(_f(1.0) / self.mass)                   # FVector::operator/=(float): scale by the reciprocal [UE4 4.9]
-            for a in range(3):
-                self.com[a] = _f(self.com[a] * rv)
+            if _PyCell.divide:                             # the other reading of FVector::operator/=: three divisions
+                for a in range(3):
+                    self.com[a] = _f(self.com[a] / self.mass)
+            else:
+                rv = _f(_f(1.0) / self.mass)               # FVector::operator/=(float): scale by the reciprocal [UE4 4.9]
+                for a in range(3):
+                    self.com[a] = _f(self.com[a] * rv)
         else:
             self.com = self.origin.copy()
 
@@ -260,7 +266,18 @@ class _PyCell:
                 k.forces(p, theta, acc)
 
 
-def _py_create_octree(pos, mass, theta, root_origin, root_size):
+def _py_draw(cell, boxes, order):                          # DrawOctreeBoxes, OctreeSearch.cpp:36-45
+    if cell is None:
+        return
+    if cell.kids is None and cell.body is not None:
+        boxes.append((cell.origin[0], cell.origin[1], cell.origin[2], cell.size))   # DrawDebugBox(Origin, (Size,Size,Size))
+        order.append(cell.body)                                                      # DrawDebugPoint(Particle->Position)
+    elif cell.kids is not None:
+        for k in cell.kids:
+            _py_draw(k, boxes, order)
+
+
+def _py_create_octree(pos, mass, theta, root_origin, root_size, draw=None):
     root = _PyCell(np.asarray(root_origin, np.float32).copy(), root_size)       # OctreeSearch.cpp:77-79
     for i in range(len(pos)):
         root.add(i, pos)                                                         # .cpp:80
@@ -268,6 +285,8 @@ def _py_create_octree(pos, mass, theta, root_origin, root_size):
     acc = np.zeros((len(pos), 3), np.float32)
     for i in range(len(pos)):
         root.forces(pos[i], _f(theta), acc[i])                                   # .cpp:83-86
+    if draw is not None:
+        _py_draw(root, draw[0], draw[1])
     return acc, root.com
 
 
@@ -290,6 +309,35 @@ def test_c_octree_agrees_with_an_independent_python_restatement(oracle, n, seed,
     # the float-overload reading of pow (pow_mode 2: d*(d*d) in fp32, a pre-C++11 <cmath>) stays within an ulp or two
     got2, _, _ = oracle.octree_forces_f32(pos, mass, theta, root_origin=origin, root_size=size, pow_mode=2)
     assert np.abs(got2 - want).max() <= np.abs(want).max() * 2.0 ** -22
+
+
+@pytest.mark.parametrize("n,seed", [(9, 1), (200, 3)])
+def test_c_octree_draw_order_and_division_reading(oracle, n, seed):
+    # what DrawOctreeBoxes draws (occupied leaves depth first, .cpp:36-45) and the second reading of `/=` in ComputeMass
+    # (.h:95: divide instead of reciprocal-multiply), C restatement against the Python one
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-500, 500, (n, 3)).astype(np.float32)
+    mass = rng.uniform(1, 5000, n).astype(np.float32)
+    origin = np.array([3.5, -1.25, 0.75], np.float32)
+    size = oracle.bounds_f32(pos)
+    boxes, order = [], []
+    with np.errstate(over="ignore"):
+        _py_create_octree(pos, mass, 1.0, origin, size, draw=(boxes, order))
+    got_boxes, got_order = oracle.octree_leaves_f32(pos, mass, root_origin=origin, root_size=size)
+    np.testing.assert_array_equal(got_order, np.array(order, np.int32))
+    np.testing.assert_array_equal(got_boxes, np.array(boxes, np.float32))
+    assert sorted(order) == list(range(n))                  # every body is drawn exactly once
+    _PyCell.divide = True
+    try:
+        with np.errstate(over="ignore"):
+            want, want_com = _py_create_octree(pos, mass, 1.0, origin, size)
+    finally:
+        _PyCell.divide = False
+    got, got_com, _ = oracle.octree_forces_f32(pos, mass, 1.0, root_origin=origin, root_size=size, div_mode=1)
+    np.testing.assert_array_equal(got_com, want_com)
+    np.testing.assert_array_equal(got, want)
+    base, _, _ = oracle.octree_forces_f32(pos, mass, 1.0, root_origin=origin, root_size=size, div_mode=0)
+    assert np.abs(base - got).max() <= np.abs(got).max() * 1e-5     # the two readings differ by rounding only
 
 
 def test_c_tick_agrees_with_the_python_restatement_over_frames(nb, oracle):
