@@ -107,7 +107,9 @@ typedef struct nbody_params {
   int32_t algorithm;      /* NBODY_ALGO_*; 0 = auto */
   float theta;            /* Barnes-Hut opening angle.  0 (default) = exact all-pairs, the hot path of this engine.  > 0 =
                              the reference's own tree walk (OctreeSearch.h:99-108; it ships 1.0, OctreeSearch.cpp:85) */
-  int32_t reserved0;
+  int32_t bh_div_mode;    /* theta > 0 only: reading of `CenterOfMass /= TotalMass` in ComputeMass (OctreeSearch.h:95).  0 (default):
+                             FVector::operator/=(float) multiplies by the fp32 reciprocal (UE4 4.9 as remembered — the engine
+                             is not vendored); 1: three divisions.  The oracle has the same switch (div_mode). */
 } nbody_params;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
@@ -202,6 +204,9 @@ NBODY_API int nbody_bh_stats(nbody_ctx *ctx, int32_t *nodes, int32_t *levels, fl
 /* What DrawOctreeBoxes passes to DrawDebugBox when ShowOctree is set (OctreeSearch.cpp:39-40): for every body the box
  * (Origin.x, Origin.y, Origin.z, Size) of the leaf that held it in the last tree; 4 floats per body, `stride` bytes apart. */
 NBODY_API int nbody_bh_leaf_boxes(nbody_ctx *ctx, float *boxes, size_t stride);
+/* The order in which DrawOctreeBoxes (OctreeSearch.cpp:36-45) meets the bodies on the last tree built: depth first,
+ * children 0..7; order[k] = index of the body in the k-th occupied leaf.  n_total ints. */
+NBODY_API int nbody_bh_leaf_order(nbody_ctx *ctx, int32_t *order);
 
 /* ComputeCubeSize (OctreeSearch.cpp:47-56): max over owned bodies of max(|x|,|y|,|z|). */
 NBODY_API int nbody_get_bounds(nbody_ctx *ctx, float *size);

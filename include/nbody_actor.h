@@ -21,7 +21,10 @@ typedef void (*nbody_flush_fn)(void *user);
 typedef void (*nbody_draw_point_fn)(void *user, const float position[3], float point_size);
 typedef void (*nbody_draw_box_fn)(void *user, const float origin[3], float size);   /* DrawDebugBox, .cpp:40 */
 
-NBODY_API nbody_actor *nbody_actor_create(void);                                   /* AOctreeSearch(), .cpp:8 */
+/* AOctreeSearch(), .cpp:8.  The opening angle starts at 1.0 — what the reference hard-codes (OctreeSearch.cpp:85) — so
+ * the actor reproduces the shipped Barnes-Hut trajectories and ShowOctree boxes as is; nbody_actor_set_theta(a, 0)
+ * selects the exact O(N^2) all-pairs limit (the hot path of this engine; needed for fp64 / Kahan and device lists). */
+NBODY_API nbody_actor *nbody_actor_create(void);
 NBODY_API void nbody_actor_destroy(nbody_actor *a);
 NBODY_API void nbody_actor_create_space_points(nbody_actor *a, int32_t n, float size);   /* .cpp:58-72 */
 NBODY_API void nbody_actor_set_particles(nbody_actor *a, const nbody_particle *p, int32_t n);

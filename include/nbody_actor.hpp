@@ -27,10 +27,12 @@ class OctreeSearchActor {
   float PhDeltaTime = 0.01f;            // .h:127  BlueprintReadWrite; default from the ctor, .cpp:8
 
   // ---- build-defined knobs (no reference counterpart) ----
-  // Opening angle.  The reference hard-codes 1.0 (.cpp:85).  0 (the default here) is the theta = 0 limit of that
-  // walk — exact all-pairs, the hot path this engine exists for; any value > 0 runs the reference's own tree walk
-  // on the device (fp32 only; other precisions report NBODY_ERR_UNSUPPORTED in LastStatus).
-  float Theta = 0.0f;
+  // Opening angle: the argument the reference hard-codes in `ComputeForces(&Particles[i], 1.0)` (.cpp:85), and the
+  // default here too, so that an actor swapped in for AOctreeSearch reproduces its trajectories and its ShowOctree
+  // boxes without further ado: the reference's own tree build, upsweep and walk run on the device (fp32, one device;
+  // other precisions / device lists report NBODY_ERR_UNSUPPORTED in LastStatus).  Set Theta = 0 for the theta -> 0
+  // limit of that walk — exact O(N^2) all-pairs, the hot path this engine exists for (any precision, any device list).
+  float Theta = 1.0f;
   uint64_t Seed = 0x4E426F6479ull;      // CreateSpacePoints' generator seed (the reference is unseeded)
   float ActorLocation[3] = {0, 0, 0};   // GetActorLocation(), .cpp:64
   bool MirrorParticles = true;          // refresh `Particles` after every Tick, as the reference's TArray is live
@@ -126,11 +128,25 @@ class OctreeSearchActor {
   void DrawOctreeBoxes() {
     if (!Initialized || !forces_fresh_) return;   // the reference draws from the tree: nothing before the first force pass (.cpp:38)
     if (MirrorParticles) SyncParticles(); else SyncPositions();
-    if (ShowOctree && OnDrawDebugBox && Theta > 0.0f) {                        // .cpp:40
-      boxes_.resize(4 * Particles.size());
-      if (nbody_bh_leaf_boxes(ctx_, boxes_.data(), 16) == NBODY_OK)
-        for (size_t i = 0; i < Particles.size(); ++i) OnDrawDebugBox(&boxes_[4 * i], boxes_[4 * i + 3]);
+    if (Theta > 0.0f) {
+      // the reference walks its tree depth first, children 0..7, and at every occupied leaf draws the box (if
+      // ShowOctree) and then the point (.cpp:39-41): same order, same interleaving
+      const bool boxes = ShowOctree && OnDrawDebugBox;
+      if (!boxes && !OnDrawDebugPoint) return;
+      order_.resize(Particles.size());
+      if (nbody_bh_leaf_order(ctx_, order_.data()) == NBODY_OK) {
+        if (boxes) {
+          boxes_.resize(4 * Particles.size());
+          if (nbody_bh_leaf_boxes(ctx_, boxes_.data(), 16) != NBODY_OK) boxes_.clear();
+        }
+        for (int32_t i : order_) {
+          if (boxes && !boxes_.empty()) OnDrawDebugBox(&boxes_[4 * (size_t)i], boxes_[4 * (size_t)i + 3]);          // .cpp:40
+          if (OnDrawDebugPoint) OnDrawDebugPoint(Particles[(size_t)i].Position, 10.0f);                                // .cpp:41
+        }
+        return;
+      }
     }
+    // theta = 0: there is no tree; bodies in index order, no boxes
     if (OnDrawDebugPoint)
       for (const FParticle &p : Particles) OnDrawDebugPoint(p.Position, 10.0f);
   }
@@ -191,6 +207,7 @@ class OctreeSearchActor {
 
   nbody_ctx *ctx_ = nullptr;
   std::vector<float> boxes_;
+  std::vector<int32_t> order_;
   bool forces_fresh_ = false;
   bool dirty_ = false;
 };

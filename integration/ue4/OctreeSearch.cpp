@@ -1,0 +1,87 @@
+// integration/ue4/OctreeSearch.cpp — see OctreeSearch.h next to it.  Every method keeps the reference's observable
+// behaviour (silent guards, what gets drawn and in which order); its body is a call into nbody::OctreeSearchActor.
+// NOT COMPILED IN THIS REPOSITORY (no Unreal Engine 4.9 here).
+#include "NBody.h"
+#include "OctreeSearch.h"
+#include "DrawDebugHelpers.h"
+
+#include <cstring>
+
+AOctreeSearch::AOctreeSearch() : Size(0), Initialized(false), ShowOctree(false), PhDeltaTime(0.01), Theta(1.0f)
+{
+  PrimaryActorTick.bCanEverTick = true;                       // OctreeSearch.cpp:11
+}
+
+void AOctreeSearch::BeginPlay()
+{
+  Super::BeginPlay();
+  // What the reference draws itself (OctreeSearch.cpp:24, 40, 41) arrives through callbacks, in the same order: per
+  // occupied leaf, depth first, the box (if ShowOctree) and then the point.
+  Engine.OnFlushPersistentDebugLines = [this]() { FlushPersistentDebugLines(GetWorld()); };
+  Engine.OnDrawDebugBox = [this](const float* Origin, float HalfWidth) {
+    DrawDebugBox(GetWorld(), FVector(Origin[0], Origin[1], Origin[2]), FVector(HalfWidth, HalfWidth, HalfWidth), FColor::Red, true);
+  };
+  Engine.OnDrawDebugPoint = [this](const float* Position, float PointSize) {
+    DrawDebugPoint(GetWorld(), FVector(Position[0], Position[1], Position[2]), PointSize, FColor::Black, true);
+  };
+}
+
+void AOctreeSearch::PushKnobs()
+{
+  Engine.PhDeltaTime = PhDeltaTime;
+  Engine.ShowOctree = ShowOctree;
+  Engine.Theta = Theta;
+  Engine.Devices.assign(Devices.GetData(), Devices.GetData() + Devices.Num());
+}
+
+void AOctreeSearch::PullMirror()
+{
+  Size = Engine.Size;
+  Initialized = Engine.Initialized;
+  Particles.SetNumUninitialized((int32)Engine.Particles.size());
+  if (Particles.Num() > 0)
+    std::memcpy(Particles.GetData(), Engine.Particles.data(), sizeof(FParticle) * (size_t)Particles.Num());
+}
+
+// OctreeSearch.cpp:21-34: flush, (if PhDeltaTime > 0) bounds + force pass + kick-drift, draw.
+void AOctreeSearch::Tick(float DeltaSeconds)
+{
+  Super::Tick(DeltaSeconds);
+  PushKnobs();
+  Engine.Tick(DeltaSeconds);                                  // DeltaSeconds is ignored, as in the reference
+  PullMirror();
+}
+
+// OctreeSearch.cpp:47-56
+void AOctreeSearch::ComputeCubeSize()
+{
+  Engine.ComputeCubeSize();
+  Size = Engine.Size;
+}
+
+// OctreeSearch.cpp:58-72.  The reference draws from the engine's global unseeded RNG; the distribution is the same here,
+// the generator is seeded (Engine.Seed) so that a scene can be replayed.
+void AOctreeSearch::CreateSpacePoints(int32 N, float SizeArg)
+{
+  const FVector L = GetActorLocation();
+  Engine.ActorLocation[0] = L.X; Engine.ActorLocation[1] = L.Y; Engine.ActorLocation[2] = L.Z;
+  PushKnobs();
+  Engine.CreateSpacePoints(N, SizeArg);
+  PullMirror();
+}
+
+// OctreeSearch.cpp:74-89: the force pass alone (the reference's Blueprints never call it; Tick does).
+void AOctreeSearch::CreateOctree()
+{
+  PushKnobs();
+  Engine.CreateOctree();
+  Engine.SyncParticles();
+  PullMirror();
+}
+
+// OctreeSearch.cpp:91-97
+void AOctreeSearch::CleanParticles()
+{
+  Engine.CleanParticles();
+  PullMirror();
+}

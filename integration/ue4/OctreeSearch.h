@@ -1,0 +1,78 @@
+// integration/ue4/OctreeSearch.h — the UE4 side of the drop-in: AOctreeSearch with the public surface the Blueprints of
+// Milias/ParallelNbody bind to (BP_NBodyHUD spawns the actor and calls CreateSpacePoints / SetActorTickEnabled;
+// BP_ScreenUI calls CleanParticles / CreateSpacePoints and writes PhDeltaTime / ShowOctree), and the physics handed to
+// libnbody_amd.so through include/nbody_actor.hpp.  It replaces Source/NBody/OctreeSearch.h of the reference module
+// (reference lines cited as OctreeSearch.h:N / OctreeSearch.cpp:N); the Octree class and the per-particle loops of the
+// reference are gone — their work happens on the GPU.
+//
+// NOT COMPILED IN THIS REPOSITORY: Unreal Engine 4.9 and UnrealBuildTool are not available here.  What the file
+// forwards to is compiled and tested (tests/cpp/actor_parity.cpp, tests/test_actor_gpu.py).
+// Module wiring, Source/NBody/NBody.Build.cs:
+//     PublicIncludePaths.Add(Path.Combine(ThirdPartyPath, "nbody_amd", "include"));
+//     PublicAdditionalLibraries.Add(Path.Combine(ThirdPartyPath, "nbody_amd", "lib", "libnbody_amd.so"));
+#pragma once
+
+#include "GameFramework/Actor.h"
+#include "nbody_actor.hpp"            // nbody::OctreeSearchActor, nbody::FParticle (same 40-byte layout as the USTRUCT below)
+#include "OctreeSearch.generated.h"
+
+// OctreeSearch.h:8-18.  Kept as a USTRUCT so that existing Blueprint references to the type stay valid.
+USTRUCT()
+struct FParticle {
+  GENERATED_USTRUCT_BODY()
+
+  float Mass;
+  FVector Position;
+  FVector Velocity;
+  FVector Acceleration;
+
+  FParticle() : Mass(0), Position(FVector::ZeroVector), Velocity(FVector::ZeroVector), Acceleration(FVector::ZeroVector) {}
+};
+static_assert(sizeof(FParticle) == sizeof(nbody::FParticle), "FParticle must stay 40 bytes: Mass, Position, Velocity, Acceleration");
+
+UCLASS()
+class NBODY_API AOctreeSearch : public AActor
+{
+  GENERATED_BODY()
+
+public:
+  // ---- the reference's members (OctreeSearch.h:117-127) ----
+  float Size;                               // half-width of the scene, refreshed by every Tick (ComputeCubeSize)
+  TArray<FParticle> Particles;              // mirror of the device state, refreshed by every Tick
+  bool Initialized;
+
+  UPROPERTY(BlueprintReadWrite)
+  bool ShowOctree;
+
+  UPROPERTY(BlueprintReadWrite)
+  float PhDeltaTime;
+
+  // ---- new, optional (defaults reproduce the reference) ----
+  // Opening angle of the tree walk; the reference hard-codes 1.0 (OctreeSearch.cpp:85).  0 = exact O(N^2) all-pairs.
+  UPROPERTY(BlueprintReadWrite)
+  float Theta;
+
+  // GPUs to share the bodies over (empty = device 0).  More than one needs Theta = 0 (nbody_create_multi).
+  TArray<int32> Devices;
+
+  AOctreeSearch();
+
+  virtual void BeginPlay() override;
+  virtual void Tick(float DeltaSeconds) override;
+
+  void ComputeCubeSize();
+
+  UFUNCTION(BlueprintCallable, Category = "Octree")
+  void CreateSpacePoints(int32 N, float Size = 200);
+
+  UFUNCTION(BlueprintCallable, Category = "Octree")
+  void CreateOctree();
+
+  UFUNCTION(BlueprintCallable, Category = "Octree")
+  void CleanParticles();
+
+private:
+  nbody::OctreeSearchActor Engine;          // owns the nbody_ctx; never touched from Blueprints
+  void PullMirror();                        // Engine.Particles / Size / Initialized -> the members above
+  void PushKnobs();                         // PhDeltaTime / ShowOctree / Theta / Devices -> Engine
+};

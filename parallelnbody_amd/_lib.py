@@ -43,7 +43,7 @@ class Params(ctypes.Structure):
         ("zero_mode", ctypes.c_int32),
         ("algorithm", ctypes.c_int32),
         ("theta", ctypes.c_float),
-        ("reserved0", ctypes.c_int32),
+        ("bh_div_mode", ctypes.c_int32),
     ]
 
 
@@ -103,6 +103,7 @@ def lib():
     sig("nbody_set_theta", c_int, vp, c_f)
     sig("nbody_bh_stats", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), fp)
     sig("nbody_bh_leaf_boxes", c_int, vp, fp, sz)
+    sig("nbody_bh_leaf_order", c_int, vp, ctypes.POINTER(c_i32))
     sig("nbody_get_bounds", c_int, vp, fp)
     sig("nbody_get_positions", c_int, vp, fp, sz, c_i32, c_i32)
     sig("nbody_get_particles", c_int, vp, vp, sz)

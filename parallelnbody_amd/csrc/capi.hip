@@ -299,6 +299,7 @@ int run_forces_bh(nbody_ctx *c) {
   if (!c->bh) {
     hipError_t e = nbody::bh_create(&c->bh, c->p.n_total);
     if (e != hipSuccess) return fail(c, NBODY_ERR_HIP, "bh_create: %s", hipGetErrorString(e));
+    nbody::bh_set_div_mode(c->bh, c->p.bh_div_mode);
     HIP_TRY(c, hipMalloc(&c->bh_acc, (size_t)c->p.n_total * 16));
   }
   EventPair ev;
@@ -497,6 +498,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if (p.j_split < 0) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: j_split must be >= 0");
   if (p.zero_mode < 0 || p.zero_mode > NBODY_ZERO_FLOOR) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown zero_mode %d", p.zero_mode);
   if (p.algorithm < 0 || p.algorithm > NBODY_ALGO_SYMMETRIC) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: unknown algorithm %d", p.algorithm);
+  if (p.bh_div_mode != 0 && p.bh_div_mode != 1) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: bh_div_mode must be 0 or 1");
 
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -1113,6 +1115,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
       if (!c->bh) {
         hipError_t e = nbody::bh_create(&c->bh, c->p.n_total);
         if (e != hipSuccess) return fail(c, NBODY_ERR_HIP, "bh_create: %s", hipGetErrorString(e));
+        nbody::bh_set_div_mode(c->bh, c->p.bh_div_mode);
         HIP_TRY(c, hipMalloc(&c->bh_acc, (size_t)c->p.n_total * 16));
       }
       const float zero[3] = {0.f, 0.f, 0.f};
@@ -1157,6 +1160,13 @@ int nbody_bh_leaf_boxes(nbody_ctx *c, float *boxes, size_t stride) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (stride == 16) memcpy(boxes, c->h_stage, bytes);
   else for (int i = 0; i < c->p.n_total; ++i) memcpy((char *)boxes + (size_t)i * stride, (const char *)c->h_stage + (size_t)i * 16, 16);
+  return NBODY_OK;
+}
+
+int nbody_bh_leaf_order(nbody_ctx *c, int32_t *order) {
+  if (!c || !order) return c ? fail(c, NBODY_ERR_INVALID, "nbody_bh_leaf_order: null buffer") : NBODY_ERR_INVALID;
+  if (c->multi || !c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_order: no tree has been built on this context (theta == 0?)");
+  HIP_TRY(c, nbody::bh_leaf_order(c->bh, order, c->stream));
   return NBODY_OK;
 }
 

@@ -74,6 +74,9 @@ hipError_t bh_reset_root(BhState *b, hipStream_t s);          // previous CoM :=
 // *status: 0 ok, 1 tree deeper than 42 levels, 2 node pool exhausted.  Synchronises the stream once per tree level.
 hipError_t bh_forces(BhState *b, const void *posm, void *acc, const unsigned int *size_bits, float theta, double G,
                      hipStream_t s, int *status);
+void bh_set_div_mode(BhState *b, int div_mode);            // 0: `/=` in ComputeMass multiplies by the reciprocal; 1: divides
+// order[k] = the body whose leaf a depth-first walk (children 0..7) meets k-th in the last tree built (host array, n ints)
+hipError_t bh_leaf_order(BhState *b, int *out_host, hipStream_t s);
 void bh_stats(const BhState *b, int *nodes, int *levels);
 // out[body] = (ox, oy, oz, Size) of the leaf holding the body, for the last tree built
 hipError_t bh_leaf_boxes(BhState *b, void *out, hipStream_t s);

@@ -10,7 +10,7 @@
 //                                          centre = centre +- Size*0.5 evaluated as float(double + double)) is
 //                                          computed exactly as Add walks it, packed 3 bits per level into two
 //                                          64-bit keys (42 levels), sorted (rocPRIM radix sort), and cells are split level by level.
-//   Octree::ComputeMass    .h:83-97    -> bh_upsweep_kernel, children 0..7 in order, fp32, /= as reciprocal multiply
+//   Octree::ComputeMass    .h:83-97    -> bh_upsweep_kernel, children 0..7 in order, fp32, /= as reciprocal multiply (or division: div_mode)
 //   Octree::ComputeForces  .h:99-108   -> bh_walk_kernel: depth-first, children 0..7, `Size/d < Theta || leaf`,
 //                                          d == 0 skips (also a whole subtree whose CoM coincides with the body),
 //                                          scale factor 1e4*M/d^3 in double rounded once to float, separate fp32
@@ -254,7 +254,9 @@ __global__ __launch_bounds__(kB) void bh_split_kernel(Nodes nd, const unsigned l
 }
 
 // Octree::ComputeMass of one cell whose children are done, .h:89-95.
-__device__ __forceinline__ void upsweep_cell(const Nodes &nd, int me) {
+// div_mode: the reading of `CenterOfMass /= TotalMass` (.h:95) — 0: FVector::operator/=(float) multiplies by the fp32
+// reciprocal (UE4's implementation as remembered; the engine is not vendored), 1: three divisions.
+__device__ __forceinline__ void upsweep_cell(const Nodes &nd, int me, int div_mode) {
 #pragma clang fp contract(off)
   const int base = nd.link[me].x;
   float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
@@ -264,8 +266,12 @@ __device__ __forceinline__ void upsweep_cell(const Nodes &nd, int me) {
     cx = cx + ch.w * ch.x; cy = cy + ch.w * ch.y; cz = cz + ch.w * ch.z;
   }
   if (M != 0.f) {
-    const float rv = 1.0f / M;                             // FVector::operator/=(float): multiply by the reciprocal
-    cx = cx * rv; cy = cy * rv; cz = cz * rv;
+    if (div_mode == 0) {
+      const float rv = 1.0f / M;                           // FVector::operator/=(float): multiply by the reciprocal
+      cx = cx * rv; cy = cy * rv; cz = cz * rv;
+    } else {
+      cx = cx / M; cy = cy / M; cz = cz / M;               // correctly rounded fp32 divisions
+    }
   } else {
     const float4 bx = nd.box[me];
     cx = bx.x; cy = bx.y; cz = bx.z;
@@ -274,10 +280,10 @@ __device__ __forceinline__ void upsweep_cell(const Nodes &nd, int me) {
 }
 
 // The cells of one level (deepest level first).
-__global__ __launch_bounds__(kB) void bh_upsweep_kernel(Nodes nd, const int *__restrict__ cells, int ncells) {
+__global__ __launch_bounds__(kB) void bh_upsweep_kernel(Nodes nd, const int *__restrict__ cells, int ncells, int div_mode) {
   const int f = blockIdx.x * kB + threadIdx.x;
   if (f >= ncells) return;
-  upsweep_cell(nd, cells[f]);
+  upsweep_cell(nd, cells[f], div_mode);
 }
 
 // Small systems (the reference ships N = 2000): the whole Add + ComputeMass — root, every level's splits, the upsweep
@@ -292,7 +298,8 @@ __global__ __launch_bounds__(kSmallThreads) void bh_build_small_kernel(Nodes nd,
                                                                        const unsigned long long *__restrict__ klo,
                                                                        const unsigned int *__restrict__ sidx, int n,
                                                                        int *__restrict__ frontier, int *__restrict__ counters,
-                                                                       int node_cap, float *__restrict__ prev_com) {
+                                                                       int node_cap, float *__restrict__ prev_com,
+                                                                       int div_mode) {
   __shared__ int s_off[kMaxLevels + 2], s_cnt[kMaxLevels + 2];
   __shared__ int s_nodes, s_next, s_err;
   __shared__ unsigned long long s_khi[kLdsKeys];          // the first 21 levels' digits: binary searches at LDS latency
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(kSmallThreads) void bh_build_small_kernel(Nodes nd,
   if (!failed) {
     for (int l = levels - 1; l >= 0; --l) {                  // ComputeMass: children before parents
       const int off = s_off[l], cnt = s_cnt[l];
-      for (int f = t; f < cnt; f += kSmallThreads) upsweep_cell(nd, frontier[off + f]);
+      for (int f = t; f < cnt; f += kSmallThreads) upsweep_cell(nd, frontier[off + f], div_mode);
       __threadfence();
       __syncthreads();
     }
@@ -426,6 +433,7 @@ struct BhState {
   float *root = nullptr;       // ox, oy, oz, size
   float *prev_com = nullptr;   // the previous tree's root CoM (zero before the first frame)
   int last_nodes = 0, last_levels = 0;
+  int div_mode = 0;            // reading of `/=` in ComputeMass (upsweep_cell)
 };
 
 #define BH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
@@ -493,7 +501,7 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
     // one launch builds and sweeps the tree; the walk follows at once, the verdict is read after it (a refused tree
     // is still walkable: unsplit cells look like empty leaves)
     hipLaunchKernelGGL(bh_build_small_kernel, dim3(1), dim3(kSmallThreads), 0, s, b->nd, b->root, posm, b->khi, b->klo2,
-                       b->idx, n, b->frontier, b->counters, b->node_cap, b->prev_com);
+                       b->idx, n, b->frontier, b->counters, b->node_cap, b->prev_com, b->div_mode);
     hipLaunchKernelGGL(bh_walk_kernel, grd, blk, 0, s, b->nd, posm, b->idx, n, theta, G, acc);
     BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
     BH_TRY(hipStreamSynchronize(s));
@@ -530,7 +538,7 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   }
   b->last_levels = levels;
   for (int l = levels - 1; l >= 0; --l)                      // ComputeMass: children before parents
-    hipLaunchKernelGGL(bh_upsweep_kernel, dim3((cnt[l] + kB - 1) / kB), blk, 0, s, b->nd, b->frontier + off[l], cnt[l]);
+    hipLaunchKernelGGL(bh_upsweep_kernel, dim3((cnt[l] + kB - 1) / kB), blk, 0, s, b->nd, b->frontier + off[l], cnt[l], b->div_mode);
   hipLaunchKernelGGL(bh_save_com_kernel, dim3(1), dim3(1), 0, s, b->nd, b->prev_com);   // next frame's root centre, .cpp:78
   hipLaunchKernelGGL(bh_walk_kernel, grd, blk, 0, s, b->nd, posm, b->idx, n, theta, G, acc);
   return hipGetLastError();
@@ -541,6 +549,16 @@ hipError_t bh_leaf_boxes(BhState *b, void *out, hipStream_t s) {
   hipLaunchKernelGGL(bh_leaf_boxes_kernel, dim3((b->last_nodes + kB - 1) / kB), dim3(kB), 0, s, b->nd, b->last_nodes,
                      (float4 *)out);
   return hipGetLastError();
+}
+
+void bh_set_div_mode(BhState *b, int div_mode) { b->div_mode = div_mode ? 1 : 0; }
+
+// The bodies in the order DrawOctreeBoxes meets their leaves (OctreeSearch.cpp:36-45: depth first, children 0..7): the
+// path keys are the octant digits root to leaf, so key order IS that order.
+hipError_t bh_leaf_order(BhState *b, int *out_host, hipStream_t s) {
+  if (b->last_nodes <= 0) return hipErrorInvalidValue;
+  BH_TRY(hipStreamSynchronize(s));
+  return hipMemcpy(out_host, b->idx, sizeof(unsigned int) * (size_t)b->n, hipMemcpyDeviceToHost);
 }
 
 void bh_stats(const BhState *b, int *nodes, int *levels) {

@@ -72,7 +72,7 @@ class NBodyEngine:
     """One context = one GPU's share [i_begin, i_begin+i_count) of an n_total-body system."""
 
     def __init__(self, n_total, *, i_begin=0, i_count=0, device=0, precision="f32", G=REF_G, eps=0.0, tile=0,
-                 i_per_thread=0, j_split=0, time_kernels=False, zero_mode=0, algorithm=0, theta=0.0, devices=None):
+                 i_per_thread=0, j_split=0, time_kernels=False, zero_mode=0, algorithm=0, theta=0.0, devices=None, bh_div_mode=0):
         L = _lib.lib()
         p = Params()
         L.nbody_default_params(ctypes.byref(p))
@@ -84,6 +84,7 @@ class NBodyEngine:
         p.zero_mode = zero_mode
         p.algorithm = algorithm
         p.theta = theta
+        p.bh_div_mode = bh_div_mode
         h = ctypes.c_void_p()
         if devices is not None:
             # one context over several GPUs, driven from this thread (nbody_create_multi: RCCL between the devices)
@@ -190,6 +191,13 @@ class NBodyEngine:
         """[n,4]: (Origin, Size) of the leaf holding each body in the last Barnes-Hut tree."""
         out = np.empty((self.n_total, 4), np.float32)
         self._check(self._L.nbody_bh_leaf_boxes(self._h, _fp(out), 16))
+        return out
+
+    def bh_leaf_order(self):
+        """order[k] = the body in the k-th occupied leaf of a depth-first walk (children 0..7) of the last tree: the order in
+        which the reference's DrawOctreeBoxes draws (OctreeSearch.cpp:36-45)."""
+        out = np.empty(self.n_total, np.int32)
+        self._check(self._L.nbody_bh_leaf_order(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
         return out
 
     def synchronize(self):

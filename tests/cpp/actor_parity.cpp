@@ -44,7 +44,9 @@ int main() {
   actor.OnDrawDebugPoint = [&](const float *, float size) { points += size == 10.0f; };
   actor.OnDrawDebugBox = [&](const float *, float) { ++boxes; };
 
+  CHECK(actor.Theta == 1.0f, "the opening angle defaults to the reference's hard-coded 1.0 (.cpp:85)");
   actor.Seed = 1;
+  actor.Theta = 0.0f;                                   // first the exact all-pairs limit
   actor.CreateSpacePoints(2000, 1000.0f);               // BP_NBodyHUD BeginPlay
   CHECK(actor.Initialized && actor.LastStatus == NBODY_OK && actor.Particles.size() == 2000, "CreateSpacePoints status %d", actor.LastStatus);
   CHECK(actor.Particles[0].Mass == 5000.0f && actor.Particles[0].Position[0] == 0.0f, "body 0 pinned (.cpp:68-70)");

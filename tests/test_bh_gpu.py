@@ -45,6 +45,43 @@ def test_bh_forces_match_the_oracle_tree(nb, oracle, fixture, theta):
     assert 0.001 < rel_err(a, g["acc_direct"]).mean() < 1.5
 
 
+@pytest.mark.parametrize("div_mode", [0, 1])
+@pytest.mark.parametrize("fixture", ["refbox_n2000_seed1", "plummer_n1024_seed1"])
+def test_bh_matches_the_oracle_under_both_readings_of_the_centre_of_mass_division(nb, oracle, fixture, div_mode):
+    # `CenterOfMass /= TotalMass` (OctreeSearch.h:95) goes through UE4's FVector::operator/=(float), which is not in the
+    # reference tree: reciprocal-multiply (div_mode 0, UE4 4.9 as remembered) or three divisions (1).  Device and oracle
+    # carry the same switch, and agree in every bit under either reading.
+    g = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    n = g["posm"].shape[0]
+    pos = np.ascontiguousarray(g["posm"][:, :3]); m = np.ascontiguousarray(g["posm"][:, 3])
+    ref, com, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3, div_mode=div_mode)
+    with nb.NBodyEngine(n, theta=REF_THETA, bh_div_mode=div_mode) as e:
+        e.set_state(g["posm"], g["vel"])
+        e.compute_forces()
+        a = e.accelerations()
+        st = e.bh_stats()
+    np.testing.assert_array_equal(a, ref)
+    np.testing.assert_array_equal(st["root_com"], com)
+    assert st["nodes"] == nodes
+
+
+@pytest.mark.parametrize("n,seed", [(2000, 1), (20000, 2), (70000, 3)])
+def test_leaf_boxes_and_draw_order_equal_the_oracle_tree(nb, oracle, n, seed):
+    # what DrawOctreeBoxes (OctreeSearch.cpp:36-45) draws: (Origin, Size) of every occupied leaf and the body in it, depth
+    # first with children 0..7 — exactly, for the one-workgroup build (n <= 16384) and the level-by-level one
+    posm, vel = nb.ic_reference_box(n, 1000.0, seed=seed)
+    boxes, order = oracle.octree_leaves_f32(posm[:, :3], posm[:, 3])
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        got_order = e.bh_leaf_order()
+        got_boxes = e.bh_leaf_boxes()              # indexed by body
+    np.testing.assert_array_equal(got_order, order)
+    np.testing.assert_array_equal(got_boxes[order], boxes)
+    inside = np.all(np.abs(posm[order, :3] - boxes[:, :3]) <= boxes[:, 3:4] * (1 + 1e-6), axis=1)
+    assert inside.mean() > 0.999                   # a body sits in its leaf's box (the root box need not hold every body)
+
+
 def test_vanishing_theta_is_all_pairs_in_the_reference_order(nb, oracle):
     # theta -> 0+ never accepts a cell, so the walk visits every leaf in the reference's depth-first order: the exact
     # all-pairs sum, added up in the order the reference adds it.  Bit for bit the oracle's tree at the same theta; and
