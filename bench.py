@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--algorithm", default="auto", choices=["auto", "tiled", "symmetric"])
     ap.add_argument("--zero-mode", default="exact", choices=["exact", "floor"],
                     help="exact = the reference's d == 0 skip for every distance; floor = ~1e-20 eps^2 floor")
+    ap.add_argument("--no-tiled-row", action="store_true",
+                    help="multi-GPU: skip the extra timing of the one-sided kernel + all-gather-only step (config.all_gather_only_row)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length; 0 = skip")
     ap.add_argument("--settle-seconds", type=float, default=0.3,
                     help="untimed force passes before the warm-up steps (state unchanged): lets the GPU clock settle")
@@ -254,6 +256,21 @@ def main():
         raise SystemExit(f"bench.py: the benched force pass disagrees with the fp64 direct sum on sampled bodies: "
                          f"max rel err {err:.3e} >= {tol:.1e} (finite={finite})")
 
+    # Multi-GPU only: north_star's literal step — one-sided kernel, per-step all-gather of positions, no other collective —
+    # timed next to the default (symmetric + all-to-all) in the same job, same K steps, after the main measurement.
+    tiled_row = None
+    if world > 1 and args.algorithm == "auto" and cfg["algorithm"] == "symmetric" and not args.no_tiled_row:
+        sim.close()
+        sim = build("tiled")
+        fence()
+        t0 = time.perf_counter()
+        sim.step(args.dt, args.steps)
+        fence()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tiled_row = {"algorithm": "tiled", "parallelism": f"range-partition x{world}, per step 1 RCCL all-gather(posm)",
+                     "value": pairs_per_step * args.steps / float(tt[0]), "ms_per_step": float(tt[0]) / args.steps * 1e3}
+
     if rank == 0:
         out = {
             "metric": "body-pair interactions/s at N=2^20" if n == (1 << 20) else f"body-pair interactions/s at N={n}",
@@ -272,7 +289,8 @@ def main():
                        "super_tile_bodies": cfg["super_tile"] or None,
                        "workgroups": cfg["blocks"], "accumulate": args.precision, "finite": finite,
                        "max_rel_err_sampled": err, "bodies_sampled": n_sampled, "rel_err_tolerance": tol,
-                       **({"fallback": fallback} if fallback else {})},
+                       **({"fallback": fallback} if fallback else {}),
+                       **({"all_gather_only_row": tiled_row} if tiled_row else {})},
             "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64",
                          "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
                          "achieved_is": "algorithmic: N_i x N ordered interactions x 20 flop (SURVEY 8d) / launch time",

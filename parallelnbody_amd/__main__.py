@@ -50,6 +50,11 @@ def main(argv=None):
     ap.add_argument("--dump-positions", help="write the final positions (n x 3 float32, .npy)")
     ap.add_argument("--theta", type=float, default=0.0,
                     help="opening angle: 0 = exact all-pairs (default); 1.0 = the reference's shipped Barnes-Hut walk")
+    ap.add_argument("--sync-energy", action="store_true",
+                    help="energy lines also carry the total with the staggered velocity pulled to the positions' time "
+                         "(v_n = v_{n-1/2} + dt/2 a_n: one extra force pass per line; the state is not touched)")
+    ap.add_argument("--leapfrog-start", action="store_true",
+                    help="fresh runs only: store v_{-1/2} = v_0 - dt/2 a_0, so the update (v += dt a; x += dt v) is a proper leapfrog")
     ap.add_argument("--trajectory", help="write positions every --trajectory-every frames to this file (read_trajectory reads it back)")
     ap.add_argument("--trajectory-every", type=int, default=1)
     a = ap.parse_args(argv)
@@ -60,6 +65,22 @@ def main(argv=None):
     with NBodyEngine(a.n, device=a.device, precision=a.precision, G=a.G, eps=a.eps, theta=a.theta) as e:
         e.set_state(posm, vel)
         start = e.load_checkpoint(a.resume) if a.resume else 0
+        f64 = a.precision == "f64"
+        if a.leapfrog_start and not a.resume and a.dt > 0:
+            e.compute_forces()
+            p0, v0, a0 = e.state(np.float64 if f64 else np.float32)
+            v0[:, :3] = (v0[:, :3].astype(np.float64) - 0.5 * a.dt * a0[:, :3].astype(np.float64)).astype(v0.dtype)
+            e.set_state(p0, v0)
+
+        def energies():
+            ke, pe = e.energy()
+            out = {"kinetic": ke, "potential": pe, "total": ke + pe}
+            if a.sync_energy:
+                e.compute_forces()                               # a(x_n); positions and velocities are not touched
+                p, v, acc = e.state(np.float64)
+                vs = v[:, :3] + 0.5 * a.dt * acc[:, :3]
+                out["total_synchronised"] = 0.5 * float((p[:, 3] * (vs ** 2).sum(1)).sum()) + pe
+            return out
         trj = None
         if a.trajectory:
             trj = open(a.trajectory, "wb")
@@ -68,6 +89,8 @@ def main(argv=None):
             e.pin(frame_buf)                                     # frames land in it by one DMA
         # advance in chunks that end on every frame somebody wants to see
         marks = [m for m in (a.energy_every, a.trajectory_every if trj else 0) if m > 0]
+        if a.energy_every > 0 and a.sync_energy and not a.resume:
+            print(json.dumps({"frame": start, **energies()}), flush=True)
         t0 = time.perf_counter()
         done = 0
         while done < a.steps:
@@ -76,8 +99,7 @@ def main(argv=None):
             done += k
             frame = start + done
             if a.energy_every > 0 and frame % a.energy_every == 0:
-                ke, pe = e.energy()
-                print(json.dumps({"frame": frame, "kinetic": ke, "potential": pe, "total": ke + pe}))
+                print(json.dumps({"frame": frame, **energies()}), flush=True)
             if trj and frame % a.trajectory_every == 0:
                 e.positions(out=frame_buf)
                 trj.write(np.int64(frame).tobytes() + frame_buf.tobytes())

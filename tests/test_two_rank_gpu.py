@@ -20,3 +20,37 @@ def test_two_processes_one_gpu_end_to_end():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "two ranks on one GPU over gloo: algorithm symmetric, exchange ranks 2" in out.stdout
+
+
+def _bench_two_ranks(extra_env):
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--bodies", "65536", "--settle-seconds", "0.02"]
+    env = dict(os.environ, NBODY_DIST_BACKEND="gloo", **extra_env)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0]), out.stderr
+
+
+def test_bench_multi_rank_line_on_one_gpu():
+    # bench.py's own multi-rank path (the one the driver launches on 8 GPUs), rehearsed with two ranks sharing this GPU over
+    # gloo: symmetric kernel + all-to-all as the headline, the all-gather-only step (north_star's literal one) beside it,
+    # and the fp64-sampled parity check on every rank's slice
+    r, _ = _bench_two_ranks({})
+    cf = r["config"]
+    assert r["n_gpus"] == 2 and cf["algorithm"] == "symmetric" and "fallback" not in cf
+    assert cf["max_rel_err_sampled"] < 2e-5 and cf["bodies_sampled"] >= 48
+    row = cf["all_gather_only_row"]
+    assert row["algorithm"] == "tiled" and row["value"] > 0 and "all-to-all" not in row["parallelism"]
+
+
+def test_bench_falls_back_together_when_one_rank_cannot_build_the_symmetric_engine():
+    # rank 1 "fails" to create its symmetric engine: both ranks learn it from the same collective and rebuild on the
+    # one-sided kernel; the line says so
+    r, err = _bench_two_ranks({"NBODY_REHEARSE_CREATE_FAILURE": "1"})
+    assert r["config"]["algorithm"] == "tiled" and "symmetric engines could not be created" in r["config"]["fallback"]
+    assert "every rank rebuilds" in err
