@@ -37,7 +37,10 @@ void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict
                            const SymItem *__restrict__ items, int n_total, double gscale, double eps2,
                            const int *__restrict__ dup_flag, int run_if_dup) {
   if (dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
-  __shared__ double4 sh_pos[4][128];       // subtile images, doubled: entries l and l+64 hold body l (16 KB)
+  // subtile images, doubled: entries l and l+64 hold body l.  Two 16-byte planes (x, y) and (z, G m) rather than one
+  // 32-byte record: a per-lane ds_read_b128 at a 32-byte stride is a 2-way bank conflict (1.1e9 conflict cycles per
+  // N = 262144 pass, profiles/r02_pmc_forces_sym_f64_kernel_n262144_ipt4.txt), at a 16-byte stride it is conflict-free
+  __shared__ double2 sh_xy[4][128], sh_zw[4][128];   // 8 KB each
   __shared__ double sh_acc[4][3][kJT];     // per-wave j-side sums of the tile (24 KB)
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -67,9 +70,9 @@ void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict
     return q;
   };
   auto stage = [&](double4 q) {
-    q.w *= gscale;
-    sh_pos[wave][lane] = q;
-    sh_pos[wave][lane + 64] = q;
+    const double2 a = make_double2(q.x, q.y), b = make_double2(q.z, q.w * gscale);
+    sh_xy[wave][lane] = a; sh_xy[wave][lane + 64] = a;
+    sh_zw[wave][lane] = b; sh_zw[wave][lane + 64] = b;
   };
   stage(fetch(0));
   __syncthreads();
@@ -82,11 +85,12 @@ void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict
 
     if (!one_sided) {
       for (int sub = 0; sub < nsub; ++sub) {
-        const double4 *sp = &sh_pos[sub][lane + 64];
+        const double2 *sxy = &sh_xy[sub][lane + 64], *szw = &sh_zw[sub][lane + 64];
         double jx = 0.0, jy = 0.0, jz = 0.0;
 #pragma unroll 2
         for (int k = 0; k < 64; ++k) {
-          const double4 pj = sp[-k];
+          const double2 pxy = sxy[-k], pzw = szw[-k];
+          double4 pj; pj.x = pxy.x; pj.y = pxy.y; pj.z = pzw.x; pj.w = pzw.y;
 #pragma unroll
           for (int q = 0; q < IPT; ++q) {
             const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
@@ -106,7 +110,8 @@ void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict
       for (int q4 = 0; q4 < nsub; ++q4) {
 #pragma unroll 2
         for (int k = 0; k < 64; ++k) {
-          const double4 pj = sh_pos[q4][k];
+          const double2 pxy = sh_xy[q4][k], pzw = sh_zw[q4][k];     // every lane the same address: a broadcast
+          double4 pj; pj.x = pxy.x; pj.y = pxy.y; pj.z = pzw.x; pj.w = pzw.y;
 #pragma unroll
           for (int q = 0; q < IPT; ++q) {
             const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
@@ -119,7 +124,7 @@ void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict
         }
       }
     }
-    __syncthreads();   // every wave is done with sh_pos; the tile's j-side sums are complete
+    __syncthreads();   // every wave is done with the tile images; the tile's j-side sums are complete
     if (!one_sided && t < nsub * 64) {
       double4 o;
       o.x = ((sh_acc[0][0][t] + sh_acc[1][0][t]) + sh_acc[2][0][t]) + sh_acc[3][0][t];
