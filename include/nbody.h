@@ -278,11 +278,12 @@ NBODY_API int nbody_get_algorithm(nbody_ctx *ctx, int32_t *algorithm, int32_t *s
 /* Host only (no device needed): the work plan of the symmetric force pass for a context owning [i_begin, i_begin +
  * i_count) of n_total bodies — i-sets of `bodies_per_iset` bodies (256 x i_per_thread) against strips of 64-body
  * subtiles, strip lengths by guided self-scheduling over `slots` resident workgroups (csrc/sym_plan.h).  items, when
- * not NULL, receives 8 int32 per work item: i0, j0, n_sub, flags (1 = one-sided strip inside the i-set's own block),
- * slot_i, slot_j (element offsets of its partial-sum segments), 0, 0.  Build-defined diagnostics; the CPU tests use it
+ * not NULL, receives 8 int32 per work item: i0, j0, n_sub, flags (1 = the strip lies inside the i-set's own block, 2 = it
+ * writes no j-side sums), slot_i, slot_j (element offsets of its partial-sum segments), 0, 0.  own_mode: how own-block strips are
+ * costed — 1 = the fp32 kernels (symmetric between register pairs of two slots), 2 = the fp64 kernel (between slots).  Build-defined diagnostics; the CPU tests use it
  * to check that every body pair is evaluated exactly once. */
 NBODY_API int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
-                                      int32_t slots, int32_t k_guided, int32_t min_sub, int32_t *n_items,
+                                      int32_t slots, int32_t k_guided, int32_t min_sub, int32_t own_mode, int32_t *n_items,
                                       uint64_t *pool_elems, int32_t *items, int32_t items_cap);
 
 /* ---- checkpoint / resume (build-defined: the reference keeps its state in a non-serialised TArray) ---------- */

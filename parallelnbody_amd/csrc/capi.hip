@@ -194,7 +194,7 @@ void choose_algorithm(nbody_ctx *c) {
   nbody::SymPlan *plan = new (std::nothrow) nbody::SymPlan();
   if (!plan) return;
   std::string why;
-  if (!nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, plan, &why)) {
+  if (!nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, f64 ? 2 : 1, plan, &why)) {
     g_create_error = "symmetric plan: " + why;
     delete plan;
     return;

@@ -51,6 +51,77 @@ constexpr int sym_waves(int np, bool kahan) {
   return np == 8 ? 2 : (np == 4 ? (kahan ? 2 : 3) : (kahan && np == 2 ? 3 : 4));
 }
 
+// One 64-body subtile against the lane's register pairs P0 .. NP-1.  At step k lane l meets body (l - k) & 63 of the
+// subtile (sp points at the lane's entry in the upper copy of the doubled image); that body's running j-side sum sits in
+// the same lane and moves on with it (wave_ror:1: lane l+1 takes lane l's value) after every step; after 64 moves lane l
+// holds the sum of body l again (ox, oy, oz).
+//   ONE = false, P0 = 0: a symmetric strip — every register pair meets the body symmetrically.
+//   ONE = true: the subtile lies in the i-set's OWN block, in register pair P0's slots.  Pairs above P0 hold other bodies of
+//   the block: symmetric, each unordered pair once (the pairs below P0 met these bodies when THEIR subtiles came up);
+//   pair P0 itself runs one-sided — every ordered pair inside a register pair's 512 bodies is evaluated from both
+//   ends, the self pair (d == 0) dropped by the guard — and credits nothing to the j side.
+template <int NP, int P0, bool ONE, int ZMODE, bool BARE, bool KAHAN>
+__device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[NP], const f2 (&zi)[NP], const f2 (&nmi)[NP],
+                                            Acc3pk<KAHAN> (&acc)[NP], const float4 *sp, f2 zp2, f2 one2, float &ox, float &oy,
+                                            float &oz) {
+  constexpr int NA = NP - P0;                                     // active register pairs
+  // steps in flight: four for one or two register pairs, two from four pairs up; the own-block forms (a small share
+  // of the work) keep one step in flight where many pairs are active, so that they never raise the kernel's register need
+  constexpr int kUnroll = ONE ? (NA >= 5 ? 1 : 2) : ((NA >= 4) ? NBODY_SYM_UNROLL4 : NBODY_SYM_UNROLL);
+  f2 qx = splat2(0.f), qy = splat2(0.f), qz = splat2(0.f);        // (lo, hi) partial sums
+#pragma unroll kUnroll
+  for (int k = 0; k < 64; ++k) {
+    const float4 pj = sp[-k];
+    f2 dx[NA], dy[NA], dz[NA], w[NA], u[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { dx[a] = splat2(pj.x) - xi[P0 + a]; dy[a] = splat2(pj.y) - yi[P0 + a]; dz[a] = splat2(pj.z) - zi[P0 + a]; }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      if (ZMODE == Z_SOFT) w[a] = fma2(dz[a], dz[a], zp2);
+      else                 w[a] = dz[a] * dz[a];
+      w[a] = fma2(dy[a], dy[a], w[a]);
+      w[a] = fma2(dx[a], dx[a], w[a]);
+    }
+    if (ZMODE == Z_CLAMP) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        if (!BARE || (ONE && a == 0)) {                           // the one-sided pair holds the self pair: always guarded
+          f2 nf;
+          asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nf) : "v"(w[a]), "v"(zp2), "v"(one2));
+          w[a] = w[a] + nf;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) u[a] = f2{rsq_dev(w[a].x), rsq_dev(w[a].y)};
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      w[a] = u[a] * u[a];
+      w[a] = w[a] * u[a];                                         // |d|^-3 (ordinary ops between rsq and the asm)
+      if (!(ONE && a == 0)) u[a] = w[a] * nmi[P0 + a];            // -G m_i |d|^-3
+      w[a] = mul_bcast_hi(w[a], f2{pj.z, pj.w});                  //  G m_j |d|^-3
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      acc[P0 + a].add(w[a], dx[a], dy[a], dz[a]);
+      if (!(ONE && a == 0)) { qx = fma2(u[a], dx[a], qx); qy = fma2(u[a], dy[a], qy); qz = fma2(u[a], dz[a], qz); }
+    }
+    if (NA > (ONE ? 1 : 0)) {                                     // the sums move on with their body
+      qx = f2{wave_ror1(qx.x), wave_ror1(qx.y)}; qy = f2{wave_ror1(qy.x), wave_ror1(qy.y)};
+      qz = f2{wave_ror1(qz.x), wave_ror1(qz.y)};
+    }
+  }
+  ox = qx.x + qx.y; oy = qy.x + qy.y; oz = qz.x + qz.y;
+}
+
+// own-block subtile in register pair pc's slots: pick the instantiation (pc is wave-uniform)
+template <int NP, int PC, int ZMODE, bool BARE, bool KAHAN>
+__device__ __forceinline__ void own_block_subtile(int pc, const f2 (&xi)[NP], const f2 (&yi)[NP], const f2 (&zi)[NP],
+                                                  const f2 (&nmi)[NP], Acc3pk<KAHAN> (&acc)[NP], const float4 *sp, f2 zp2,
+                                                  f2 one2, float &ox, float &oy, float &oz) {
+  if (pc == PC) sym_subtile<NP, PC, true, ZMODE, BARE, KAHAN>(xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
+  else if constexpr (PC + 1 < NP) own_block_subtile<NP, PC + 1, ZMODE, BARE, KAHAN>(pc, xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
+}
+
 using lds_f4 = __attribute__((address_space(3))) float4;
 using glb_f4 = const __attribute__((address_space(1))) float4;
 
@@ -60,7 +131,6 @@ __attribute__((amdgpu_waves_per_eu(sym_waves(NP, KAHAN), sym_waves(NP, KAHAN))))
 void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ pool, const SymItem *__restrict__ items,
                           float zp, const int *__restrict__ dup_flag, int run_if_dup) {
   if (dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
-  constexpr int kUnroll = (NP >= 4) ? NBODY_SYM_UNROLL4 : NBODY_SYM_UNROLL;
   __shared__ float4 sh_pos[2][4][128];   // double-buffered subtile images, doubled: entries l and l+64 hold body l
   __shared__ float sh_acc[4][3][kJT];    // per-WAVE j-side sums of the tile (private: no ordering between waves needed)
 
@@ -68,18 +138,18 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
   const SymItem *__restrict__ itp = items + blockIdx.x;          // wave-uniform: scalar loads
   const int i0 = itp->i0, j0 = itp->j0, n_sub = itp->n_sub;
   const unsigned int slot_i = itp->slot_i, slot_j = itp->slot_j;
-  const bool one_sided = (itp->flags & kSymOneSided) != 0;
+  const bool own_block = (itp->flags & kSymOneSided) != 0;      // the strip lies inside the i-set's own block
   const int n_tiles = (n_sub + 3) >> 2;
 
   // Tile c of the strip -> LDS buffer c & 1: wave w brings subtile w, twice (the doubled image), 1 KiB per DMA.
-  auto stage = [&](int c) {
+  auto stage = [&](int c, int wave, int lane) {
     if (4 * c + wave < n_sub) {
       glb_f4 *src = (glb_f4 *)(posg + j0 + (4 * c + wave) * 64 + lane);
       __builtin_amdgcn_global_load_lds(src, (lds_f4 *)&sh_pos[c & 1][wave][0], 16, 0, 0);
       __builtin_amdgcn_global_load_lds(src, (lds_f4 *)&sh_pos[c & 1][wave][64], 16, 0, 0);
     }
   };
-  stage(0);
+  stage(0, wave, lane);
 
   f2 zp2 = splat2(zp), one2 = splat2(1.0f);
   asm volatile("" : "+v"(zp2), "+v"(one2));
@@ -99,72 +169,24 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
   for (int c = 0; c < n_tiles; ++c) {
     const int buf = c & 1;
     const int nsub = min(4, n_sub - 4 * c);
-    if (c + 1 < n_tiles) stage(c + 1);                           // in flight under this tile's arithmetic
+    // lane and wave are derived afresh from the thread id in every tile (opaque to the optimiser): hoisted out of the
+    // loop, the addresses computed from them would sit in VGPRs across the arithmetic and push it into scratch
+    int tc = threadIdx.x;
+    asm volatile("" : "+v"(tc));
+    const int lane = tc & 63, wave = tc >> 6;
+    if (c + 1 < n_tiles) stage(c + 1, wave, lane);               // in flight under this tile's arithmetic
 
-    if (!one_sided) {
-      for (int sub = 0; sub < nsub; ++sub) {
-        // At step k lane l meets body (l - k) & 63 of the subtile; that body's running j-side sum sits in the
-        // same lane and moves on with it (wave_ror:1: lane l+1 takes lane l's value) after every step.
-        const float4 *sp = &sh_pos[buf][sub][lane + 64];
-        f2 qx = splat2(0.f), qy = splat2(0.f), qz = splat2(0.f);            // (lo, hi) partial sums
-#pragma unroll kUnroll
-        for (int k = 0; k < 64; ++k) {
-          const float4 pj = sp[-k];
-          f2 dx[NP], dy[NP], dz[NP], w[NP], u[NP];
-#pragma unroll
-          for (int p = 0; p < NP; ++p) { dx[p] = splat2(pj.x) - xi[p]; dy[p] = splat2(pj.y) - yi[p]; dz[p] = splat2(pj.z) - zi[p]; }
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            if (ZMODE == Z_SOFT && !BARE) w[p] = fma2(dz[p], dz[p], zp2);
-            else                          w[p] = dz[p] * dz[p];
-            w[p] = fma2(dy[p], dy[p], w[p]);
-            w[p] = fma2(dx[p], dx[p], w[p]);
-          }
-          if (ZMODE == Z_CLAMP && !BARE) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-              f2 nf;
-              asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nf) : "v"(w[p]), "v"(zp2), "v"(one2));
-              w[p] = w[p] + nf;
-            }
-          }
-#pragma unroll
-          for (int p = 0; p < NP; ++p) u[p] = f2{rsq_dev(w[p].x), rsq_dev(w[p].y)};
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            w[p] = u[p] * u[p];
-            w[p] = w[p] * u[p];                                     // |d|^-3 (ordinary ops between rsq and the asm)
-            u[p] = w[p] * nmi[p];                                   // -G m_i |d|^-3
-            w[p] = mul_bcast_hi(w[p], f2{pj.z, pj.w});              //  G m_j |d|^-3
-          }
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            a[p].add(w[p], dx[p], dy[p], dz[p]);
-            qx = fma2(u[p], dx[p], qx); qy = fma2(u[p], dy[p], qy); qz = fma2(u[p], dz[p], qz);
-          }
-          // the sums move on with their body
-          qx = f2{wave_ror1(qx.x), wave_ror1(qx.y)}; qy = f2{wave_ror1(qy.x), wave_ror1(qy.y)};
-          qz = f2{wave_ror1(qz.x), wave_ror1(qz.y)};
-        }
-        // after 64 moves lane l holds the sum of body l of the subtile again
-        sh_acc[wave][0][sub * 64 + lane] = qx.x + qx.y; sh_acc[wave][1][sub * 64 + lane] = qy.x + qy.y;
-        sh_acc[wave][2][sub * 64 + lane] = qz.x + qz.y;
-      }
-    } else {
-      // one-sided step inside the i-set's own block: every ordered pair, self pairs dropped by ZMODE
-      constexpr int JB = (NP == 1) ? 4 : (NP == 2 ? 2 : 1);   // j-bodies in flight
-      for (int q = 0; q < nsub; ++q) {
-#pragma unroll 2
-        for (int k = 0; k < 64; k += JB) {
-          float4 pj[JB];
-#pragma unroll
-          for (int g = 0; g < JB; ++g) pj[g] = sh_pos[buf][q][k + g];
-          pair_group_pk<NP, JB, ZMODE, KAHAN>(xi, yi, zi, pj, zp2, one2, a);
-        }
-      }
+    for (int sub = 0; sub < nsub; ++sub) {
+      const float4 *sp = &sh_pos[buf][sub][lane + 64];
+      float ox, oy, oz;
+      if (!own_block)
+        sym_subtile<NP, 0, false, ZMODE, BARE, KAHAN>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+      else   // the subtile's bodies sit in the slots of register pair (offset from the i-set's first body) / 512
+        own_block_subtile<NP, 0, ZMODE, BARE, KAHAN>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+      sh_acc[wave][0][sub * 64 + lane] = ox; sh_acc[wave][1][sub * 64 + lane] = oy; sh_acc[wave][2][sub * 64 + lane] = oz;
     }
     __syncthreads();   // the four waves' tile sums are complete; the next tile has landed
-    if (!one_sided) {
+    {
       // thread e adds body e's sums (waves in fixed order) and stores them in the item's j-side segment
       int e = threadIdx.x;
       asm volatile("" : "+v"(e));   // recomputed here rather than kept in a register across the tile

@@ -27,7 +27,48 @@ __device__ __forceinline__ double rsq64(double x) {
   return fma(y, q, y);
 }
 
-// BARE: symmetric strips without a d == 0 guard (see kernels_sym.hip); the one-sided strips always select.
+// One 64-body subtile against the lane's bodies K0 .. IPT-1 (see sym_subtile in kernels_sym.hip): ONE = false, K0 = 0 is
+// a symmetric strip; ONE = true is a subtile of the i-set's OWN block that lies in the lanes' slot K0 — the slots above meet
+// it symmetrically, slot K0 one-sided (the self pair selected away), the slots below are idle.
+template <int IPT, int K0, bool ONE, bool BARE, bool SOFT>
+__device__ __forceinline__ void sym_subtile64(const double (&xi)[IPT], const double (&yi)[IPT], const double (&zi)[IPT],
+                                              const double (&nmi)[IPT], double (&ax)[IPT], double (&ay)[IPT],
+                                              double (&az)[IPT], const double2 *sxy, const double2 *szw, double eps2,
+                                              double &ox, double &oy, double &oz) {
+  double jx = 0.0, jy = 0.0, jz = 0.0;
+#pragma unroll 2
+  for (int k = 0; k < 64; ++k) {
+    const double2 pxy = sxy[-k], pzw = szw[-k];
+#pragma unroll
+    for (int q = K0; q < IPT; ++q) {
+      const bool own = ONE && q == K0;
+      const double dx = pxy.x - xi[q], dy = pxy.y - yi[q], dz = pzw.x - zi[q];
+      const double r2 = SOFT ? fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2))) : fma(dx, dx, fma(dy, dy, dz * dz));
+      double rinv = rsq64(r2);
+      if (!SOFT && (!BARE || own)) rinv = (r2 > 0.0) ? rinv : 0.0;
+      const double u3 = (rinv * rinv) * rinv;
+      const double s_i = u3 * pzw.y;
+      ax[q] = fma(s_i, dx, ax[q]); ay[q] = fma(s_i, dy, ay[q]); az[q] = fma(s_i, dz, az[q]);
+      if (!own) {
+        const double s_j = u3 * nmi[q];
+        jx = fma(s_j, dx, jx); jy = fma(s_j, dy, jy); jz = fma(s_j, dz, jz);
+      }
+    }
+    if (IPT - K0 > (ONE ? 1 : 0)) { jx = wave_ror1(jx); jy = wave_ror1(jy); jz = wave_ror1(jz); }
+  }
+  ox = jx; oy = jy; oz = jz;
+}
+
+template <int IPT, int K, bool BARE, bool SOFT>
+__device__ __forceinline__ void own_block_subtile64(int slot, const double (&xi)[IPT], const double (&yi)[IPT],
+                                                    const double (&zi)[IPT], const double (&nmi)[IPT], double (&ax)[IPT],
+                                                    double (&ay)[IPT], double (&az)[IPT], const double2 *sxy,
+                                                    const double2 *szw, double eps2, double &ox, double &oy, double &oz) {
+  if (slot == K) sym_subtile64<IPT, K, true, BARE, SOFT>(xi, yi, zi, nmi, ax, ay, az, sxy, szw, eps2, ox, oy, oz);
+  else if constexpr (K + 1 < IPT) own_block_subtile64<IPT, K + 1, BARE, SOFT>(slot, xi, yi, zi, nmi, ax, ay, az, sxy, szw, eps2, ox, oy, oz);
+}
+
+// BARE: symmetric strips without a d == 0 guard (see kernels_sym.hip); the one-sided slot of an own-block strip always selects.
 // SOFT: eps2 > 0 is added to every r^2, which keeps rsq finite everywhere: no guard at all (BARE is then irrelevant).
 // Work items, segments and their summation order: sym_plan.h.  State is read from posm itself (double4 is 32 bytes —
 // two LDS-DMA pieces per body — so tiles are staged through registers here, and nothing spills).
@@ -47,7 +88,7 @@ void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict
   const SymItem *__restrict__ itp = items + blockIdx.x;          // wave-uniform: scalar loads
   const int i0 = itp->i0, j0 = itp->j0, n_sub = itp->n_sub;
   const unsigned int slot_i = itp->slot_i, slot_j = itp->slot_j;
-  const bool one_sided = (itp->flags & kSymOneSided) != 0;
+  const bool own_block = (itp->flags & kSymOneSided) != 0;      // the strip lies inside the i-set's own block
   const int n_tiles = (n_sub + 3) >> 2;
   const double padc = (BARE && !SOFT) ? kPadFar64 : 0.0;     // zero-mass padding: (padc, padc, padc, 0)
 
@@ -83,49 +124,17 @@ void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict
     double4 nxt;
     if (more) nxt = fetch(c + 1);
 
-    if (!one_sided) {
-      for (int sub = 0; sub < nsub; ++sub) {
-        const double2 *sxy = &sh_xy[sub][lane + 64], *szw = &sh_zw[sub][lane + 64];
-        double jx = 0.0, jy = 0.0, jz = 0.0;
-#pragma unroll 2
-        for (int k = 0; k < 64; ++k) {
-          const double2 pxy = sxy[-k], pzw = szw[-k];
-          double4 pj; pj.x = pxy.x; pj.y = pxy.y; pj.z = pzw.x; pj.w = pzw.y;
-#pragma unroll
-          for (int q = 0; q < IPT; ++q) {
-            const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
-            const double r2 = SOFT ? fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2))) : fma(dx, dx, fma(dy, dy, dz * dz));
-            double rinv = rsq64(r2);
-            if (!BARE && !SOFT) rinv = (r2 > 0.0) ? rinv : 0.0;
-            const double u3 = (rinv * rinv) * rinv;
-            const double s_i = u3 * pj.w, s_j = u3 * nmi[q];
-            ax[q] = fma(s_i, dx, ax[q]); ay[q] = fma(s_i, dy, ay[q]); az[q] = fma(s_i, dz, az[q]);
-            jx = fma(s_j, dx, jx); jy = fma(s_j, dy, jy); jz = fma(s_j, dz, jz);
-          }
-          jx = wave_ror1(jx); jy = wave_ror1(jy); jz = wave_ror1(jz);
-        }
-        sh_acc[wave][0][sub * 64 + lane] = jx; sh_acc[wave][1][sub * 64 + lane] = jy; sh_acc[wave][2][sub * 64 + lane] = jz;
-      }
-    } else {
-      for (int q4 = 0; q4 < nsub; ++q4) {
-#pragma unroll 2
-        for (int k = 0; k < 64; ++k) {
-          const double2 pxy = sh_xy[q4][k], pzw = sh_zw[q4][k];     // every lane the same address: a broadcast
-          double4 pj; pj.x = pxy.x; pj.y = pxy.y; pj.z = pzw.x; pj.w = pzw.y;
-#pragma unroll
-          for (int q = 0; q < IPT; ++q) {
-            const double dx = pj.x - xi[q], dy = pj.y - yi[q], dz = pj.z - zi[q];
-            const double r2 = SOFT ? fma(dx, dx, fma(dy, dy, fma(dz, dz, eps2))) : fma(dx, dx, fma(dy, dy, dz * dz));
-            double rinv = rsq64(r2);
-            if (!SOFT) rinv = (r2 > 0.0) ? rinv : 0.0;          // self pairs live here
-            const double s_i = ((rinv * rinv) * rinv) * pj.w;
-            ax[q] = fma(s_i, dx, ax[q]); ay[q] = fma(s_i, dy, ay[q]); az[q] = fma(s_i, dz, az[q]);
-          }
-        }
-      }
+    for (int sub = 0; sub < nsub; ++sub) {
+      const double2 *sxy = &sh_xy[sub][lane + 64], *szw = &sh_zw[sub][lane + 64];
+      double ox, oy, oz;
+      if (!own_block)
+        sym_subtile64<IPT, 0, false, BARE, SOFT>(xi, yi, zi, nmi, ax, ay, az, sxy, szw, eps2, ox, oy, oz);
+      else   // the subtile's bodies sit in the lanes' slot (offset from the i-set's first body) / 256
+        own_block_subtile64<IPT, 0, BARE, SOFT>((j0 - i0 + (4 * c + sub) * 64) >> 8, xi, yi, zi, nmi, ax, ay, az, sxy, szw, eps2, ox, oy, oz);
+      sh_acc[wave][0][sub * 64 + lane] = ox; sh_acc[wave][1][sub * 64 + lane] = oy; sh_acc[wave][2][sub * 64 + lane] = oz;
     }
     __syncthreads();   // every wave is done with the tile images; the tile's j-side sums are complete
-    if (!one_sided && t < nsub * 64) {
+    if (t < nsub * 64) {
       double4 o;
       o.x = ((sh_acc[0][0][t] + sh_acc[1][0][t]) + sh_acc[2][0][t]) + sh_acc[3][0][t];
       o.y = ((sh_acc[0][1][t] + sh_acc[1][1][t]) + sh_acc[2][1][t]) + sh_acc[3][1][t];

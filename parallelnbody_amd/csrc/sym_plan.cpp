@@ -25,6 +25,18 @@ bool ring_assigned(int a, int b, int T) {
 
 struct Range { int row, j_sub0, n_sub, one_sided; };
 
+// Cost of one 64-body subtile against an i-set, in lane-slot steps (a lane holds S = bi / 256 bodies).  A symmetric strip
+// works all S slots.  Inside the own block (own_mode 1, the fp32 kernels) the register pairs — two slots — above the
+// subtile's own pair work symmetrically and its own pair one-sided, the pairs below are idle: 2 (NP - pc); own_mode 2
+// (the fp64 kernel) does the same slot by slot: S - slot; own_mode 0 would run the whole i-set one-sided.
+inline int subtile_cost(const Range &r, int sub_in_range, int bi, int own_mode) {
+  const int S = bi / 256;
+  if (!r.one_sided || own_mode == 0) return S;
+  const int off = (r.j_sub0 + sub_in_range) * 64 - r.row * bi;     // body offset inside the block
+  if (own_mode == 2) return S - (off >> 8);                        // slot-granular (fp64 kernel)
+  return S < 2 ? S : S - 2 * (off >> 9);
+}
+
 bool fail(std::string *err, const char *msg) {
   if (err) *err = msg;
   return false;
@@ -32,8 +44,8 @@ bool fail(std::string *err, const char *msg) {
 
 }  // namespace
 
-bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, int k_guided, int min_sub, SymPlan *out,
-                    std::string *err) {
+bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, int k_guided, int min_sub, int own_mode,
+                    SymPlan *out, std::string *err) {
   if (n_total <= 0 || i_count <= 0 || i_begin < 0 || i_begin + i_count > n_total) return fail(err, "bad body range");
   if (bi < 64 || bi % 64 != 0) return fail(err, "bodies per i-set must be a multiple of 64");
   if (slots < 1 || k_guided < 1 || min_sub < 1) return fail(err, "bad scheduling parameters");
@@ -63,7 +75,7 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, in
     if (d0 >= P.n_gran) continue;                                    // (cannot happen: the last block holds a body)
     const int dn = std::min(sub_per_block, P.n_gran - d0);
     ranges.push_back({a, d0, dn, 1});
-    total_cost += 2LL * dn;                                          // a one-sided subtile costs about two symmetric ones
+    for (int k = 0; k < dn; ++k) total_cost += subtile_cost(ranges.back(), k, bi, own_mode);
     int h = 0;
     while (h + 1 < P.T && ring_assigned(a, (a + h + 1) % P.T, P.T)) ++h;
     for (int d = h + 1; d < P.T; ++d)
@@ -76,7 +88,7 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, in
       const long long lo = pc[0], hi = std::min<long long>(pc[1], P.n_gran);
       if (hi <= lo) continue;
       ranges.push_back({a, (int)lo, (int)(hi - lo), 0});
-      total_cost += hi - lo;
+      total_cost += (hi - lo) * (bi / 256);
     }
   }
 
@@ -85,25 +97,34 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, in
   uint64_t pool = 0;
   const long long kp = (long long)k_guided * slots;
   for (const Range &r : ranges) {
-    const int unit = r.one_sided ? 2 : 1;
     int pos = 0;
     while (pos < r.n_sub) {
-      long long n = (remaining / kp) / unit;
-      if (n < min_sub) n = min_sub;
-      if (n >= 4) n -= n % 4;                                       // whole 256-body tiles except at a range's end
-      if (n > r.n_sub - pos) n = r.n_sub - pos;
-      if (r.n_sub - pos - n < min_sub) n = r.n_sub - pos;           // no slivers
+      const long long target = remaining / kp;
+      long long cost = 0;
+      int n = 0;
+      while (pos + n < r.n_sub && (n < min_sub || cost + subtile_cost(r, pos + n, bi, own_mode) <= target)) {
+        cost += subtile_cost(r, pos + n, bi, own_mode);
+        ++n;
+      }
+      if (n >= 4 && n < r.n_sub - pos) {                             // whole 256-body tiles except at a range's end
+        for (int k = n - n % 4; k < n; ++k) cost -= subtile_cost(r, pos + k, bi, own_mode);
+        n -= n % 4;
+      }
+      if (r.n_sub - pos - n < min_sub)                              // no slivers
+        for (; pos + n < r.n_sub; ++n) cost += subtile_cost(r, pos + n, bi, own_mode);
       SymItem it{};
       it.i0 = r.row * bi;
       it.j0 = (r.j_sub0 + pos) * 64;
-      it.n_sub = (int)n;
+      it.n_sub = n;
       it.flags = r.one_sided ? kSymOneSided : 0;
+      const bool j_side = !r.one_sided || own_mode != 0;              // does the item produce j-side sums
       if (pool + (uint64_t)bi + (uint64_t)n * 64 >= (1ull << 32)) return fail(err, "partial-sum pool exceeds 2^32 elements");
       it.slot_i = (uint32_t)pool; pool += (uint64_t)bi;
-      if (!r.one_sided) { it.slot_j = (uint32_t)pool; pool += (uint64_t)n * 64; }
+      if (j_side) { it.slot_j = (uint32_t)pool; pool += (uint64_t)n * 64; }
+      else it.flags |= kSymNoJSide;
       P.items.push_back(it);
-      pos += (int)n;
-      remaining -= n * unit;
+      pos += n;
+      remaining -= cost;
     }
   }
   P.pool_elems = pool;
@@ -127,14 +148,14 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, in
   // CSR over all granules: j-side segments
   P.j_ptr.assign((size_t)P.n_gran + 1, 0);
   for (const SymItem &it : P.items)
-    if (!(it.flags & kSymOneSided))
+    if (!(it.flags & kSymNoJSide))
       for (int k = 0; k < it.n_sub; ++k) P.j_ptr[(size_t)(it.j0 / 64 + k) + 1] += 1;
   for (int g = 0; g < P.n_gran; ++g) P.j_ptr[(size_t)g + 1] += P.j_ptr[(size_t)g];
   P.j_off.assign(P.j_ptr.back(), 0);
   {
     std::vector<uint32_t> fill(P.j_ptr.begin(), P.j_ptr.end() - 1);
     for (const SymItem &it : P.items)
-      if (!(it.flags & kSymOneSided))
+      if (!(it.flags & kSymNoJSide))
         for (int k = 0; k < it.n_sub; ++k) P.j_off[fill[(size_t)(it.j0 / 64 + k)]++] = it.slot_j + (uint32_t)k * 64u;
   }
   *out = std::move(P);
@@ -146,12 +167,12 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, in
 // C-ABI view of the planner (host only, no device): lets the CPU test suite check that a plan covers every body pair
 // exactly once and that its segments do not overlap.
 extern "C" int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
-                                       int32_t slots, int32_t k_guided, int32_t min_sub, int32_t *n_items,
+                                       int32_t slots, int32_t k_guided, int32_t min_sub, int32_t own_mode, int32_t *n_items,
                                        uint64_t *pool_elems, int32_t *items, int32_t items_cap) {
   nbody::SymPlan P;
   std::string why;
   if (i_count == 0) i_count = n_total - i_begin;
-  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided, min_sub, &P, &why))
+  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided, min_sub, own_mode, &P, &why))
     return NBODY_ERR_UNSUPPORTED;
   if (n_items) *n_items = (int32_t)P.items.size();
   if (pool_elems) *pool_elems = P.pool_elems;

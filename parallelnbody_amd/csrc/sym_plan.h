@@ -26,12 +26,13 @@ struct SymItem {          // 32 bytes, read by the force kernels with scalar loa
   int32_t i0;             // first body of the i-set (multiple of bi)
   int32_t j0;             // first j body of the strip (multiple of 64)
   int32_t n_sub;          // 64-body subtiles in the strip (>= 1)
-  int32_t flags;          // kSymOneSided: the strip lies inside the i-set's own block
+  int32_t flags;          // kSymOneSided, kSymNoJSide
   uint32_t slot_i;        // pool element where the i-side sums of bodies [i0, i0 + bi) start
   uint32_t slot_j;        // pool element where the j-side sums of bodies [j0, j0 + 64 n_sub) start (symmetric items)
   int32_t reserved0, reserved1;
 };
-enum { kSymOneSided = 1 };
+enum { kSymOneSided = 1,      // the strip lies in the i-set's own block
+       kSymNoJSide = 2 };     // the item writes no j-side sums (own_mode 0 only)
 
 struct SymPlan {
   int bi = 0;             // bodies per i-set
@@ -48,8 +49,10 @@ struct SymPlan {
 };
 
 // slots: workgroups the chip holds at a time; k_guided: a strip is 1/(k_guided * slots) of the remaining work;
-// min_sub: shortest strip, in subtiles.  Returns false (and says why) when the owned range does not fit the plan.
-bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, int k_guided, int min_sub, SymPlan *out,
-                    std::string *err);
+// min_sub: shortest strip, in subtiles; own_mode: how the kernel treats strips inside the i-set's own block — 1 (fp32):
+// register pairs above the subtile's own pair symmetric, that pair one-sided, j-side sums written; 2 (fp64): the same
+// slot by slot; 0: one-sided throughout, no j-side sums (no kernel does that any more; kept for the cost model's tests).  Returns false (and says why) when the owned range does not fit the plan.
+bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, int k_guided, int min_sub, int own_mode,
+                    SymPlan *out, std::string *err);
 
 }  // namespace nbody

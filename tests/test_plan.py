@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 
-def _coverage(nb, n, ranks, bi, slots, k, min_sub):
+def _coverage(nb, n, ranks, bi, slots, k, min_sub, own_mode=1):
     """sym[a, g] / one[a, g]: how many items pair block a's i-set with 64-body subtile g, over all ranks."""
     T, G = -(-n // bi), -(-n // 64)
     sym = np.zeros((T, G), np.int32)
@@ -17,7 +17,7 @@ def _coverage(nb, n, ranks, bi, slots, k, min_sub):
     pools = []
     for r in range(ranks):
         ib, ic = (r * (n // ranks), n // ranks) if ranks > 1 else (0, 0)
-        items, pool = nb.sym_plan(n, ib, ic, bi, slots, k, min_sub)
+        items, pool = nb.sym_plan(n, ib, ic, bi, slots, k, min_sub, own_mode)
         assert len(items) > 0
         segs = []
         for i0, j0, n_sub, flags, slot_i, slot_j, _, _ in items:
@@ -27,7 +27,8 @@ def _coverage(nb, n, ranks, bi, slots, k, min_sub):
             tgt = one if flags & 1 else sym
             tgt[i0 // bi, j0 // 64:j0 // 64 + n_sub] += 1
             segs.append((np.uint32(slot_i), bi))
-            if not flags & 1:
+            assert bool(flags & 2) == bool(flags & 1 and own_mode == 0)      # only the fp64 own-block strips lack j-side sums
+            if not flags & 2:
                 segs.append((np.uint32(slot_j), 64 * n_sub))
         segs.sort()
         end = 0
@@ -43,11 +44,14 @@ def _coverage(nb, n, ranks, bi, slots, k, min_sub):
     (1024, 1, 512, 1024), (2000, 1, 512, 1024), (5000, 1, 1024, 1024), (40000, 1, 2048, 768), (65536, 1, 4096, 512),
     (65536, 1, 1024, 1024), (100003, 1, 2048, 768), (65536, 2, 2048, 768), (65536, 8, 4096, 512), (49152, 3, 1024, 1024),
     (32768, 4, 512, 1024)])
-def test_every_pair_exactly_once(nb, n, ranks, bi, slots):
-    sym, one, _ = _coverage(nb, n, ranks, bi, slots, 3, 4)
+@pytest.mark.parametrize("own_mode", [0, 1, 2])
+def test_every_pair_exactly_once(nb, n, ranks, bi, slots, own_mode):
+    sym, one, _ = _coverage(nb, n, ranks, bi, slots, 3, 4, own_mode)
     T, G = sym.shape
     blk = np.arange(G) * 64 // bi                       # block of each subtile
-    # inside its own block an i-set meets every subtile one-sided, exactly once, and never symmetrically
+    # inside its own block an i-set meets every subtile exactly once through an own-block strip (the kernel then works the
+    # register pairs above the subtile's own pair symmetrically and that pair one-sided — or, fp64, all of it one-sided),
+    # and never through a symmetric strip
     own = blk[None, :] == np.arange(T)[:, None]
     assert np.array_equal(one, own.astype(np.int32))
     assert not sym[own].any()
