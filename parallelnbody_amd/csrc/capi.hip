@@ -165,9 +165,10 @@ void choose_algorithm(nbody_ctx *c) {
   } else {
     if (ipt == 0) {
       // measured on one box, sustained load (profiles/r02_sweep_symmetric_by_n.txt): sixteen bodies per lane win from
-      // N = 131072 up (2.71 vs 2.75 ms there, 164 vs 172 ms at N = 2^20), eight at N = 32768 and 65536 (0.722 vs 0.757 ms
-      // with four at N = 65536), four below; the Kahan form has no sixteen (its i-side compensation doubles the accumulators)
-      if (!kahan && p.n_total >= 131072) ipt = 16;
+      // N = 65536 up (0.697 vs 0.706 ms there, 2.62 vs 2.68 at N = 131072, 162 vs 170.5 ms at N = 2^20), eight at N = 32768
+      // (0.208 ms; sixteen 0.204 but with 2 265 work items for 512 slots), four below; the Kahan form has no sixteen (its
+      // i-side compensation doubles the accumulators)
+      if (!kahan && p.n_total >= 65536) ipt = 16;
       else if (p.n_total >= 32768) ipt = 8;
       else ipt = 4;
       ipt = env_int("NBODY_SYM_IPT", ipt);
