@@ -40,10 +40,12 @@ namespace {
 // bodies on one point.  sym_prep_kernel looks for that before every pass and leaves the verdict in *dup_flag: the BARE
 // launch runs only when there is none (run_if_dup == 0), the guarded launch only when there is one (run_if_dup == 1);
 // dup_flag == nullptr runs unconditionally.  Results are those of the guarded kernel either way.
-// KAHAN: the i-side register pairs are compensated (Acc3pk<true>), and so are the sums over segments in
-// reduce_j_kernel / update_sym_kernel.  The travelling j-side sums are NOT: one of them collects at most 64 * 2 * NP
-// terms before it is folded, and its rounding error (~sqrt(terms) * 2^-24 of a partial sum that is itself one of
-// thousands) vanishes in the compensated sum over the segments.  Each travelling sum is a register PAIR (lo: what the
+// KAHAN: blocked compensated summation.  Inside a 64-step subtile every sum is a plain packed-FMA chain, exactly the
+// plain kernel's loop: the i-side register pairs collect 128 terms per component, a travelling j-side sum at most
+// 64 * 2 * NP.  The rounding error of such a short chain (~sqrt(terms) * 2^-24 of a partial sum that is itself one of
+// thousands) vanishes in what follows, which IS compensated: the i-side partials are Kahan-added to the lane's running
+// sums after every subtile (Acc3pk<true>::fold), the four waves' j-side sums are added in double, and reduce_j_kernel /
+// update_sym_kernel add the segments with compensation.  Each travelling sum is a register PAIR (lo: what the
 // lanes' first bodies contributed, hi: the second bodies'), fed by three v_pk_fma_f32 per register pair and folded
 // once, after the 64 steps: six v_mov_b32_dpp per step shared by the lane's NP register pairs.
 // waves per SIMD: packed ops are 4-cycle, two waves keep a SIMD within 2 % of four.
@@ -60,9 +62,9 @@ constexpr int sym_waves(int np, bool kahan) {
 //   the block: symmetric, each unordered pair once (the pairs below P0 met these bodies when THEIR subtiles came up);
 //   pair P0 itself runs one-sided — every ordered pair inside a register pair's 512 bodies is evaluated from both
 //   ends, the self pair (d == 0) dropped by the guard — and credits nothing to the j side.
-template <int NP, int P0, bool ONE, int ZMODE, bool BARE, bool KAHAN>
+template <int NP, int P0, bool ONE, int ZMODE, bool BARE>
 __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[NP], const f2 (&zi)[NP], const f2 (&nmi)[NP],
-                                            Acc3pk<KAHAN> (&acc)[NP], const float4 *sp, f2 zp2, f2 one2, float &ox, float &oy,
+                                            Acc3pk<false> (&acc)[NP], const float4 *sp, f2 zp2, f2 one2, float &ox, float &oy,
                                             float &oz) {
   constexpr int NA = NP - P0;                                     // active register pairs
   // steps in flight: four for one or two register pairs, two from four pairs up; the own-block forms (a small share
@@ -114,12 +116,12 @@ __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[N
 }
 
 // own-block subtile in register pair pc's slots: pick the instantiation (pc is wave-uniform)
-template <int NP, int PC, int ZMODE, bool BARE, bool KAHAN>
+template <int NP, int PC, int ZMODE, bool BARE>
 __device__ __forceinline__ void own_block_subtile(int pc, const f2 (&xi)[NP], const f2 (&yi)[NP], const f2 (&zi)[NP],
-                                                  const f2 (&nmi)[NP], Acc3pk<KAHAN> (&acc)[NP], const float4 *sp, f2 zp2,
+                                                  const f2 (&nmi)[NP], Acc3pk<false> (&acc)[NP], const float4 *sp, f2 zp2,
                                                   f2 one2, float &ox, float &oy, float &oz) {
-  if (pc == PC) sym_subtile<NP, PC, true, ZMODE, BARE, KAHAN>(xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
-  else if constexpr (PC + 1 < NP) own_block_subtile<NP, PC + 1, ZMODE, BARE, KAHAN>(pc, xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
+  if (pc == PC) sym_subtile<NP, PC, true, ZMODE, BARE>(xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
+  else if constexpr (PC + 1 < NP) own_block_subtile<NP, PC + 1, ZMODE, BARE>(pc, xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
 }
 
 using lds_f4 = __attribute__((address_space(3))) float4;
@@ -155,7 +157,11 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
   asm volatile("" : "+v"(zp2), "+v"(one2));
 
   f2 xi[NP], yi[NP], zi[NP], nmi[NP];
-  Acc3pk<KAHAN> a[NP];
+  // i-side sums.  Plain: `a` runs through the whole strip.  KAHAN: `a` collects one subtile (64 steps, 128 terms per
+  // component) with plain packed FMAs — the loop is the plain kernel's — and is then folded, compensated, into `ka`:
+  // twelve packed ops per register pair and subtile instead of nine more per STEP.
+  Acc3pk<false> a[NP];
+  Acc3pk<true> ka[KAHAN ? NP : 1];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const float4 pa = posg[i0 + t + (2 * p) * kBlock], pb = posg[i0 + t + (2 * p + 1) * kBlock];
@@ -180,9 +186,13 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
       const float4 *sp = &sh_pos[buf][sub][lane + 64];
       float ox, oy, oz;
       if (!own_block)
-        sym_subtile<NP, 0, false, ZMODE, BARE, KAHAN>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+        sym_subtile<NP, 0, false, ZMODE, BARE>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
       else   // the subtile's bodies sit in the slots of register pair (offset from the i-set's first body) / 512
-        own_block_subtile<NP, 0, ZMODE, BARE, KAHAN>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+        own_block_subtile<NP, 0, ZMODE, BARE>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+      if (KAHAN) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { ka[p].fold(a[p]); a[p] = Acc3pk<false>(); }
+      }
       sh_acc[wave][0][sub * 64 + lane] = ox; sh_acc[wave][1][sub * 64 + lane] = oy; sh_acc[wave][2][sub * 64 + lane] = oz;
     }
     __syncthreads();   // the four waves' tile sums are complete; the next tile has landed
@@ -215,8 +225,9 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
   float4 *__restrict__ Pi = pool + (size_t)slot_i + te;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    Pi[(2 * p) * kBlock] = make_float4(a[p].x.x, a[p].y.x, a[p].z.x, 0.f);
-    Pi[(2 * p + 1) * kBlock] = make_float4(a[p].x.y, a[p].y.y, a[p].z.y, 0.f);
+    const f2 sx = KAHAN ? ka[KAHAN ? p : 0].x : a[p].x, sy = KAHAN ? ka[KAHAN ? p : 0].y : a[p].y, sz = KAHAN ? ka[KAHAN ? p : 0].z : a[p].z;
+    Pi[(2 * p) * kBlock] = make_float4(sx.x, sy.x, sz.x, 0.f);
+    Pi[(2 * p + 1) * kBlock] = make_float4(sx.y, sy.y, sz.y, 0.f);
   }
 }
 

@@ -45,6 +45,14 @@ template <> struct Acc3pk<true> {
     sum = t;
   }
   __device__ __forceinline__ void add(f2 s, f2 dx, f2 dy, f2 dz) { kadd(x, cx, s, dx); kadd(y, cy, s, dy); kadd(z, cz, s, dz); }
+  // sum += v with compensation (v: a short plain partial sum)
+  static __device__ __forceinline__ void kadd1(f2 &sum, f2 &c, f2 v) {
+    const f2 yv = v - c;
+    const f2 t = sum + yv;
+    c = (t - sum) - yv;
+    sum = t;
+  }
+  __device__ __forceinline__ void fold(const Acc3pk<false> &p) { kadd1(x, cx, p.x); kadd1(y, cy, p.y); kadd1(z, cz, p.z); }
 };
 
 
