@@ -164,11 +164,11 @@ void choose_algorithm(nbody_ctx *c) {
     if (ipt != 2 && ipt != 4) return;
   } else {
     if (ipt == 0) {
-      // measured on one box, sustained load (profiles/r02_sweep_symmetric_by_n.txt): sixteen bodies per lane win from
-      // N = 65536 up (0.697 vs 0.706 ms there, 2.62 vs 2.68 at N = 131072, 162 vs 170.5 ms at N = 2^20), eight at N = 32768
-      // (0.208 ms; sixteen 0.204 but with 2 265 work items for 512 slots), four below; the Kahan form has no sixteen (its
-      // i-side compensation doubles the accumulators)
-      if (!kahan && p.n_total >= 65536) ipt = 16;
+      // measured on one box, sustained load (profiles/r02_sweep_symmetric_by_n.txt, r02_tune_mid_sizes.txt): sixteen bodies
+      // per lane win wherever the symmetric pass runs (N = 32768: 0.206 vs 0.211 ms with eight, 65536: 0.691 vs 0.718,
+      // 131072: 2.62 vs 2.70, 2^20: 162 vs 170.5 ms); the Kahan form has no sixteen (its running compensated sums double the
+      // accumulators) and runs eight
+      if (!kahan && p.n_total >= 32768) ipt = 16;
       else if (p.n_total >= 32768) ipt = 8;
       else ipt = 4;
       ipt = env_int("NBODY_SYM_IPT", ipt);
