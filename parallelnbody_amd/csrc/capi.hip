@@ -53,7 +53,8 @@ struct nbody_ctx {
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
   // symmetric algorithm (kernels_sym.hip, kernels_sym64.hip; plan: sym_plan.h)
   bool sym = false;
-  int sym_bi = 0, sym_pad = 0, sym_items_n = 0, sym_nsrc = 1, sym_slots = 0, sym_k = 0, sym_min_sub = 0;
+  int sym_bi = 0, sym_pad = 0, sym_items_n = 0, sym_nsrc = 1, sym_slots = 0, sym_min_sub = 0;
+  double sym_k = 0.0;
   size_t sym_pool_elems = 0;
   nbody::SymPlan *plan = nullptr;                  // host copy, dropped once uploaded
   void *sym_pool = nullptr, *sym_items = nullptr, *sym_iptr = nullptr, *sym_ioff = nullptr, *sym_jptr = nullptr,
@@ -186,12 +187,23 @@ void choose_algorithm(nbody_ctx *c) {
   const int np = ipt / 2;
   const int wps = f64 ? (ipt == 4 ? 2 : 4) : (np == 8 ? 2 : (np == 4 ? (kahan ? 2 : 3) : (kahan && np == 2 ? 3 : 4)));
   c->sym_slots = cus * wps;
-  // a strip = 1/(K * slots) of the work still to hand out.  K = 3 leaves the first strips too long for slots of unequal
-  // speed to even out (N = 2^20: 170.1 ms; fp64 464 ms); 6: 164.1 / 400; 24: 163.3 / 397 at three times the segments.
-  c->sym_k = env_int("NBODY_SYM_K", 6);
-  // shortest strip, in 64-body subtiles: small systems need the finest grain to fill 1024 SIMDs evenly (N = 32768:
-  // 0.211 ms with 1, 0.230 with 4), large ones save segments with whole 256-body tiles
-  c->sym_min_sub = env_int("NBODY_SYM_MIN_SUB", p.n_total < 65536 ? 1 : (p.n_total < 262144 ? 2 : 4));
+  // A strip = 1/(K * slots) of the work still to hand out.  Large K = many short strips = best balance of the force pass but
+  // one i-side segment (bodies-per-i-set x 16 B, written and read back) per strip; small K = a first round of long strips.
+  // Long passes want K = 6 (N = 2^20, force pass: K = 3 170.1 ms — slots of unequal speed drift apart over 100 ms —, 6
+  // 164.1, 24 163.3 at three times the segments; profiles/r02_tune_guided_k_n2p20.txt).  Short passes do not care about K
+  // but their update pays for every segment (whole step, profiles/r02_tune_whole_step_mid_sizes.txt: N = 65536 K = 6
+  // 0.781 ms, K <= 3 0.752; N = 131072 2.780 vs 2.653; N = 32768 0.2675 vs 0.2518).
+  // What decides is how long the pass runs (fp64 at N = 262144 takes 25 ms and wants K = 6: 25.5 vs 26.9 ms with 3), so K
+  // follows the expected duration of this context's share: >= 15 ms 6, >= 5 ms 3, >= 0.5 ms 1.5, below 1.
+  {
+    const double rate = f64 ? 2.7e12 : (kahan ? 6.0e12 : 6.6e12);                      // interactions per second, measured
+    const double est_ms = (double)p.n_total * (double)p.i_count / rate * 1e3;
+    c->sym_k = est_ms >= 15.0 ? 6.0 : (est_ms >= 5.0 ? 3.0 : (est_ms >= 0.5 ? 1.5 : 1.0));
+  }
+  if (const char *e = getenv("NBODY_SYM_K")) { const int v = atoi(e); if (v >= 1) c->sym_k = v; }                     // tuning only
+  if (const char *e = getenv("NBODY_SYM_K_X10")) { const int v = atoi(e); if (v >= 5) c->sym_k = v / 10.0; }         // tuning only
+  // shortest strip, in 64-body subtiles: whole 256-body tiles from N = 131072, half tiles below (same table)
+  c->sym_min_sub = env_int("NBODY_SYM_MIN_SUB", p.n_total < 131072 ? 2 : 4);
   nbody::SymPlan *plan = new (std::nothrow) nbody::SymPlan();
   if (!plan) return;
   std::string why;
@@ -570,7 +582,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
       int slots = 1024;
       while (slots < 2 * p.n_total) slots *= 2;
       c->sym_dup_slots = slots;
-      if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 8)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
+      if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
     }
     if ((e = hipMalloc(&c->sym_send, (size_t)p.n_total * c->elem)) != hipSuccess) return bail(e, "hipMalloc send row");
     c->own_send = true;
@@ -592,7 +604,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
       int slots = 1024;
       while (slots < 2 * p.n_total) slots *= 2;
       c->sym_dup_slots = slots;
-      if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 8)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
+      if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
     }
   }
   if ((e = hipMalloc(&c->scratch, 64)) != hipSuccess) return bail(e, "hipMalloc scratch");

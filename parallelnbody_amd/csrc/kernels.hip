@@ -518,7 +518,7 @@ hipError_t launch_forces_t(const ForceLaunch &L, hipStream_t s) {
       if (L.eps2 > 0.0) {
         NBODY_LAUNCH_PK(Z_SOFT, L.eps2, nullptr);
       } else if (L.dup_table != nullptr) {
-        hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 8, s);   // slots + {flag, near-origin count}
+        hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 64, s);   // slots + {flag, near-origin count}
         if (e0 != hipSuccess) return e0;
         int *flag = (int *)((unsigned long long *)L.dup_table + L.dup_slots);
         hipLaunchKernelGGL(dup_detect_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), dim3(kBlock), 0, s,

@@ -245,7 +245,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   int *flag = detect ? (int *)((unsigned long long *)L.dup_table + L.dup_slots) : nullptr;
   // positions -> (x, y, z, G m) with far-away zero-mass padding; the coincident-body detector rides along
   if (detect) {
-    hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 8, s);   // slots + {flag, near-origin count}
+    hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 64, s);   // slots + {flag, near-origin count}
     if (e0 != hipSuccess) return e0;
     hipLaunchKernelGGL(sym_prep_kernel<true>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
                        L.n_pad, (float)L.G, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag);

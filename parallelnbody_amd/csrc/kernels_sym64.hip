@@ -165,7 +165,7 @@ hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
   if (L.eps2 > 0.0) {
     NBODY_SYM64(true, true, nullptr, 0);
   } else if (L.dup_table != nullptr) {
-    hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 8, s);   // slots + {flag, near-origin count}
+    hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 64, s);   // slots + {flag, near-origin count}
     if (e0 != hipSuccess) return e0;
     int *flag = (int *)((unsigned long long *)L.dup_table + L.dup_slots);
     hipLaunchKernelGGL(dup_detect_kernel<double>, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s,

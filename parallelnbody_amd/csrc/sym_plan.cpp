@@ -44,11 +44,11 @@ bool fail(std::string *err, const char *msg) {
 
 }  // namespace
 
-bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, int k_guided, int min_sub, int own_mode,
+bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, double k_guided, int min_sub, int own_mode,
                     SymPlan *out, std::string *err) {
   if (n_total <= 0 || i_count <= 0 || i_begin < 0 || i_begin + i_count > n_total) return fail(err, "bad body range");
   if (bi < 64 || bi % 64 != 0) return fail(err, "bodies per i-set must be a multiple of 64");
-  if (slots < 1 || k_guided < 1 || min_sub < 1) return fail(err, "bad scheduling parameters");
+  if (slots < 1 || !(k_guided >= 0.5) || min_sub < 1) return fail(err, "bad scheduling parameters");
   SymPlan P;
   P.bi = bi;
   P.T = (n_total + bi - 1) / bi;
@@ -95,11 +95,11 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, in
   // guided self-scheduling: each strip takes 1/(k * slots) of the cost still to hand out
   long long remaining = total_cost;
   uint64_t pool = 0;
-  const long long kp = (long long)k_guided * slots;
+  const double kp = k_guided * slots;
   for (const Range &r : ranges) {
     int pos = 0;
     while (pos < r.n_sub) {
-      const long long target = remaining / kp;
+      const long long target = (long long)((double)remaining / kp);
       long long cost = 0;
       int n = 0;
       while (pos + n < r.n_sub && (n < min_sub || cost + subtile_cost(r, pos + n, bi, own_mode) <= target)) {
@@ -172,7 +172,7 @@ extern "C" int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t
   nbody::SymPlan P;
   std::string why;
   if (i_count == 0) i_count = n_total - i_begin;
-  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided, min_sub, own_mode, &P, &why))
+  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, (double)k_guided, min_sub, own_mode, &P, &why))
     return NBODY_ERR_UNSUPPORTED;
   if (n_items) *n_items = (int32_t)P.items.size();
   if (pool_elems) *pool_elems = P.pool_elems;

@@ -52,7 +52,7 @@ struct SymPlan {
 // min_sub: shortest strip, in subtiles; own_mode: how the kernel treats strips inside the i-set's own block — 1 (fp32):
 // register pairs above the subtile's own pair symmetric, that pair one-sided, j-side sums written; 2 (fp64): the same
 // slot by slot; 0: one-sided throughout, no j-side sums (no kernel does that any more; kept for the cost model's tests).  Returns false (and says why) when the owned range does not fit the plan.
-bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, int k_guided, int min_sub, int own_mode,
+bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, double k_guided, int min_sub, int own_mode,
                     SymPlan *out, std::string *err);
 
 }  // namespace nbody

@@ -18,7 +18,7 @@ rows = rows[skip:]
 stats = {}
 for k in range(1, len(rows)):
     s, e, name = rows[k]
-    short = name.split("(")[0].replace("void nbody::(anonymous namespace)::", "")[:70]
+    short = name.replace("(anonymous namespace)::", "").replace("void nbody::", "").split("(")[0][:70]
     d = stats.setdefault(short, [0, 0.0, 0.0])
     d[0] += 1
     d[1] += (e - s) * 1e-3
