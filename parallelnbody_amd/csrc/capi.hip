@@ -583,6 +583,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
       while (slots < 2 * p.n_total) slots *= 2;
       c->sym_dup_slots = slots;
       if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
+      if ((e = hipMemset(c->sym_dup_table, 0, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMemset duplicate detector");
     }
     if ((e = hipMalloc(&c->sym_send, (size_t)p.n_total * c->elem)) != hipSuccess) return bail(e, "hipMalloc send row");
     c->own_send = true;

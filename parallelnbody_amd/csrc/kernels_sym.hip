@@ -244,9 +244,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   const bool detect = L.eps2 == 0.0 && L.dup_table != nullptr;
   int *flag = detect ? (int *)((unsigned long long *)L.dup_table + L.dup_slots) : nullptr;
   // positions -> (x, y, z, G m) with far-away zero-mass padding; the coincident-body detector rides along
-  if (detect) {
-    hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 64, s);   // slots + {flag, near-origin count}
-    if (e0 != hipSuccess) return e0;
+  if (detect) {      // the table and its flag words are zero: cleared at creation and by every pass's reduce_j_kernel
     hipLaunchKernelGGL(sym_prep_kernel<true>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
                        L.n_pad, (float)L.G, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag);
   } else {
@@ -283,10 +281,12 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   dim3 rgrid((L.n_total + kBlock - 1) / kBlock);
   if (L.kahan)
     hipLaunchKernelGGL((reduce_j_kernel<float, true>), rgrid, block, 0, s, (const float4 *)L.pool, (float4 *)L.send,
-                       (const unsigned int *)L.j_ptr, (const unsigned int *)L.j_off, L.n_total);
+                       (const unsigned int *)L.j_ptr, (const unsigned int *)L.j_off, L.n_total,
+                       (unsigned long long *)L.dup_table, detect ? L.dup_slots + 8 : 0);
   else
     hipLaunchKernelGGL((reduce_j_kernel<float, false>), rgrid, block, 0, s, (const float4 *)L.pool, (float4 *)L.send,
-                       (const unsigned int *)L.j_ptr, (const unsigned int *)L.j_off, L.n_total);
+                       (const unsigned int *)L.j_ptr, (const unsigned int *)L.j_off, L.n_total,
+                       (unsigned long long *)L.dup_table, detect ? L.dup_slots + 8 : 0);
   return hipGetLastError();
 }
 

@@ -165,8 +165,7 @@ hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
   if (L.eps2 > 0.0) {
     NBODY_SYM64(true, true, nullptr, 0);
   } else if (L.dup_table != nullptr) {
-    hipError_t e0 = hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 64, s);   // slots + {flag, near-origin count}
-    if (e0 != hipSuccess) return e0;
+    // the table and its flag words are zero: cleared at creation and by every pass's reduce_j_kernel
     int *flag = (int *)((unsigned long long *)L.dup_table + L.dup_slots);
     hipLaunchKernelGGL(dup_detect_kernel<double>, dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s,
                        (const double4 *)L.posm, L.n_total, (unsigned long long *)L.dup_table,
@@ -182,7 +181,8 @@ hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((reduce_j_kernel<double, false>), dim3((L.n_total + kBlock - 1) / kBlock), block, 0, s,
                      (const double4 *)L.pool, (double4 *)L.send, (const unsigned int *)L.j_ptr,
-                     (const unsigned int *)L.j_off, L.n_total);
+                     (const unsigned int *)L.j_off, L.n_total, (unsigned long long *)L.dup_table,
+                     (L.eps2 == 0.0 && L.dup_table != nullptr) ? L.dup_slots + 8 : 0);
   return hipGetLastError();
 }
 

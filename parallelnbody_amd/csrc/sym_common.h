@@ -95,13 +95,19 @@ __global__ __launch_bounds__(kBlock) void sym_prep_kernel(const float4 *__restri
 // send[b] = sum, in item order, of the j-side segments that cover body b: what this rank's pairs contribute to b's
 // acceleration as the "other" body.  One wave per 64-body granule; the granule's segment list is CSR (sym_plan.h).
 // KAHAN: segments are added with a compensated sum.
+// It also clears the coincident-body detector's table and flag words for the NEXT pass (they were last read by this
+// pass's force kernels, which precede this launch on the stream): a hipMemsetAsync per pass costs a launch plus ~6 us of
+// host time in front of it, which at N = 32768 is 4 % of the step.  The table is zeroed once at creation; a pass that dies
+// between the detector and this kernel leaves stale entries, which can only select the guarded kernel — never a wrong sum.
 template <typename R, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void reduce_j_kernel(const typename SymVec<R>::type *__restrict__ pool,
                                                           typename SymVec<R>::type *__restrict__ send,
                                                           const unsigned int *__restrict__ j_ptr,
-                                                          const unsigned int *__restrict__ j_off, int n_total) {
+                                                          const unsigned int *__restrict__ j_off, int n_total,
+                                                          unsigned long long *__restrict__ dup_table, int dup_words) {
   using V = typename SymVec<R>::type;
   const int b = blockIdx.x * kBlock + threadIdx.x;
+  for (int w = b; w < dup_words; w += gridDim.x * kBlock) dup_table[w] = 0ull;
   if (b >= n_total) return;
   const int g = b >> 6, l = b & 63;
   R sx = 0, sy = 0, sz = 0, cx = 0, cy = 0, cz = 0;
