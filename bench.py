@@ -148,6 +148,7 @@ def main():
     import numpy as np
     import torch
     import parallelnbody_amd as nb
+    from parallelnbody_amd.sharded import hip_engine_factory
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,8 +179,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def factory(*a, **kw):
+        # NBODY_REHEARSE_CREATE_FAILURE=<rank>: rehearsal (tests/test_two_rank_gpu.py) of one rank failing to create its
+        # symmetric engine; everything else is the product's own factory
+        if os.environ.get("NBODY_REHEARSE_CREATE_FAILURE") == str(rank) and kw.get("algorithm", 0) == 0:
+            raise RuntimeError("NBODY_REHEARSE_CREATE_FAILURE")
+        return hip_engine_factory(*a, **kw)
+
     def build(algorithm):
-        sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device=f"cuda:{local_rank}",
+        sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device=f"cuda:{local_rank}", engine_factory=factory,
                                    precision=args.precision, eps=args.eps, tile=args.tile, i_per_thread=args.ipt,
                                    j_split=args.jsplit, time_kernels=True,
                                    algorithm={"auto": 0, "tiled": 1, "symmetric": 2}[algorithm],

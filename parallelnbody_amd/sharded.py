@@ -33,7 +33,7 @@ def partition(n_total, world_size, rank):
     return rank * cnt, cnt
 
 
-def _hip_engine_factory(n_total, i_begin, i_count, posm_tensor, device_index, stream=None, **kw):
+def hip_engine_factory(n_total, i_begin, i_count, posm_tensor, device_index, stream=None, **kw):
     eng = NBodyEngine(n_total, i_begin=i_begin, i_count=i_count, device=device_index, **kw)
     eng.bind_device_state(posm=posm_tensor)
     if stream is not None:
@@ -65,18 +65,15 @@ class ShardedSimulation:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         # the replicated position+mass array lives in a torch tensor so that torch.distributed can gather into it
         self.posm = torch.empty((self.n_total, 4), dtype=tdt, device=self.device)
-        factory = engine_factory or _hip_engine_factory
+        factory = engine_factory or hip_engine_factory
         dev_index = self.device.index if self.device.type == "cuda" else -1
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        if engine_factory is None:
+        if self.stream is not None:          # GPU engines launch on the simulation's stream (hip_engine_factory's `stream`)
             engine_kw = dict(engine_kw, stream=self.stream)
         # Engine creation can fail on one rank only (memory, an unsupported geometry).  The ranks agree on the outcome
         # with ONE matched collective, the first this object issues, before anything else can diverge.
         self.engine, failure = None, None
         try:
-            import os
-            if os.environ.get("NBODY_REHEARSE_CREATE_FAILURE") == str(rank) and engine_kw.get("algorithm", 0) == 0:
-                raise RuntimeError("NBODY_REHEARSE_CREATE_FAILURE")      # rehearsal of the path below (tests, tools)
             self.engine = factory(self.n_total, self.i_begin, self.i_count, self.posm, dev_index, **engine_kw)
         except Exception as e:  # noqa: BLE001
             if world_size == 1:
