@@ -272,7 +272,8 @@ NBODY_API int nbody_get_launch_config(nbody_ctx *ctx, int32_t *tile, int32_t *i_
 /* Name of the force kernel this context launches (for logs and profiles). */
 NBODY_API const char *nbody_force_kernel_name(const nbody_ctx *ctx);
 
-/* NBODY_ALGO_* actually in use, and (symmetric only) the super-tile size in bodies. */
+/* NBODY_ALGO_* actually in use, and (symmetric only) the bodies per i-set = per block of the ring, 256 x i_per_thread
+ * (the parameter keeps its round-1 name). */
 NBODY_API int nbody_get_algorithm(nbody_ctx *ctx, int32_t *algorithm, int32_t *super_tile);
 
 /* Host only (no device needed): the work plan of the symmetric force pass for a context owning [i_begin, i_begin +

@@ -12,7 +12,9 @@
 //     to lane (v_mov_b32_dpp wave_ror:1; ds_add_f32 on LDS was measured ~190 cycles per wave instruction and is not
 //     used).  After 64 steps the sums are home; the four waves' sums are added in wave order into the item's j-side
 //     segment;
-//   * strips inside the i-set's own block run the plain one-sided step (every ordered pair, d == 0 skipped);
+//   * strips inside the i-set's own block: the register pairs above the subtile's own pair meet it symmetrically (their
+//     bodies are other bodies of the block), its own pair one-sided (every ordered pair of its 512 bodies from both
+//     ends, d == 0 skipped), the pairs below are idle — they met these bodies when their own subtiles came up;
 //   * results go to item-private segments of the partial-sum pool.  reduce_j_kernel folds the j-side segments into one
 //     row per body (the send buffer of the all-to-all when the bodies are sharded over GPUs); update_sym_kernel adds a
 //     body's i-side segments and the received rows in a fixed order.  No global atomics: bit-reproducible.

@@ -128,7 +128,7 @@ class ShardedSimulation:
             torch.cuda.synchronize(self.device)
 
     def _check_same_geometry(self):
-        """Every rank must have arrived at the same algorithm and super tiles: which rank evaluates which body pair
+        """Every rank must have arrived at the same algorithm and i-set size: which rank evaluates which body pair
         depends on them, and a disagreement would double-count or drop pairs silently."""
         if not hasattr(self.engine, "launch_config"):
             return
@@ -140,7 +140,7 @@ class ShardedSimulation:
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         if lo.tolist() != hi.tolist():
-            raise RuntimeError(f"ranks disagree on the force-pass geometry (algorithm, super tile, exchange ranks): "
+            raise RuntimeError(f"ranks disagree on the force-pass geometry (algorithm, bodies per i-set, exchange ranks): "
                                f"this rank {mine}, minimum {lo.tolist()}, maximum {hi.tolist()}")
 
     def _forces(self):
