@@ -228,7 +228,10 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
   const int ntiles = (j1 > j0) ? (j1 - j0 + TILE - 1) / TILE : 0;
 
   f2 xi[NP], yi[NP], zi[NP];
-  Acc3pk<KAHAN> a[NP];
+  // KAHAN = blocked compensated summation (as in kernels_sym.hip): a tile's TILE terms per component are a plain packed-FMA
+  // chain in `a`, which is then Kahan-added to the running sums `ka`; update_kernel adds the chunks with compensation
+  Acc3pk<false> a[NP];
+  Acc3pk<true> ka[KAHAN ? NP : 1];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const float4 p0 = posm[i_begin + min(ibase + t + (2 * p) * kBlock, i_count - 1)];
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
         float4 pj[JB];
 #pragma unroll
         for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
-        pair_group_pk<NP, JB, Z_BARE, KAHAN>(xi, yi, zi, pj, zp2, one2, a);
+        pair_group_pk<NP, JB, Z_BARE, false>(xi, yi, zi, pj, zp2, one2, a);
       }
     } else {
 #pragma unroll 2
@@ -286,8 +289,12 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
         float4 pj[JB];
 #pragma unroll
         for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
-        pair_group_pk<NP, JB, ZMODE, KAHAN>(xi, yi, zi, pj, zp2, one2, a);
+        pair_group_pk<NP, JB, ZMODE, false>(xi, yi, zi, pj, zp2, one2, a);
       }
+    }
+    if (KAHAN) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { ka[p].fold(a[p]); a[p] = Acc3pk<false>(); }
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
@@ -296,8 +303,9 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int il0 = ibase + t + (2 * p) * kBlock, il1 = il0 + kBlock;
-    if (il0 < i_count) accp[(size_t)c * i_count + il0] = make_float4(a[p].x.x, a[p].y.x, a[p].z.x, 0.f);
-    if (il1 < i_count) accp[(size_t)c * i_count + il1] = make_float4(a[p].x.y, a[p].y.y, a[p].z.y, 0.f);
+    const f2 sx = KAHAN ? ka[KAHAN ? p : 0].x : a[p].x, sy = KAHAN ? ka[KAHAN ? p : 0].y : a[p].y, sz = KAHAN ? ka[KAHAN ? p : 0].z : a[p].z;
+    if (il0 < i_count) accp[(size_t)c * i_count + il0] = make_float4(sx.x, sy.x, sz.x, 0.f);
+    if (il1 < i_count) accp[(size_t)c * i_count + il1] = make_float4(sx.y, sy.y, sz.y, 0.f);
   }
 }
 
