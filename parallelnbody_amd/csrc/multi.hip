@@ -98,6 +98,7 @@ int gather_positions(Multi *m) {
   RCCL_TRY(m, m->rccl.GroupStart(), "ncclGroupStart");
   for (int k = 0; k < m->n_dev; ++k) {
     char *base = (char *)m->posm[(size_t)k];
+    (void)hipSetDevice(m->devices[(size_t)k]);              // one thread, several devices: each call on its communicator's device
     ncclResult_t r = m->rccl.AllGather(base + (size_t)k * m->slice * m->elem, base, (size_t)m->slice * 4, ty, m->comm[(size_t)k],
                                        m->stream[(size_t)k]);
     if (r != ncclSuccess) { (void)m->rccl.GroupEnd(); return rccl_fail(m, r, "ncclAllGather(positions)"); }
@@ -114,6 +115,7 @@ int exchange_sums(Multi *m) {
   RCCL_TRY(m, m->rccl.GroupStart(), "ncclGroupStart");
   for (int k = 0; k < m->n_dev; ++k)
     for (int q = 0; q < m->n_dev; ++q) {
+      (void)hipSetDevice(m->devices[(size_t)k]);
       ncclResult_t r = m->rccl.Send((const char *)m->ex_send[(size_t)k] + (size_t)q * m->ex_bytes, count, ty, q, m->comm[(size_t)k],
                                     m->stream[(size_t)k]);
       if (r == ncclSuccess)
