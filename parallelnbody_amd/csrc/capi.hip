@@ -108,7 +108,7 @@ void choose_geometry(nbody_ctx *c) {
   const nbody_params &p = c->p;
   c->tile = p.tile > 0 ? p.tile : 256;
   if (p.i_per_thread > 0) c->ipt = p.i_per_thread > 4 ? 4 : p.i_per_thread;   // 8 and 16 exist for the symmetric kernel only
-  else c->ipt = (p.precision == NBODY_PREC_F64) ? 1 : (p.n_total >= 65536 ? 4 : (p.n_total >= 8192 ? 2 : 1));
+  else c->ipt = (p.precision == NBODY_PREC_F64) ? 1 : (p.n_total >= 8192 ? 4 : 1);   // N = 16384: 0.102 ms per step with 4, 0.106 with 2
   int js;
   if (p.j_split > 0) {
     js = p.j_split;
@@ -154,7 +154,9 @@ void choose_algorithm(nbody_ctx *c) {
   c->sym = false;
   if (p.algorithm == NBODY_ALGO_TILED) return;
   if (p.zero_mode == NBODY_ZERO_SELECT) return;                         // compare+select lives in the one-sided kernel only
-  if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < env_int("NBODY_SYM_MIN_N", 32768)) return;
+  // whole steps, one box (profiles/r02_threshold_symmetric_vs_one_sided.txt): N = 16384 one-sided 0.102 ms vs symmetric
+  // 0.108, N = 20480 0.153 vs 0.131, N = 32768 0.328 vs 0.265
+  if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < env_int("NBODY_SYM_MIN_N", 20480)) return;
   const bool f64 = p.precision == NBODY_PREC_F64, kahan = p.precision == NBODY_PREC_F32_KAHAN;
   if (f64 && !(p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT)) return;
   // bodies per lane.  fp32: 2 * register pairs; more of them amortise the travelling sums' dpp moves over more
@@ -170,7 +172,7 @@ void choose_algorithm(nbody_ctx *c) {
       // 131072: 2.62 vs 2.70, 2^20: 162 vs 170.5 ms); the Kahan form has no sixteen (its running compensated sums double the
       // accumulators) and runs eight
       if (!kahan && p.n_total >= 32768) ipt = 16;
-      else if (p.n_total >= 32768) ipt = 8;
+      else if (p.n_total >= 24576) ipt = 8;
       else ipt = 4;
       ipt = env_int("NBODY_SYM_IPT", ipt);
       if (kahan && ipt == 16) ipt = 8;
