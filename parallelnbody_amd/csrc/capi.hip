@@ -62,6 +62,11 @@ struct nbody_ctx {
   void *sym_send = nullptr, *sym_recv = nullptr;   // exchange buffers (recv == send when the context owns all bodies)
   void *sym_dup_table = nullptr;                   // coincident-body detector (hash slots + flag)
   int sym_dup_slots = 0;
+  // fused single-device fp32 stepping: the update prepares the next pass (posg + the OTHER detector table)
+  void *sym_dup_table2 = nullptr;
+  int sym_dup_cur = 0;                             // which of the two tables holds the verdict on the current positions
+  bool sym_posg_valid = false;                     // posg (and that table) describe the current positions
+  bool posm_escaped = false;                       // the caller holds / owns the position buffer: it may change behind our back
   bool own_send = false, own_recv = false;
   bool step_open = false;      // nbody_step_begin done, nbody_step_end pending
   int64_t steps_done = 0;      // updates applied since the state was set (saved in checkpoints)
@@ -228,6 +233,14 @@ void choose_algorithm(nbody_ctx *c) {
   c->sym = true;
 }
 
+// Fused stepping (update_sym_fused_kernel) is for fp32 symmetric contexts that own all bodies AND their position buffer:
+// then nothing but this library's kernels moves a body, and the update can prepare the next pass.
+bool sym_fused(const nbody_ctx *c) {
+  static const bool off = [] { const char *e = getenv("NBODY_SYM_NO_FUSE"); return e && e[0] == '1'; }();   // A/B measurements only
+  return !off && c->sym && c->p.precision != NBODY_PREC_F64 && c->sym_nsrc == 1 && c->own_posm && !c->posm_escaped &&
+         (c->sym_dup_table == nullptr || c->sym_dup_table2 != nullptr);
+}
+
 nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   nbody::SymLaunch L;
   L.posm = c->posm; L.posg = c->sym_posg; L.pool = c->sym_pool; L.items = c->sym_items; L.n_items = c->sym_items_n;
@@ -240,6 +253,14 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps;
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
   L.dup_table = c->sym_dup_table; L.dup_slots = c->sym_dup_slots;
+  if (sym_fused(c)) {
+    L.fused = 1;
+    L.skip_prep = c->sym_posg_valid ? 1 : 0;
+    if (c->sym_dup_table) {
+      L.dup_table = c->sym_dup_cur ? c->sym_dup_table2 : c->sym_dup_table;
+      L.dup_table_next = c->sym_dup_cur ? c->sym_dup_table : c->sym_dup_table2;
+    }
+  }
   return L;
 }
 
@@ -337,8 +358,16 @@ int run_forces(nbody_ctx *c) {
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
-  if (c->sym) HIP_TRY(c, nbody::launch_forces_sym(make_sym_launch(c), c->stream));
-  else HIP_TRY(c, nbody::launch_forces(make_launch(c), c->stream));
+  if (c->sym) {
+    const nbody::SymLaunch L = make_sym_launch(c);
+    // a fused context about to run the preparation kernel again (new state): its current table may hold the entries
+    // the last update left for positions that are gone
+    if (L.fused && !L.skip_prep && L.dup_table && L.eps2 == 0.0)
+      HIP_TRY(c, hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 64, c->stream));
+    HIP_TRY(c, nbody::launch_forces_sym(L, c->stream));
+  } else {
+    HIP_TRY(c, nbody::launch_forces(make_launch(c), c->stream));
+  }
   if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
   // bound the number of live events on long untimed-drain runs
   if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) return timer_drain(c, NBODY_KERNEL_FORCES);
@@ -351,9 +380,11 @@ int run_update(nbody_ctx *c, float dt) {
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_UPDATE, &ev); if (rc) return rc; }
   if (c->theta > 0.0f)
     HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->bh_acc, 0, c->p.n_total, 1, dt, c->stream));
-  else if (c->sym)
-    HIP_TRY(c, nbody::launch_update_sym(make_sym_launch(c), c->posm, c->vel, c->acc, c->p.i_begin, c->p.i_count, dt,
-                                        c->stream));
+  else if (c->sym) {
+    const nbody::SymLaunch L = make_sym_launch(c);
+    HIP_TRY(c, nbody::launch_update_sym(L, c->posm, c->vel, c->acc, c->p.i_begin, c->p.i_count, dt, c->stream));
+    if (L.fused) { c->sym_posg_valid = true; c->sym_dup_cur ^= 1; }   // the update wrote posg and the other table
+  }
   else
     HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->accp, c->p.i_begin, c->p.i_count,
                                     c->j_split, dt, c->stream));
@@ -400,6 +431,7 @@ int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
   c->have_state = true;
   c->floor_eps2 = -1.0;
   c->steps_done = 0;
+  c->sym_posg_valid = false;
   if (c->bh) HIP_TRY(c, nbody::bh_reset_root(c->bh, c->stream));   // a new scene: root centre starts at zero again
   return NBODY_OK;
 }
@@ -586,6 +618,10 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
       c->sym_dup_slots = slots;
       if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
       if ((e = hipMemset(c->sym_dup_table, 0, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMemset duplicate detector");
+      if (p.precision != NBODY_PREC_F64 && c->sym_nsrc == 1) {       // fused stepping alternates between two tables
+        if ((e = hipMalloc(&c->sym_dup_table2, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
+        if ((e = hipMemset(c->sym_dup_table2, 0, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMemset duplicate detector");
+      }
     }
     if ((e = hipMalloc(&c->sym_send, (size_t)p.n_total * c->elem)) != hipSuccess) return bail(e, "hipMalloc send row");
     c->own_send = true;
@@ -651,6 +687,7 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->own_send && c->sym_send) (void)hipFree(c->sym_send);
   if (c->own_recv && c->sym_recv) (void)hipFree(c->sym_recv);
   if (c->sym_dup_table) (void)hipFree(c->sym_dup_table);
+  if (c->sym_dup_table2) (void)hipFree(c->sym_dup_table2);
   if (c->bh) nbody::bh_destroy(c->bh);
   if (c->bh_acc) (void)hipFree(c->bh_acc);
   if (c->d_stage) (void)hipFree(c->d_stage);
@@ -674,7 +711,10 @@ int nbody_device_ptr(nbody_ctx *c, int32_t which, void **ptr, size_t *bytes) {
   if (c && c->multi) return multi_unsupported(c, "nbody_device_ptr");
   if (!c || !ptr) return NBODY_ERR_INVALID;
   switch (which) {
-    case NBODY_BUF_POSM: *ptr = c->posm; if (bytes) *bytes = (size_t)c->p.n_total * c->elem; break;
+    case NBODY_BUF_POSM:
+      *ptr = c->posm; if (bytes) *bytes = (size_t)c->p.n_total * c->elem;
+      c->posm_escaped = true; c->sym_posg_valid = false;          // the caller may write positions from now on
+      break;
     case NBODY_BUF_VEL:  *ptr = c->vel;  if (bytes) *bytes = (size_t)c->p.i_count * c->elem; break;
     case NBODY_BUF_ACC:  *ptr = c->acc;  if (bytes) *bytes = (size_t)c->p.i_count * c->elem; break;
     default: return fail(c, NBODY_ERR_INVALID, "nbody_device_ptr: unknown buffer %d", which);
@@ -686,7 +726,7 @@ int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
   if (c && c->multi) return multi_unsupported(c, "nbody_bind_device_state");
   if (!c) return NBODY_ERR_INVALID;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (posm) { if (c->own_posm) (void)hipFree(c->posm); c->posm = posm; c->own_posm = false; }
+  if (posm) { if (c->own_posm) (void)hipFree(c->posm); c->posm = posm; c->own_posm = false; c->posm_escaped = true; c->sym_posg_valid = false; }
   if (vel)  { if (c->own_vel) (void)hipFree(c->vel);   c->vel = vel;   c->own_vel = false; }
   if (acc)  { if (c->own_acc) (void)hipFree(c->acc);   c->acc = acc;   c->own_acc = false; }
   // the caller vouches that bound buffers hold a valid state
@@ -1121,7 +1161,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
   HIP_TRY(c, hipMemcpy(c->posm, posm.data(), posm.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size(), hipMemcpyHostToDevice));
-  c->have_state = true; c->floor_eps2 = -1.0; c->step_open = false;
+  c->have_state = true; c->floor_eps2 = -1.0; c->step_open = false; c->sym_posg_valid = false;
   c->steps_done = h.steps_done;
   // Barnes-Hut: the opening angle and the root of the next tree (the previous tree's CoM, OctreeSearch.cpp:77-79) are
   // part of the trajectory.  Only contexts that can run the walk take them over.

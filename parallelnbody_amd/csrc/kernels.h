@@ -58,6 +58,11 @@ struct SymLaunch {
   double eps2;          // > 0 softened / floor; == 0 exact d == 0 skip (clamp form)
   void *dup_table;      // eps2 == 0 only: dup_slots x 8-byte hash slots + one flag word; nullptr = always run the guarded kernel
   int dup_slots;        // power of two >= 2 * n_total
+  // fused single-device fp32 stepping (update_sym_fused_kernel): the update folds the j-side rows itself and prepares the
+  // next pass (posg, the other detector table); a force pass then launches no prep and no reduce_j kernel
+  int fused = 0;              // launch_forces_sym: no reduce_j; launch_update_sym: the fused kernel
+  int skip_prep = 0;          // posg and dup_table are already those of the current positions
+  void *dup_table_next = nullptr;
 };
 // forces + fold of the j-side rows into L.send
 hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);

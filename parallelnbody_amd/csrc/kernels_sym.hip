@@ -246,7 +246,9 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   const bool detect = L.eps2 == 0.0 && L.dup_table != nullptr;
   int *flag = detect ? (int *)((unsigned long long *)L.dup_table + L.dup_slots) : nullptr;
   // positions -> (x, y, z, G m) with far-away zero-mass padding; the coincident-body detector rides along
-  if (detect) {      // the table and its flag words are zero: cleared at creation and by every pass's reduce_j_kernel
+  if (L.skip_prep) {
+    // the previous update_sym_fused_kernel left posg and the detector's verdict for exactly these positions
+  } else if (detect) {      // the table and its flag words are zero: cleared at creation and by every pass's fold
     hipLaunchKernelGGL(sym_prep_kernel<true>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
                        L.n_pad, (float)L.G, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag);
   } else {
@@ -279,7 +281,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
 #undef NBODY_SYM
 #undef NBODY_SYM_K
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || L.fused) return e;                       // fused: update_sym_fused_kernel folds the j-side rows
   dim3 rgrid((L.n_total + kBlock - 1) / kBlock);
   if (L.kahan)
     hipLaunchKernelGGL((reduce_j_kernel<float, true>), rgrid, block, 0, s, (const float4 *)L.pool, (float4 *)L.send,
@@ -297,6 +299,20 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
   if (i_count <= 0) return hipErrorInvalidValue;
   dim3 grid((i_count + kBlock - 1) / kBlock), block(kBlock);
   const unsigned int *ip = (const unsigned int *)L.i_ptr, *io = (const unsigned int *)L.i_off;
+  if (L.fused) {
+    if (L.precision == NBODY_PREC_F64 || i_begin != 0 || i_count != L.n_total || L.n_src != 1) return hipErrorInvalidValue;
+    const bool detect = L.eps2 == 0.0 && L.dup_table != nullptr && L.dup_table_next != nullptr;
+#define NBODY_FUSED(KH, DT)                                                                                       \
+    hipLaunchKernelGGL((update_sym_fused_kernel<KH, DT>), grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc, \
+                       (float4 *)L.posg, (const float4 *)L.pool, ip, io, (const unsigned int *)L.j_ptr,             \
+                       (const unsigned int *)L.j_off, L.n_total, (float)L.G, dt, dt > 0.0f ? 1 : 0,                  \
+                       (unsigned long long *)L.dup_table_next, (unsigned int)(L.dup_slots - 1),                      \
+                       (unsigned long long *)L.dup_table, L.dup_slots + 8)
+    if (L.kahan) { if (detect) NBODY_FUSED(true, true); else NBODY_FUSED(true, false); }
+    else { if (detect) NBODY_FUSED(false, true); else NBODY_FUSED(false, false); }
+#undef NBODY_FUSED
+    return hipGetLastError();
+  }
   if (L.precision == NBODY_PREC_F64)
     hipLaunchKernelGGL((update_sym_kernel<double, false>), grid, block, 0, s, (double4 *)posm, (double4 *)vel, (double4 *)acc,
                        (const double4 *)L.pool, ip, io, (const double4 *)L.recv, i_begin, i_count, L.n_src, (double)dt,

@@ -173,5 +173,63 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
   }
 }
 
+// The single-device fp32 form of the two kernels above in ONE launch, for contexts whose positions nobody else writes:
+// acc = i-side segments + (j-side segments summed on their own, exactly as reduce_j_kernel would, then added as one
+// term: the same bits as the two-kernel path), the reference's update, and the NEXT pass's preparation while the new
+// position is in registers — posg[i] = (x, y, z, G m) and, DETECT, the body's entry in the next pass's coincident-body
+// table (`next`; this pass's table `cur`, last read by this pass's force kernels, is cleared for the pass after).  A
+// stepping loop then runs force kernel + this kernel per step: no sym_prep_kernel, no reduce_j_kernel, no memset.
+template <bool KAHAN, bool DETECT>
+__global__ __launch_bounds__(kBlock) void update_sym_fused_kernel(float4 *__restrict__ posm, float4 *__restrict__ vel,
+                                                                  float4 *__restrict__ acc, float4 *__restrict__ posg,
+                                                                  const float4 *__restrict__ pool,
+                                                                  const unsigned int *__restrict__ i_ptr,
+                                                                  const unsigned int *__restrict__ i_off,
+                                                                  const unsigned int *__restrict__ j_ptr,
+                                                                  const unsigned int *__restrict__ j_off, int n_total,
+                                                                  float gscale, float dt, int integrate,
+                                                                  unsigned long long *__restrict__ next, unsigned int mask,
+                                                                  unsigned long long *__restrict__ cur, int cur_words) {
+  const int bl = blockIdx.x * kBlock + threadIdx.x;
+  if (DETECT) for (int w = bl; w < cur_words; w += gridDim.x * kBlock) cur[w] = 0ull;
+  if (bl >= n_total) return;
+  const int g = bl >> 6, l = bl & 63;
+  auto add = [](float &sum, float &c, float v) {
+    if (KAHAN) { const float yv = v - c; const float tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
+    else sum += v;
+  };
+  float sx = 0, sy = 0, sz = 0, dx = 0, dy = 0, dz = 0;           // the j-side row of this body (reduce_j_kernel's sum)
+  {
+    const unsigned int k1 = j_ptr[g + 1];
+#pragma unroll 4
+    for (unsigned int k = j_ptr[g]; k < k1; ++k) {
+      const float4 p = pool[(size_t)j_off[k] + l];
+      add(sx, dx, p.x); add(sy, dy, p.y); add(sz, dz, p.z);
+    }
+  }
+  float ax = 0, ay = 0, az = 0, cx = 0, cy = 0, cz = 0;
+  {
+    const unsigned int k1 = i_ptr[g + 1];
+#pragma unroll 4
+    for (unsigned int k = i_ptr[g]; k < k1; ++k) {
+      const float4 p = pool[(size_t)i_off[k] + l];
+      add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
+    }
+  }
+  add(ax, cx, sx); add(ay, cy, sy); add(az, cz, sz);
+  acc[bl] = make_float4(ax, ay, az, 0.f);
+  float4 x = posm[bl];
+  if (integrate) {
+    float4 v = vel[bl];
+    v.x = mul_add_sep2(dt, ax, v.x); v.y = mul_add_sep2(dt, ay, v.y); v.z = mul_add_sep2(dt, az, v.z);
+    x.x = mul_add_sep2(dt, v.x, x.x); x.y = mul_add_sep2(dt, v.y, x.y); x.z = mul_add_sep2(dt, v.z, x.z);
+    vel[bl] = v;
+    posm[bl] = x;
+  }
+  if (DETECT) dup_detect<float>(x, next, mask, (int *)(next + (size_t)mask + 1));
+  x.w *= gscale;
+  posg[bl] = x;
+}
+
 }  // namespace
 }  // namespace nbody

@@ -35,7 +35,11 @@ def partition(n_total, world_size, rank):
 
 def hip_engine_factory(n_total, i_begin, i_count, posm_tensor, device_index, stream=None, **kw):
     eng = NBodyEngine(n_total, i_begin=i_begin, i_count=i_count, device=device_index, **kw)
-    eng.bind_device_state(posm=posm_tensor)
+    if i_count != n_total:
+        # the replicated array is a torch tensor so that torch.distributed can gather into it.  A single rank gathers
+        # nothing: the engine keeps its own buffer, which also lets it fuse the update with the next pass's preparation
+        # (nobody else can move a body then)
+        eng.bind_device_state(posm=posm_tensor)
     if stream is not None:
         # Kernels and collectives must be ordered on ONE stream.  torch's default stream has handle 0, which the
         # C-ABI reads as "use the context's own stream", so the simulation owns a real side stream and issues both
