@@ -306,7 +306,9 @@ def main():
                          "executed_is": ("VALU flops issued: each unordered pair evaluated once, 25 flop"
                                          if cfg["algorithm"] == "symmetric" else "every ordered pair evaluated, 20 flop"),
                          "traffic": traffic[0], "traffic_source": traffic[1],
-                         "kernel": cfg["kernel"] + (" (+sym_prep_kernel, reduce_j_kernel)"
+                         "kernel": cfg["kernel"] + (" (the events bracket the whole force pass: sym_prep_kernel and reduce_j_kernel too "
+                                                    "where they are launches of their own — sharded ranks, fp64; a single fp32 "
+                                                    "device folds them into update_sym_fused_kernel)"
                                                     if cfg["algorithm"] == "symmetric" else ""),
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
                          "launch_ms_min_max_over_ranks": launch_ms_minmax,
