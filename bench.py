@@ -30,7 +30,7 @@ FLOP_PER_EVAL_SYM = 25        # what the symmetric kernel executes per UNORDERED
 # file the number comes from.  Configurations that were not profiled report null.
 TRAFFIC_BYTES_PER_LAUNCH = {
     ("tiled", 1 << 20, 1, 4, "f32"): (2 * 173606 * 1024 + 262144 * 1024, "profiles/r01_pmc_forces_tile_kernel.txt"),
-    ("symmetric", 1 << 20, 1, 16, "f32"): (5403401557, "profiles/r02_pmc_forces_sym_kernel_n1048576_ipt16.txt"),
+    ("symmetric", 1 << 20, 1, 16, "f32"): (5404842240, "profiles/r02_pmc_forces_sym_kernel_n1048576_ipt16.txt"),
     ("symmetric", 1 << 16, 1, 16, "f32"): (301033491, "profiles/r02_pmc_forces_sym_kernel_n65536_ipt16.txt"),
     ("symmetric", 1 << 21, 1, 8, "f32_kahan"): (31471647019, "profiles/r02_pmc_forces_sym_kernel_kahan_n2097152_ipt8.txt"),
     ("symmetric", 1 << 18, 1, 4, "f64"): (2361977562, "profiles/r02_pmc_forces_sym_f64_kernel_n262144_ipt4.txt"),
