@@ -492,6 +492,64 @@ def test_symmetric_step_and_duplicates(nb, oracle):
     np.testing.assert_array_equal(p[:, :3], p1)
 
 
+def test_fused_stepping_follows_new_states_and_coincident_bodies(nb, oracle):
+    # A single fp32 device steps with two launches: the update prepares the next pass (scaled positions + the coincident-body
+    # verdict in the other of two tables).  Coincident bodies that APPEAR while stepping must switch the next pass to the
+    # guarded form; a new state must bring the preparation kernel back; the two-kernel path gives the same bits throughout.
+    n = 24576
+    rng = np.random.default_rng(77)
+    # light bodies: accelerations stay far below the velocities, so that a velocity exists, ulp by ulp, which lands a body
+    # exactly on a chosen point
+    posm = np.concatenate([rng.normal(0, 200, (n, 3)), rng.uniform(1e-6, 5e-5, (n, 1))], 1).astype(np.float32)
+    posm[[10, 9000], :3] = np.round(posm[[10, 9000], :3] * 16) / 16
+    vel = np.zeros((n, 4), np.float32)
+    # bodies 10 and 9000 (different i-sets) are to sit on ONE point after the first update, x' = x + dt (v + dt a): get a,
+    # then choose v
+    with nb.NBodyEngine(n) as e:
+        assert e.launch_config()["algorithm"] == "symmetric"
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+    dt = np.float32(0.5)
+    target = np.array([3.0, -7.0, 11.0], np.float32)
+
+    def landing(v, x, acc):                        # the update's own arithmetic: separate fp32 multiplies and adds
+        return np.float32(x + np.float32(dt * np.float32(v + np.float32(dt * acc))))
+
+    for b in (10, 9000):
+        for k in range(3):
+            x, acc, want = posm[b, k], a[b, k], target[k]
+            v = np.float32((np.float64(want) - np.float64(x)) / np.float64(dt) - np.float64(dt) * np.float64(acc))
+            for _ in range(64):                    # walk v by single ulps until the body lands exactly on the point
+                got = landing(v, x, acc)
+                if got == want:
+                    break
+                v = np.nextafter(v, np.float32(np.inf) if got < want else np.float32(-np.inf), dtype=np.float32)
+            assert landing(v, x, acc) == want
+            vel[b, k] = v
+    with nb.NBodyEngine(n) as e, nb.NBodyEngine(n) as two:
+        two.device_ptr(nb.BUF_POSM)                   # handing the pointer out switches that context to the two-kernel path
+        for eng in (e, two):
+            eng.set_state(posm, vel)
+            eng.step(float(dt), 1)
+        p1 = e.state()[0]
+        landed = np.array_equal(p1[10, :3], p1[9000, :3])
+        for eng in (e, two):
+            eng.step(float(dt), 1)                    # this pass sees the pair at d == 0 (if they landed together)
+        pa, va, aa = e.state(); pb, vb, ab = two.state()
+        np.testing.assert_array_equal(aa, ab); np.testing.assert_array_equal(pa, pb); np.testing.assert_array_equal(va, vb)
+        assert np.all(np.isfinite(aa))
+        ref = oracle.forces_direct_f64(p1[:, :3].astype(np.float64), p1[:, 3].astype(np.float64), i0=10, i1=11)
+        assert rel_err(aa[10:11, :3], ref).max() < TOL_ACC
+        ref = oracle.forces_direct_f64(p1[:, :3].astype(np.float64), p1[:, 3].astype(np.float64), i0=9000, i1=9001)
+        assert rel_err(aa[9000:9001, :3], ref).max() < TOL_ACC
+        # a new state: the preparation kernel runs again, on a cleared table
+        e.set_state(posm, np.zeros((n, 4), np.float32))
+        e.compute_forces()
+        np.testing.assert_array_equal(e.accelerations(), a)
+    assert landed, "the two bodies were meant to coincide after the first update (test construction)"
+
+
 @pytest.mark.parametrize("ipt", [2, 8, 16])
 @pytest.mark.parametrize("n", [257, 1000, 4096, 5000])
 def test_symmetric_ragged_sizes(nb, oracle, n, ipt):
