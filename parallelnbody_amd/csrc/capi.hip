@@ -176,7 +176,7 @@ void choose_algorithm(nbody_ctx *c) {
       // per lane win wherever the symmetric pass runs (N = 32768: 0.206 vs 0.211 ms with eight, 65536: 0.691 vs 0.718,
       // 131072: 2.62 vs 2.70, 2^20: 162 vs 170.5 ms); the Kahan form has no sixteen (its running compensated sums double the
       // accumulators) and runs eight
-      if (!kahan && p.n_total >= 32768) ipt = 16;
+      if (!kahan && p.n_total >= 40960) ipt = 16;      // whole step, N = 32768: 0.2353 ms with eight, 0.2408 with sixteen; 40960: 0.3355 / 0.3336
       else if (p.n_total >= 24576) ipt = 8;
       else ipt = 4;
       ipt = env_int("NBODY_SYM_IPT", ipt);
