@@ -231,6 +231,7 @@ void choose_algorithm(nbody_ctx *c) {
   c->sym_bi = bi; c->sym_np = f64 ? ipt / 2 : np; c->sym_pad = plan->n_pad; c->sym_items_n = (int)plan->items.size();
   c->sym_nsrc = plan->n_src; c->sym_pool_elems = (size_t)plan->pool_elems;
   c->sym = true;
+  c->wave = 0;            // the small-system one-launch step belongs to the one-sided path
 }
 
 // Fused stepping (update_sym_fused_kernel) is for fp32 symmetric contexts that own all bodies AND their position buffer:
