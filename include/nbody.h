@@ -249,9 +249,10 @@ NBODY_API int nbody_energy(nbody_ctx *ctx, double *ke, double *pe);
 /* Launch on the caller's HIP stream (hipStream_t as void*); NULL = the context's own stream. */
 NBODY_API int nbody_set_stream(nbody_ctx *ctx, void *hip_stream);
 
-/* Raw device pointer of one state buffer (e.g. as the send/recv buffer of an all-gather).  On a small single-context
- * system (n_total < 8192) that owns its buffers, NBODY_BUF_POSM alternates between two allocations from step to step:
- * ask again after nbody_step, or bind your own buffer (which switches that off). */
+/* Raw device pointer of one state buffer (e.g. as the send/recv buffer of an all-gather).  It stays valid, and keeps
+ * naming the live buffer, until nbody_destroy or a nbody_bind_device_state of that buffer.  Asking for NBODY_BUF_POSM
+ * tells the context that positions may change behind its back: from then on it re-reads them before every force pass
+ * (no fused update + preparation, no buffer-swapping one-launch step on small systems) — same results, a little slower. */
 NBODY_API int nbody_device_ptr(nbody_ctx *ctx, int32_t which, void **ptr, size_t *bytes);
 
 /* Use caller-owned device memory for the state (any may be NULL = keep the context's own).

@@ -1,5 +1,6 @@
 // C-ABI of libnbody_amd.so (include/nbody.h): context, device state, launches.  Host C++ over the
-// HIP runtime; no torch types, no exceptions across the boundary, no CPU fallback.
+// HIP runtime; no torch types, no exceptions across the boundary (the entry points that allocate host memory catch
+// std::bad_alloc), no CPU fallback.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -214,7 +215,13 @@ void choose_algorithm(nbody_ctx *c) {
   nbody::SymPlan *plan = new (std::nothrow) nbody::SymPlan();
   if (!plan) return;
   std::string why;
-  if (!nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, f64 ? 2 : 1, plan, &why)) {
+  bool planned = false;
+  try {
+    planned = nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, f64 ? 2 : 1, plan, &why);
+  } catch (const std::bad_alloc &) {
+    why = "out of host memory";
+  }
+  if (!planned) {
     g_create_error = "symmetric plan: " + why;
     delete plan;
     return;
@@ -488,6 +495,18 @@ void unstage_particles(const nbody_ctx *c, void *aos, size_t stride, size_t coun
   for (size_t i = 0; i < count; ++i) memcpy(base + i * stride, src + i * sizeof(nbody_particle), sizeof(nbody_particle));
 }
 
+// The position buffer becomes visible to (or is replaced by) the caller: bodies may move behind the library's back from
+// now on, so fused stepping and the buffer-swapping one-launch step end here, for the life of the context.  The detector
+// table the two-kernel path uses may still hold what the last fused update left in it.
+int posm_escapes(nbody_ctx *c) {
+  if (c->posm_escaped) return NBODY_OK;
+  if (c->sym_dup_table2)
+    HIP_TRY(c, hipMemsetAsync(c->sym_dup_table, 0, (size_t)c->sym_dup_slots * 8 + 64, c->stream));
+  c->posm_escaped = true;
+  c->sym_posg_valid = false;
+  return NBODY_OK;
+}
+
 int check_ready(nbody_ctx *c) {
   if (!c) return NBODY_ERR_INVALID;
   if (!c->have_state) return fail(c, NBODY_ERR_STATE, "no particles set (call nbody_set_particles / nbody_set_state_soa first)");
@@ -518,7 +537,7 @@ int nbody_default_params(nbody_params *p) {
 
 const char *nbody_last_error(const nbody_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int nbody_create(const nbody_params *pin, nbody_ctx **out) {
+int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
   if (!pin || !out) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create: null argument");
   *out = nullptr;
   if (pin->struct_size != sizeof(nbody_params))
@@ -651,9 +670,11 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) {
   if ((e = hipHostMalloc(&c->h_scratch, 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   *out = c;
   return NBODY_OK;
+} catch (const std::bad_alloc &) {
+  return fail(nullptr, NBODY_ERR_NOMEM, "nbody_create: out of host memory");
 }
 
-int nbody_create_multi(const nbody_params *pin, const int32_t *devices, int32_t n_dev, nbody_ctx **out) {
+int nbody_create_multi(const nbody_params *pin, const int32_t *devices, int32_t n_dev, nbody_ctx **out) try {
   if (!pin || !devices || !out) return fail(nullptr, NBODY_ERR_INVALID, "nbody_create_multi: null argument");
   *out = nullptr;
   nbody_ctx *c = new (std::nothrow) nbody_ctx();
@@ -667,6 +688,8 @@ int nbody_create_multi(const nbody_params *pin, const int32_t *devices, int32_t 
   c->elem = (pin->precision == NBODY_PREC_F64) ? 32 : 16;
   *out = c;
   return NBODY_OK;
+} catch (const std::bad_alloc &) {
+  return fail(nullptr, NBODY_ERR_NOMEM, "nbody_create_multi: out of host memory");
 }
 
 void nbody_destroy(nbody_ctx *c) {
@@ -714,7 +737,7 @@ int nbody_device_ptr(nbody_ctx *c, int32_t which, void **ptr, size_t *bytes) {
   switch (which) {
     case NBODY_BUF_POSM:
       *ptr = c->posm; if (bytes) *bytes = (size_t)c->p.n_total * c->elem;
-      c->posm_escaped = true; c->sym_posg_valid = false;          // the caller may write positions from now on
+      if (int rc = posm_escapes(c)) return rc;                    // the caller may write positions from now on
       break;
     case NBODY_BUF_VEL:  *ptr = c->vel;  if (bytes) *bytes = (size_t)c->p.i_count * c->elem; break;
     case NBODY_BUF_ACC:  *ptr = c->acc;  if (bytes) *bytes = (size_t)c->p.i_count * c->elem; break;
@@ -727,7 +750,11 @@ int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
   if (c && c->multi) return multi_unsupported(c, "nbody_bind_device_state");
   if (!c) return NBODY_ERR_INVALID;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (posm) { if (c->own_posm) (void)hipFree(c->posm); c->posm = posm; c->own_posm = false; c->posm_escaped = true; c->sym_posg_valid = false; }
+  if (posm) {
+    if (int rc = posm_escapes(c)) return rc;
+    if (c->own_posm) (void)hipFree(c->posm);
+    c->posm = posm; c->own_posm = false;
+  }
   if (vel)  { if (c->own_vel) (void)hipFree(c->vel);   c->vel = vel;   c->own_vel = false; }
   if (acc)  { if (c->own_acc) (void)hipFree(c->acc);   c->acc = acc;   c->own_acc = false; }
   // the caller vouches that bound buffers hold a valid state
@@ -743,21 +770,25 @@ int nbody_synchronize(nbody_ctx *c) {
   return NBODY_OK;
 }
 
-int nbody_set_state_soa(nbody_ctx *c, const float *posm4, const float *vel4, int32_t n) {
+int nbody_set_state_soa(nbody_ctx *c, const float *posm4, const float *vel4, int32_t n) try {
   if (!c || !posm4 || !vel4) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa: null buffer") : NBODY_ERR_INVALID;
   if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa: n = %d but the context holds %d bodies", n, c->p.n_total);
   if (c->multi) { const int rc = multi_rc(c, nbody::multi_set_state_soa(c->multi, posm4, vel4, n)); if (!rc) { c->have_state = true; c->steps_done = 0; } return rc; }
   return upload_soa<float>(c, posm4, vel4);
+} catch (const std::bad_alloc &) {
+  return fail(c, NBODY_ERR_NOMEM, "nbody_set_state_soa: out of host memory");
 }
 
-int nbody_set_state_soa_f64(nbody_ctx *c, const double *posm4, const double *vel4, int32_t n) {
+int nbody_set_state_soa_f64(nbody_ctx *c, const double *posm4, const double *vel4, int32_t n) try {
   if (!c || !posm4 || !vel4) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa_f64: null buffer") : NBODY_ERR_INVALID;
   if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_state_soa_f64: n = %d but the context holds %d bodies", n, c->p.n_total);
   if (c->multi) { const int rc = multi_rc(c, nbody::multi_set_state_soa_f64(c->multi, posm4, vel4, n)); if (!rc) { c->have_state = true; c->steps_done = 0; } return rc; }
   return upload_soa<double>(c, posm4, vel4);
+} catch (const std::bad_alloc &) {
+  return fail(c, NBODY_ERR_NOMEM, "nbody_set_state_soa_f64: out of host memory");
 }
 
-int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n) {
+int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n) try {
   if (!c || !aos) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_particles: null buffer") : NBODY_ERR_INVALID;
   if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_particles: n = %d but the context holds %d bodies", n, c->p.n_total);
   if (stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "nbody_set_particles: stride %zu < %zu", stride, sizeof(nbody_particle));
@@ -789,6 +820,8 @@ int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n)
     HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size() * 4, hipMemcpyHostToDevice));
   }
   return NBODY_OK;
+} catch (const std::bad_alloc &) {
+  return fail(c, NBODY_ERR_NOMEM, "nbody_set_particles: out of host memory");
 }
 
 // A sharded symmetric context has an exchange between the force pass and the update: the caller must drive
@@ -893,8 +926,9 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
     return fail(c, NBODY_ERR_STATE, "nbody_step: a sharded context advances one step per call (all-gather NBODY_BUF_POSM in between)");
   HIP_TRY(c, hipSetDevice(c->p.device));
   // small single-context fp32 systems: forces + update in ONE launch per step, ping-ponging the position buffer
-  const bool one_launch = c->wave != 0 && c->theta == 0.0f && c->own_posm && c->p.i_count == c->p.n_total &&
-                          c->p.precision == NBODY_PREC_F32;
+  // (it swaps the two position buffers: not once the caller holds a pointer to one of them)
+  const bool one_launch = c->wave != 0 && c->theta == 0.0f && c->own_posm && !c->posm_escaped &&
+                          c->p.i_count == c->p.n_total && c->p.precision == NBODY_PREC_F32;
   if (one_launch && !c->posm_alt) HIP_TRY(c, hipMalloc(&c->posm_alt, (size_t)c->p.n_total * c->elem));
   for (int s = 0; s < nsteps; ++s) {
     if (one_launch) {
@@ -969,7 +1003,7 @@ int nbody_get_positions(nbody_ctx *c, float *xyz, size_t stride, int32_t first, 
   return NBODY_OK;
 }
 
-int nbody_get_state_soa(nbody_ctx *c, float *posm4, float *vel4, float *acc4) {
+int nbody_get_state_soa(nbody_ctx *c, float *posm4, float *vel4, float *acc4) try {
   int rc = check_ready(c);
   if (rc) return rc;
   if (c->multi) return multi_rc(c, nbody::multi_get_state_soa(c->multi, posm4, vel4, acc4));
@@ -977,9 +1011,11 @@ int nbody_get_state_soa(nbody_ctx *c, float *posm4, float *vel4, float *acc4) {
   if (vel4 && (rc = download4<float>(c, c->vel, 0, (size_t)c->p.i_count, vel4))) return rc;
   if (acc4 && (rc = download4<float>(c, c->acc, 0, (size_t)c->p.i_count, acc4))) return rc;
   return NBODY_OK;
+} catch (const std::bad_alloc &) {
+  return fail(c, NBODY_ERR_NOMEM, "nbody_get_state_soa: out of host memory");
 }
 
-int nbody_get_state_soa_f64(nbody_ctx *c, double *posm4, double *vel4, double *acc4) {
+int nbody_get_state_soa_f64(nbody_ctx *c, double *posm4, double *vel4, double *acc4) try {
   int rc = check_ready(c);
   if (rc) return rc;
   if (c->multi) return multi_rc(c, nbody::multi_get_state_soa_f64(c->multi, posm4, vel4, acc4));
@@ -987,6 +1023,8 @@ int nbody_get_state_soa_f64(nbody_ctx *c, double *posm4, double *vel4, double *a
   if (vel4 && (rc = download4<double>(c, c->vel, 0, (size_t)c->p.i_count, vel4))) return rc;
   if (acc4 && (rc = download4<double>(c, c->acc, 0, (size_t)c->p.i_count, acc4))) return rc;
   return NBODY_OK;
+} catch (const std::bad_alloc &) {
+  return fail(c, NBODY_ERR_NOMEM, "nbody_get_state_soa_f64: out of host memory");
 }
 
 int nbody_get_particles(nbody_ctx *c, void *aos, size_t stride) {
@@ -1085,7 +1123,7 @@ struct CkptHeader {
 };
 }  // namespace
 
-int nbody_save_checkpoint(nbody_ctx *c, const char *path) {
+int nbody_save_checkpoint(nbody_ctx *c, const char *path) try {
   int rc = check_ready(c);
   if (rc) return rc;
   if (!path) return fail(c, NBODY_ERR_INVALID, "nbody_save_checkpoint: null path");
@@ -1119,9 +1157,11 @@ int nbody_save_checkpoint(nbody_ctx *c, const char *path) {
                   fwrite(vel.data(), 1, vel.size(), f) == vel.size() && fwrite(acc.data(), 1, acc.size(), f) == acc.size();
   if (fclose(f) != 0 || !ok) return fail(c, NBODY_ERR_INVALID, "nbody_save_checkpoint: short write to %s", path);
   return NBODY_OK;
+} catch (const std::bad_alloc &) {
+  return fail(c, NBODY_ERR_NOMEM, "nbody_save_checkpoint: out of host memory");
 }
 
-int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
+int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) try {
   if (!c || !path) return c ? fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: null path") : NBODY_ERR_INVALID;
   if (c->multi) {                                                  // every device reads its slice of the same file
     int64_t n = 0;
@@ -1131,13 +1171,13 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
     if (steps_done) *steps_done = n;
     return NBODY_OK;
   }
-  FILE *f = fopen(path, "rb");
-  if (!f) return fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: cannot open %s", path);
   CkptHeader h;
   const bool f64 = c->p.precision == NBODY_PREC_F64;
   const size_t eb = f64 ? 8 : 4, n = (size_t)c->p.n_total, ic = (size_t)c->p.i_count;
   int rc = NBODY_OK;
   std::vector<char> posm(n * 4 * eb), vel(ic * 4 * eb), acc(ic * 4 * eb);
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: cannot open %s", path);
   if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "NBDYCKP2", 8) != 0 || h.header_bytes != sizeof h)
     rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: %s is not a checkpoint of this engine (format NBDYCKP2)", path);
   // the file's owned range must contain the context's: a whole-system file also feeds the slices of a sharded job
@@ -1182,6 +1222,8 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) {
   }
   if (steps_done) *steps_done = h.steps_done;
   return NBODY_OK;
+} catch (const std::bad_alloc &) {
+  return fail(c, NBODY_ERR_NOMEM, "nbody_load_checkpoint: out of host memory");
 }
 
 int nbody_set_theta(nbody_ctx *c, float theta) {

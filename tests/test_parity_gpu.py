@@ -1032,3 +1032,37 @@ def test_geometry_fuzz_sizes_ranks_and_precisions(nb, oracle):
                 assert np.linalg.norm(a[i] - ref) / scale < tol, (trial, n, ranks, prec, eps, forced, kernels, int(i))
     assert ran >= 100, ran
     assert {"forces_sym_pk_kernel", "forces_tile_pk_kernel", "small_pk_kernel", "forces_sym_f64_kernel"} <= seen, seen
+
+
+@pytest.mark.parametrize("n", [2000, 40000])
+def test_a_position_pointer_handed_out_stays_the_live_buffer(nb, n):
+    """nbody_device_ptr(NBODY_BUF_POSM) is what a renderer or a collective holds on to: once it is out, the context must
+    neither swap its position buffers (small systems' one-launch step) nor trust a private copy of the positions (fused
+    stepping) — and it walks the same trajectory as a context that kept the buffer to itself."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    rng = np.random.default_rng(n)
+    posm = np.concatenate([rng.uniform(-500, 500, (n, 3)), rng.uniform(1, 5000, (n, 1))], 1).astype(np.float32)
+    vel = np.concatenate([rng.uniform(-5, 5, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    with nb.NBodyEngine(n) as held, nb.NBodyEngine(n) as private:
+        for e in (held, private):
+            e.set_state(posm, vel)
+            e.step(0.01, 3)                            # an odd number of steps: the small system's buffers have swapped
+        ptr, nbytes = held.device_ptr(nb.BUF_POSM)
+        assert nbytes == n * 16
+        for e in (held, private):
+            e.step(0.01, 3)
+        held.synchronize()
+        seen = np.empty((n, 4), np.float32)
+        assert hip.hipMemcpy(seen.ctypes.data, ptr, nbytes, 2) == 0          # hipMemcpyDeviceToHost
+        np.testing.assert_array_equal(seen, held.state()[0])
+        np.testing.assert_array_equal(seen, private.state()[0])              # the same trajectory either way, bit for bit
+        assert held.device_ptr(nb.BUF_POSM)[0] == ptr
+        # the caller moves a body through the pointer: the next pass must see it
+        seen[7, :3] += np.float32(25.0)
+        assert hip.hipMemcpy(ptr, seen.ctypes.data, nbytes, 1) == 0          # hipMemcpyHostToDevice
+        held.compute_forces()
+        private.set_state(seen, private.state()[1])
+        private.compute_forces()
+        np.testing.assert_array_equal(held.accelerations(), private.accelerations())
