@@ -25,6 +25,7 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X vector fp32 peak, MI355X_MICROARCH.md "Ch
 FLOP_PER_PAIR = 20            # 3 sub + 6 (dot) + 4 (rsqrt cubed) + 1 (mass) + 6 (3 FMA)
 FLOP_PER_EVAL_SYM = 25        # what the symmetric kernel executes per UNORDERED pair: 3 sub + 5 (r^2) + 1 rsq + 2 (cube)
                               # + 2 (the two mass factors) + 12 (six FMAs); matches the PMC count (profiles/r02_pmc_*.txt)
+FLOP_PER_EVAL_SYM_EQUAL = 23  # its equal-mass form (all bodies of one mass, as in a Plummer sphere): no mass factors in the loop
 # HBM bytes per force launch, measured by PMC passes (tools/profile_kernel.sh: FETCH_SIZE x2 — the gfx950 correction of
 # MI355X_MICROARCH.md — + WRITE_SIZE, separate passes), keyed by (algorithm, n, gpus, bodies per lane, precision) with the
 # file the number comes from.  Configurations that were not profiled report null.
@@ -138,6 +139,8 @@ def main():
     ap.add_argument("--algorithm", default="auto", choices=["auto", "tiled", "symmetric"])
     ap.add_argument("--zero-mode", default="exact", choices=["exact", "floor"],
                     help="exact = the reference's d == 0 skip for every distance; floor = ~1e-20 eps^2 floor")
+    ap.add_argument("--no-distinct-row", action="store_true",
+                    help="skip the second measurement of the same bodies with distinct masses (one GPU, equal-mass workloads)")
     ap.add_argument("--no-tiled-row", action="store_true",
                     help="multi-GPU: skip the extra timing of the one-sided kernel + all-gather-only step (config.all_gather_only_row)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length; 0 = skip")
@@ -241,7 +244,9 @@ def main():
     achieved_tflops = launch_pairs * FLOP_PER_PAIR / avg_launch_s * 1e-12
     # what the hardware executed: the symmetric kernel evaluates each unordered pair once (25 flop) and credits both
     # bodies; the one-sided kernel evaluates every ordered pair (20 flop)
-    executed_tflops = (launch_pairs / 2 * FLOP_PER_EVAL_SYM if cfg["algorithm"] == "symmetric"
+    equal_mass = sim.engine.equal_mass_form()      # which form of the symmetric kernel the timed passes ran
+    flop_eval = FLOP_PER_EVAL_SYM_EQUAL if equal_mass else FLOP_PER_EVAL_SYM
+    executed_tflops = (launch_pairs / 2 * flop_eval if cfg["algorithm"] == "symmetric"
                        else launch_pairs * FLOP_PER_PAIR) / avg_launch_s * 1e-12
     peak = PEAK_FP32_TFLOPS if args.precision != "f64" else PEAK_FP32_TFLOPS / 2
     traffic = TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, world, cfg["i_per_thread"], args.precision), (None, None))
@@ -263,6 +268,39 @@ def main():
     if not (finite and err < tol):
         raise SystemExit(f"bench.py: the benched force pass disagrees with the fp64 direct sum on sampled bodies: "
                          f"max rel err {err:.3e} >= {tol:.1e} (finite={finite})")
+
+    # The Plummer sphere's bodies all have one mass, and the symmetric kernel has a form for exactly that (no mass factor
+    # inside the pair loop: nbody_equal_mass_form).  One GPU only: the same bodies with DISTINCT masses — the kernel's
+    # general form — timed right after, same K steps, same parity check, so that both numbers stand in the one line.
+    distinct = None
+    if world == 1 and equal_mass and not args.no_distinct_row:
+        posm2 = posm.copy()
+        posm2[:, 3] *= np.random.default_rng(20261004).uniform(0.5, 1.5, n).astype(np.float32)
+        sim2 = nb.ShardedSimulation(posm2, vel, rank=0, world_size=1, device=f"cuda:{local_rank}", engine_factory=factory,
+                                    precision=args.precision, eps=args.eps, tile=args.tile, i_per_thread=args.ipt,
+                                    j_split=args.jsplit, time_kernels=True,
+                                    algorithm={"auto": 0, "tiled": 1, "symmetric": 2}[args.algorithm],
+                                    zero_mode={"exact": 0, "floor": 2}[args.zero_mode])
+        sim2.step(args.dt, max(args.warmup, 1))
+        fence()
+        sim2.engine.kernel_time_reset()
+        t0 = time.perf_counter()
+        sim2.step(args.dt, args.steps)
+        fence()
+        el2 = time.perf_counter() - t0
+        f2_ms, f2_n = sim2.engine.kernel_time(nb.KERNEL_FORCES)
+        p2, _ = sim2.gather_state()
+        sim2.compute_forces()
+        err2 = sampled_force_error(p2, sim2.engine.accelerations(np.float64 if args.precision == "f64" else np.float32), 0, bodies, 1.0e4, args.eps)
+        still_equal = sim2.engine.equal_mass_form()
+        sim2.close()
+        if still_equal or not err2 < tol:
+            raise SystemExit(f"bench.py: distinct-mass row: equal-mass form in use = {still_equal}, max rel err {err2:.3e} (tolerance {tol:.1e})")
+        distinct = {"masses": "the same bodies, each mass scaled by its own factor in [0.5, 1.5): the kernel's general form",
+                    "value": pairs_per_step * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3,
+                    "force_pass_avg_ms": f2_ms / max(f2_n, 1),
+                    "roofline_frac": launch_pairs * FLOP_PER_PAIR / (f2_ms / max(f2_n, 1) * 1e-3) * 1e-12 / peak,
+                    "max_rel_err_sampled": err2}
 
     # Multi-GPU only: north_star's literal step — one-sided kernel, per-step all-gather of positions, no other collective —
     # timed next to the default (symmetric + all-to-all) in the same job, same K steps, after the main measurement.
@@ -286,7 +324,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": {"f32": "f32", "f32_kahan": "f32", "f64": "f64"}[args.precision], "data": "synthetic",
-            "config": {"workload": f"N={n} all-pairs {args.precision}, seeded Plummer sphere, G=1e4, eps={args.eps}, "
+            "config": {"workload": f"N={n} all-pairs {args.precision}, seeded Plummer sphere (equal masses), G=1e4, eps={args.eps}, "
                                    f"dt={args.dt}, one force pass + kick-drift per step",
                        "parallelism": (f"range-partition x{world}, per step 1 RCCL all-gather(posm)"
                                        + (" + 1 all-to-all(j-side sums)" if cfg["algorithm"] == "symmetric" else ""))
@@ -296,6 +334,8 @@ def main():
                        "j_split": cfg["j_split"] if cfg["algorithm"] == "tiled" else None,
                        "super_tile_bodies": cfg["super_tile"] or None,
                        "workgroups": cfg["blocks"], "accumulate": args.precision, "finite": finite,
+                       "equal_mass_form": equal_mass,
+                       **({"distinct_masses": distinct} if distinct else {}),
                        "max_rel_err_sampled": err, "bodies_sampled": n_sampled, "rel_err_tolerance": tol,
                        **({"fallback": fallback} if fallback else {}),
                        **({"all_gather_only_row": tiled_row} if tiled_row else {})},
@@ -303,7 +343,8 @@ def main():
                          "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
                          "achieved_is": "algorithmic: N_i x N ordered interactions x 20 flop (SURVEY 8d) / launch time",
                          "executed": executed_tflops, "executed_frac": executed_tflops / peak,
-                         "executed_is": ("VALU flops issued: each unordered pair evaluated once, 25 flop"
+                         "executed_is": (f"VALU flops issued: each unordered pair evaluated once, {flop_eval} flop"
+                                         + (" (equal-mass form: no mass factors inside the loop)" if equal_mass else "")
                                          if cfg["algorithm"] == "symmetric" else "every ordered pair evaluated, 20 flop"),
                          "traffic": traffic[0], "traffic_source": traffic[1],
                          "kernel": cfg["kernel"] + (" (the events bracket the whole force pass: sym_prep_kernel and reduce_j_kernel too "

@@ -122,6 +122,7 @@ def lib():
     sig("nbody_get_launch_config", c_int, vp, *([ctypes.POINTER(c_i32)] * 5))
     sig("nbody_force_kernel_name", ctypes.c_char_p, vp)
     sig("nbody_get_algorithm", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32))
+    sig("nbody_equal_mass_form", c_int, vp, ctypes.POINTER(c_i32))
     sig("nbody_save_checkpoint", c_int, vp, ctypes.c_char_p)
     sig("nbody_load_checkpoint", c_int, vp, ctypes.c_char_p, ctypes.POINTER(c_i64))
     sig("nbody_steps_done", c_int, vp, ctypes.POINTER(c_i64))

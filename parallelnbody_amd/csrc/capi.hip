@@ -68,6 +68,10 @@ struct nbody_ctx {
   int sym_dup_cur = 0;                             // which of the two tables holds the verdict on the current positions
   bool sym_posg_valid = false;                     // posg (and that table) describe the current positions
   bool posm_escaped = false;                       // the caller holds / owns the position buffer: it may change behind our back
+  // fp32 equal-mass kernels: device word the preparation kernel raises when two masses differ (sticky; the host resets it
+  // with every state it uploads) and what the host itself saw in that state (1 all equal, 0 not, -1 never saw one)
+  void *sym_general = nullptr;
+  int masses_equal = -1;
   bool own_send = false, own_recv = false;
   bool step_open = false;      // nbody_step_begin done, nbody_step_end pending
   int64_t steps_done = 0;      // updates applied since the state was set (saved in checkpoints)
@@ -261,6 +265,10 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps;
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
   L.dup_table = c->sym_dup_table; L.dup_slots = c->sym_dup_slots;
+  L.general = c->sym_general;
+  // the host's own finding is final while nothing but this library writes the position buffer; otherwise "not equal"
+  // still is (the device word is sticky), "equal" is only the state of things at the last upload
+  L.uni_host = c->masses_equal == 0 ? 0 : ((c->masses_equal == 1 && c->own_posm && !c->posm_escaped) ? 1 : -1);
   if (sym_fused(c)) {
     L.fused = 1;
     L.skip_prep = c->sym_posg_valid ? 1 : 0;
@@ -411,6 +419,19 @@ void convert4(const SRC *src, DST *dst, size_t n_elems4, bool zero_w) {
   }
 }
 
+// A new state arrives from the host: are all masses (as the fp32 kernels will see them) equal?  The device word the
+// equal-mass kernels are gated on is reset to that finding.
+template <typename T>
+int note_masses(nbody_ctx *c, const T *posm4) {
+  if (!c->sym_general) return NBODY_OK;
+  const float m0 = (float)posm4[3];
+  bool equal = true;
+  for (size_t i = 1; i < (size_t)c->p.n_total && equal; ++i) equal = (float)posm4[4 * i + 3] == m0;
+  c->masses_equal = equal ? 1 : 0;
+  HIP_TRY(c, hipMemsetAsync(c->sym_general, equal ? 0 : 0xFF, 4, c->stream));
+  return NBODY_OK;
+}
+
 // Upload host SoA state given as T (float or double); converts to the context's precision.
 template <typename T>
 int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
@@ -435,6 +456,7 @@ int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
     HIP_TRY(c, hipMemcpy(c->vel, tv.data(), tv.size() * 4, hipMemcpyHostToDevice));
   }
   HIP_TRY(c, hipMemsetAsync(c->acc, 0, (size_t)ic * c->elem, c->stream));
+  { const int rc = note_masses(c, posm4); if (rc) return rc; }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_state = true;
   c->floor_eps2 = -1.0;
@@ -643,6 +665,13 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
         if ((e = hipMemset(c->sym_dup_table2, 0, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMemset duplicate detector");
       }
     }
+    // equal-mass kernels (fp32; not with the eps floor, which is sized for G m |d|^-3, not for a bare |d|^-3).
+    // NBODY_SYM_NO_UNI=1 (A/B measurements only) keeps every context on the general kernels.
+    const char *no_uni = getenv("NBODY_SYM_NO_UNI");
+    if (p.precision != NBODY_PREC_F64 && p.zero_mode != NBODY_ZERO_FLOOR && !(no_uni && no_uni[0] == '1')) {
+      if ((e = hipMalloc(&c->sym_general, 64)) != hipSuccess) return bail(e, "hipMalloc equal-mass flag");
+      if ((e = hipMemset(c->sym_general, 0, 64)) != hipSuccess) return bail(e, "hipMemset equal-mass flag");
+    }
     if ((e = hipMalloc(&c->sym_send, (size_t)p.n_total * c->elem)) != hipSuccess) return bail(e, "hipMalloc send row");
     c->own_send = true;
     if (c->sym_nsrc > 1) {
@@ -712,6 +741,7 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->own_recv && c->sym_recv) (void)hipFree(c->sym_recv);
   if (c->sym_dup_table) (void)hipFree(c->sym_dup_table);
   if (c->sym_dup_table2) (void)hipFree(c->sym_dup_table2);
+  if (c->sym_general) (void)hipFree(c->sym_general);
   if (c->bh) nbody::bh_destroy(c->bh);
   if (c->bh_acc) (void)hipFree(c->bh_acc);
   if (c->d_stage) (void)hipFree(c->d_stage);
@@ -754,6 +784,10 @@ int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
     if (int rc = posm_escapes(c)) return rc;
     if (c->own_posm) (void)hipFree(c->posm);
     c->posm = posm; c->own_posm = false;
+    if (c->sym_general) {                       // masses nobody here has seen: every pass's preparation kernel looks
+      c->masses_equal = -1;
+      HIP_TRY(c, hipMemsetAsync(c->sym_general, 0, 4, c->stream));
+    }
   }
   if (vel)  { if (c->own_vel) (void)hipFree(c->vel);   c->vel = vel;   c->own_vel = false; }
   if (acc)  { if (c->own_acc) (void)hipFree(c->acc);   c->acc = acc;   c->own_acc = false; }
@@ -1202,6 +1236,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) t
   HIP_TRY(c, hipMemcpy(c->posm, posm.data(), posm.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size(), hipMemcpyHostToDevice));
+  if (!f64) { const int rc2 = note_masses(c, (const float *)posm.data()); if (rc2) return rc2; }
   c->have_state = true; c->floor_eps2 = -1.0; c->step_open = false; c->sym_posg_valid = false;
   c->steps_done = h.steps_done;
   // Barnes-Hut: the opening angle and the root of the next tree (the previous tree's CoM, OctreeSearch.cpp:77-79) are
@@ -1313,6 +1348,20 @@ int nbody_get_algorithm(nbody_ctx *c, int32_t *algorithm, int32_t *super_tile) {
   if (c->multi) return nbody_get_algorithm(nbody::multi_part(c->multi, 0), algorithm, super_tile);
   if (algorithm) *algorithm = c->sym ? NBODY_ALGO_SYMMETRIC : NBODY_ALGO_TILED;
   if (super_tile) *super_tile = c->sym ? c->sym_bi : 0;
+  return NBODY_OK;
+}
+
+int nbody_equal_mass_form(nbody_ctx *c, int32_t *in_use) {
+  if (!c || !in_use) return NBODY_ERR_INVALID;
+  if (c->multi) return nbody_equal_mass_form(nbody::multi_part(c->multi, 0), in_use);
+  *in_use = 0;
+  if (!c->sym || !c->sym_general || c->theta > 0.0f) return NBODY_OK;
+  HIP_TRY(c, hipSetDevice(c->p.device));
+  HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->sym_general, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int32_t word;
+  memcpy(&word, c->h_scratch, 4);
+  *in_use = word == 0 ? 1 : 0;
   return NBODY_OK;
 }
 

@@ -63,6 +63,12 @@ struct SymLaunch {
   int fused = 0;              // launch_forces_sym: no reduce_j; launch_update_sym: the fused kernel
   int skip_prep = 0;          // posg and dup_table are already those of the current positions
   void *dup_table_next = nullptr;
+  // fp32 equal-mass form (forces_sym_pk_kernel, UNI): `general` is a device int the preparation kernel raises when a
+  // body's mass differs from body 0's; nullptr = general kernels only.  uni_host: 1 = the host knows the masses are equal
+  // and nobody else writes the buffer (equal-mass launches only), 0 = it knows they are not (general launches only),
+  // -1 = launch both, each looks at `general`.
+  void *general = nullptr;
+  int uni_host = 0;
 };
 // forces + fold of the j-side rows into L.send
 hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);

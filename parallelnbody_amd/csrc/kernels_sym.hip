@@ -64,7 +64,10 @@ constexpr int sym_waves(int np, bool kahan) {
 //   the block: symmetric, each unordered pair once (the pairs below P0 met these bodies when THEIR subtiles came up);
 //   pair P0 itself runs one-sided — every ordered pair inside a register pair's 512 bodies is evaluated from both
 //   ends, the self pair (d == 0) dropped by the guard — and credits nothing to the j side.
-template <int NP, int P0, bool ONE, int ZMODE, bool BARE>
+//   UNI: every body has the same mass.  The lane sums s d = |d|^-3 d on both sides — no mass factor per pair: 14 packed
+//   ops per register pair and step instead of 16, and no -G m_i registers; the common G m is applied once per body
+//   by the update.  The j-side sums travel with the i side's sign and are negated when they come home.
+template <int NP, int P0, bool ONE, int ZMODE, bool BARE, bool UNI>
 __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[NP], const f2 (&zi)[NP], const f2 (&nmi)[NP],
                                             Acc3pk<false> (&acc)[NP], const float4 *sp, f2 zp2, f2 one2, float &ox, float &oy,
                                             float &oz) {
@@ -101,13 +104,18 @@ __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[N
     for (int a = 0; a < NA; ++a) {
       w[a] = u[a] * u[a];
       w[a] = w[a] * u[a];                                         // |d|^-3 (ordinary ops between rsq and the asm)
-      if (!(ONE && a == 0)) u[a] = w[a] * nmi[P0 + a];            // -G m_i |d|^-3
-      w[a] = mul_bcast_hi(w[a], f2{pj.z, pj.w});                  //  G m_j |d|^-3
+      if (!UNI) {
+        if (!(ONE && a == 0)) u[a] = w[a] * nmi[P0 + a];          // -G m_i |d|^-3
+        w[a] = mul_bcast_hi(w[a], f2{pj.z, pj.w});                //  G m_j |d|^-3
+      }
     }
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
       acc[P0 + a].add(w[a], dx[a], dy[a], dz[a]);
-      if (!(ONE && a == 0)) { qx = fma2(u[a], dx[a], qx); qy = fma2(u[a], dy[a], qy); qz = fma2(u[a], dz[a], qz); }
+      if (!(ONE && a == 0)) {
+        const f2 sj = UNI ? w[a] : u[a];
+        qx = fma2(sj, dx[a], qx); qy = fma2(sj, dy[a], qy); qz = fma2(sj, dz[a], qz);
+      }
     }
     if (NA > (ONE ? 1 : 0)) {                                     // the sums move on with their body
       qx = f2{wave_ror1(qx.x), wave_ror1(qx.y)}; qy = f2{wave_ror1(qy.x), wave_ror1(qy.y)};
@@ -115,26 +123,32 @@ __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[N
     }
   }
   ox = qx.x + qx.y; oy = qy.x + qy.y; oz = qz.x + qz.y;
+  if (UNI) { ox = -ox; oy = -oy; oz = -oz; }
 }
 
 // own-block subtile in register pair pc's slots: pick the instantiation (pc is wave-uniform)
-template <int NP, int PC, int ZMODE, bool BARE>
+template <int NP, int PC, int ZMODE, bool BARE, bool UNI>
 __device__ __forceinline__ void own_block_subtile(int pc, const f2 (&xi)[NP], const f2 (&yi)[NP], const f2 (&zi)[NP],
                                                   const f2 (&nmi)[NP], Acc3pk<false> (&acc)[NP], const float4 *sp, f2 zp2,
                                                   f2 one2, float &ox, float &oy, float &oz) {
-  if (pc == PC) sym_subtile<NP, PC, true, ZMODE, BARE>(xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
-  else if constexpr (PC + 1 < NP) own_block_subtile<NP, PC + 1, ZMODE, BARE>(pc, xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
+  if (pc == PC) sym_subtile<NP, PC, true, ZMODE, BARE, UNI>(xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
+  else if constexpr (PC + 1 < NP) own_block_subtile<NP, PC + 1, ZMODE, BARE, UNI>(pc, xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
 }
 
 using lds_f4 = __attribute__((address_space(3))) float4;
 using glb_f4 = const __attribute__((address_space(1))) float4;
 
-template <int NP, int ZMODE, bool BARE, bool KAHAN>
+// UNI = the equal-mass form (sym_subtile).  Whether the bodies' masses are all equal is sym_prep_kernel's finding,
+// *general (0 = equal): the UNI launch runs only when it is clear (run_if_general == 0), the general launch only when it
+// is raised; general == nullptr runs unconditionally (the host already knows).
+template <int NP, int ZMODE, bool BARE, bool KAHAN, bool UNI>
 __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu(sym_waves(NP, KAHAN), sym_waves(NP, KAHAN))))
 void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ pool, const SymItem *__restrict__ items,
-                          float zp, const int *__restrict__ dup_flag, int run_if_dup) {
+                          float zp, const int *__restrict__ dup_flag, int run_if_dup, const int *__restrict__ general,
+                          int run_if_general) {
   if (dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
+  if (general != nullptr && ((*general != 0) ? 1 : 0) != run_if_general) return;
   __shared__ float4 sh_pos[2][4][128];   // double-buffered subtile images, doubled: entries l and l+64 hold body l
   __shared__ float sh_acc[4][3][kJT];    // per-WAVE j-side sums of the tile (private: no ordering between waves needed)
 
@@ -168,10 +182,13 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
   for (int p = 0; p < NP; ++p) {
     const float4 pa = posg[i0 + t + (2 * p) * kBlock], pb = posg[i0 + t + (2 * p + 1) * kBlock];
     xi[p] = f2{pa.x, pb.x}; yi[p] = f2{pa.y, pb.y}; zi[p] = f2{pa.z, pb.z};
-    nmi[p] = f2{-pa.w, -pb.w};                                 // -G m_i: the j side gets a_j -= G m_i s d
+    nmi[p] = UNI ? splat2(0.f) : f2{-pa.w, -pb.w};             // -G m_i: the j side gets a_j -= G m_i s d
   }
 #pragma unroll
-  for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(xi[p]), "v"(yi[p]), "v"(zi[p]), "v"(nmi[p]));
+  for (int p = 0; p < NP; ++p) {
+    asm volatile("" ::"v"(xi[p]), "v"(yi[p]), "v"(zi[p]));
+    if (!UNI) asm volatile("" ::"v"(nmi[p]));
+  }
   __syncthreads();                                               // tile 0 has landed (the barrier waits for the DMA)
 
   for (int c = 0; c < n_tiles; ++c) {
@@ -188,9 +205,9 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
       const float4 *sp = &sh_pos[buf][sub][lane + 64];
       float ox, oy, oz;
       if (!own_block)
-        sym_subtile<NP, 0, false, ZMODE, BARE>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+        sym_subtile<NP, 0, false, ZMODE, BARE, UNI>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
       else   // the subtile's bodies sit in the slots of register pair (offset from the i-set's first body) / 512
-        own_block_subtile<NP, 0, ZMODE, BARE>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+        own_block_subtile<NP, 0, ZMODE, BARE, UNI>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
       if (KAHAN) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) { ka[p].fold(a[p]); a[p] = Acc3pk<false>(); }
@@ -246,26 +263,36 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   const bool detect = L.eps2 == 0.0 && L.dup_table != nullptr;
   int *flag = detect ? (int *)((unsigned long long *)L.dup_table + L.dup_slots) : nullptr;
   // positions -> (x, y, z, G m) with far-away zero-mass padding; the coincident-body detector rides along
+  // equal masses (L.general: the device's finding, raised by the preparation kernel; L.uni_host: what the host knows —
+  // 1 equal and nobody else can write the buffer, 0 not equal / not applicable, -1 ask the device)
+  int *general = (int *)L.general;
+  const bool run_uni = general != nullptr && L.uni_host != 0, run_gen = general == nullptr || L.uni_host != 1;
+  const int *gate = (run_uni && run_gen) ? general : nullptr;     // both forms launched: each looks at the finding
   if (L.skip_prep) {
     // the previous update_sym_fused_kernel left posg and the detector's verdict for exactly these positions
   } else if (detect) {      // the table and its flag words are zero: cleared at creation and by every pass's fold
     hipLaunchKernelGGL(sym_prep_kernel<true>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
-                       L.n_pad, (float)L.G, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag);
+                       L.n_pad, (float)L.G, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag, general);
   } else {
     hipLaunchKernelGGL(sym_prep_kernel<false>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
-                       L.n_pad, (float)L.G, (unsigned long long *)nullptr, 0u, (int *)nullptr);
+                       L.n_pad, (float)L.G, (unsigned long long *)nullptr, 0u, (int *)nullptr, general);
   }
-#define NBODY_SYM_K(NPV, ZM, BARE, KH, ZP, FLAG, RUNIF)                                                          \
-  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH>), grid, block, 0, s, (const float4 *)L.posg,      \
-                     (float4 *)L.pool, (const SymItem *)L.items, (float)(ZP), (const int *)(FLAG), RUNIF)
+#define NBODY_SYM_K(NPV, ZM, BARE, KH, UNI, ZP, FLAG, RUNIF)                                                     \
+  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, UNI>), grid, block, 0, s, (const float4 *)L.posg, \
+                     (float4 *)L.pool, (const SymItem *)L.items, (float)(ZP), (const int *)(FLAG), RUNIF, gate, UNI ? 0 : 1)
+#define NBODY_SYM_U(NPV, ZM, BARE, KH, ZP, FLAG, RUNIF)                                                          \
+  do {                                                                                                           \
+    if (run_uni) NBODY_SYM_K(NPV, ZM, BARE, KH, true, ZP, FLAG, RUNIF);                                          \
+    if (run_gen) NBODY_SYM_K(NPV, ZM, BARE, KH, false, ZP, FLAG, RUNIF);                                         \
+  } while (0)
 #define NBODY_SYM(NPV, ZM, BARE, ZP, FLAG, RUNIF)                                                                \
-  do { if (L.kahan) NBODY_SYM_K(NPV, ZM, BARE, true, ZP, FLAG, RUNIF); else NBODY_SYM_K(NPV, ZM, BARE, false, ZP, FLAG, RUNIF); } while (0)
+  do { if (L.kahan) NBODY_SYM_U(NPV, ZM, BARE, true, ZP, FLAG, RUNIF); else NBODY_SYM_U(NPV, ZM, BARE, false, ZP, FLAG, RUNIF); } while (0)
 #define NBODY_SYM_NP(ZM, BARE, ZP, FLAG, RUNIF)                                                                  \
   do {                                                                                                           \
     if (L.np == 1) NBODY_SYM(1, ZM, BARE, ZP, FLAG, RUNIF);                                                      \
     else if (L.np == 2) NBODY_SYM(2, ZM, BARE, ZP, FLAG, RUNIF);                                                 \
     else if (L.np == 4) NBODY_SYM(4, ZM, BARE, ZP, FLAG, RUNIF);                                                 \
-    else NBODY_SYM_K(8, ZM, BARE, false, ZP, FLAG, RUNIF);                                                       \
+    else NBODY_SYM_U(8, ZM, BARE, false, ZP, FLAG, RUNIF);                                                       \
   } while (0)
   if (L.eps2 > 0.0) {
     NBODY_SYM_NP(Z_SOFT, false, L.eps2, nullptr, 0);
@@ -279,6 +306,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   }
 #undef NBODY_SYM_NP
 #undef NBODY_SYM
+#undef NBODY_SYM_U
 #undef NBODY_SYM_K
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || L.fused) return e;                       // fused: update_sym_fused_kernel folds the j-side rows
@@ -307,7 +335,7 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
                        (float4 *)L.posg, (const float4 *)L.pool, ip, io, (const unsigned int *)L.j_ptr,             \
                        (const unsigned int *)L.j_off, L.n_total, (float)L.G, dt, dt > 0.0f ? 1 : 0,                  \
                        (unsigned long long *)L.dup_table_next, (unsigned int)(L.dup_slots - 1),                      \
-                       (unsigned long long *)L.dup_table, L.dup_slots + 8)
+                       (unsigned long long *)L.dup_table, L.dup_slots + 8, (const int *)L.general)
     if (L.kahan) { if (detect) NBODY_FUSED(true, true); else NBODY_FUSED(true, false); }
     else { if (detect) NBODY_FUSED(false, true); else NBODY_FUSED(false, false); }
 #undef NBODY_FUSED
@@ -316,15 +344,15 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
   if (L.precision == NBODY_PREC_F64)
     hipLaunchKernelGGL((update_sym_kernel<double, false>), grid, block, 0, s, (double4 *)posm, (double4 *)vel, (double4 *)acc,
                        (const double4 *)L.pool, ip, io, (const double4 *)L.recv, i_begin, i_count, L.n_src, (double)dt,
-                       dt > 0.0f ? 1 : 0);
+                       dt > 0.0f ? 1 : 0, (const int *)nullptr, L.G);
   else if (L.kahan)
     hipLaunchKernelGGL((update_sym_kernel<float, true>), grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
                        (const float4 *)L.pool, ip, io, (const float4 *)L.recv, i_begin, i_count, L.n_src, dt,
-                       dt > 0.0f ? 1 : 0);
+                       dt > 0.0f ? 1 : 0, (const int *)L.general, (float)L.G);
   else
     hipLaunchKernelGGL((update_sym_kernel<float, false>), grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
                        (const float4 *)L.pool, ip, io, (const float4 *)L.recv, i_begin, i_count, L.n_src, dt,
-                       dt > 0.0f ? 1 : 0);
+                       dt > 0.0f ? 1 : 0, (const int *)L.general, (float)L.G);
   return hipGetLastError();
 }
 

@@ -16,7 +16,6 @@ namespace nbody {
 
 namespace {
 
-constexpr double kPadFar64 = 1.0e18;
 
 // 1/sqrt(x): v_rsq_f64 seed (~2^-26 relative) and ONE third-order step, y (1 + e/2 + 3/8 e^2) with e = 1 - x y^2:
 // the error goes to ~e^3/3 — far below 2^-53 — in five ops where two Newton steps take seven.

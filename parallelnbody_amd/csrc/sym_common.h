@@ -11,9 +11,17 @@ namespace {
 constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
 
 // Zero-mass padding bodies sit far outside any scene: the symmetric tiles may run without a d == 0 guard, and a pad at
-// the origin would coincide with a body at the origin — the reference pins body 0 there — and 0 * inf = NaN.  At 1e18
-// every pad-to-body term is |d|^-3 = 1e-55 -> 0 times a zero mass, exactly 0.
-constexpr float kPadFar = 1.0e18f;
+// the origin would coincide with a body at the origin — the reference pins body 0 there — and 0 * inf = NaN.
+// fp32: at 1e30 the squared distance from a pad to any body overflows to +inf, v_rsq_f32(+inf) = +0, so |d|^-3 is
+// exactly 0 and so is the term — whatever it is multiplied with (G m_j = 0 in the general kernels, nothing at all in the
+// equal-mass kernels, which have no per-body factor to hide a pad behind).  The only float within reach of the pad
+// point is the pad point itself (ulp(1e30) = 7.6e22); a body exactly there selects the guarded kernel (dup_detect).
+// fp64: 1e18, where |d|^-3 = 1e-55 times the pad's zero mass is exactly 0.
+constexpr float kPadFar = 1.0e30f;
+constexpr double kPadFar64 = 1.0e18;
+template <typename T> __device__ __forceinline__ T pad_far();
+template <> __device__ __forceinline__ float pad_far<float>() { return kPadFar; }
+template <> __device__ __forceinline__ double pad_far<double>() { return kPadFar64; }
 
 // lane l+1 <- lane l, lane 0 <- lane 63 (v_mov_b32_dpp wave_ror:1; a half-rate VALU op on gfx950)
 __device__ __forceinline__ float wave_ror1(float v) {
@@ -47,8 +55,8 @@ __device__ __forceinline__ void dup_detect(const V p, unsigned long long *__rest
   // their own size).  Two or more bodies in that cube -> guarded kernel.  flag[1] counts them.
   if (fabs((double)p.x) < 1e-12 && fabs((double)p.y) < 1e-12 && fabs((double)p.z) < 1e-12)
     if (atomicAdd(flag + 1, 1) >= 1) atomicExch(flag, 1);
-  // the unguarded kernels park their zero-mass padding at (1e18, 1e18, 1e18): a body exactly there would meet it at d == 0
-  if (p.x == (T)1.0e18 && p.y == (T)1.0e18 && p.z == (T)1.0e18) atomicExch(flag, 1);
+  // the unguarded kernels park their zero-mass padding at pad_far on all three axes: a body exactly there would meet it at d == 0
+  if (p.x == pad_far<T>() && p.y == pad_far<T>() && p.z == pad_far<T>()) atomicExch(flag, 1);
   // coord_bits adds +0 first: -0 and +0 are the same position
   unsigned long long h = coord_bits(p.x) * 0x9E3779B97F4A7C15ull;
   h = (h ^ (h >> 29)) + coord_bits(p.y) * 0xBF58476D1CE4E5B9ull;
@@ -77,17 +85,20 @@ __global__ __launch_bounds__(kBlock) void dup_detect_kernel(const typename SymVe
 // fp32: what the force kernel reads is not posm but posg = (x, y, z, G*m), n_pad entries, zero-mass padding at kPadFar
 // beyond n_total — so that its loads need neither bounds checks nor a multiply, and whole j tiles can go from HBM to
 // LDS by DMA.  One pass over the positions per force pass (16 B read + 16 B written per body); the coincident-body
-// detector rides along (DETECT).
+// detector rides along (DETECT), and so does the equal-mass test: a body whose mass differs from body 0's raises
+// *general (sticky until the host resets it on a new state), which selects the general kernels and tells the update not
+// to scale (see forces_sym_pk_kernel, UNI).
 template <bool DETECT>
 __global__ __launch_bounds__(kBlock) void sym_prep_kernel(const float4 *__restrict__ posm, float4 *__restrict__ posg,
                                                           int n_total, int n_pad, float gscale,
                                                           unsigned long long *__restrict__ table, unsigned int mask,
-                                                          int *__restrict__ flag) {
+                                                          int *__restrict__ flag, int *__restrict__ general) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_pad) return;
   if (i >= n_total) { posg[i] = make_float4(kPadFar, kPadFar, kPadFar, 0.f); return; }
   float4 p = posm[i];
   if (DETECT) dup_detect<float>(p, table, mask, flag);
+  if (general != nullptr && !(p.w == posm[0].w)) *general = 1;     // every writer writes the same value
   p.w *= gscale;
   posg[i] = p;
 }
@@ -131,8 +142,8 @@ template <typename T> __device__ __forceinline__ T mul_add_sep2(T a, T b, T c) {
   return c + p;
 }
 
-// Own body bl: acc = its i-side segments (item order) + the rows received from every rank (rank order); then
-// optionally the reference's update (OctreeSearch.cpp:29-30), multiply and add kept apart.
+// Own body bl: acc = its i-side segments (item order) + the rows received from every rank (rank order), times the
+// common G m if the equal-mass kernels ran (`general` non-null and clear); then optionally the reference's update (OctreeSearch.cpp:29-30), multiply and add kept apart.
 template <typename R, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::type *__restrict__ posm,
                                                             typename SymVec<R>::type *__restrict__ vel,
@@ -141,7 +152,8 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
                                                             const unsigned int *__restrict__ i_ptr,
                                                             const unsigned int *__restrict__ i_off,
                                                             const typename SymVec<R>::type *__restrict__ recv, int i_begin,
-                                                            int i_count, int n_src, R dt, int integrate) {
+                                                            int i_count, int n_src, R dt, int integrate,
+                                                            const int *__restrict__ general, R gscale) {
   using V = typename SymVec<R>::type;
   const int bl = blockIdx.x * kBlock + threadIdx.x;
   if (bl >= i_count) return;
@@ -161,6 +173,10 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
   for (int q = 0; q < n_src; ++q) {
     const V p = recv[(size_t)q * i_count + bl];
     add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
+  }
+  if (general != nullptr && *general == 0) {      // the equal-mass kernels summed |d|^-3 d: the common G m comes in here
+    const R gm = posm[0].w * gscale;
+    ax *= gm; ay *= gm; az *= gm;
   }
   V ao; ao.x = ax; ao.y = ay; ao.z = az; ao.w = 0;
   acc[bl] = ao;
@@ -189,7 +205,8 @@ __global__ __launch_bounds__(kBlock) void update_sym_fused_kernel(float4 *__rest
                                                                   const unsigned int *__restrict__ j_off, int n_total,
                                                                   float gscale, float dt, int integrate,
                                                                   unsigned long long *__restrict__ next, unsigned int mask,
-                                                                  unsigned long long *__restrict__ cur, int cur_words) {
+                                                                  unsigned long long *__restrict__ cur, int cur_words,
+                                                                  const int *__restrict__ general) {
   const int bl = blockIdx.x * kBlock + threadIdx.x;
   if (DETECT) for (int w = bl; w < cur_words; w += gridDim.x * kBlock) cur[w] = 0ull;
   if (bl >= n_total) return;
@@ -217,6 +234,10 @@ __global__ __launch_bounds__(kBlock) void update_sym_fused_kernel(float4 *__rest
     }
   }
   add(ax, cx, sx); add(ay, cy, sy); add(az, cz, sz);
+  if (general != nullptr && *general == 0) {      // equal-mass kernels: the common G m comes in here (update_sym_kernel)
+    const float gm = posm[0].w * gscale;
+    ax *= gm; ay *= gm; az *= gm;
+  }
   acc[bl] = make_float4(ax, ay, az, 0.f);
   float4 x = posm[bl];
   if (integrate) {

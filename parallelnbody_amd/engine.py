@@ -310,6 +310,12 @@ class NBodyEngine:
     def kernel_time_reset(self):
         self._check(self._L.nbody_kernel_time_reset(self._h))
 
+    def equal_mass_form(self):
+        """Did the last force pass run the equal-mass form of the fp32 symmetric kernel (nbody.h)?"""
+        v = ctypes.c_int32()
+        self._check(self._L.nbody_equal_mass_form(self._h, ctypes.byref(v)))
+        return bool(v.value)
+
     def launch_config(self):
         v = [ctypes.c_int32() for _ in range(5)]
         self._check(self._L.nbody_get_launch_config(self._h, *[ctypes.byref(x) for x in v]))

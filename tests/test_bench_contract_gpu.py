@@ -40,4 +40,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # parity of the benched pass inside the bench run itself, and the executed-flop figure next to the credited one
     cf = r["config"]
     assert cf["bodies_sampled"] >= 24 and cf["max_rel_err_sampled"] < cf["rel_err_tolerance"] == 2e-5
-    assert rf["executed"] == pytest.approx(rf["achieved"] * 25 / 40) and "traffic_source" in rf
+    # the Plummer sphere has equal masses: the timed passes ran the equal-mass form (23 flop per unordered pair), and the
+    # same bodies with distinct masses — the general form, 25 flop — are timed and checked in the same line
+    assert cf["equal_mass_form"] is True
+    assert rf["executed"] == pytest.approx(rf["achieved"] * 23 / 40) and "traffic_source" in rf
+    dm = cf["distinct_masses"]
+    assert dm["max_rel_err_sampled"] < 2e-5 and 0.2 < dm["roofline_frac"] < rf["frac"] * 1.02
+    assert dm["value"] == pytest.approx(65536.0 ** 2 * 3 / (dm["ms_per_step"] * 3e-3), rel=1e-6)

@@ -1,0 +1,174 @@
+"""The equal-mass form of the fp32 symmetric kernel (forces_sym_pk_kernel, UNI; nbody_equal_mass_form): when every body
+has the same mass the pair loop carries no mass factor and the common G m is applied once per body.  Same pair law
+(OctreeSearch.h:101-104) — so the checker is the same oracle at the same tolerance — and the choice must follow the
+masses wherever they come from: the host's upload, a checkpoint, a write through a device pointer handed out."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACC = 2e-5          # asserted;  stated contract 1e-4 (tests/test_parity_gpu.py)
+
+
+def scene(n, seed, equal=True):
+    rng = np.random.default_rng(seed)
+    posm = np.concatenate([rng.uniform(-500, 500, (n, 3)),
+                           np.full((n, 1), 37.5) if equal else rng.uniform(1, 5000, (n, 1))], 1).astype(np.float32)
+    vel = np.concatenate([rng.uniform(-5, 5, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    return posm, vel
+
+
+@pytest.mark.parametrize("eps", [0.0, 0.05])
+@pytest.mark.parametrize("precision,ipt", [("f32", 2), ("f32", 4), ("f32", 8), ("f32", 16), ("f32_kahan", 2), ("f32_kahan", 4),
+                                           ("f32_kahan", 8)])
+def test_equal_masses_against_the_oracle(nb, oracle, precision, ipt, eps):
+    n = 5000                                           # ragged: the last i-set is mostly zero-mass padding
+    posm, vel = scene(n, 100 + ipt)
+    with nb.NBodyEngine(n, algorithm=2, i_per_thread=ipt, precision=precision, eps=eps) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        assert e.equal_mass_form()
+        a = e.accelerations()
+    ref = oracle.forces_direct_f64(posm[:, :3].astype(np.float64), posm[:, 3].astype(np.float64), eps=eps)
+    assert rel_err(a[:, :3], ref).max() < TOL_ACC
+
+
+@pytest.mark.parametrize("n", [24576, 65536])
+def test_equal_and_general_forms_agree_and_step_alike(nb, oracle, n):
+    """The library's own choice of kernel at these sizes, stepping (fused update): the equal-mass form against the general
+    form forced on the same scene (NBODY_SYM_NO_UNI, read when the context is created)."""
+    posm, vel = nb.ic_plummer(n, seed=n)
+    with nb.NBodyEngine(n) as uni:
+        os.environ["NBODY_SYM_NO_UNI"] = "1"
+        try:
+            gen = nb.NBodyEngine(n)
+        finally:
+            del os.environ["NBODY_SYM_NO_UNI"]
+        with gen:
+            for e in (uni, gen):
+                e.set_state(posm, vel)
+                e.step(0.01, 3)
+            assert uni.equal_mass_form() and not gen.equal_mass_form()
+            assert uni.launch_config()["algorithm"] == "symmetric"
+            pu, vu, au = uni.state(); pg, vg, ag = gen.state()
+    scale = np.abs(ag[:, :3]).max(axis=1, keepdims=True)
+    assert (np.abs(au[:, :3] - ag[:, :3]) / scale).max() < 1e-4      # two steps apart: rounding differences have fed back
+    np.testing.assert_allclose(pu[:, :3], pg[:, :3], rtol=0, atol=1e-3)
+    sample = np.arange(0, n, n // 32)
+    ref = np.concatenate([oracle.forces_direct_f64(pg[:, :3].astype(np.float64), pg[:, 3].astype(np.float64), i0=int(i), i1=int(i) + 1)
+                          for i in sample])
+    # accelerations in the state belong to the positions BEFORE the last update: recompute on the final positions
+    with nb.NBodyEngine(n) as again:
+        again.set_state(pg, vg)
+        again.compute_forces()
+        assert again.equal_mass_form()
+        assert rel_err(again.accelerations()[sample, :3], ref).max() < TOL_ACC
+
+
+def test_the_choice_follows_every_new_state(nb, oracle, tmp_path):
+    n = 6000
+    same, vel = scene(n, 1)
+    mixed, _ = scene(n, 2, equal=False)
+    with nb.NBodyEngine(n, algorithm=2, i_per_thread=4) as e:
+        for posm, want in ((same, True), (mixed, False), (same, True)):
+            e.set_state(posm, vel)
+            e.compute_forces()
+            assert e.equal_mass_form() == want
+            ref = oracle.forces_direct_f64(posm[:, :3].astype(np.float64), posm[:, 3].astype(np.float64))
+            assert rel_err(e.accelerations()[:, :3], ref).max() < TOL_ACC
+        # one body heavier than the rest is enough — the last one, in the ragged i-set
+        odd = same.copy(); odd[n - 1, 3] = np.nextafter(odd[n - 1, 3], np.float32(np.inf))
+        e.set_state(odd, vel)
+        e.compute_forces()
+        assert not e.equal_mass_form()
+        # a checkpoint brings its own masses
+        e.set_state(same, vel); e.step(0.01, 2)
+        path = str(tmp_path / "equal.ckpt")
+        e.save_checkpoint(path)
+        p_saved = e.state()[0]
+        e.set_state(mixed, vel); e.compute_forces()
+        assert not e.equal_mass_form()
+        e.load_checkpoint(path)
+        e.compute_forces()
+        assert e.equal_mass_form()
+        ref = oracle.forces_direct_f64(p_saved[:, :3].astype(np.float64), p_saved[:, 3].astype(np.float64))
+        assert rel_err(e.accelerations()[:, :3], ref).max() < TOL_ACC
+
+
+@pytest.mark.parametrize("n", [6000, 40000])
+def test_a_mass_changed_through_the_device_pointer_is_seen(nb, oracle, n):
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    posm, vel = scene(n, 3)
+    kw = dict(algorithm=2, i_per_thread=4) if n < 20480 else {}
+    with nb.NBodyEngine(n, **kw) as e:
+        e.set_state(posm, vel)
+        e.step(0.01, 2)
+        assert e.equal_mass_form()
+        ptr, nbytes = e.device_ptr(nb.BUF_POSM)
+        e.step(0.01, 1)                                # both forms are launched now; the device's finding picks
+        assert e.equal_mass_form()
+        cur = e.state()[0].copy()
+        cur[n // 2, 3] *= np.float32(3.0)
+        assert hip.hipMemcpy(ptr, cur.ctypes.data, nbytes, 1) == 0
+        e.compute_forces()
+        assert not e.equal_mass_form()
+        sample = np.array([0, 7, n // 2, n - 1])
+        ref = np.concatenate([oracle.forces_direct_f64(cur[:, :3].astype(np.float64), cur[:, 3].astype(np.float64), i0=int(i), i1=int(i) + 1)
+                              for i in sample])
+        assert rel_err(e.accelerations()[sample, :3], ref).max() < TOL_ACC
+        # put the mass back: the finding is sticky until the host uploads a state (correct either way)
+        cur[n // 2, 3] = posm[0, 3]
+        assert hip.hipMemcpy(ptr, cur.ctypes.data, nbytes, 1) == 0
+        e.compute_forces()
+        assert not e.equal_mass_form()
+        ref = np.concatenate([oracle.forces_direct_f64(cur[:, :3].astype(np.float64), cur[:, 3].astype(np.float64), i0=int(i), i1=int(i) + 1)
+                              for i in sample])
+        assert rel_err(e.accelerations()[sample, :3], ref).max() < TOL_ACC
+        e.set_state(cur, vel)
+        e.compute_forces()
+        assert e.equal_mass_form()
+
+
+def test_equal_masses_with_coincident_bodies_and_a_body_at_the_origin(nb, oracle):
+    """d == 0 between different bodies selects the guarded kernel — also in the equal-mass form; the reference pins body 0
+    at the origin (OctreeSearch.cpp:68-70), where no padding body may sit."""
+    n = 4500
+    posm, vel = scene(n, 4)
+    posm[0, :3] = 0.0
+    posm[4000, :3] = posm[17, :3]
+    with nb.NBodyEngine(n, algorithm=2, i_per_thread=8) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        assert e.equal_mass_form()
+        a = e.accelerations()
+    assert np.all(np.isfinite(a))
+    ref = oracle.forces_direct_f64(posm[:, :3].astype(np.float64), posm[:, 3].astype(np.float64))
+    assert rel_err(a[:, :3], ref).max() < TOL_ACC
+
+
+def test_equal_mass_form_is_not_used_where_it_does_not_apply(nb):
+    n = 4096
+    posm, vel = scene(n, 5)
+    for kw in (dict(algorithm=2, i_per_thread=2, precision="f64"), dict(algorithm=2, i_per_thread=4, zero_mode=2),
+               dict(algorithm=1), dict(theta=1.0)):
+        with nb.NBodyEngine(n, **kw) as e:
+            e.set_state(posm, vel)
+            e.compute_forces()
+            assert not e.equal_mass_form()
+
+
+def test_massless_bodies_all_alike(nb):
+    n = 3000
+    posm, vel = scene(n, 6)
+    posm[:, 3] = 0.0
+    with nb.NBodyEngine(n, algorithm=2, i_per_thread=4) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        assert e.equal_mass_form()
+        np.testing.assert_array_equal(e.accelerations()[:, :3], np.zeros((n, 3), np.float32))
