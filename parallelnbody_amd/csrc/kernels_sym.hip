@@ -76,9 +76,17 @@ __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[N
   // of the work) keep one step in flight where many pairs are active, so that they never raise the kernel's register need
   constexpr int kUnroll = ONE ? (NA >= 5 ? 1 : 2) : ((NA >= 4) ? NBODY_SYM_UNROLL4 : NBODY_SYM_UNROLL);
   f2 qx = splat2(0.f), qy = splat2(0.f), qz = splat2(0.f);        // (lo, hi) partial sums
+  // the next step's body is read while this step computes (the last read, sp[-64], is the image's first copy of the
+  // lane's own entry: in bounds, unused) — except in the one form that has no four registers left for it
+  constexpr bool kAhead = !(NP == 8 && !BARE && !UNI);
+  float4 pj_next = sp[0];
 #pragma unroll kUnroll
   for (int k = 0; k < 64; ++k) {
-    const float4 pj = sp[-k];
+    const float4 pj = kAhead ? pj_next : sp[-k];
+    if (kAhead) {
+      pj_next = sp[-k - 1];
+      __builtin_amdgcn_sched_barrier(0x47F);                      // everything may cross but LDS accesses: the read is issued here
+    }
     f2 dx[NA], dy[NA], dz[NA], w[NA], u[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) { dx[a] = splat2(pj.x) - xi[P0 + a]; dy[a] = splat2(pj.y) - yi[P0 + a]; dz[a] = splat2(pj.z) - zi[P0 + a]; }
@@ -169,8 +177,10 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
   };
   stage(0, wave, lane);
 
+  // the d == 0 guard's two constants live in VGPRs (packed ops take no literals).  The BARE kernels need them only in
+  // own-block strips: there they are made on the spot, so that the symmetric strips have four registers more
   f2 zp2 = splat2(zp), one2 = splat2(1.0f);
-  asm volatile("" : "+v"(zp2), "+v"(one2));
+  if (!BARE) asm volatile("" : "+v"(zp2), "+v"(one2));
 
   f2 xi[NP], yi[NP], zi[NP], nmi[NP];
   // i-side sums.  Plain: `a` runs through the whole strip.  KAHAN: `a` collects one subtile (64 steps, 128 terms per
@@ -206,8 +216,11 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
       float ox, oy, oz;
       if (!own_block)
         sym_subtile<NP, 0, false, ZMODE, BARE, UNI>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
-      else   // the subtile's bodies sit in the slots of register pair (offset from the i-set's first body) / 512
-        own_block_subtile<NP, 0, ZMODE, BARE, UNI>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+      else {   // the subtile's bodies sit in the slots of register pair (offset from the i-set's first body) / 512
+        f2 zq = zp2, oq = one2;
+        if (BARE) { zq = splat2(zp); oq = splat2(1.0f); asm volatile("" : "+v"(zq), "+v"(oq)); }
+        own_block_subtile<NP, 0, ZMODE, BARE, UNI>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zq, oq, ox, oy, oz);
+      }
       if (KAHAN) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) { ka[p].fold(a[p]); a[p] = Acc3pk<false>(); }

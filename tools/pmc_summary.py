@@ -43,7 +43,8 @@ g = lambda n: next((v for (t, k), v in vals.items() if k == n), None)
 steps = N * (N - 1) / 2 / (64.0 * BPL)   # wave-steps: 64 lanes x BPL bodies meet one j
 if g("SQ_INSTS_VALU"):
     print(f"# derived: wave-steps = N(N-1)/2/{64 * BPL} = {steps:.4g}; SQ_INSTS_VALU per wave-step = {g('SQ_INSTS_VALU') / steps:.1f}"
-          f" (fp32 symmetric strips: {8 * BPL} packed + {BPL} v_rsq_f32 + 6 v_mov_b32_dpp = {9 * BPL + 6})")
+          f" (fp32 symmetric strips, general form: {8 * BPL} packed + {BPL} v_rsq_f32 + 6 v_mov_b32_dpp = {9 * BPL + 6};"
+          f" equal-mass form: {7 * BPL} packed + {BPL} + 6 = {8 * BPL + 6})")
 if g("SQ_WAVE_CYCLES") and g("SQ_BUSY_CYCLES"):
     print(f"# SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = {g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.3f} (waves queueing for the VALU), "
           f"SQ_WAIT_ANY / SQ_WAVE_CYCLES = {g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'):.3f} (parked on memory / barriers), "
