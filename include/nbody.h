@@ -278,9 +278,10 @@ NBODY_API const char *nbody_force_kernel_name(const nbody_ctx *ctx);
  * (the parameter keeps its round-1 name). */
 NBODY_API int nbody_get_algorithm(nbody_ctx *ctx, int32_t *algorithm, int32_t *super_tile);
 
-/* fp32 symmetric contexts: did the last force pass run the equal-mass form of the kernel?  When every body has the same
- * mass (the usual Plummer-sphere set-up) the pair loop sums |d|^-3 d with no mass factor — 14 packed instructions per
- * register pair and step instead of 16 — and the common G m is applied once per body afterwards; same pair law, summation
+/* Symmetric contexts (fp32, Kahan fp32, fp64): did the last force pass run the equal-mass form of the kernel?  When every
+ * body has the same mass (the usual Plummer-sphere set-up) the pair loop sums |d|^-3 d with no mass factor — fp32: 14
+ * packed instructions per register pair and step instead of 16; fp64: 20 operations per pair instead of 22 — and the
+ * common G m is applied once per body afterwards; same pair law, summation
  * order and d == 0 handling, results equal to the general form's to rounding.  Found out on the device before every
  * pass (from the host's copy when only this library writes the positions), so a mass changed through a bound or
  * handed-out buffer is seen.  *in_use = 0 on every other kind of context.  Synchronises the stream. */

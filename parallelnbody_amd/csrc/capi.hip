@@ -68,7 +68,7 @@ struct nbody_ctx {
   int sym_dup_cur = 0;                             // which of the two tables holds the verdict on the current positions
   bool sym_posg_valid = false;                     // posg (and that table) describe the current positions
   bool posm_escaped = false;                       // the caller holds / owns the position buffer: it may change behind our back
-  // fp32 equal-mass kernels: device word the preparation kernel raises when two masses differ (sticky; the host resets it
+  // equal-mass kernels: device word the preparation kernel (fp64: mass_check_kernel) raises when two masses differ (sticky; the host resets it
   // with every state it uploads) and what the host itself saw in that state (1 all equal, 0 not, -1 never saw one)
   void *sym_general = nullptr;
   int masses_equal = -1;
@@ -268,7 +268,9 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   L.general = c->sym_general;
   // the host's own finding is final while nothing but this library writes the position buffer; otherwise "not equal"
   // still is (the device word is sticky), "equal" is only the state of things at the last upload
-  L.uni_host = c->masses_equal == 0 ? 0 : ((c->masses_equal == 1 && c->own_posm && !c->posm_escaped) ? 1 : -1);
+  // (fp64 always asks the device: its test also looks for bodies out where the padding is)
+  L.uni_host = c->masses_equal == 0 ? 0 : ((c->masses_equal == 1 && c->own_posm && !c->posm_escaped &&
+                                            c->p.precision != NBODY_PREC_F64) ? 1 : -1);
   if (sym_fused(c)) {
     L.fused = 1;
     L.skip_prep = c->sym_posg_valid ? 1 : 0;
@@ -424,9 +426,11 @@ void convert4(const SRC *src, DST *dst, size_t n_elems4, bool zero_w) {
 template <typename T>
 int note_masses(nbody_ctx *c, const T *posm4) {
   if (!c->sym_general) return NBODY_OK;
-  const float m0 = (float)posm4[3];
+  const bool ctx64 = c->p.precision == NBODY_PREC_F64;
+  auto seen = [&](T v) { return ctx64 ? (double)v : (double)(float)v; };
+  const double m0 = seen(posm4[3]);
   bool equal = true;
-  for (size_t i = 1; i < (size_t)c->p.n_total && equal; ++i) equal = (float)posm4[4 * i + 3] == m0;
+  for (size_t i = 1; i < (size_t)c->p.n_total && equal; ++i) equal = seen(posm4[4 * i + 3]) == m0;
   c->masses_equal = equal ? 1 : 0;
   HIP_TRY(c, hipMemsetAsync(c->sym_general, equal ? 0 : 0xFF, 4, c->stream));
   return NBODY_OK;
@@ -665,10 +669,10 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
         if ((e = hipMemset(c->sym_dup_table2, 0, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMemset duplicate detector");
       }
     }
-    // equal-mass kernels (fp32; not with the eps floor, which is sized for G m |d|^-3, not for a bare |d|^-3).
+    // equal-mass kernels (not with the eps floor, which is sized for G m |d|^-3, not for a bare |d|^-3).
     // NBODY_SYM_NO_UNI=1 (A/B measurements only) keeps every context on the general kernels.
     const char *no_uni = getenv("NBODY_SYM_NO_UNI");
-    if (p.precision != NBODY_PREC_F64 && p.zero_mode != NBODY_ZERO_FLOOR && !(no_uni && no_uni[0] == '1')) {
+    if (p.zero_mode != NBODY_ZERO_FLOOR && !(no_uni && no_uni[0] == '1')) {
       if ((e = hipMalloc(&c->sym_general, 64)) != hipSuccess) return bail(e, "hipMalloc equal-mass flag");
       if ((e = hipMemset(c->sym_general, 0, 64)) != hipSuccess) return bail(e, "hipMemset equal-mass flag");
     }
@@ -1236,7 +1240,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) t
   HIP_TRY(c, hipMemcpy(c->posm, posm.data(), posm.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size(), hipMemcpyHostToDevice));
-  if (!f64) { const int rc2 = note_masses(c, (const float *)posm.data()); if (rc2) return rc2; }
+  { const int rc2 = f64 ? note_masses(c, (const double *)posm.data()) : note_masses(c, (const float *)posm.data()); if (rc2) return rc2; }
   c->have_state = true; c->floor_eps2 = -1.0; c->step_open = false; c->sym_posg_valid = false;
   c->steps_done = h.steps_done;
   // Barnes-Hut: the opening angle and the root of the next tree (the previous tree's CoM, OctreeSearch.cpp:77-79) are

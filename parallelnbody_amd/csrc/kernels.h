@@ -63,8 +63,8 @@ struct SymLaunch {
   int fused = 0;              // launch_forces_sym: no reduce_j; launch_update_sym: the fused kernel
   int skip_prep = 0;          // posg and dup_table are already those of the current positions
   void *dup_table_next = nullptr;
-  // fp32 equal-mass form (forces_sym_pk_kernel, UNI): `general` is a device int the preparation kernel raises when a
-  // body's mass differs from body 0's; nullptr = general kernels only.  uni_host: 1 = the host knows the masses are equal
+  // equal-mass form (forces_sym_pk_kernel / forces_sym_f64_kernel, UNI): `general` is a device int the preparation
+  // kernel (fp64: mass_check_kernel) raises when a body's mass differs from body 0's; nullptr = general kernels only.  uni_host: 1 = the host knows the masses are equal
   // and nobody else writes the buffer (equal-mass launches only), 0 = it knows they are not (general launches only),
   // -1 = launch both, each looks at `general`.
   void *general = nullptr;

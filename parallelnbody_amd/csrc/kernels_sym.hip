@@ -357,7 +357,7 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
   if (L.precision == NBODY_PREC_F64)
     hipLaunchKernelGGL((update_sym_kernel<double, false>), grid, block, 0, s, (double4 *)posm, (double4 *)vel, (double4 *)acc,
                        (const double4 *)L.pool, ip, io, (const double4 *)L.recv, i_begin, i_count, L.n_src, (double)dt,
-                       dt > 0.0f ? 1 : 0, (const int *)nullptr, L.G);
+                       dt > 0.0f ? 1 : 0, (const int *)L.general, L.G);
   else if (L.kahan)
     hipLaunchKernelGGL((update_sym_kernel<float, true>), grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc,
                        (const float4 *)L.pool, ip, io, (const float4 *)L.recv, i_begin, i_count, L.n_src, dt,

@@ -16,9 +16,11 @@ constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
 // exactly 0 and so is the term — whatever it is multiplied with (G m_j = 0 in the general kernels, nothing at all in the
 // equal-mass kernels, which have no per-body factor to hide a pad behind).  The only float within reach of the pad
 // point is the pad point itself (ulp(1e30) = 7.6e22); a body exactly there selects the guarded kernel (dup_detect).
-// fp64: 1e18, where |d|^-3 = 1e-55 times the pad's zero mass is exactly 0.
+// fp64: 1e120 — the squared distance stays finite (the Newton step of rsq64 would turn inf into NaN) and |d|^-3 =
+// 1e-361 underflows to exactly 0.  Doubles within ~6e107 of that point exist (ulp = 1.5e104); mass_check_kernel sends
+// a scene with a body out there (all three coordinates > 9e119) to the general kernels, where the pad's zero mass does it.
 constexpr float kPadFar = 1.0e30f;
-constexpr double kPadFar64 = 1.0e18;
+constexpr double kPadFar64 = 1.0e120;
 template <typename T> __device__ __forceinline__ T pad_far();
 template <> __device__ __forceinline__ float pad_far<float>() { return kPadFar; }
 template <> __device__ __forceinline__ double pad_far<double>() { return kPadFar64; }
@@ -80,6 +82,18 @@ __global__ __launch_bounds__(kBlock) void dup_detect_kernel(const typename SymVe
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   dup_detect<T>(posm[i], table, mask, flag);
+}
+
+// fp64 (no preparation kernel there): the equal-mass test on its own — *general is raised (sticky) when a body's mass
+// differs from body 0's or a body sits where the far-away padding is.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mass_check_kernel(const typename SymVec<T>::type *__restrict__ posm, int n,
+                                                            int *__restrict__ general) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const typename SymVec<T>::type p = posm[i];
+  const T edge = pad_far<T>() * (T)0.9;
+  if (!(p.w == posm[0].w) || (p.x > edge && p.y > edge && p.z > edge)) *general = 1;
 }
 
 // fp32: what the force kernel reads is not posm but posg = (x, y, z, G*m), n_pad entries, zero-mass padding at kPadFar

@@ -25,7 +25,7 @@ def scene(n, seed, equal=True):
 
 @pytest.mark.parametrize("eps", [0.0, 0.05])
 @pytest.mark.parametrize("precision,ipt", [("f32", 2), ("f32", 4), ("f32", 8), ("f32", 16), ("f32_kahan", 2), ("f32_kahan", 4),
-                                           ("f32_kahan", 8)])
+                                           ("f32_kahan", 8), ("f64", 2), ("f64", 4)])
 def test_equal_masses_against_the_oracle(nb, oracle, precision, ipt, eps):
     n = 5000                                           # ragged: the last i-set is mostly zero-mass padding
     posm, vel = scene(n, 100 + ipt)
@@ -33,9 +33,44 @@ def test_equal_masses_against_the_oracle(nb, oracle, precision, ipt, eps):
         e.set_state(posm, vel)
         e.compute_forces()
         assert e.equal_mass_form()
-        a = e.accelerations()
+        a = e.accelerations(np.float64 if precision == "f64" else np.float32)
     ref = oracle.forces_direct_f64(posm[:, :3].astype(np.float64), posm[:, 3].astype(np.float64), eps=eps)
-    assert rel_err(a[:, :3], ref).max() < TOL_ACC
+    assert rel_err(a[:, :3], ref).max() < (1e-12 if precision == "f64" else TOL_ACC)
+
+
+def test_fp64_equal_and_general_forms_step_alike(nb, oracle):
+    """configs[3]'s kernel at a small size: three steps in the equal-mass form against the general form forced on the same
+    scene; a body out where the far-away padding sits sends the scene to the general kernels."""
+    n = 24576
+    posm, vel = nb.ic_plummer(n, seed=11)
+    with nb.NBodyEngine(n, precision="f64") as uni:
+        os.environ["NBODY_SYM_NO_UNI"] = "1"
+        try:
+            gen = nb.NBodyEngine(n, precision="f64")
+        finally:
+            del os.environ["NBODY_SYM_NO_UNI"]
+        with gen:
+            for e in (uni, gen):
+                assert e.launch_config()["kernel"] == "forces_sym_f64_kernel"
+                e.set_state(posm, vel)
+                e.step(0.01, 3)
+            assert uni.equal_mass_form() and not gen.equal_mass_form()
+            pu, vu, au = uni.state(np.float64); pg, vg, ag = gen.state(np.float64)
+            np.testing.assert_allclose(pu[:, :3], pg[:, :3], rtol=1e-11, atol=1e-11)
+            np.testing.assert_allclose(au[:, :3], ag[:, :3], rtol=1e-9, atol=1e-9 * np.abs(ag).max())
+            far = pu.copy()
+            far[5, :3] = 0.95e120
+            uni.set_state(far, vu)
+            uni.compute_forces()
+            assert not uni.equal_mass_form()
+            a = uni.accelerations(np.float64)
+            assert np.all(np.isfinite(a))
+            np.testing.assert_array_equal(a[5, :3], 0.0)          # too far away to feel or exert anything
+    sample = np.array([0, 5, 77, n - 1])
+    near = np.delete(far, 5, axis=0)
+    for i in (0, 77):
+        ref = oracle.forces_direct_f64(near[:, :3], near[:, 3], i0=(i if i < 5 else i - 1), i1=(i if i < 5 else i - 1) + 1)
+        assert rel_err(a[i:i + 1, :3], ref).max() < 1e-12
 
 
 @pytest.mark.parametrize("n", [24576, 65536])
@@ -155,8 +190,8 @@ def test_equal_masses_with_coincident_bodies_and_a_body_at_the_origin(nb, oracle
 def test_equal_mass_form_is_not_used_where_it_does_not_apply(nb):
     n = 4096
     posm, vel = scene(n, 5)
-    for kw in (dict(algorithm=2, i_per_thread=2, precision="f64"), dict(algorithm=2, i_per_thread=4, zero_mode=2),
-               dict(algorithm=1), dict(theta=1.0)):
+    for kw in (dict(algorithm=2, i_per_thread=4, zero_mode=2), dict(algorithm=1), dict(algorithm=1, precision="f64"),
+               dict(theta=1.0)):
         with nb.NBodyEngine(n, **kw) as e:
             e.set_state(posm, vel)
             e.compute_forces()
