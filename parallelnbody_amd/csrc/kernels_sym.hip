@@ -33,6 +33,9 @@ namespace {
 #ifndef NBODY_SYM_UNROLL
 #define NBODY_SYM_UNROLL 4
 #endif
+#ifndef NBODY_SYM_AHEAD
+#define NBODY_SYM_AHEAD 0     // A/B builds only (tools/ab_read_ahead.sh): 1 / 2 read the next step's body from LDS one step ahead
+#endif
 #ifndef NBODY_SYM_UNROLL4
 #define NBODY_SYM_UNROLL4 2   // four and more register pairs per lane: two steps in flight, not four
 #endif
@@ -76,9 +79,11 @@ __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[N
   // of the work) keep one step in flight where many pairs are active, so that they never raise the kernel's register need
   constexpr int kUnroll = ONE ? (NA >= 5 ? 1 : 2) : ((NA >= 4) ? NBODY_SYM_UNROLL4 : NBODY_SYM_UNROLL);
   f2 qx = splat2(0.f), qy = splat2(0.f), qz = splat2(0.f);        // (lo, hi) partial sums
-  // the next step's body is read while this step computes (the last read, sp[-64], is the image's first copy of the
-  // lane's own entry: in bounds, unused) — except in the one form that has no four registers left for it
-  constexpr bool kAhead = !(NP == 8 && !BARE && !UNI);
+  // Reading the next step's body one step ahead (pinned with a scheduling barrier; the last read, sp[-64], is the image's
+  // first copy of the lane's own entry: in bounds, unused) halves the wave-cycles parked on LDS (10.4 % -> 4.8 %) and
+  // buys nothing: two waves per SIMD already cover the latency (same-box A/B, N = 2^20: 150.65 vs 150.30 ms,
+  // profiles/r02_ab_lds_read_ahead.txt).  Off.
+  constexpr bool kAhead = NBODY_SYM_AHEAD == 2 ? !(NP == 8 && !BARE && !UNI) : (NBODY_SYM_AHEAD == 1 && UNI);
   float4 pj_next = sp[0];
 #pragma unroll kUnroll
   for (int k = 0; k < 64; ++k) {
