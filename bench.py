@@ -27,14 +27,18 @@ FLOP_PER_EVAL_SYM = 25        # what the symmetric kernel executes per UNORDERED
                               # + 2 (the two mass factors) + 12 (six FMAs); matches the PMC count (profiles/r02_pmc_*.txt)
 FLOP_PER_EVAL_SYM_EQUAL = 23  # its equal-mass form (all bodies of one mass, as in a Plummer sphere): no mass factors in the loop
 # HBM bytes per force launch, measured by PMC passes (tools/profile_kernel.sh: FETCH_SIZE x2 — the gfx950 correction of
-# MI355X_MICROARCH.md — + WRITE_SIZE, separate passes), keyed by (algorithm, n, gpus, bodies per lane, precision) with the
+# MI355X_MICROARCH.md — + WRITE_SIZE, separate passes), keyed by (algorithm, n, gpus, bodies per lane, precision, equal-mass form) with the
 # file the number comes from.  Configurations that were not profiled report null.
 TRAFFIC_BYTES_PER_LAUNCH = {
-    ("tiled", 1 << 20, 1, 4, "f32"): (2 * 173606 * 1024 + 262144 * 1024, "profiles/r01_pmc_forces_tile_kernel.txt"),
-    ("symmetric", 1 << 20, 1, 16, "f32"): (5404842240, "profiles/r02_pmc_forces_sym_kernel_n1048576_ipt16.txt"),
-    ("symmetric", 1 << 16, 1, 16, "f32"): (301033491, "profiles/r02_pmc_forces_sym_kernel_n65536_ipt16.txt"),
-    ("symmetric", 1 << 21, 1, 8, "f32_kahan"): (31471647019, "profiles/r02_pmc_forces_sym_kernel_kahan_n2097152_ipt8.txt"),
-    ("symmetric", 1 << 18, 1, 4, "f64"): (2361977562, "profiles/r02_pmc_forces_sym_f64_kernel_n262144_ipt4.txt"),
+    ("tiled", 1 << 20, 1, 4, "f32", False): (2 * 173606 * 1024 + 262144 * 1024, "profiles/r01_pmc_forces_tile_kernel.txt"),
+    ("symmetric", 1 << 20, 1, 16, "f32", True): (5394388053, "profiles/r02_pmc_forces_sym_kernel_equal_mass_n1048576_ipt16.txt"),
+    ("symmetric", 1 << 20, 1, 16, "f32", False): (5396041643, "profiles/r02_pmc_forces_sym_kernel_n1048576_ipt16.txt"),
+    ("symmetric", 1 << 16, 1, 16, "f32", True): (182662522, "profiles/r02_pmc_forces_sym_kernel_equal_mass_n65536_ipt16.txt"),
+    ("symmetric", 1 << 16, 1, 16, "f32", False): (301033491, "profiles/r02_pmc_forces_sym_kernel_n65536_ipt16.txt"),
+    ("symmetric", 1 << 21, 1, 8, "f32_kahan", True): (31367423019, "profiles/r02_pmc_forces_sym_kernel_kahan_equal_mass_n2097152_ipt8.txt"),
+    ("symmetric", 1 << 21, 1, 8, "f32_kahan", False): (31471647019, "profiles/r02_pmc_forces_sym_kernel_kahan_n2097152_ipt8.txt"),
+    ("symmetric", 1 << 18, 1, 4, "f64", True): (2362121984, "profiles/r02_pmc_forces_sym_f64_kernel_equal_mass_n262144_ipt4.txt"),
+    ("symmetric", 1 << 18, 1, 4, "f64", False): (2361977562, "profiles/r02_pmc_forces_sym_f64_kernel_n262144_ipt4.txt"),
 }
 
 
@@ -246,10 +250,10 @@ def main():
     # bodies; the one-sided kernel evaluates every ordered pair (20 flop)
     equal_mass = sim.engine.equal_mass_form()      # which form of the symmetric kernel the timed passes ran
     flop_eval = FLOP_PER_EVAL_SYM_EQUAL if equal_mass else FLOP_PER_EVAL_SYM
+    traffic = TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, world, cfg["i_per_thread"], args.precision, equal_mass), (None, None))
     executed_tflops = (launch_pairs / 2 * flop_eval if cfg["algorithm"] == "symmetric"
                        else launch_pairs * FLOP_PER_PAIR) / avg_launch_s * 1e-12
     peak = PEAK_FP32_TFLOPS if args.precision != "f64" else PEAK_FP32_TFLOPS / 2
-    traffic = TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, world, cfg["i_per_thread"], args.precision), (None, None))
     p_end, _ = sim.gather_state()
     finite = bool(np.isfinite(p_end).all())
     # parity of the benched instantiation at the benched size, after the timed region: one more force pass of the

@@ -10,6 +10,15 @@ namespace {
 
 constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
 
+// segment loads in flight per thread in the row folds (reduce_j_kernel, update_sym_kernel, update_sym_fused_kernel): one
+// thread per body walks its granule's segment list, so at mid sizes (N = 65536: ~150 segments per body, 256 workgroups)
+// the fold is bound by load latency, not bandwidth.  Same-box A/B of whole steps (profiles/r02_ab_fold_unroll.txt): update
+// 59 -> 47 us at N = 65536 and 37 -> 31 us at N = 32768 with eight in flight (step 0.686 -> 0.673 ms, 0.221 -> 0.214 ms);
+// sixteen no better.  The adds stay one dependent chain in list order: the bits do not change.
+#ifndef NBODY_SYM_FOLD_UNROLL
+#define NBODY_SYM_FOLD_UNROLL 8
+#endif
+
 // Zero-mass padding bodies sit far outside any scene: the symmetric tiles may run without a d == 0 guard, and a pad at
 // the origin would coincide with a body at the origin — the reference pins body 0 there — and 0 * inf = NaN.
 // fp32: at 1e30 the squared distance from a pad to any body overflows to +inf, v_rsq_f32(+inf) = +0, so |d|^-3 is
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void reduce_j_kernel(const typename SymVec<
     else sum += v;
   };
   const unsigned int k1 = j_ptr[g + 1];
-#pragma unroll 4
+#pragma unroll NBODY_SYM_FOLD_UNROLL
   for (unsigned int k = j_ptr[g]; k < k1; ++k) {
     const V p = pool[(size_t)j_off[k] + l];
     add(sx, cx, p.x); add(sy, cy, p.y); add(sz, cz, p.z);
@@ -178,12 +187,12 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
     else sum += v;
   };
   const unsigned int k1 = i_ptr[g + 1];
-#pragma unroll 4
+#pragma unroll NBODY_SYM_FOLD_UNROLL
   for (unsigned int k = i_ptr[g]; k < k1; ++k) {
     const V p = pool[(size_t)i_off[k] + l];
     add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
   }
-#pragma unroll 4
+#pragma unroll NBODY_SYM_FOLD_UNROLL
   for (int q = 0; q < n_src; ++q) {
     const V p = recv[(size_t)q * i_count + bl];
     add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void update_sym_fused_kernel(float4 *__rest
   float sx = 0, sy = 0, sz = 0, dx = 0, dy = 0, dz = 0;           // the j-side row of this body (reduce_j_kernel's sum)
   {
     const unsigned int k1 = j_ptr[g + 1];
-#pragma unroll 4
+#pragma unroll NBODY_SYM_FOLD_UNROLL
     for (unsigned int k = j_ptr[g]; k < k1; ++k) {
       const float4 p = pool[(size_t)j_off[k] + l];
       add(sx, dx, p.x); add(sy, dy, p.y); add(sz, dz, p.z);
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void update_sym_fused_kernel(float4 *__rest
   float ax = 0, ay = 0, az = 0, cx = 0, cy = 0, cz = 0;
   {
     const unsigned int k1 = i_ptr[g + 1];
-#pragma unroll 4
+#pragma unroll NBODY_SYM_FOLD_UNROLL
     for (unsigned int k = i_ptr[g]; k < k1; ++k) {
       const float4 p = pool[(size_t)i_off[k] + l];
       add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
