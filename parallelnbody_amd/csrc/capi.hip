@@ -292,6 +292,10 @@ nbody::ForceLaunch make_launch(const nbody_ctx *c) {
   L.wave = c->wave;
   L.dup_table = c->sym_dup_table; L.dup_slots = c->sym_dup_slots;
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
+  // equal-mass form of the packed one-sided kernel: the host's scan of the uploaded state stands while nothing else writes
+  // the position buffer ("not equal" always stands: the device word is sticky); otherwise the device looks before the launch
+  L.general = c->sym_general;
+  L.check_masses = (c->sym_general && c->masses_equal != 0 && !(c->masses_equal == 1 && c->own_posm && !c->posm_escaped)) ? 1 : 0;
   return L;
 }
 
@@ -697,6 +701,13 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
       while (slots < 2 * p.n_total) slots *= 2;
       c->sym_dup_slots = slots;
       if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
+    }
+    // equal-mass form of the packed one-sided kernel (not the small-system kernels, whose one launch has no room for a test)
+    const char *no_uni = getenv("NBODY_SYM_NO_UNI");
+    if (p.precision != NBODY_PREC_F64 && !c->wave && c->ipt % 2 == 0 && p.zero_mode != NBODY_ZERO_SELECT &&
+        p.zero_mode != NBODY_ZERO_FLOOR && !(no_uni && no_uni[0] == '1')) {
+      if ((e = hipMalloc(&c->sym_general, 64)) != hipSuccess) return bail(e, "hipMalloc equal-mass flag");
+      if ((e = hipMemset(c->sym_general, 0, 64)) != hipSuccess) return bail(e, "hipMemset equal-mass flag");
     }
   }
   if ((e = hipMalloc(&c->scratch, 64)) != hipSuccess) return bail(e, "hipMalloc scratch");
@@ -1359,7 +1370,7 @@ int nbody_equal_mass_form(nbody_ctx *c, int32_t *in_use) {
   if (!c || !in_use) return NBODY_ERR_INVALID;
   if (c->multi) return nbody_equal_mass_form(nbody::multi_part(c->multi, 0), in_use);
   *in_use = 0;
-  if (!c->sym || !c->sym_general || c->theta > 0.0f) return NBODY_OK;
+  if (!c->sym_general || c->theta > 0.0f) return NBODY_OK;
   HIP_TRY(c, hipSetDevice(c->p.device));
   HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->sym_general, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

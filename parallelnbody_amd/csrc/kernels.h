@@ -22,6 +22,11 @@ struct ForceLaunch {
   int wave;             // 0: tile kernels; != 0: small-N kernel, one workgroup per pair of bodies (j_split must be 1)
   void *dup_table = nullptr;   // packed fp32 kernel, exact mode: coincident-body detector's table [dup_slots] + {flag, count};
   int dup_slots = 0;           // with it, tiles that hold no self pair run without the d == 0 guard when no two bodies coincide
+  // packed fp32 kernel: device int that is 0 when every body has body 0's mass (equal-mass form: no mass factor in the
+  // pair loop); nullptr = general form only.  check_masses: run mass_check_kernel on the positions first (somebody else
+  // may have written the buffer since the host last looked).
+  void *general = nullptr;
+  int check_masses = 0;
 };
 
 // All-pairs force partials.  Returns hipSuccess or the launch error.

@@ -8,6 +8,8 @@
 //   bounds_kernel       <- OctreeSearch.cpp:47-56 (ComputeCubeSize)
 #include "kernels.h"
 
+#include <type_traits>
+
 #include "../../include/nbody.h"
 #include "pk_common.h"
 #include "sym_common.h"
@@ -211,12 +213,23 @@ __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T
 // dup_flag (Z_CLAMP only): verdict of dup_detect_kernel on this pass's positions.  With no two bodies on one point
 // (*dup_flag == 0) d == 0 can only be a self pair, so full tiles that do not overlap the workgroup's own i-range run
 // the pair law bare — 5 packed ops + 1 v_rsq_f32 per pair-lane instead of 7 + 1.  The results are the guarded ones.
+#ifndef NBODY_TILE_UNI
+#define NBODY_TILE_UNI 1      // 0 compiles the equal-mass branch out (A/B builds: tools/ab_tile_uni.sh)
+#endif
 template <int NP, int TILE, int ZMODE, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__restrict__ posm,
                                                                 float4 *__restrict__ accp, int n_total, int i_begin,
                                                                 int i_count, int j_chunk, float gscale, float zp,
-                                                                const int *__restrict__ dup_flag) {
+                                                                const int *__restrict__ dup_flag,
+                                                                const int *__restrict__ general) {
   constexpr int IPT = 2 * NP;
+  // equal-mass form (see forces_sym_pk_kernel, UNI): *general == 0 says every body has body 0's mass — found by the host
+  // in the state it uploaded, or by mass_check_kernel before this launch when somebody else can write the buffer.  Then
+  // the pair loop carries no mass factor (11 packed ops per register pair and j instead of 12), the padding of ragged tiles
+  // goes far away instead of to the origin (there is no zero mass to hide it behind), and the sums get the common G m
+  // on their way out.  One kernel, a wave-uniform branch: small systems cannot afford a second launch.
+  const bool uni = NBODY_TILE_UNI && general != nullptr && *general == 0;
+  const float padc = uni ? kPadFar : 0.f;
   constexpr int LPT = (TILE + kBlock - 1) / kBlock;
   __shared__ float4 sh[2][TILE];
 
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
       if (e < TILE) {
         const int j = j0 + tile * TILE + e;
         if (j < j1) r[l] = posm[j];
-        else        r[l] = make_float4(0.f, 0.f, 0.f, 0.f);   // zero-mass padding
+        else        r[l] = make_float4(padc, padc, padc, 0.f);   // zero-mass padding
       }
     }
   };
@@ -275,22 +288,22 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
     constexpr int JB = (NP == 1) ? 4 : 2;
     const int t_lo = j0 + tile * TILE, t_hi = t_lo + TILE;
     // no self pair in the tile and no zero-mass padding (pads sit on the origin, where a body may be)
+    auto walk = [&](auto zm, auto un) {
+#pragma unroll 2
+      for (int jj = 0; jj < TILE; jj += JB) {
+        float4 pj[JB];
+#pragma unroll
+        for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
+        pair_group_pk<NP, JB, decltype(zm)::value, false, decltype(un)::value>(xi, yi, zi, pj, zp2, one2, a);
+      }
+    };
+    using std::integral_constant;
     if (ZMODE == Z_CLAMP && bare_ok && t_hi <= j1 && (t_hi <= own_lo || t_lo >= own_hi)) {
-#pragma unroll 2
-      for (int jj = 0; jj < TILE; jj += JB) {
-        float4 pj[JB];
-#pragma unroll
-        for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
-        pair_group_pk<NP, JB, Z_BARE, false>(xi, yi, zi, pj, zp2, one2, a);
-      }
+      if (uni) walk(integral_constant<int, Z_BARE>{}, integral_constant<bool, true>{});
+      else     walk(integral_constant<int, Z_BARE>{}, integral_constant<bool, false>{});
     } else {
-#pragma unroll 2
-      for (int jj = 0; jj < TILE; jj += JB) {
-        float4 pj[JB];
-#pragma unroll
-        for (int b = 0; b < JB; ++b) pj[b] = sh[buf][jj + b];
-        pair_group_pk<NP, JB, ZMODE, false>(xi, yi, zi, pj, zp2, one2, a);
-      }
+      if (uni) walk(integral_constant<int, ZMODE>{}, integral_constant<bool, true>{});
+      else     walk(integral_constant<int, ZMODE>{}, integral_constant<bool, false>{});
     }
     if (KAHAN) {
 #pragma unroll
@@ -303,7 +316,8 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int il0 = ibase + t + (2 * p) * kBlock, il1 = il0 + kBlock;
-    const f2 sx = KAHAN ? ka[KAHAN ? p : 0].x : a[p].x, sy = KAHAN ? ka[KAHAN ? p : 0].y : a[p].y, sz = KAHAN ? ka[KAHAN ? p : 0].z : a[p].z;
+    f2 sx = KAHAN ? ka[KAHAN ? p : 0].x : a[p].x, sy = KAHAN ? ka[KAHAN ? p : 0].y : a[p].y, sz = KAHAN ? ka[KAHAN ? p : 0].z : a[p].z;
+    if (uni) { const f2 gm = splat2(posm[0].w * gscale); sx = sx * gm; sy = sy * gm; sz = sz * gm; }
     if (il0 < i_count) accp[(size_t)c * i_count + il0] = make_float4(sx.x, sy.x, sz.x, 0.f);
     if (il1 < i_count) accp[(size_t)c * i_count + il1] = make_float4(sx.y, sy.y, sz.y, 0.f);
   }
@@ -522,7 +536,11 @@ hipError_t launch_forces_t(const ForceLaunch &L, hipStream_t s) {
 #define NBODY_LAUNCH_PK(ZM, ZP, FLAG)                                                                            \
   hipLaunchKernelGGL((forces_tile_pk_kernel<IPT / 2, TILE, ZM, KAHAN>), grid, block, 0, s, (const float4 *)L.posm, \
                      (float4 *)L.accp, L.n_total, L.i_begin, L.i_count, L.j_chunk, (float)L.G, (float)(ZP),        \
-                     (const int *)(FLAG))
+                     (const int *)(FLAG), (const int *)L.general)
+      // equal masses?  The host's finding stands while only this library writes the buffer; otherwise the device looks
+      if (L.general != nullptr && L.check_masses)
+        hipLaunchKernelGGL(mass_check_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                           (const float4 *)L.posm, L.n_total, (int *)L.general);
       if (L.eps2 > 0.0) {
         NBODY_LAUNCH_PK(Z_SOFT, L.eps2, nullptr);
       } else if (L.dup_table != nullptr) {

@@ -59,7 +59,8 @@ template <> struct Acc3pk<true> {
 // The pair law for JB j-bodies (x, y, z, G*m as read from the LDS tile) against NP register pairs of i-bodies,
 // stage by stage (all differences, then all r^2, ...) so that no instruction's consumer is adjacent to it.
 // zp2 = eps^2 (Z_SOFT) or -2^126 (Z_CLAMP) in both halves; one2 = (1, 1); both live in VGPRs.
-template <int NP, int JB, int ZMODE, bool KAHAN>
+// UNI: every body has the same mass — no G*m_j factor here; the caller multiplies the finished sums by the common G*m.
+template <int NP, int JB, int ZMODE, bool KAHAN, bool UNI = false>
 __device__ __forceinline__ void pair_group_pk(const f2 (&xi)[NP], const f2 (&yi)[NP], const f2 (&zi)[NP],
                                               const float4 (&pj)[JB], f2 zp2, f2 one2, Acc3pk<KAHAN> (&a)[NP]) {
   f2 dx[JB][NP], dy[JB][NP], dz[JB][NP], w[JB][NP], u[JB][NP];
@@ -100,7 +101,7 @@ __device__ __forceinline__ void pair_group_pk(const f2 (&xi)[NP], const f2 (&yi)
       // hazard only for its own instructions.  It therefore takes rinv^3, produced by two ordinary ops.
       w[b][p] = u[b][p] * u[b][p];
       w[b][p] = w[b][p] * u[b][p];
-      w[b][p] = mul_bcast_hi(w[b][p], f2{pj[b].z, pj[b].w});   // * G*m_j
+      if (!UNI) w[b][p] = mul_bcast_hi(w[b][p], f2{pj[b].z, pj[b].w});   // * G*m_j
     }
 #pragma unroll
   for (int b = 0; b < JB; ++b)

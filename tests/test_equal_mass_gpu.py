@@ -38,6 +38,73 @@ def test_equal_masses_against_the_oracle(nb, oracle, precision, ipt, eps):
     assert rel_err(a[:, :3], ref).max() < (1e-12 if precision == "f64" else TOL_ACC)
 
 
+@pytest.mark.parametrize("eps", [0.0, 0.05])
+@pytest.mark.parametrize("precision,ipt", [("f32", 2), ("f32", 4), ("f32_kahan", 2), ("f32_kahan", 4)])
+@pytest.mark.parametrize("n", [9000, 33000])
+def test_one_sided_kernel_equal_masses_against_the_oracle(nb, oracle, n, precision, ipt, eps):
+    """The packed one-sided kernel has the same form behind a wave-uniform branch (ragged tiles pad far away then);
+    N = 33000 also runs the coincident-body detector and with it the unguarded tiles."""
+    posm, vel = scene(n, n + ipt)
+    with nb.NBodyEngine(n, algorithm=1, i_per_thread=ipt, precision=precision, eps=eps) as e:
+        assert e.launch_config()["kernel"] == "forces_tile_pk_kernel"
+        e.set_state(posm, vel)
+        e.compute_forces()
+        assert e.equal_mass_form()
+        a = e.accelerations()
+        mixed, _ = scene(n, 5, equal=False)
+        e.set_state(mixed, vel)
+        e.compute_forces()
+        assert not e.equal_mass_form()
+        b = e.accelerations()
+    sample = np.concatenate([np.arange(0, n, n // 16), [n - 1]])
+    for acc, pm in ((a, posm), (b, mixed)):
+        ref = np.concatenate([oracle.forces_direct_f64(pm[:, :3].astype(np.float64), pm[:, 3].astype(np.float64), eps=eps, i0=int(i), i1=int(i) + 1)
+                              for i in sample])
+        assert rel_err(acc[sample, :3], ref).max() < TOL_ACC
+
+
+def test_one_sided_sharded_contexts_agree_bit_for_bit_in_the_equal_mass_form(nb):
+    """TILED's promise — every bit independent of how many GPUs share the bodies — holds in the equal-mass form too."""
+    n = 12288
+    posm, vel = nb.ic_plummer(n, seed=3)
+    with nb.NBodyEngine(n, algorithm=1) as one:
+        one.set_state(posm, vel)
+        one.compute_forces()
+        assert one.equal_mass_form()
+        whole = one.accelerations()
+    parts = []
+    for r in range(3):
+        with nb.NBodyEngine(n, i_begin=r * 4096, i_count=4096, algorithm=1) as e:
+            e.set_state(posm, vel)
+            e.compute_forces()
+            assert e.equal_mass_form()
+            parts.append(e.accelerations())
+    np.testing.assert_array_equal(np.concatenate(parts), whole)
+
+
+def test_one_sided_kernel_sees_a_mass_changed_through_the_device_pointer(nb, oracle):
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    n = 10000
+    posm, vel = scene(n, 8)
+    with nb.NBodyEngine(n, algorithm=1) as e:
+        e.set_state(posm, vel)
+        e.step(0.01, 2)
+        assert e.equal_mass_form()
+        ptr, nbytes = e.device_ptr(nb.BUF_POSM)
+        e.step(0.01, 1)
+        assert e.equal_mass_form()                        # mass_check_kernel runs before every pass now, and agrees
+        cur = e.state()[0].copy()
+        cur[123, 3] *= np.float32(2.0)
+        assert hip.hipMemcpy(ptr, cur.ctypes.data, nbytes, 1) == 0
+        e.compute_forces()
+        assert not e.equal_mass_form()
+        sample = np.array([0, 123, n - 1])
+        ref = np.concatenate([oracle.forces_direct_f64(cur[:, :3].astype(np.float64), cur[:, 3].astype(np.float64), i0=int(i), i1=int(i) + 1)
+                              for i in sample])
+        assert rel_err(e.accelerations()[sample, :3], ref).max() < TOL_ACC
+
+
 def test_fp64_equal_and_general_forms_step_alike(nb, oracle):
     """configs[3]'s kernel at a small size: three steps in the equal-mass form against the general form forced on the same
     scene; a body out where the far-away padding sits sends the scene to the general kernels."""
@@ -190,8 +257,8 @@ def test_equal_masses_with_coincident_bodies_and_a_body_at_the_origin(nb, oracle
 def test_equal_mass_form_is_not_used_where_it_does_not_apply(nb):
     n = 4096
     posm, vel = scene(n, 5)
-    for kw in (dict(algorithm=2, i_per_thread=4, zero_mode=2), dict(algorithm=1), dict(algorithm=1, precision="f64"),
-               dict(theta=1.0)):
+    for kw in (dict(algorithm=2, i_per_thread=4, zero_mode=2), dict(algorithm=1, zero_mode=1), dict(algorithm=1, zero_mode=2),
+               dict(algorithm=1, precision="f64"), dict(algorithm=1, i_per_thread=1), dict(theta=1.0), dict()):   # dict(): small_pk_kernel
         with nb.NBodyEngine(n, **kw) as e:
             e.set_state(posm, vel)
             e.compute_forces()
