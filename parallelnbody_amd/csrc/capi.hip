@@ -164,9 +164,10 @@ void choose_algorithm(nbody_ctx *c) {
   c->sym = false;
   if (p.algorithm == NBODY_ALGO_TILED) return;
   if (p.zero_mode == NBODY_ZERO_SELECT) return;                         // compare+select lives in the one-sided kernel only
-  // whole steps, one box (profiles/r02_threshold_symmetric_vs_one_sided.txt): N = 16384 one-sided 0.102 ms vs symmetric
-  // 0.108, N = 20480 0.153 vs 0.131, N = 32768 0.328 vs 0.265
-  if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < env_int("NBODY_SYM_MIN_N", 20480)) return;
+  // whole steps, one box, final kernels (profiles/r02_threshold_symmetric_vs_one_sided.txt): N = 10240 one-sided 0.0597 ms vs
+  // symmetric 0.0597, N = 12288 0.0763 vs 0.0700, 14336 0.0934 vs 0.0841, 16384 (the one-sided geometry's best case) 0.0978
+  // vs 0.0948, 18432 0.1287 vs 0.1024, 20480 0.147 vs 0.116; Kahan and fp64 likewise from 12288 (0.0735 vs 0.0639, 0.129 vs 0.119)
+  if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < env_int("NBODY_SYM_MIN_N", 12288)) return;
   const bool f64 = p.precision == NBODY_PREC_F64, kahan = p.precision == NBODY_PREC_F32_KAHAN;
   if (f64 && !(p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT)) return;
   // bodies per lane.  fp32: 2 * register pairs; more of them amortise the travelling sums' dpp moves over more
@@ -183,7 +184,8 @@ void choose_algorithm(nbody_ctx *c) {
       // accumulators) and runs eight
       if (!kahan && p.n_total >= 40960) ipt = 16;      // whole step, N = 32768: 0.2353 ms with eight, 0.2408 with sixteen; 40960: 0.3355 / 0.3336
       else if (p.n_total >= 24576) ipt = 8;
-      else ipt = 4;
+      else if (p.n_total >= 17408) ipt = 4;
+      else ipt = 2;                                    // N = 12288: 0.0700 ms with two, 0.0713 with four; 16384: 0.0948 / 0.0964; 18432: 0.1037 / 0.1024
       ipt = env_int("NBODY_SYM_IPT", ipt);
       if (kahan && ipt == 16) ipt = 8;
       // sharded slices must be whole i-sets

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
     add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
   }
   if (general != nullptr && *general == 0) {      // the equal-mass kernels summed |d|^-3 d: the common G m comes in here
+    // (body 0's owner may be storing its new position at this moment: the mass word it stores is the one already there)
     const R gm = posm[0].w * gscale;
     ax *= gm; ay *= gm; az *= gm;
   }
