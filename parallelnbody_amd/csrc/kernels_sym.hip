@@ -328,7 +328,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
 #undef NBODY_SYM_K
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || L.fused) return e;                       // fused: update_sym_fused_kernel folds the j-side rows
-  dim3 rgrid((L.n_total + kBlock - 1) / kBlock);
+  dim3 rgrid((L.n_total + 63) / 64);                               // one workgroup per 64-body granule (sym_common.h, row folds)
   if (L.kahan)
     hipLaunchKernelGGL((reduce_j_kernel<float, true>), rgrid, block, 0, s, (const float4 *)L.pool, (float4 *)L.send,
                        (const unsigned int *)L.j_ptr, (const unsigned int *)L.j_off, L.n_total,
@@ -343,7 +343,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
 hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *acc, int i_begin, int i_count, float dt,
                              hipStream_t s) {
   if (i_count <= 0) return hipErrorInvalidValue;
-  dim3 grid((i_count + kBlock - 1) / kBlock), block(kBlock);
+  dim3 grid((i_count + 63) / 64), block(kBlock);                  // one workgroup per own granule
   const unsigned int *ip = (const unsigned int *)L.i_ptr, *io = (const unsigned int *)L.i_off;
   if (L.fused) {
     if (L.precision == NBODY_PREC_F64 || i_begin != 0 || i_count != L.n_total || L.n_src != 1) return hipErrorInvalidValue;

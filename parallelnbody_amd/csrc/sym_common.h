@@ -10,11 +10,9 @@ namespace {
 
 constexpr int kJT = 256;    // j tile (bodies), 4 subtiles of 64
 
-// segment loads in flight per thread in the row folds (reduce_j_kernel, update_sym_kernel, update_sym_fused_kernel): one
-// thread per body walks its granule's segment list, so at mid sizes (N = 65536: ~150 segments per body, 256 workgroups)
-// the fold is bound by load latency, not bandwidth.  Same-box A/B of whole steps (profiles/r02_ab_fold_unroll.txt): update
-// 59 -> 47 us at N = 65536 and 37 -> 31 us at N = 32768 with eight in flight (step 0.686 -> 0.673 ms, 0.221 -> 0.214 ms);
-// sixteen no better.  The adds stay one dependent chain in list order: the bits do not change.
+// segment loads in flight per wave of a row fold (fold_way below).  Same-box A/B of whole steps with one thread per body
+// (profiles/r02_ab_fold_unroll.txt): update 59 -> 47 us at N = 65536 and 37 -> 31 us at N = 32768 with eight in flight;
+// sixteen no better.
 #ifndef NBODY_SYM_FOLD_UNROLL
 #define NBODY_SYM_FOLD_UNROLL 8
 #endif
@@ -126,9 +124,52 @@ __global__ __launch_bounds__(kBlock) void sym_prep_kernel(const float4 *__restri
   posg[i] = p;
 }
 
-// send[b] = sum, in item order, of the j-side segments that cover body b: what this rank's pairs contribute to b's
-// acceleration as the "other" body.  One wave per 64-body granule; the granule's segment list is CSR (sym_plan.h).
-// KAHAN: segments are added with a compensated sum.
+// ---- row folds ------------------------------------------------------------------------------------------------------
+// A body's acceleration is the sum of the partial-sum segments that cover its 64-body granule, named in item order by a
+// CSR list (sym_plan.h).  One thread per body walking that list is bound by load latency wherever the lists are long and
+// the bodies few (N = 65536: ~150 segments per body, one wave per SIMD).  So a granule is folded by a WORKGROUP of four
+// waves: wave w adds the list entries k = w, w + 4, w + 8, ... in order (NBODY_SYM_FOLD_UNROLL loads in flight each), the
+// four partial sums meet in LDS and wave 0 adds them ((s0 + s1) + s2) + s3.  That — not the plain sequential sum — is the
+// summation order of the symmetric pass; reduce_j_kernel, update_sym_kernel and update_sym_fused_kernel all use it, so
+// the two-kernel and the fused path still agree in every bit.  KAHAN: every one of those additions is compensated.
+constexpr int kFoldWays = kBlock / 64;
+
+template <typename R, bool KAHAN> __device__ __forceinline__ void fold_add(R &sum, R &c, R v) {
+  if (KAHAN) { const R yv = v - c; const R tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
+  else sum += v;
+}
+
+// this wave's share of granule g's list: entries ptr[g] + way, + kFoldWays, ...
+template <typename R, bool KAHAN>
+__device__ __forceinline__ void fold_way(const typename SymVec<R>::type *__restrict__ pool, const unsigned int *__restrict__ ptr,
+                                         const unsigned int *__restrict__ off, int g, int l, int way, R &sx, R &sy, R &sz) {
+  using V = typename SymVec<R>::type;
+  R cx = 0, cy = 0, cz = 0;
+  sx = 0; sy = 0; sz = 0;
+  const unsigned int k1 = ptr[g + 1];
+#pragma unroll NBODY_SYM_FOLD_UNROLL
+  for (unsigned int k = ptr[g] + (unsigned int)way; k < k1; k += kFoldWays) {
+    const V p = pool[(size_t)off[k] + l];
+    fold_add<R, KAHAN>(sx, cx, p.x); fold_add<R, KAHAN>(sy, cy, p.y); fold_add<R, KAHAN>(sz, cz, p.z);
+  }
+}
+
+// the four waves' partial sums -> wave 0 (all threads of the workgroup must call this; the result is valid for way 0)
+template <typename R, bool KAHAN>
+__device__ __forceinline__ void fold_meet(R (&sh)[kFoldWays][3][64], int l, int way, R &sx, R &sy, R &sz, R &cx, R &cy, R &cz) {
+  sh[way][0][l] = sx; sh[way][1][l] = sy; sh[way][2][l] = sz;
+  __syncthreads();
+  cx = 0; cy = 0; cz = 0;
+  if (way == 0) {
+#pragma unroll
+    for (int w = 1; w < kFoldWays; ++w) {
+      fold_add<R, KAHAN>(sx, cx, sh[w][0][l]); fold_add<R, KAHAN>(sy, cy, sh[w][1][l]); fold_add<R, KAHAN>(sz, cz, sh[w][2][l]);
+    }
+  }
+}
+
+// send[b] = sum of the j-side segments that cover body b: what this rank's pairs contribute to b's acceleration as the
+// "other" body.  One workgroup per 64-body granule (grid = granules of the whole system).
 // It also clears the coincident-body detector's table and flag words for the NEXT pass (they were last read by this
 // pass's force kernels, which precede this launch on the stream): a hipMemsetAsync per pass costs a launch plus ~6 us of
 // host time in front of it, which at N = 32768 is 4 % of the step.  The table is zeroed once at creation; a pass that dies
@@ -140,21 +181,13 @@ __global__ __launch_bounds__(kBlock) void reduce_j_kernel(const typename SymVec<
                                                           const unsigned int *__restrict__ j_off, int n_total,
                                                           unsigned long long *__restrict__ dup_table, int dup_words) {
   using V = typename SymVec<R>::type;
-  const int b = blockIdx.x * kBlock + threadIdx.x;
-  for (int w = b; w < dup_words; w += gridDim.x * kBlock) dup_table[w] = 0ull;
-  if (b >= n_total) return;
-  const int g = b >> 6, l = b & 63;
-  R sx = 0, sy = 0, sz = 0, cx = 0, cy = 0, cz = 0;
-  auto add = [](R &sum, R &c, R v) {
-    if (KAHAN) { const R yv = v - c; const R tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
-    else sum += v;
-  };
-  const unsigned int k1 = j_ptr[g + 1];
-#pragma unroll NBODY_SYM_FOLD_UNROLL
-  for (unsigned int k = j_ptr[g]; k < k1; ++k) {
-    const V p = pool[(size_t)j_off[k] + l];
-    add(sx, cx, p.x); add(sy, cy, p.y); add(sz, cz, p.z);
-  }
+  __shared__ R sh[kFoldWays][3][64];
+  const int t = threadIdx.x, l = t & 63, way = t >> 6, g = blockIdx.x, b = g * 64 + l;
+  for (int w = g * kBlock + t; w < dup_words; w += gridDim.x * kBlock) dup_table[w] = 0ull;
+  R sx, sy, sz, cx, cy, cz;
+  fold_way<R, KAHAN>(pool, j_ptr, j_off, g, l, way, sx, sy, sz);
+  fold_meet<R, KAHAN>(sh, l, way, sx, sy, sz, cx, cy, cz);
+  if (way != 0 || b >= n_total) return;
   V o; o.x = sx; o.y = sy; o.z = sz; o.w = 0;
   send[b] = o;
 }
@@ -165,8 +198,9 @@ template <typename T> __device__ __forceinline__ T mul_add_sep2(T a, T b, T c) {
   return c + p;
 }
 
-// Own body bl: acc = its i-side segments (item order) + the rows received from every rank (rank order), times the
-// common G m if the equal-mass kernels ran (`general` non-null and clear); then optionally the reference's update (OctreeSearch.cpp:29-30), multiply and add kept apart.
+// Own body bl: acc = its i-side segments + the rows received from every rank (rank order), times the common G m if
+// the equal-mass kernels ran (`general` non-null and clear); then optionally the reference's update
+// (OctreeSearch.cpp:29-30), multiply and add kept apart.  One workgroup per own granule.
 template <typename R, bool KAHAN>
 __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::type *__restrict__ posm,
                                                             typename SymVec<R>::type *__restrict__ vel,
@@ -178,24 +212,16 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
                                                             int i_count, int n_src, R dt, int integrate,
                                                             const int *__restrict__ general, R gscale) {
   using V = typename SymVec<R>::type;
-  const int bl = blockIdx.x * kBlock + threadIdx.x;
-  if (bl >= i_count) return;
-  const int g = bl >> 6, l = bl & 63;
-  R ax = 0, ay = 0, az = 0, cx = 0, cy = 0, cz = 0;
-  auto add = [](R &sum, R &c, R v) {
-    if (KAHAN) { const R yv = v - c; const R tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
-    else sum += v;
-  };
-  const unsigned int k1 = i_ptr[g + 1];
-#pragma unroll NBODY_SYM_FOLD_UNROLL
-  for (unsigned int k = i_ptr[g]; k < k1; ++k) {
-    const V p = pool[(size_t)i_off[k] + l];
-    add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
-  }
-#pragma unroll NBODY_SYM_FOLD_UNROLL
+  __shared__ R sh[kFoldWays][3][64];
+  const int t = threadIdx.x, l = t & 63, way = t >> 6, g = blockIdx.x, bl = g * 64 + l;
+  R ax, ay, az, cx, cy, cz;
+  fold_way<R, KAHAN>(pool, i_ptr, i_off, g, l, way, ax, ay, az);
+  fold_meet<R, KAHAN>(sh, l, way, ax, ay, az, cx, cy, cz);
+  if (way != 0 || bl >= i_count) return;
+#pragma unroll 4
   for (int q = 0; q < n_src; ++q) {
     const V p = recv[(size_t)q * i_count + bl];
-    add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
+    fold_add<R, KAHAN>(ax, cx, p.x); fold_add<R, KAHAN>(ay, cy, p.y); fold_add<R, KAHAN>(az, cz, p.z);
   }
   if (general != nullptr && *general == 0) {      // the equal-mass kernels summed |d|^-3 d: the common G m comes in here
     // (body 0's owner may be storing its new position at this moment: the mass word it stores is the one already there)
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
 }
 
 // The single-device fp32 form of the two kernels above in ONE launch, for contexts whose positions nobody else writes:
-// acc = i-side segments + (j-side segments summed on their own, exactly as reduce_j_kernel would, then added as one
+// acc = i-side segments + (j-side segments folded on their own, exactly as reduce_j_kernel would, then added as one
 // term: the same bits as the two-kernel path), the reference's update, and the NEXT pass's preparation while the new
 // position is in registers — posg[i] = (x, y, z, G m) and, DETECT, the body's entry in the next pass's coincident-body
 // table (`next`; this pass's table `cur`, last read by this pass's force kernels, is cleared for the pass after).  A
@@ -231,33 +257,18 @@ __global__ __launch_bounds__(kBlock) void update_sym_fused_kernel(float4 *__rest
                                                                   unsigned long long *__restrict__ next, unsigned int mask,
                                                                   unsigned long long *__restrict__ cur, int cur_words,
                                                                   const int *__restrict__ general) {
-  const int bl = blockIdx.x * kBlock + threadIdx.x;
-  if (DETECT) for (int w = bl; w < cur_words; w += gridDim.x * kBlock) cur[w] = 0ull;
-  if (bl >= n_total) return;
-  const int g = bl >> 6, l = bl & 63;
-  auto add = [](float &sum, float &c, float v) {
-    if (KAHAN) { const float yv = v - c; const float tt = sum + yv; c = (tt - sum) - yv; sum = tt; }
-    else sum += v;
-  };
-  float sx = 0, sy = 0, sz = 0, dx = 0, dy = 0, dz = 0;           // the j-side row of this body (reduce_j_kernel's sum)
-  {
-    const unsigned int k1 = j_ptr[g + 1];
-#pragma unroll NBODY_SYM_FOLD_UNROLL
-    for (unsigned int k = j_ptr[g]; k < k1; ++k) {
-      const float4 p = pool[(size_t)j_off[k] + l];
-      add(sx, dx, p.x); add(sy, dy, p.y); add(sz, dz, p.z);
-    }
-  }
-  float ax = 0, ay = 0, az = 0, cx = 0, cy = 0, cz = 0;
-  {
-    const unsigned int k1 = i_ptr[g + 1];
-#pragma unroll NBODY_SYM_FOLD_UNROLL
-    for (unsigned int k = i_ptr[g]; k < k1; ++k) {
-      const float4 p = pool[(size_t)i_off[k] + l];
-      add(ax, cx, p.x); add(ay, cy, p.y); add(az, cz, p.z);
-    }
-  }
-  add(ax, cx, sx); add(ay, cy, sy); add(az, cz, sz);
+  __shared__ float sh[kFoldWays][3][64];
+  const int t = threadIdx.x, l = t & 63, way = t >> 6, g = blockIdx.x, bl = g * 64 + l;
+  if (DETECT) for (int w = g * kBlock + t; w < cur_words; w += gridDim.x * kBlock) cur[w] = 0ull;
+  float sx, sy, sz, dx, dy, dz;                                   // the j-side row of this body (reduce_j_kernel's sum)
+  fold_way<float, KAHAN>(pool, j_ptr, j_off, g, l, way, sx, sy, sz);
+  fold_meet<float, KAHAN>(sh, l, way, sx, sy, sz, dx, dy, dz);
+  __syncthreads();                                                // sh is used again
+  float ax, ay, az, cx, cy, cz;
+  fold_way<float, KAHAN>(pool, i_ptr, i_off, g, l, way, ax, ay, az);
+  fold_meet<float, KAHAN>(sh, l, way, ax, ay, az, cx, cy, cz);
+  if (way != 0 || bl >= n_total) return;
+  fold_add<float, KAHAN>(ax, cx, sx); fold_add<float, KAHAN>(ay, cy, sy); fold_add<float, KAHAN>(az, cz, sz);
   if (general != nullptr && *general == 0) {      // equal-mass kernels: the common G m comes in here (update_sym_kernel)
     const float gm = posm[0].w * gscale;
     ax *= gm; ay *= gm; az *= gm;
