@@ -154,14 +154,21 @@ using glb_f4 = const __attribute__((address_space(1))) float4;
 // UNI = the equal-mass form (sym_subtile).  Whether the bodies' masses are all equal is sym_prep_kernel's finding,
 // *general (0 = equal): the UNI launch runs only when it is clear (run_if_general == 0), the general launch only when it
 // is raised; general == nullptr runs unconditionally (the host already knows).
+// run_if_dup == -1 (one or two register pairs per lane, where registers allow it): ONE launch holds both forms and the
+// detector's verdict picks the loop — systems of 12288 ... 24576 bodies step in ~100 us, and the twin that returns at
+// its first instruction still costs a launch (4 us of kernel + the gap in front of it).  BARE is then the form that
+// runs when no two bodies coincide.
 template <int NP, int ZMODE, bool BARE, bool KAHAN, bool UNI>
 __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu(sym_waves(NP, KAHAN), sym_waves(NP, KAHAN))))
 void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ pool, const SymItem *__restrict__ items,
                           float zp, const int *__restrict__ dup_flag, int run_if_dup, const int *__restrict__ general,
                           int run_if_general) {
-  if (dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
+  constexpr bool kCanMerge = BARE && NP <= 2;
+  const bool merged = kCanMerge && run_if_dup < 0;
+  if (!merged && dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
   if (general != nullptr && ((*general != 0) ? 1 : 0) != run_if_general) return;
+  const bool guard_all = merged && *dup_flag != 0;               // merged launch, coincident bodies: the guarded loops
   __shared__ float4 sh_pos[2][4][128];   // double-buffered subtile images, doubled: entries l and l+64 hold body l
   __shared__ float sh_acc[4][3][kJT];    // per-WAVE j-side sums of the tile (private: no ordering between waves needed)
 
@@ -185,7 +192,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
   // the d == 0 guard's two constants live in VGPRs (packed ops take no literals).  The BARE kernels need them only in
   // own-block strips: there they are made on the spot, so that the symmetric strips have four registers more
   f2 zp2 = splat2(zp), one2 = splat2(1.0f);
-  if (!BARE) asm volatile("" : "+v"(zp2), "+v"(one2));
+  if (!BARE || kCanMerge) asm volatile("" : "+v"(zp2), "+v"(one2));
 
   f2 xi[NP], yi[NP], zi[NP], nmi[NP];
   // i-side sums.  Plain: `a` runs through the whole strip.  KAHAN: `a` collects one subtile (64 steps, 128 terms per
@@ -219,11 +226,16 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
     for (int sub = 0; sub < nsub; ++sub) {
       const float4 *sp = &sh_pos[buf][sub][lane + 64];
       float ox, oy, oz;
-      if (!own_block)
+      if (kCanMerge && guard_all) {
+        if (!own_block)
+          sym_subtile<NP, 0, false, ZMODE, false, UNI>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+        else
+          own_block_subtile<NP, 0, ZMODE, false, UNI>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+      } else if (!own_block)
         sym_subtile<NP, 0, false, ZMODE, BARE, UNI>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
       else {   // the subtile's bodies sit in the slots of register pair (offset from the i-set's first body) / 512
         f2 zq = zp2, oq = one2;
-        if (BARE) { zq = splat2(zp); oq = splat2(1.0f); asm volatile("" : "+v"(zq), "+v"(oq)); }
+        if (BARE && !kCanMerge) { zq = splat2(zp); oq = splat2(1.0f); asm volatile("" : "+v"(zq), "+v"(oq)); }
         own_block_subtile<NP, 0, ZMODE, BARE, UNI>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zq, oq, ox, oy, oz);
       }
       if (KAHAN) {
@@ -317,8 +329,12 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   } else if (detect) {
     // exact d == 0 semantics at the unguarded kernel's price: both forms are launched — exactly one of them runs (the
     // other returns at its first instruction)
-    NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, 0);
-    NBODY_SYM_NP(Z_CLAMP, false, -0x1p126, flag, 1);
+    if (L.np <= 2) {
+      NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, -1);            // one launch, both forms (see the kernel)
+    } else {
+      NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, 0);
+      NBODY_SYM_NP(Z_CLAMP, false, -0x1p126, flag, 1);
+    }
   } else {
     NBODY_SYM_NP(Z_CLAMP, false, -0x1p126, nullptr, 0);
   }

@@ -476,12 +476,13 @@ def test_symmetric_forces_match_oracle(nb, fixture, ipt, zero_mode):
     assert rel_err(a, g["acc_f64"]).max() < TOL_ACC
 
 
-def test_symmetric_step_and_duplicates(nb, oracle):
+@pytest.mark.parametrize("ipt", [2, 4, 8])           # 2, 4: one launch holds the bare and the guarded loops; 8: twin launches
+def test_symmetric_step_and_duplicates(nb, oracle, ipt):
     g = _golden("refbox_n2000_seed1")
     posm = g["posm"].copy()
     posm[5, :3] = posm[1500, :3]                     # coincident pair across super tiles
     posm[700, :3] = posm[701, :3]                    # coincident pair inside one i-set
-    with nb.NBodyEngine(2000, algorithm=2, i_per_thread=2) as e:
+    with nb.NBodyEngine(2000, algorithm=2, i_per_thread=ipt) as e:
         e.set_state(posm, g["vel"])
         e.step(0.01, 1)
         p, v, a = e.state()
