@@ -1,7 +1,8 @@
 // Symmetric all-pairs force kernel for gfx950: every unordered pair {i, j} is evaluated ONCE and feeds both
 // accelerations (a_i += G m_j s d, a_j -= G m_i s d with s = |d|^-3, d = r_j - r_i) — the same pair law,
 // OctreeSearch.h:101-104, at 16 packed ops + 2 v_rsq_f32 per two pairs (four interactions) instead of 14 + 2 per
-// two interactions.
+// two interactions; 14 + 2 when all bodies have the same mass (the equal-mass form, UNI: the common G m is taken out of
+// the sums and applied by the update — which form runs is decided on the device before every pass).
 //
 // Structure (the plan — who evaluates what, where partial sums go, how they are added up — is sym_plan.h):
 //   * a workgroup takes one work item: an i-set of 256*IPT bodies (register pairs, as in kernels.hip) against a strip
