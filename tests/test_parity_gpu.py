@@ -986,10 +986,12 @@ def _forces_over_ranks(nb, n, ranks, posm, vel, **kw):
     return a, kernels
 
 
-def test_geometry_fuzz_sizes_ranks_and_precisions(nb, oracle):
+@pytest.mark.parametrize("equal_masses", [False, True])
+def test_geometry_fuzz_sizes_ranks_and_precisions(nb, oracle, equal_masses):
     # Whatever geometry the library picks for a size / slicing / precision — kernel, bodies per lane, super tiles,
     # j chunks, padding — or whatever the caller forces (algorithm, bodies per lane, zero-distance mode) and the library
-    # accepts, the accelerations are the pair law's: 160 random configurations, sampled against the fp64 sum.
+    # accepts, the accelerations are the pair law's: 160 random configurations, sampled against the fp64 sum; once with
+    # every body its own mass (the kernels' general forms) and once with one mass for all (their equal-mass forms).
     rng = np.random.default_rng(20261004)
     seen, ran = set(), 0
     for trial in range(160):
@@ -1011,6 +1013,8 @@ def test_geometry_fuzz_sizes_ranks_and_precisions(nb, oracle):
             forced = dict(algorithm=int(rng.choice([0, 1, 2])), i_per_thread=int(rng.choice([0, 1, 2, 4, 8, 16])),
                           zero_mode=int(rng.choice([0, 0, 2])))
         posm = np.concatenate([rng.normal(0, 300, (n, 3)), rng.uniform(1, 100, (n, 1))], 1)
+        if equal_masses:
+            posm[:, 3] = posm[0, 3]
         if n > 3:
             posm[0, :3] = 0.0                                    # the shipped scene pins body 0 at the origin
         vel = np.zeros((n, 4))
