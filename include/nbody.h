@@ -297,6 +297,10 @@ NBODY_API int nbody_equal_mass_form(nbody_ctx *ctx, int32_t *in_use);
 NBODY_API int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
                                       int32_t slots, int32_t k_guided, int32_t min_sub, int32_t own_mode, int32_t *n_items,
                                       uint64_t *pool_elems, int32_t *items, int32_t items_cap);
+/* The same with the strip divisor K given in tenths (the library's own choices include K = 1.5). */
+NBODY_API int nbody_sym_plan_describe_tenths(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
+                                             int32_t slots, int32_t k_guided_x10, int32_t min_sub, int32_t own_mode,
+                                             int32_t *n_items, uint64_t *pool_elems, int32_t *items, int32_t items_cap);
 
 /* ---- checkpoint / resume (build-defined: the reference keeps its state in a non-serialised TArray) ---------- */
 

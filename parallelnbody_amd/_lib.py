@@ -130,6 +130,8 @@ def lib():
     sig("nbody_ic_plummer", c_int, c_i32, c_d, c_d, c_d, ctypes.c_uint64, fp, fp)
     sig("nbody_sym_plan_describe", c_int, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32),
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i32), c_i32)
+    sig("nbody_sym_plan_describe_tenths", c_int, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32),
+        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i32), c_i32)
     # actor mirror (include/nbody_actor.h)
     sig("nbody_actor_create", vp)
     sig("nbody_actor_destroy", None, vp)

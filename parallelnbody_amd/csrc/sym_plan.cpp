@@ -166,13 +166,14 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
 
 // C-ABI view of the planner (host only, no device): lets the CPU test suite check that a plan covers every body pair
 // exactly once and that its segments do not overlap.
-extern "C" int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
-                                       int32_t slots, int32_t k_guided, int32_t min_sub, int32_t own_mode, int32_t *n_items,
-                                       uint64_t *pool_elems, int32_t *items, int32_t items_cap) {
+extern "C" int nbody_sym_plan_describe_tenths(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
+                                              int32_t slots, int32_t k_guided_x10, int32_t min_sub, int32_t own_mode,
+                                              int32_t *n_items, uint64_t *pool_elems, int32_t *items, int32_t items_cap) {
   nbody::SymPlan P;
   std::string why;
   if (i_count == 0) i_count = n_total - i_begin;
-  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, (double)k_guided, min_sub, own_mode, &P, &why))
+  if (k_guided_x10 < 1) return NBODY_ERR_INVALID;
+  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided_x10 / 10.0, min_sub, own_mode, &P, &why))
     return NBODY_ERR_UNSUPPORTED;
   if (n_items) *n_items = (int32_t)P.items.size();
   if (pool_elems) *pool_elems = P.pool_elems;
@@ -187,4 +188,12 @@ extern "C" int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t
     }
   }
   return NBODY_OK;
+}
+
+extern "C" int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
+                                       int32_t slots, int32_t k_guided, int32_t min_sub, int32_t own_mode, int32_t *n_items,
+                                       uint64_t *pool_elems, int32_t *items, int32_t items_cap) {
+  if (k_guided < 1 || k_guided > 100000) return NBODY_ERR_INVALID;
+  return nbody_sym_plan_describe_tenths(n_total, i_begin, i_count, bodies_per_iset, slots, 10 * k_guided, min_sub, own_mode,
+                                        n_items, pool_elems, items, items_cap);
 }

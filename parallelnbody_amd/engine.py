@@ -49,18 +49,22 @@ def ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=REF_G, seed=1):
 
 def sym_plan(n_total, i_begin=0, i_count=0, bodies_per_iset=4096, slots=512, k_guided=3, min_sub=4, own_mode=1):
     """The work plan of the symmetric force pass (csrc/sym_plan.h), host only.  Returns (items[n,8] int32 —
-    i0, j0, n_sub, flags (1 = own-block strip, 2 = no j-side sums), slot_i, slot_j, 0, 0 —, pool_elems)."""
+    i0, j0, n_sub, flags (1 = own-block strip, 2 = no j-side sums), slot_i, slot_j, 0, 0 —, pool_elems).
+    k_guided may be fractional in tenths (the library itself uses 1, 1.5, 3 and 6)."""
     L = _lib.lib()
     n, pe = ctypes.c_int32(), ctypes.c_uint64()
-    rc = L.nbody_sym_plan_describe(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided, min_sub, own_mode, ctypes.byref(n),
-                                   ctypes.byref(pe), None, 0)
+    k10 = int(round(float(k_guided) * 10))
+    if abs(k10 - float(k_guided) * 10) > 1e-9:
+        raise ValueError("k_guided must be a multiple of 0.1")
+    rc = L.nbody_sym_plan_describe_tenths(n_total, i_begin, i_count, bodies_per_iset, slots, k10, min_sub, own_mode, ctypes.byref(n),
+                                          ctypes.byref(pe), None, 0)
     if rc:
         raise NBodyError(rc, "nbody_sym_plan_describe: this range cannot be planned")
     items = np.zeros((n.value, 8), np.int32)
-    rc = L.nbody_sym_plan_describe(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided, min_sub, own_mode, ctypes.byref(n),
-                                   ctypes.byref(pe), items.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n.value)
+    rc = L.nbody_sym_plan_describe_tenths(n_total, i_begin, i_count, bodies_per_iset, slots, k10, min_sub, own_mode, ctypes.byref(n),
+                                          ctypes.byref(pe), items.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n.value)
     if rc:
-        raise NBodyError(rc, "nbody_sym_plan_describe")
+        raise NBodyError(rc, "nbody_sym_plan_describe: this range cannot be planned")
     return items, pe.value
 
 

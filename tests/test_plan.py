@@ -61,6 +61,22 @@ def test_every_pair_exactly_once(nb, n, ranks, bi, slots, own_mode):
     assert np.array_equal((E + E.T)[off], np.ones(off.sum(), np.int32))
 
 
+@pytest.mark.parametrize("n,ranks,bi,slots,k,min_sub", [
+    # what capi's choose_algorithm arrives at on a 256-CU device: (bodies per i-set, workgroup slots, K, shortest strip)
+    (12288, 1, 512, 1024, 1, 2), (16384, 1, 512, 1024, 1, 2), (20480, 1, 1024, 1024, 1, 2), (32768, 1, 2048, 768, 1, 2),
+    (65536, 1, 4096, 512, 1.5, 2), (131072, 1, 4096, 512, 1.5, 4), (262144, 1, 4096, 512, 3, 4), (65536, 2, 4096, 512, 1, 2),
+    (131072, 8, 4096, 512, 1, 4), (100003, 1, 4096, 512, 1.5, 2)])
+def test_the_librarys_own_plans_cover_every_pair_once(nb, n, ranks, bi, slots, k, min_sub):
+    sym, one, _ = _coverage(nb, n, ranks, bi, slots, k, min_sub, 1)
+    T, G = sym.shape
+    blk = np.arange(G) * 64 // bi
+    own = blk[None, :] == np.arange(T)[:, None]
+    assert np.array_equal(one, own.astype(np.int32)) and not sym[own].any()
+    E = sym[blk, :]
+    off = blk[:, None] != blk[None, :]
+    assert np.array_equal((E + E.T)[off], np.ones(off.sum(), np.int32))
+
+
 def test_headline_plan_shape(nb):
     # N = 2^20, sixteen bodies per lane, 512 resident workgroups: long strips first, 256-body strips last, a pool of a
     # few GB (the round-1 layout needed 8.6 GB of private rows here)
