@@ -1084,3 +1084,15 @@ def test_stepping_is_reproducible_and_path_independent(nb):
     lines = []
     assert mod.run(steps=25, sizes=(9000, 12288, 20480, 33000, 49152), out=lines.append) == 0, "\n".join(l for l in lines if "DIFFERENT" in l)
     assert len(lines) == 5 * 2 * 5
+
+
+def test_auto_falls_back_to_the_one_sided_kernel_when_the_pool_would_not_fit(nb):
+    """The symmetric pass keeps N^2 / (2 x bodies per i-set) partial sums; beyond a third of the card AUTO must not try."""
+    with nb.NBodyEngine(1 << 23) as e:
+        cfg = e.launch_config()
+        assert cfg["algorithm"] == "tiled" and cfg["kernel"] == "forces_tile_pk_kernel"
+    with pytest.raises(nb.NBodyError) as err:
+        nb.NBodyEngine(1 << 23, algorithm=2)
+    assert err.value.code == nb._lib.ERR_UNSUPPORTED and "partial-sum pool" in str(err.value)
+    with nb.NBodyEngine(1 << 22) as e:
+        assert e.launch_config()["algorithm"] == "symmetric"
