@@ -17,6 +17,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / device-tensor sharing fail with hipIpcGetMemHandle: invalid
+# argument otherwise); the boxes export it already — kept here so that a bare environment behaves the same
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
