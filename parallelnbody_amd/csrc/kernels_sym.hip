@@ -155,17 +155,17 @@ using glb_f4 = const __attribute__((address_space(1))) float4;
 // UNI = the equal-mass form (sym_subtile).  Whether the bodies' masses are all equal is sym_prep_kernel's finding,
 // *general (0 = equal): the UNI launch runs only when it is clear (run_if_general == 0), the general launch only when it
 // is raised; general == nullptr runs unconditionally (the host already knows).
-// run_if_dup == -1 (one or two register pairs per lane, where registers allow it): ONE launch holds both forms and the
-// detector's verdict picks the loop — systems of 12288 ... 24576 bodies step in ~100 us, and the twin that returns at
-// its first instruction still costs a launch (4 us of kernel + the gap in front of it).  BARE is then the form that
-// runs when no two bodies coincide.
+// run_if_dup == -1 (where registers allow it: one or two register pairs per lane, and the equal-mass form at any number —
+// it has no -G m_i registers to keep): ONE launch holds both loops and the detector's verdict picks — systems of
+// 12288 ... 24576 bodies step in ~100 us, and a twin that returns at its first instruction still costs a launch (4-6 us
+// of kernel + the gap in front of it).  BARE is then the form that runs when no two bodies coincide.
 template <int NP, int ZMODE, bool BARE, bool KAHAN, bool UNI>
 __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu(sym_waves(NP, KAHAN), sym_waves(NP, KAHAN))))
 void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ pool, const SymItem *__restrict__ items,
                           float zp, const int *__restrict__ dup_flag, int run_if_dup, const int *__restrict__ general,
                           int run_if_general) {
-  constexpr bool kCanMerge = BARE && NP <= 2;
+  constexpr bool kCanMerge = BARE && (NP <= 2 || UNI);           // the equal-mass form has the registers at every NP
   const bool merged = kCanMerge && run_if_dup < 0;
   if (!merged && dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
   if (general != nullptr && ((*general != 0) ? 1 : 0) != run_if_general) return;
@@ -311,10 +311,11 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
 #define NBODY_SYM_K(NPV, ZM, BARE, KH, UNI, ZP, FLAG, RUNIF)                                                     \
   hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, UNI>), grid, block, 0, s, (const float4 *)L.posg, \
                      (float4 *)L.pool, (const SymItem *)L.items, (float)(ZP), (const int *)(FLAG), RUNIF, gate, UNI ? 0 : 1)
+  bool do_uni = run_uni, do_gen = run_gen;                         // which forms the next NBODY_SYM_NP launches
 #define NBODY_SYM_U(NPV, ZM, BARE, KH, ZP, FLAG, RUNIF)                                                          \
   do {                                                                                                           \
-    if (run_uni) NBODY_SYM_K(NPV, ZM, BARE, KH, true, ZP, FLAG, RUNIF);                                          \
-    if (run_gen) NBODY_SYM_K(NPV, ZM, BARE, KH, false, ZP, FLAG, RUNIF);                                         \
+    if (do_uni) NBODY_SYM_K(NPV, ZM, BARE, KH, true, ZP, FLAG, RUNIF);                                           \
+    if (do_gen) NBODY_SYM_K(NPV, ZM, BARE, KH, false, ZP, FLAG, RUNIF);                                          \
   } while (0)
 #define NBODY_SYM(NPV, ZM, BARE, ZP, FLAG, RUNIF)                                                                \
   do { if (L.kahan) NBODY_SYM_U(NPV, ZM, BARE, true, ZP, FLAG, RUNIF); else NBODY_SYM_U(NPV, ZM, BARE, false, ZP, FLAG, RUNIF); } while (0)
@@ -331,8 +332,11 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
     // exact d == 0 semantics at the unguarded kernel's price: both forms are launched — exactly one of them runs (the
     // other returns at its first instruction)
     if (L.np <= 2) {
-      NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, -1);            // one launch, both forms (see the kernel)
+      NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, -1);            // one launch holds both loops (see the kernel)
     } else {
+      do_gen = false;                                             // equal-mass form: one launch at any size
+      NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, -1);
+      do_uni = false; do_gen = run_gen;                           // general form: twins
       NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, 0);
       NBODY_SYM_NP(Z_CLAMP, false, -0x1p126, flag, 1);
     }
