@@ -155,7 +155,7 @@ using glb_f4 = const __attribute__((address_space(1))) float4;
 // UNI = the equal-mass form (sym_subtile).  Whether the bodies' masses are all equal is sym_prep_kernel's finding,
 // *general (0 = equal): the UNI launch runs only when it is clear (run_if_general == 0), the general launch only when it
 // is raised; general == nullptr runs unconditionally (the host already knows).
-// run_if_dup == -1 (where registers allow it: one or two register pairs per lane, and the equal-mass form at any number —
+// run_if_dup == -1 (where registers allow it: up to four register pairs per lane, and the equal-mass form at eight too —
 // it has no -G m_i registers to keep): ONE launch holds both loops and the detector's verdict picks — systems of
 // 12288 ... 24576 bodies step in ~100 us, and a twin that returns at its first instruction still costs a launch (4-6 us
 // of kernel + the gap in front of it).  BARE is then the form that runs when no two bodies coincide.
@@ -165,7 +165,7 @@ __attribute__((amdgpu_waves_per_eu(sym_waves(NP, KAHAN), sym_waves(NP, KAHAN))))
 void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ pool, const SymItem *__restrict__ items,
                           float zp, const int *__restrict__ dup_flag, int run_if_dup, const int *__restrict__ general,
                           int run_if_general) {
-  constexpr bool kCanMerge = BARE && (NP <= 2 || UNI);           // the equal-mass form has the registers at every NP
+  constexpr bool kCanMerge = BARE && (NP <= 4 || UNI);           // the general form at NP = 8 would spill (52 B of scratch)
   const bool merged = kCanMerge && run_if_dup < 0;
   if (!merged && dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
   if (general != nullptr && ((*general != 0) ? 1 : 0) != run_if_general) return;
@@ -331,7 +331,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   } else if (detect) {
     // exact d == 0 semantics at the unguarded kernel's price: both forms are launched — exactly one of them runs (the
     // other returns at its first instruction)
-    if (L.np <= 2) {
+    if (L.np <= 4) {
       NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, -1);            // one launch holds both loops (see the kernel)
     } else {
       do_gen = false;                                             // equal-mass form: one launch at any size
