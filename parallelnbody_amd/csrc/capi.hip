@@ -110,6 +110,11 @@ int multi_unsupported(nbody_ctx *c, const char *who) {
     if (e_ != hipSuccess) return fail((c), NBODY_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+// Below this many bodies the one-launch small-system step (small_pk_kernel: a workgroup per pair of bodies, update fused) beats
+// the tile kernel + update: N = 6000 0.0236 vs 0.0275 ms, 7000 0.0318 vs 0.0282, 8000 0.0376 vs 0.0275 (whole steps, no
+// events: profiles/r02_small_system_thresholds.txt).
+constexpr int kSmallSystem = 6656;
+
 int floor_pow2(long long v) { int p = 1; while ((long long)p * 2 <= v) p *= 2; return p; }
 
 // Launch geometry.  j_split is a function of n_total only, so that the per-body summation order
@@ -118,7 +123,9 @@ void choose_geometry(nbody_ctx *c) {
   const nbody_params &p = c->p;
   c->tile = p.tile > 0 ? p.tile : 256;
   if (p.i_per_thread > 0) c->ipt = p.i_per_thread > 4 ? 4 : p.i_per_thread;   // 8 and 16 exist for the symmetric kernel only
-  else c->ipt = (p.precision == NBODY_PREC_F64) ? 1 : (p.n_total >= 8192 ? 4 : 1);   // N = 16384: 0.102 ms per step with 4, 0.106 with 2
+  // whole steps without events (profiles/r02_small_system_thresholds.txt): N = 8192 0.0277 ms with four bodies per lane, 0.0258 with
+  // two; 10240 0.0444 / 0.0427; N = 16384: 0.102 with four, 0.106 with two
+  else c->ipt = (p.precision == NBODY_PREC_F64) ? 1 : (p.n_total >= 12288 ? 4 : (p.n_total >= kSmallSystem ? 2 : 1));
   int js;
   if (p.j_split > 0) {
     js = p.j_split;
@@ -142,7 +149,7 @@ void choose_geometry(nbody_ctx *c) {
   // cannot.  Only when the caller left the geometry to us.
   c->wave = 0;
   if (p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && p.algorithm != NBODY_ALGO_SYMMETRIC &&
-      p.tile == 0 && p.i_per_thread == 0 && p.j_split == 0 && p.n_total < 8192) {
+      p.tile == 0 && p.i_per_thread == 0 && p.j_split == 0 && p.n_total < kSmallSystem) {
     c->wave = 1;
     c->j_split = 1;
     c->j_chunk = (p.n_total + c->tile - 1) / c->tile * c->tile;
