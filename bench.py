@@ -8,6 +8,11 @@ the bodies are range-partitioned over the ranks with one RCCL all-gather of posi
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...                  # no launcher: starts the line above as a CHILD process (before any GPU
+                                                  # call of its own) and relays its one JSON line and exit code
+    python bench.py --gpus N --host single ...    # ONE process, one thread, N GPUs: nbody_create_multi (the reference's
+                                                  # game-thread model, OctreeSearch.cpp:21-34; RCCL grouped send/recv +
+                                                  # in-place all-gather between the devices)
 
 Prints ONE JSON line on rank 0.
 """
@@ -131,6 +136,115 @@ def cpu_baseline(posm, target_seconds):
     return out
 
 
+def relaunch_under_torchrun(n_gpus):
+    """`python bench.py --gpus N` with no launcher around it: run the very same command line under
+    `python -m torch.distributed.run` (one rank per GPU) as a CHILD process — started before this process has made any GPU
+    call, never an exec after one — relay what it prints and leave with its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no launcher around --gpus %d: starting %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd))
+
+
+def run_single_host(args):
+    """--host single: ONE process, one caller thread, args.gpus devices behind one context (nbody_create_multi, csrc/multi.hip)
+    — how a UE4 host, whose only caller is the game thread (OctreeSearch.cpp:21-34), would use several GPUs.  Per step the
+    library queues, on every device's stream and without waiting for the host: force pass, the symmetric algorithm's
+    exchange as grouped ncclSend/ncclRecv, kick-drift, one grouped in-place ncclAllGather of the positions.  Same metric,
+    same workload, same parity check as the one-process-per-GPU line."""
+    import numpy as np
+    import torch
+    import parallelnbody_amd as nb
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: parallelnbody_amd has no CPU path")
+    if nb.device_count() < args.gpus:
+        raise SystemExit(f"--host single --gpus {args.gpus}: only {nb.device_count()} device(s) visible")
+    n, g = args.n, args.gpus
+    posm, vel = nb.ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
+    if args.precision == "f64":
+        posm, vel = posm.astype(np.float64), vel.astype(np.float64)
+
+    def fence(e):
+        e.synchronize()                              # every device's stream
+        for d in range(g):
+            torch.cuda.synchronize(d)
+
+    with nb.NBodyEngine(n, devices=list(range(g)), precision=args.precision, eps=args.eps, tile=args.tile,
+                        i_per_thread=args.ipt, j_split=args.jsplit, time_kernels=True,
+                        algorithm={"auto": 0, "tiled": 1, "symmetric": 2}[args.algorithm],
+                        zero_mode={"exact": 0, "floor": 2}[args.zero_mode]) as e:
+        e.set_state(posm, vel)
+        cfg = e.launch_config()                      # per device
+        t0 = time.perf_counter()                     # untimed force passes: the clock needs sustained load to settle
+        e.compute_forces(); fence(e)
+        one = max(time.perf_counter() - t0, 1e-5)
+        for _ in range(int(min(2000, max(1, args.settle_seconds / one)))):
+            e.compute_forces()
+        e.step(args.dt, args.warmup)
+        fence(e)
+        e.kernel_time_reset()
+        t0 = time.perf_counter()
+        e.step(args.dt, args.steps)
+        fence(e)
+        elapsed = time.perf_counter() - t0
+        f_ms, f_n = e.kernel_time(nb.KERNEL_FORCES)   # the slowest device's total
+        u_ms, u_n = e.kernel_time(nb.KERNEL_UPDATE)
+        equal_mass = e.equal_mass_form()
+        p_end = e.state(np.float64 if args.precision == "f64" else np.float32)[0]
+        finite = bool(np.isfinite(p_end).all())
+        e.compute_forces()                           # parity of the benched instantiation, after the timed region
+        acc = e.accelerations(np.float64 if args.precision == "f64" else np.float32)
+    slice_n = n // g
+    bodies = sorted({b for k in range(g) for b in sample_bodies(k * slice_n, slice_n, cfg["super_tile"], cfg["i_per_thread"], seed=7 + k)})
+    err = sampled_force_error(p_end, acc, 0, bodies, 1.0e4, args.eps)
+    tol = {"f32": 2e-5, "f32_kahan": 2e-6 if args.eps > 0 else 2e-5, "f64": 1e-12}[args.precision]
+    if not (finite and err < tol):
+        raise SystemExit(f"bench.py: the benched force pass disagrees with the fp64 direct sum on sampled bodies: "
+                         f"max rel err {err:.3e} >= {tol:.1e} (finite={finite})")
+    pairs_per_step = float(n) * float(n)
+    launch_pairs = float(slice_n) * float(n)
+    avg_launch_s = f_ms / max(f_n, 1) * 1e-3
+    peak = PEAK_FP32_TFLOPS if args.precision != "f64" else PEAK_FP32_TFLOPS / 2
+    achieved = launch_pairs * FLOP_PER_PAIR / avg_launch_s * 1e-12
+    flop_eval = FLOP_PER_EVAL_SYM_EQUAL if equal_mass else FLOP_PER_EVAL_SYM
+    executed = (launch_pairs / 2 * flop_eval if cfg["algorithm"] == "symmetric" else launch_pairs * FLOP_PER_PAIR) / avg_launch_s * 1e-12
+    traffic = TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, g, cfg["i_per_thread"], args.precision, equal_mass), (None, None))
+    exchange = cfg["algorithm"] == "symmetric" and g > 1
+    out = {
+        "metric": "body-pair interactions/s at N=2^20" if n == (1 << 20) else f"body-pair interactions/s at N={n}",
+        "value": pairs_per_step * args.steps / elapsed, "unit": "pair-interactions/s", "n_gpus": g, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": {"f32": "f32", "f32_kahan": "f32", "f64": "f64"}[args.precision], "data": "synthetic",
+        "config": {"workload": f"N={n} all-pairs {args.precision}, seeded Plummer sphere (equal masses), G=1e4, eps={args.eps}, "
+                               f"dt={args.dt}, one force pass + kick-drift per step",
+                   "host": "single process, one thread (nbody_create_multi)",
+                   "parallelism": (f"range-partition x{g}, per step 1 grouped in-place ncclAllGather(posm)"
+                                   + (" + grouped ncclSend/ncclRecv(j-side sums)" if exchange else "")
+                                   + (" (a one-rank communicator: every collective still runs)" if g == 1 else "")),
+                   "algorithm": cfg["algorithm"], "zero_distance": args.zero_mode, "lds_tile_bodies": cfg["tile"],
+                   "i_per_lane": cfg["i_per_thread"], "j_split": cfg["j_split"] if cfg["algorithm"] == "tiled" else None,
+                   "super_tile_bodies": cfg["super_tile"] or None, "workgroups_per_device": cfg["blocks"],
+                   "accumulate": args.precision, "finite": finite, "equal_mass_form": equal_mass,
+                   "max_rel_err_sampled": err, "bodies_sampled": len(bodies), "rel_err_tolerance": tol},
+        "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64", "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak,
+                     "achieved_is": "algorithmic: N_i x N ordered interactions x 20 flop (SURVEY 8d) / the slowest device's launch time",
+                     "executed": executed, "executed_frac": executed / peak,
+                     "traffic": traffic[0], "traffic_source": traffic[1], "kernel": cfg["kernel"],
+                     "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n, "flop_per_pair": FLOP_PER_PAIR,
+                     "pairs_per_launch": launch_pairs, "update_kernel_avg_ms": u_ms / max(u_n, 1)},
+    }
+    if args.cpu_seconds > 0 and g == 1:
+        out["cpu_baseline"] = cpu_baseline(posm.astype(np.float32), args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,9 +266,18 @@ def main():
     ap.add_argument("--no-tiled-row", action="store_true",
                     help="multi-GPU: skip the extra timing of the one-sided kernel + all-gather-only step (config.all_gather_only_row)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length; 0 = skip")
+    ap.add_argument("--host", default="ranks", choices=["ranks", "single"],
+                    help="ranks = one process per GPU under torch.distributed (default; started as a child process when no "
+                         "launcher did); single = one process drives all GPUs through nbody_create_multi")
     ap.add_argument("--settle-seconds", type=float, default=0.3,
                     help="untimed force passes before the warm-up steps (state unchanged): lets the GPU clock settle")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.host == "single":
+        return run_single_host(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return relaunch_under_torchrun(args.gpus)
 
     import numpy as np
     import torch
@@ -165,8 +288,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: parallelnbody_amd has no CPU path")

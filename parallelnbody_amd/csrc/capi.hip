@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +47,7 @@ struct nbody_ctx {
   size_t stage_bytes = 0;
   void *scratch = nullptr;     // 64 B device scratch (bounds bits, energy sums)
   void *h_scratch = nullptr;   // pinned mirror
+  void *energy_part = nullptr; // nbody_energy: one pair of doubles per workgroup, folded in a fixed order
   int j_split = 1, j_chunk = 0, ipt = 1, tile = 256;
   int sym_np = 1;                        // register pairs per lane of the symmetric kernel
   std::vector<std::pair<char *, size_t>> pinned;   // caller memory page-locked by nbody_pin_host_buffer
@@ -109,6 +111,14 @@ int multi_unsupported(nbody_ctx *c, const char *who) {
     hipError_t e_ = (expr);                                                                      \
     if (e_ != hipSuccess) return fail((c), NBODY_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
+
+// One caller thread may hold contexts on several devices (nbody_create_multi does): every entry point that allocates,
+// launches, copies or records makes its context's device the current one first.
+int use_device(nbody_ctx *c) {
+  if (c->multi) return NBODY_OK;
+  HIP_TRY(c, hipSetDevice(c->p.device));
+  return NBODY_OK;
+}
 
 // Below this many bodies the one-launch small-system step (small_pk_kernel: a workgroup per pair of bodies, update fused) beats
 // the tile kernel + update: N = 6000 0.0236 vs 0.0275 ms, 7000 0.0318 vs 0.0282, 8000 0.0376 vs 0.0275 (whole steps, no
@@ -409,9 +419,12 @@ int run_update(nbody_ctx *c, float dt) {
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_UPDATE, &ev); if (rc) return rc; }
-  if (c->theta > 0.0f)
+  if (c->theta > 0.0f) {
     HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->bh_acc, 0, c->p.n_total, 1, dt, c->stream));
-  else if (c->sym) {
+    // bodies moved without the fused update's preparation of the next all-pairs pass: posg and the detector table are
+    // those of older positions (the next theta == 0 pass runs the preparation kernel again)
+    if (dt > 0.0f) c->sym_posg_valid = false;
+  } else if (c->sym) {
     const nbody::SymLaunch L = make_sym_launch(c);
     HIP_TRY(c, nbody::launch_update_sym(L, c->posm, c->vel, c->acc, c->p.i_begin, c->p.i_count, dt, c->stream));
     if (L.fused) { c->sym_posg_valid = true; c->sym_dup_cur ^= 1; }   // the update wrote posg and the other table
@@ -452,6 +465,7 @@ int note_masses(nbody_ctx *c, const T *posm4) {
 // Upload host SoA state given as T (float or double); converts to the context's precision.
 template <typename T>
 int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
+  if (int rc = use_device(c)) return rc;
   const int n = c->p.n_total, ib = c->p.i_begin, ic = c->p.i_count;
   const bool ctx64 = c->p.precision == NBODY_PREC_F64;
   const bool same = ctx64 == (sizeof(T) == 8);
@@ -549,7 +563,7 @@ int posm_escapes(nbody_ctx *c) {
 int check_ready(nbody_ctx *c) {
   if (!c) return NBODY_ERR_INVALID;
   if (!c->have_state) return fail(c, NBODY_ERR_STATE, "no particles set (call nbody_set_particles / nbody_set_state_soa first)");
-  return NBODY_OK;
+  return use_device(c);
 }
 
 }  // namespace
@@ -626,7 +640,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
   if ((p.i_per_thread == 8 || p.i_per_thread == 16) && !(c->sym && c->sym_bi == 256 * p.i_per_thread)) {
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
-                "nbody_create: i_per_thread %d needs the fp32 symmetric kernel (N >= 32768 or NBODY_ALGO_SYMMETRIC; "
+                "nbody_create: i_per_thread %d needs the fp32 symmetric kernel (N >= 12288 or NBODY_ALGO_SYMMETRIC; "
                 "sharded slices in multiples of %d bodies)", p.i_per_thread, 256 * p.i_per_thread);
   }
   if (p.algorithm == NBODY_ALGO_SYMMETRIC && !c->sym) {
@@ -721,6 +735,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
   }
   if ((e = hipMalloc(&c->scratch, 64)) != hipSuccess) return bail(e, "hipMalloc scratch");
   if ((e = hipHostMalloc(&c->h_scratch, 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+  g_create_error.clear();   // e.g. the reason AUTO passed over the symmetric plan: not an error of this call
   *out = c;
   return NBODY_OK;
 } catch (const std::bad_alloc &) {
@@ -748,6 +763,7 @@ int nbody_create_multi(const nbody_params *pin, const int32_t *devices, int32_t 
 void nbody_destroy(nbody_ctx *c) {
   if (c && c->multi) { nbody::multi_destroy(c->multi); delete c; return; }
   if (!c) return;
+  (void)hipSetDevice(c->p.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (KernelTimer &t : c->timers) {
     for (EventPair &e : t.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -771,6 +787,7 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->energy_part) (void)hipFree(c->energy_part);
   if (c->h_scratch) (void)hipHostFree(c->h_scratch);
   for (const auto &r : c->pinned) (void)hipHostUnregister(r.first);   // the memory itself stays the caller's
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -780,6 +797,7 @@ void nbody_destroy(nbody_ctx *c) {
 int nbody_set_stream(nbody_ctx *c, void *hip_stream) {
   if (c && c->multi) return multi_unsupported(c, "nbody_set_stream");
   if (!c) return NBODY_ERR_INVALID;
+  if (int rc = use_device(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return NBODY_OK;
@@ -788,6 +806,7 @@ int nbody_set_stream(nbody_ctx *c, void *hip_stream) {
 int nbody_device_ptr(nbody_ctx *c, int32_t which, void **ptr, size_t *bytes) {
   if (c && c->multi) return multi_unsupported(c, "nbody_device_ptr");
   if (!c || !ptr) return NBODY_ERR_INVALID;
+  if (int rc = use_device(c)) return rc;
   switch (which) {
     case NBODY_BUF_POSM:
       *ptr = c->posm; if (bytes) *bytes = (size_t)c->p.n_total * c->elem;
@@ -803,6 +822,7 @@ int nbody_device_ptr(nbody_ctx *c, int32_t which, void **ptr, size_t *bytes) {
 int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
   if (c && c->multi) return multi_unsupported(c, "nbody_bind_device_state");
   if (!c) return NBODY_ERR_INVALID;
+  if (int rc = use_device(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (posm) {
     if (int rc = posm_escapes(c)) return rc;
@@ -824,6 +844,7 @@ int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
 int nbody_synchronize(nbody_ctx *c) {
   if (c && c->multi) return multi_rc(c, nbody::multi_synchronize(c->multi));
   if (!c) return NBODY_ERR_INVALID;
+  if (int rc = use_device(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NBODY_OK;
 }
@@ -930,6 +951,7 @@ int nbody_exchange_read_send(nbody_ctx *c, void *host) {
   if (c && c->multi) return multi_unsupported(c, "nbody_exchange_read_send");
   if (!c || !host) return NBODY_ERR_INVALID;
   if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_exchange_read_send: this context has no exchange step");
+  if (int rc = use_device(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(host, c->sym_send, (size_t)c->p.n_total * c->elem, hipMemcpyDeviceToHost));
   return NBODY_OK;
@@ -939,6 +961,7 @@ int nbody_exchange_write_recv(nbody_ctx *c, const void *host) {
   if (c && c->multi) return multi_unsupported(c, "nbody_exchange_write_recv");
   if (!c || !host) return NBODY_ERR_INVALID;
   if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_exchange_write_recv: this context has no exchange step");
+  if (int rc = use_device(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(c->sym_recv, host, (size_t)c->sym_nsrc * c->p.i_count * c->elem, hipMemcpyHostToDevice));
   return NBODY_OK;
@@ -949,6 +972,7 @@ int nbody_bind_exchange(nbody_ctx *c, void *send, void *recv) {
   if (!c) return NBODY_ERR_INVALID;
   if (!(c->sym && c->sym_nsrc > 1)) return fail(c, NBODY_ERR_STATE, "nbody_bind_exchange: this context has no exchange step");
   if (!send || !recv) return fail(c, NBODY_ERR_INVALID, "nbody_bind_exchange: null buffer");
+  if (int rc = use_device(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->own_send) (void)hipFree(c->sym_send);
   if (c->own_recv) (void)hipFree(c->sym_recv);
@@ -1024,9 +1048,10 @@ int nbody_energy(nbody_ctx *c, double *ke, double *pe) {
   int rc = check_ready(c);
   if (rc) return rc;
   if (c->multi) return multi_rc(c, nbody::multi_energy(c->multi, ke, pe));
-  HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 16, c->stream));
+  if (!c->energy_part)
+    HIP_TRY(c, hipMalloc(&c->energy_part, nbody::energy_partials(c->p.n_total, c->p.i_count) * sizeof(double)));
   HIP_TRY(c, nbody::launch_energy(c->p.precision, c->posm, c->vel, c->p.n_total, c->p.i_begin, c->p.i_count, c->p.G,
-                                  c->p.eps * c->p.eps, (double *)c->scratch, c->stream));
+                                  c->p.eps * c->p.eps, (double *)c->energy_part, (double *)c->scratch, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->scratch, 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   double v[2];
@@ -1158,6 +1183,7 @@ int nbody_unpin_host_buffer(nbody_ctx *c, void *host) {
   if (c->multi) return NBODY_OK;
   for (size_t k = 0; k < c->pinned.size(); ++k)
     if (c->pinned[k].first == (char *)host) {
+      if (int rc = use_device(c)) return rc;
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       c->pinned.erase(c->pinned.begin() + (long)k);
       HIP_TRY(c, hipHostUnregister(host));
@@ -1236,8 +1262,18 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) t
   std::vector<char> posm(n * 4 * eb), vel(ic * 4 * eb), acc(ic * 4 * eb);
   FILE *f = fopen(path, "rb");
   if (!f) return fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: cannot open %s", path);
-  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "NBDYCKP2", 8) != 0 || h.header_bytes != sizeof h)
-    rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: %s is not a checkpoint of this engine (format NBDYCKP2)", path);
+  // format 1 (no Barnes-Hut state: the header ends after eps) still loads, as a theta = 0 file without a tree root
+  constexpr size_t v1_bytes = offsetof(CkptHeader, theta);
+  memset(&h, 0, sizeof h);
+  bool head_ok = fread(&h, v1_bytes, 1, f) == 1;
+  if (head_ok && memcmp(h.magic, "NBDYCKP2", 8) == 0)
+    head_ok = h.header_bytes == sizeof h && fread((char *)&h + v1_bytes, sizeof h - v1_bytes, 1, f) == 1;
+  else if (head_ok && memcmp(h.magic, "NBDYCKP1", 8) == 0) {
+    head_ok = h.header_bytes == v1_bytes;
+    h.has_root = 0; h.theta = 0.0f;
+  } else head_ok = false;
+  if (!head_ok)
+    rc = fail(c, NBODY_ERR_INVALID, "nbody_load_checkpoint: %s is not a checkpoint of this engine (formats NBDYCKP1/2)", path);
   // the file's owned range must contain the context's: a whole-system file also feeds the slices of a sharded job
   else if (h.n_total != c->p.n_total || h.elem_bytes != (int32_t)eb || h.i_begin > c->p.i_begin ||
            h.i_begin + h.i_count < c->p.i_begin + c->p.i_count)
@@ -1291,6 +1327,7 @@ int nbody_set_theta(nbody_ctx *c, float theta) {
   if (c->multi) return theta > 0.0f ? multi_unsupported(c, "nbody_set_theta(theta > 0)") : NBODY_OK;
   if (theta > 0.0f && (c->p.precision != NBODY_PREC_F32 || c->p.i_count != c->p.n_total))
     return fail(c, NBODY_ERR_UNSUPPORTED, "nbody_set_theta: Barnes-Hut needs an fp32 context that owns all bodies");
+  if (theta != c->theta) c->sym_posg_valid = false;   // the other force pass moves bodies without preparing the next all-pairs pass
   c->theta = theta;
   return NBODY_OK;
 }
@@ -1299,6 +1336,7 @@ int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com
   if (!c) return NBODY_ERR_INVALID;
   if (c->multi) return fail(c, NBODY_ERR_STATE, "nbody_bh_stats: no tree has been built on this context");
   if (!c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_stats: no tree has been built on this context");
+  if (int rc = use_device(c)) return rc;
   int n = 0, l = 0;
   nbody::bh_stats(c->bh, &n, &l);
   if (nodes) *nodes = n;
@@ -1310,6 +1348,7 @@ int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com
 int nbody_bh_leaf_boxes(nbody_ctx *c, float *boxes, size_t stride) {
   if (!c || !boxes || stride < 16) return c ? fail(c, NBODY_ERR_INVALID, "nbody_bh_leaf_boxes: null buffer or stride < 16") : NBODY_ERR_INVALID;
   if (c->multi || !c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_boxes: no tree has been built on this context (theta == 0?)");
+  if (int rc0 = use_device(c)) return rc0;
   const size_t bytes = (size_t)c->p.n_total * 16;
   int rc = ensure_stage(c, bytes);
   if (rc) return rc;
@@ -1324,6 +1363,7 @@ int nbody_bh_leaf_boxes(nbody_ctx *c, float *boxes, size_t stride) {
 int nbody_bh_leaf_order(nbody_ctx *c, int32_t *order) {
   if (!c || !order) return c ? fail(c, NBODY_ERR_INVALID, "nbody_bh_leaf_order: null buffer") : NBODY_ERR_INVALID;
   if (c->multi || !c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_order: no tree has been built on this context (theta == 0?)");
+  if (int rc = use_device(c)) return rc;
   HIP_TRY(c, nbody::bh_leaf_order(c->bh, order, c->stream));
   return NBODY_OK;
 }
@@ -1337,6 +1377,7 @@ int nbody_steps_done(nbody_ctx *c, int64_t *steps) {
 int nbody_kernel_time(nbody_ctx *c, int32_t which, double *total_ms, int64_t *launches) {
   if (!c || which < 0 || which > 1) return NBODY_ERR_INVALID;
   if (c->multi) return multi_rc(c, nbody::multi_kernel_time(c->multi, which, total_ms, launches));
+  if (int rc0 = use_device(c)) return rc0;
   int rc = timer_drain(c, which);
   if (rc) return rc;
   if (total_ms) *total_ms = c->timers[which].total_ms;
@@ -1347,6 +1388,7 @@ int nbody_kernel_time(nbody_ctx *c, int32_t which, double *total_ms, int64_t *la
 int nbody_kernel_time_reset(nbody_ctx *c) {
   if (!c) return NBODY_ERR_INVALID;
   if (c->multi) return multi_rc(c, nbody::multi_kernel_time_reset(c->multi));
+  if (int rc0 = use_device(c)) return rc0;
   for (int w = 0; w < 2; ++w) {
     int rc = timer_drain(c, w);
     if (rc) return rc;

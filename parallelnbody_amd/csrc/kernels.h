@@ -111,8 +111,10 @@ hipError_t launch_pack_particles(int precision, const void *posm, const void *ve
                                  int i_begin, int i_count, hipStream_t s);
 hipError_t launch_pack_positions(int precision, const void *posm, float *out, int first, int count, hipStream_t s);
 
-// fp64 energy pieces: out[0] += KE of owned bodies, out[1] += sum_i 1/2 m_i phi_i  (out pre-zeroed).
+// fp64 energy pieces: out[0] = KE of owned bodies, out[1] = sum_i 1/2 m_i phi_i.  Two launches: per-workgroup parts into
+// `partials` (energy_partials(n_total, i_count) doubles), then a fixed-order fold — no atomics, reproducible bits.
+size_t energy_partials(int n_total, int i_count);
 hipError_t launch_energy(int precision, const void *posm, const void *vel, int n_total, int i_begin, int i_count,
-                         double G, double eps2, double *out, hipStream_t s);
+                         double G, double eps2, double *partials, double *out, hipStream_t s);
 
 }  // namespace nbody

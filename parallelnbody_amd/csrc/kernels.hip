@@ -469,13 +469,13 @@ __global__ __launch_bounds__(kBlock) void bounds_kernel(const typename V4<T>::ty
   }
 }
 
-// fp64 energy diagnostic.  out[0] += sum_i 1/2 m_i v_i^2 (only by blockIdx.y == 0),
-// out[1] += sum_i 1/2 m_i phi_i with phi_i = -G sum_j m_j / sqrt(d^2 + eps2), d^2+eps2 == 0 skipped.
+// fp64 energy diagnostic.  Per workgroup: part[2 slot] = sum_i 1/2 m_i v_i^2 (only by blockIdx.y == 0),
+// part[2 slot + 1] = sum_i 1/2 m_i phi_i with phi_i = -G sum_j m_j / sqrt(d^2 + eps2), d^2+eps2 == 0 skipped.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void energy_kernel(const typename V4<T>::type *__restrict__ posm,
                                                         const typename V4<T>::type *__restrict__ vel, int n_total,
                                                         int i_begin, int i_count, int j_chunk, double G, double eps2,
-                                                        double *__restrict__ out) {
+                                                        double *__restrict__ part) {
   using V = typename V4<T>::type;
   __shared__ double4 sh[kBlock];
   __shared__ double red[2][kBlock / 64];
@@ -519,8 +519,29 @@ __global__ __launch_bounds__(kBlock) void energy_kernel(const typename V4<T>::ty
   if (t == 0) {
     double k = 0, p = 0;
     for (int w = 0; w < kBlock / 64; ++w) { k += red[0][w]; p += red[1][w]; }
-    atomicAdd(&out[0], k);
-    atomicAdd(&out[1], p);
+    // one slot per workgroup, added up in a fixed order by energy_fold_kernel: no atomics, the same bits every run
+    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    part[2 * slot] = k;
+    part[2 * slot + 1] = p;
+  }
+}
+
+// out[0] = sum of the workgroups' kinetic parts, out[1] = of their potential parts: lane t adds slots t, t + 256, ... in
+// order, then the fixed shuffle tree and the four waves in order.
+__global__ __launch_bounds__(kBlock) void energy_fold_kernel(const double *__restrict__ part, int slots, double *__restrict__ out) {
+  __shared__ double red[2][kBlock / 64];
+  const int t = threadIdx.x;
+  double k = 0.0, p = 0.0;
+  for (int q = t; q < slots; q += kBlock) { k += part[2 * q]; p += part[2 * q + 1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { k += __shfl_xor(k, off, 64); p += __shfl_xor(p, off, 64); }
+  if ((t & 63) == 0) { red[0][t >> 6] = k; red[1][t >> 6] = p; }
+  __syncthreads();
+  if (t == 0) {
+    double ks = 0, ps = 0;
+    for (int w = 0; w < kBlock / 64; ++w) { ks += red[0][w]; ps += red[1][w]; }
+    out[0] = ks;
+    out[1] = ps;
   }
 }
 
@@ -743,22 +764,37 @@ hipError_t launch_pack_positions(int precision, const void *posm, float *out, in
   return hipGetLastError();
 }
 
+namespace {
+void energy_geometry(int n_total, int i_count, int *iblocks, int *j_split, int *j_chunk) {
+  *iblocks = (i_count + kBlock - 1) / kBlock;
+  int js = 1;
+  while (*iblocks * js < 2048 && n_total / (js * 2) >= 4 * kBlock) js *= 2;
+  int chunk = (n_total + js - 1) / js;
+  chunk = (chunk + kBlock - 1) / kBlock * kBlock;
+  *j_split = (n_total + chunk - 1) / chunk;
+  *j_chunk = chunk;
+}
+}  // namespace
+
+size_t energy_partials(int n_total, int i_count) {
+  int iblocks, j_split, j_chunk;
+  energy_geometry(n_total, i_count > 0 ? i_count : 1, &iblocks, &j_split, &j_chunk);
+  return (size_t)iblocks * j_split * 2;
+}
+
 hipError_t launch_energy(int precision, const void *posm, const void *vel, int n_total, int i_begin, int i_count,
-                         double G, double eps2, double *out, hipStream_t s) {
+                         double G, double eps2, double *partials, double *out, hipStream_t s) {
   if (i_count <= 0) return hipErrorInvalidValue;
-  const int iblocks = (i_count + kBlock - 1) / kBlock;
-  int j_split = 1;
-  while (iblocks * j_split < 2048 && n_total / (j_split * 2) >= 4 * kBlock) j_split *= 2;
-  int j_chunk = (n_total + j_split - 1) / j_split;
-  j_chunk = (j_chunk + kBlock - 1) / kBlock * kBlock;
-  j_split = (n_total + j_chunk - 1) / j_chunk;
+  int iblocks, j_split, j_chunk;
+  energy_geometry(n_total, i_count, &iblocks, &j_split, &j_chunk);
   dim3 grid(iblocks, j_split), block(kBlock);
   if (precision == NBODY_PREC_F64)
     hipLaunchKernelGGL((energy_kernel<double>), grid, block, 0, s, (const double4 *)posm, (const double4 *)vel, n_total,
-                       i_begin, i_count, j_chunk, G, eps2, out);
+                       i_begin, i_count, j_chunk, G, eps2, partials);
   else
     hipLaunchKernelGGL((energy_kernel<float>), grid, block, 0, s, (const float4 *)posm, (const float4 *)vel, n_total,
-                       i_begin, i_count, j_chunk, G, eps2, out);
+                       i_begin, i_count, j_chunk, G, eps2, partials);
+  hipLaunchKernelGGL(energy_fold_kernel, dim3(1), block, 0, s, partials, iblocks * j_split, out);
   return hipGetLastError();
 }
 

@@ -170,6 +170,47 @@ def test_bh_large_n(nb, oracle):
     assert st["nodes"] == nodes and st["levels"] >= 8
 
 
+@pytest.mark.parametrize("n", [16384, 49152])
+def test_switching_the_opening_angle_on_a_fused_all_pairs_context(nb, oracle, n):
+    # N >= 12288 single-device fp32: the all-pairs step is the symmetric kernel with the fused update, which prepares the
+    # NEXT pass (scaled positions, coincident-body table) while it moves the bodies.  A Barnes-Hut step in between moves
+    # them with the plain update: the next all-pairs pass must prepare again, not reuse what the last fused update left.
+    # (The actor hands its public Theta field to nbody_set_theta on every Tick, so this sequence is one checkbox away.)
+    posm, vel = nb.ic_plummer(n, seed=n + 1)
+    posm[:, 3] *= np.random.default_rng(5).uniform(0.5, 1.5, n).astype(np.float32)
+    with nb.NBodyEngine(n) as e:
+        assert e.launch_config()["algorithm"] == "symmetric"
+        e.set_state(posm, vel)
+        e.step(0.01, 2)                              # fused all-pairs steps
+        e.set_theta(0.5)
+        e.step(0.01, 2)                              # Barnes-Hut steps: bodies move without the fused preparation
+        e.set_theta(0.0)
+        e.compute_forces()
+        p, v, a = e.state()
+        e.step(0.01, 1)                              # and stepping goes on from there
+        e.compute_forces()
+        p2, _, a2 = e.state()
+    for pp, aa in ((p, a), (p2, a2)):
+        p64 = pp.astype(np.float64)
+        sample = np.arange(0, n, n // 64)
+        ref = np.concatenate([oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1) for i in sample])
+        assert rel_err(aa[sample, :3], ref).max() < 2e-5
+    # theta > 0 from the start, then all-pairs
+    with nb.NBodyEngine(n, theta=1.0) as e:
+        e.set_state(posm, vel)
+        e.step(0.01, 1)
+        e.set_theta(0.0)
+        e.step(0.01, 1)
+        e.set_theta(1.0)
+        e.step(0.01, 1)
+        e.set_theta(0.0)
+        e.compute_forces()
+        p, v, a = e.state()
+    p64 = p.astype(np.float64)
+    ref = np.concatenate([oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1) for i in sample])
+    assert rel_err(a[sample, :3], ref).max() < 2e-5
+
+
 def test_bh_limits(nb):
     g = np.load(os.path.join(GOLDEN, "plummer_n1024_seed1.npz"))
     with pytest.raises(nb.NBodyError) as err:

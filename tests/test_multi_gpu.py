@@ -37,7 +37,8 @@ def test_one_device_multi_context_equals_a_plain_context(nb, n, precision):
         np.testing.assert_array_equal(a.positions(), b.positions())
         np.testing.assert_array_equal(a.particles(), b.particles())
         assert a.bounds() == b.bounds()
-        np.testing.assert_allclose(a.energy(), b.energy(), rtol=1e-12)   # the diagnostic adds with fp64 atomics: order varies
+        assert a.energy() == b.energy()              # fixed-order reduction: the diagnostic is reproducible in every bit
+        assert a.energy() == a.energy()
         assert a.steps_done() == b.steps_done() == 3
 
 

@@ -54,3 +54,43 @@ def test_bench_falls_back_together_when_one_rank_cannot_build_the_symmetric_engi
     r, err = _bench_two_ranks({"NBODY_REHEARSE_CREATE_FAILURE": "1"})
     assert r["config"]["algorithm"] == "tiled" and "symmetric engines could not be created" in r["config"]["fallback"]
     assert "every rank rebuilds" in err
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks():
+    # `python bench.py --gpus 2` with no torch.distributed.run around it (the shape of the command the driver uses for one GPU):
+    # bench.py starts the launcher as a child process before touching the GPU and relays its line and exit code
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--bodies", "65536",
+           "--settle-seconds", "0.02", "--no-tiled-row"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NBODY_DIST_BACKEND"] = "gloo"
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "no launcher around --gpus 2" in out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["config"]["max_rel_err_sampled"] < 2e-5
+    for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):
+        assert key in r, key
+
+
+def test_bench_single_host_line():
+    # `--host single`: one process, one thread, nbody_create_multi over devices 0..N-1 (here N = 1: a one-rank RCCL
+    # communicator, every collective still runs); the same contract line, cpu_baseline included at N = 1
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--host", "single", "--steps", "2", "--warmup", "1",
+           "--bodies", "65536", "--settle-seconds", "0.02", "--cpu-seconds", "0.5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["value"] > 0 and "nbody_create_multi" in r["config"]["host"]
+    assert r["config"]["algorithm"] == "symmetric" and r["config"]["max_rel_err_sampled"] < 2e-5
+    assert 0.0 < r["roofline"]["frac"] < 1.0 and r["cpu_baseline"]["value"] > 0
+    # more devices than the box has: refused before anything is measured
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--host", "single"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0 and "device(s) visible" in out.stderr
