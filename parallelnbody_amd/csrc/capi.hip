@@ -369,32 +369,77 @@ int ensure_floor(nbody_ctx *c) {
   return NBODY_OK;
 }
 
-// Barnes-Hut force pass: ComputeCubeSize -> CreateOctree, all on the device.
-int run_forces_bh(nbody_ctx *c) {
+// Barnes-Hut state of a context, on first use.
+int ensure_bh(nbody_ctx *c) {
   if (c->p.precision != NBODY_PREC_F32 || c->p.i_count != c->p.n_total)
     return fail(c, NBODY_ERR_UNSUPPORTED, "theta > 0 (Barnes-Hut) needs an fp32 context that owns all bodies");
-  if (!c->bh) {
-    hipError_t e = nbody::bh_create(&c->bh, c->p.n_total);
-    if (e != hipSuccess) return fail(c, NBODY_ERR_HIP, "bh_create: %s", hipGetErrorString(e));
-    nbody::bh_set_div_mode(c->bh, c->p.bh_div_mode);
-    HIP_TRY(c, hipMalloc(&c->bh_acc, (size_t)c->p.n_total * 16));
+  if (c->bh) return NBODY_OK;
+  hipError_t e = nbody::bh_create(&c->bh, c->p.n_total);
+  if (e == hipSuccess) e = hipMalloc(&c->bh_acc, (size_t)c->p.n_total * 16);
+  if (e != hipSuccess) {
+    nbody::bh_destroy(c->bh); c->bh = nullptr;
+    if (c->bh_acc) { (void)hipFree(c->bh_acc); c->bh_acc = nullptr; }
+    return fail(c, NBODY_ERR_HIP, "bh_create: %s", hipGetErrorString(e));
   }
+  nbody::bh_set_div_mode(c->bh, c->p.bh_div_mode);
+  return NBODY_OK;
+}
+
+int bh_status_error(nbody_ctx *c, int status) {
+  if (status == 1) return fail(c, NBODY_ERR_UNSUPPORTED, "Barnes-Hut tree deeper than 42 levels: two bodies closer than Size/2^42 (the reference's Add would recurse without bound on coincident bodies)");
+  if (status == 2) return fail(c, NBODY_ERR_NOMEM, "Barnes-Hut node pool exhausted");
+  return NBODY_OK;
+}
+
+// Small systems at theta > 0: queue `nsteps` whole frames (tree, walk, update — two launches each), nothing waits.
+int bh_small_enqueue(nbody_ctx *c, float dt, int nsteps) {
+  const bool timed = c->p.time_kernels != 0;
+  for (int s = 0; s < nsteps; ++s) {
+    EventPair ev;
+    if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
+    HIP_TRY(c, nbody::bh_small_frame(c->bh, c->posm, c->vel, c->acc, c->theta, c->p.G, dt, 0, c->stream));
+    if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
+    if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) { int rc = timer_drain(c, NBODY_KERNEL_FORCES); if (rc) return rc; }
+  }
+  c->sym_posg_valid = false;     // bodies move without the fused all-pairs update's preparation of the next pass
+  return NBODY_OK;
+}
+
+// ... and the one wait: the frames that were built count as steps; a refused frame (and all queued behind it) left the
+// state where it was.
+int bh_small_finish(nbody_ctx *c) {
+  int status = 0, frames = 0;
+  HIP_TRY(c, nbody::bh_small_collect(c->bh, c->stream, &status, &frames));
+  c->steps_done += frames;
+  return bh_status_error(c, status);
+}
+
+// Barnes-Hut force pass: ComputeCubeSize -> CreateOctree, all on the device.  diagnostic: the pass belongs to no frame
+// (nbody_compute_forces) and leaves the next tree's root centre alone.
+int run_forces_bh(nbody_ctx *c, bool diagnostic) {
+  { int rc = ensure_bh(c); if (rc) return rc; }
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
+  int status = 0;
+  if (nbody::bh_is_small(c->bh)) {
+    HIP_TRY(c, nbody::bh_small_frame(c->bh, c->posm, nullptr, c->bh_acc, c->theta, c->p.G, 0.0f, diagnostic ? 1 : 0, c->stream));
+    if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
+    HIP_TRY(c, nbody::bh_small_collect(c->bh, c->stream, &status, nullptr));
+    return bh_status_error(c, status);
+  }
   HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
   HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, 0, c->p.n_total, (unsigned int *)c->scratch, c->stream));
-  int status = 0;
-  HIP_TRY(c, nbody::bh_forces(c->bh, c->posm, c->bh_acc, (const unsigned int *)c->scratch, c->theta, c->p.G, c->stream, &status));
+  HIP_TRY(c, nbody::bh_forces(c->bh, c->posm, c->bh_acc, (const unsigned int *)c->scratch, c->theta, c->p.G, diagnostic ? 1 : 0,
+                              c->stream, &status));
   if (status != 0 && timed) c->timers[NBODY_KERNEL_FORCES].pool.push_back(ev);   // the pair goes back unused
-  if (status == 1) return fail(c, NBODY_ERR_UNSUPPORTED, "Barnes-Hut tree deeper than 42 levels: two bodies closer than Size/2^42 (the reference's Add would recurse without bound on coincident bodies)");
-  if (status == 2) return fail(c, NBODY_ERR_NOMEM, "Barnes-Hut node pool exhausted");
+  if (status != 0) return bh_status_error(c, status);
   if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
   return NBODY_OK;
 }
 
-int run_forces(nbody_ctx *c) {
-  if (c->theta > 0.0f) return run_forces_bh(c);
+int run_forces(nbody_ctx *c, bool diagnostic = false) {
+  if (c->theta > 0.0f) return run_forces_bh(c, diagnostic);
   { int rc = ensure_floor(c); if (rc) return rc; }
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
@@ -986,7 +1031,7 @@ int nbody_compute_forces(nbody_ctx *c) {
   if (c->multi) return multi_rc(c, nbody::multi_forces(c->multi, 0.0f));
   if ((rc = needs_phases(c, "nbody_compute_forces"))) return rc;
   HIP_TRY(c, hipSetDevice(c->p.device));
-  if ((rc = run_forces(c))) return rc;
+  if ((rc = run_forces(c, true))) return rc;
   if ((rc = run_update(c, 0.0f))) return rc;
   return NBODY_OK;
 }
@@ -1007,6 +1052,13 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
   if (nsteps > 1 && c->p.i_count != c->p.n_total)
     return fail(c, NBODY_ERR_STATE, "nbody_step: a sharded context advances one step per call (all-gather NBODY_BUF_POSM in between)");
   HIP_TRY(c, hipSetDevice(c->p.device));
+  if (c->theta > 0.0f) {
+    if ((rc = ensure_bh(c))) return rc;
+    if (nbody::bh_is_small(c->bh)) {                             // two launches per frame, one wait per call
+      if ((rc = bh_small_enqueue(c, dt, nsteps))) return rc;
+      return bh_small_finish(c);
+    }
+  }
   // small single-context fp32 systems: forces + update in ONE launch per step, ping-ponging the position buffer
   // (it swaps the two position buffers: not once the caller holds a pointer to one of them)
   const bool one_launch = c->wave != 0 && c->theta == 0.0f && c->own_posm && !c->posm_escaped &&
@@ -1144,12 +1196,22 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
   // the eps floor of NBODY_ZERO_FLOOR is computed through the same 64-byte scratch the bounds travel in: settle it
   // before the bounds are queued, or the first frame would return the largest mass as Size
   if (live && c->theta == 0.0f && (rc = ensure_floor(c))) return rc;
-  if (live && size) {                                            // .cpp:26, 47-56: bounds of the positions BEFORE the step
+  // small systems at theta > 0: the tree's own launch computes Size (it is the root's half-width) — the frame is queued
+  // here and its verdict collected by the frame's one wait
+  bool bh_frame = false;
+  if (live && c->theta > 0.0f) {
+    if ((rc = ensure_bh(c))) return rc;
+    bh_frame = nbody::bh_is_small(c->bh);
+  }
+  if (bh_frame) {
+    if ((rc = bh_small_enqueue(c, dt, 1))) return rc;
+    if (size) HIP_TRY(c, hipMemcpyAsync(c->h_scratch, nbody::bh_root_device(c->bh) + 3, 4, hipMemcpyDeviceToHost, c->stream));
+  } else if (live && size) {                                     // .cpp:26, 47-56: bounds of the positions BEFORE the step
     HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
     HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, c->p.i_begin, c->p.i_count, (unsigned int *)c->scratch, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->scratch, 4, hipMemcpyDeviceToHost, c->stream));
   }
-  if (live && (rc = nbody_step(c, dt, 1))) return rc;            // .cpp:27-31
+  if (live && !bh_frame && (rc = nbody_step(c, dt, 1))) return rc;   // .cpp:27-31
   const size_t ic = (size_t)c->p.i_count, bytes = ic * sizeof(nbody_particle);
   bool direct = false;
   if (aos) {                                                     // .cpp:33,41: what the frame draws
@@ -1159,10 +1221,12 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
     direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
     HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
   }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int frame_rc = NBODY_OK;
+  if (bh_frame) frame_rc = bh_small_finish(c);                   // the frame's one wait
+  else HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (live && size) memcpy(size, c->h_scratch, 4);
   if (aos && !direct) unstage_particles(c, aos, stride, ic);
-  return NBODY_OK;
+  return frame_rc;
 }
 
 int nbody_pin_host_buffer(nbody_ctx *c, void *host, size_t bytes) {
@@ -1304,12 +1368,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) t
   if (c->p.precision == NBODY_PREC_F32 && c->p.i_count == c->p.n_total) {
     c->theta = h.theta;
     if (h.has_root || c->bh) {
-      if (!c->bh) {
-        hipError_t e = nbody::bh_create(&c->bh, c->p.n_total);
-        if (e != hipSuccess) return fail(c, NBODY_ERR_HIP, "bh_create: %s", hipGetErrorString(e));
-        nbody::bh_set_div_mode(c->bh, c->p.bh_div_mode);
-        HIP_TRY(c, hipMalloc(&c->bh_acc, (size_t)c->p.n_total * 16));
-      }
+      { const int rc2 = ensure_bh(c); if (rc2) return rc2; }
       const float zero[3] = {0.f, 0.f, 0.f};
       HIP_TRY(c, nbody::bh_set_root_com(c->bh, h.has_root ? h.root_com : zero, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1341,7 +1400,7 @@ int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com
   nbody::bh_stats(c->bh, &n, &l);
   if (nodes) *nodes = n;
   if (levels) *levels = l;
-  if (root_com) HIP_TRY(c, nbody::bh_get_root_com(c->bh, root_com, c->stream));
+  if (root_com) HIP_TRY(c, nbody::bh_get_tree_com(c->bh, root_com, c->stream));
   return NBODY_OK;
 }
 
@@ -1365,6 +1424,14 @@ int nbody_bh_leaf_order(nbody_ctx *c, int32_t *order) {
   if (c->multi || !c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_order: no tree has been built on this context (theta == 0?)");
   if (int rc = use_device(c)) return rc;
   HIP_TRY(c, nbody::bh_leaf_order(c->bh, order, c->stream));
+  return NBODY_OK;
+}
+
+// Not in include/nbody.h: tuning aid of tools/bh_phases.py (meaningful in -DNBODY_BH_PHASE_CLOCKS builds only).
+__attribute__((visibility("default"))) int nbody_debug_bh_clocks(nbody_ctx *c, long long out[16 + 3 * 512]) {
+  if (!c || c->multi || !c->bh || !out) return NBODY_ERR_INVALID;
+  if (int rc = use_device(c)) return rc;
+  HIP_TRY(c, nbody::bh_debug_clocks(c->bh, out, c->stream));
   return NBODY_OK;
 }
 
@@ -1401,7 +1468,7 @@ int nbody_kernel_time_reset(nbody_ctx *c) {
 const char *nbody_force_kernel_name(const nbody_ctx *c) {
   if (!c) return "";
   if (c->multi) return nbody_force_kernel_name(nbody::multi_part(c->multi, 0));
-  if (c->theta > 0.0f) return "bh_walk_kernel (+ tree build)";
+  if (c->theta > 0.0f) return c->p.n_total <= 4096 ? "bh_walk_compact_kernel (+ bh_small_build_kernel)" : "bh_walk_kernel (+ tree build)";
   if (c->sym) return c->p.precision == NBODY_PREC_F64 ? "forces_sym_f64_kernel" : "forces_sym_pk_kernel";
   if (c->wave) return "small_pk_kernel";
   if (c->p.precision != NBODY_PREC_F64 && c->ipt % 2 == 0 && (c->p.eps > 0.0 || c->p.zero_mode != NBODY_ZERO_SELECT))

@@ -83,13 +83,24 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
 
 // GPU Barnes-Hut with the reference's tree and opening rule — kernels_bh.hip.  fp32, all bodies in one context.
 struct BhState;
-hipError_t bh_create(BhState **out, int n);
+hipError_t bh_create(BhState **out, int n);                   // *out is set even on failure: bh_destroy it
 void bh_destroy(BhState *b);
 hipError_t bh_reset_root(BhState *b, hipStream_t s);          // previous CoM := 0 (a new scene, OctreeSearch.cpp:77)
-// acc[body] = Octree::ComputeForces(body, theta) on the tree rooted at (previous CoM, *size_bits as float).
+// Large systems: acc[body] = Octree::ComputeForces(body, theta) on the tree rooted at (previous CoM, *size_bits as float).
 // *status: 0 ok, 1 tree deeper than 42 levels, 2 node pool exhausted.  Synchronises the stream once per tree level.
+// keep_root != 0: the next tree's root centre stays what it was (a diagnostic pass).
 hipError_t bh_forces(BhState *b, const void *posm, void *acc, const unsigned int *size_bits, float theta, double G,
-                     hipStream_t s, int *status);
+                     int keep_root, hipStream_t s, int *status);
+// Small systems (bh_is_small): one frame = two launches, queued without waiting for the host — ComputeCubeSize + tree +
+// upsweep by one workgroup, then the walk, which with dt > 0 also applies the Tick's update to (posm, vel) in place.
+// bh_small_collect waits for the stream and reports the frames queued since the last collect.
+bool bh_is_small(const BhState *b);
+hipError_t bh_small_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root,
+                          hipStream_t s);
+hipError_t bh_small_collect(BhState *b, hipStream_t s, int *status, int *frames);
+hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t s);   // tuning builds only (tools/bh_phases.py)
+const float *bh_root_device(const BhState *b);                // device (ox, oy, oz, Size) of the last tree (small systems)
+hipError_t bh_get_tree_com(BhState *b, float out[3], hipStream_t s);   // root CoM of the last tree built
 void bh_set_div_mode(BhState *b, int div_mode);            // 0: `/=` in ComputeMass multiplies by the reciprocal; 1: divides
 // order[k] = the body whose leaf a depth-first walk (children 0..7) meets k-th in the last tree built (host array, n ints)
 hipError_t bh_leaf_order(BhState *b, int *out_host, hipStream_t s);

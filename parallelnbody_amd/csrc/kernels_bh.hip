@@ -286,76 +286,585 @@ __global__ __launch_bounds__(kB) void bh_upsweep_kernel(Nodes nd, const int *__r
   upsweep_cell(nd, cells[f], div_mode);
 }
 
-// Small systems (the reference ships N = 2000): the whole Add + ComputeMass — root, every level's splits, the upsweep
-// from the deepest level, the next frame's root centre — by ONE workgroup in one launch, levels separated by
-// barriers instead of a launch and a host round trip each (N = 2000: 12 levels).
-// counters out: [0] nodes, [1] levels, [2] error (0 ok, 1 depth limit, 2 node pool full).
-constexpr int kSmallThreads = 1024;
-constexpr int kLdsKeys = 8192;
-__global__ __launch_bounds__(kSmallThreads) void bh_build_small_kernel(Nodes nd, const float *__restrict__ root,
-                                                                       const float4 *__restrict__ posm,
-                                                                       const unsigned long long *khi,
-                                                                       const unsigned long long *__restrict__ klo,
-                                                                       const unsigned int *__restrict__ sidx, int n,
-                                                                       int *__restrict__ frontier, int *__restrict__ counters,
-                                                                       int node_cap, float *__restrict__ prev_com,
-                                                                       int div_mode) {
-  __shared__ int s_off[kMaxLevels + 2], s_cnt[kMaxLevels + 2];
-  __shared__ int s_nodes, s_next, s_err;
-  __shared__ unsigned long long s_khi[kLdsKeys];          // the first 21 levels' digits: binary searches at LDS latency
-  const int t = threadIdx.x;
-  if (n <= kLdsKeys) {
-    for (int i = t; i < n; i += kSmallThreads) s_khi[i] = khi[i];
-    khi = s_khi;                                            // generic pointer: flat loads resolve to LDS
+// ---------------------------------------------------------------------------------------------------------------------
+// Small systems (the reference ships N = 2000; up to kSmBodies): the whole CreateOctree head — ComputeCubeSize, the root
+// rule, Add, ComputeMass (.cpp:47-56, 77-81; .h:60-97) — by ONE workgroup in ONE launch, and a COMPACT tree for the walk.
+//
+// Which cells exist follows from the sorted path keys alone: with lcp(i) = the number of leading octant digits bodies i
+// and i+1 (key order) share, the cells holding >= 2 bodies whose first body is i are those of levels
+// lcp(i-1)+1 .. lcp(i) — every one of them, chains of single-child cells included (the reference creates them, each
+// with its own CoM rounding and its own Size in the opening test).  In depth-first order, children 0..7 — the order
+// ComputeForces recurses in — the nodes are: for body i, those cells by level, then the body's leaf.  So an exclusive
+// scan of (cells opened at i) + 1 numbers all nodes in PREORDER with no level-by-level construction and no atomics:
+// "descend" is node + 1, "do not descend" is the node after the cell's last body (a binary search on the keys), and
+// the empty leaves of the reference's 8-way split (.h:100: a walk returns from them at once; ComputeMass adds +0 for
+// them, which cannot change a sum that started at +0) are simply not there.  A node is 20 bytes: (CoM, M) and one word
+// {leaf, level, skip link | body}; Size comes from the level (halved exactly per level, .h:74).  Up to kSmNodesLds nodes
+// the tree lives in LDS while it is built and swept, and the walk's workgroups read it from LDS too.
+constexpr int kSmT = 1024;                 // threads of the build workgroup
+constexpr int kSmBodies = 4096;            // bodies the in-LDS sort holds
+constexpr int kSmNodesLds = 6656;          // compact nodes that fit in LDS: the walk keeps 22 B of each (146 KB)
+// LDS of the build, bytes.  While the structure is found: two (key word, body) buffers the merge sort ping-pongs between,
+// the second key word by body; afterwards the nodes' (CoM, M) take that space.  Behind it the node words and the list of
+// cells by level, which must not overlap anything the node-word phase still reads.
+constexpr int kSmBuf = kSmBodies * (8 + 2);                    // one sort buffer: hi[P], idx[P]
+constexpr int kSmRegionA = 2 * kSmBuf + kSmBodies * 8;         // 114688
+static_assert(kSmRegionA >= kSmNodesLds * 16, "the CoMs must fit where the sort ran");
+constexpr int kSmLds = kSmRegionA + kSmNodesLds * 4 + kSmNodesLds * 2;
+constexpr unsigned int kLeafBit = 0x80000000u;
+constexpr int kLevelShift = 25;
+constexpr unsigned int kLinkMask = (1u << kLevelShift) - 1u;
+constexpr int kWalkT = 256;                // threads per workgroup of the compact walk
+constexpr int kWalkG = 16;                 // lanes per body there
+
+struct SmallTree {
+  float4 *com;                  // [cap] preorder nodes: centre of mass, total mass
+  unsigned int *meta;           // [cap] leaf bit | level << 25 | (internal: the node after the subtree; leaf: the body)
+  unsigned long long *khi, *klo;   // [n] sorted path keys (what the leaf boxes are rebuilt from)
+  unsigned int *sidx;           // [n] body at each sorted position = DrawOctreeBoxes' order
+  unsigned char *leaf_level;    // [n] level of the leaf of the body at each sorted position
+  int *hdr;                     // [0] compact nodes, [1] cells with >= 2 bodies, [2] levels, [3] status (sticky), [4] frames built
+  float *root;                  // ox, oy, oz, Size of the current tree
+  float *prev_com;              // the previous tree's root CoM = the next tree's root centre (.cpp:77-79)
+  float *thr;                   // [kMaxLevels + 2] a cell of level l is accepted (.h:103) iff the squared distance >= thr[l]
+  long long *clocks;            // build with -DNBODY_BH_PHASE_CLOCKS: wall_clock64 at the kernels' phase boundaries
+  int cap;
+};
+
+constexpr int kDbgClocks = 16 + 3 * 512;   // tuning builds: 16 phase stamps + (start, fill end, end) of up to 512 walk workgroups
+#ifdef NBODY_BH_PHASE_CLOCKS
+#define BH_CLOCK(k) do { if (threadIdx.x == 0) T.clocks[k] = wall_clock64(); } while (0)
+#define BH_WALK_CLOCK(k) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) T.clocks[k] = wall_clock64(); } while (0)
+#define BH_WALK_COUNT(k, v) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) T.clocks[k] = (v); } while (0)
+#define BH_WG_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512) T.clocks[16 + 3 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+#else
+#define BH_CLOCK(k) do { } while (0)
+#define BH_WALK_CLOCK(k) do { } while (0)
+#define BH_WALK_COUNT(k, v) do { } while (0)
+#define BH_WG_STAMP(slot) do { } while (0)
+#endif
+
+// Octree::ComputeForces accepts a cell when `Size / d < Theta` (.h:103) with d = FVector::Dist = sqrtf(d2) (.h:101), both
+// correctly rounded.  Quotient and root are monotone in their argument, so for every Size there is ONE float D with
+// (Size / sqrtf(d2) < Theta)  <=>  d2 >= D.  It is found with the very operations the test itself uses — a guess, a short
+// scan over neighbouring bit patterns, bisection over all of them should the guess be far off — and the walk then decides
+// with a compare; it needs the root only where a term is added.
+template <typename PRED>
+__device__ __forceinline__ unsigned int first_true(unsigned int lo, unsigned int hi, unsigned int guess, PRED pred) {
+  // smallest pattern in [lo, hi] for which pred holds (pred is monotone: false ... false true ... true, true at hi)
+  if (guess > lo + 4u && guess + 4u < hi && !pred(guess - 4u) && pred(guess + 4u)) {
+    unsigned int g = guess - 3u;
+    while (!pred(g)) ++g;
+    return g;
   }
-  if (t == 0) {
-    nd.box[0] = make_float4(root[0], root[1], root[2], root[3]);
-    nd.range[0] = make_int2(0, n);
-    s_nodes = 1; s_next = 0; s_err = 0;
-    if (n >= 2) {
-      nd.link[0] = make_int4(-1, -1, -1, 0);
-      nd.com[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-      frontier[0] = 0;
-      s_cnt[0] = 1;
-    } else {
-      const unsigned int b = sidx[0];
-      nd.link[0] = make_int4(-1, (int)b, -1, 0);
-      nd.com[0] = posm[b];
-      s_cnt[0] = 0;
+  unsigned int a = lo, b = hi;
+  while (a < b) {
+    const unsigned int mid = a + ((b - a) >> 1);
+    if (pred(mid)) b = mid; else a = mid + 1u;
+  }
+  return a;
+}
+
+__device__ __forceinline__ float accept_threshold(float size, float theta) {
+  // smallest d > 0 with size / d < theta (d = +inf: 0 < theta), then the smallest d2 >= 0 with sqrtf(d2) >= that d
+  const unsigned int db = first_true(1u, 0x7F800000u, __float_as_uint(size / theta),
+                                     [&](unsigned int v) { return size / __uint_as_float(v) < theta; });
+  const float dmin = __uint_as_float(db);
+  const unsigned int d2b = first_true(0u, 0x7F800000u, __float_as_uint(dmin * dmin),
+                                      [&](unsigned int v) { return sqrtf(__uint_as_float(v)) >= dmin; });
+  return __uint_as_float(d2b);
+}
+
+// One level of Octree::Add's descent (.h:50-56, 68-75): the octant of p in the cell (o, size), then the child's box.
+// float(double(o) +- double(size) * 0.5) equals the plain fp32 o +- 0.5f * size whenever 0.5f * size is exact (the sum
+// of two floats rounds once to float either way: it is exact in double unless the smaller one is below a 2^-29th of an
+// ulp of the larger — tests/cpp/child_centre_equiv.c checks the claim on random operand pairs); only sizes down in the
+// denormal range take the double path.
+__device__ __forceinline__ int descend_level(const float4 &p, float o[3], float &size) {
+  int c = 0;                                                   // GetOctant
+  if (p.x >= o[0]) c |= 4;
+  if (p.y >= o[1]) c |= 2;
+  if (p.z >= o[2]) c |= 1;
+  if (size >= 0x1p-100f) {
+#pragma clang fp contract(off)
+    const float h = 0.5f * size;
+    o[0] = (c & 4) ? o[0] + h : o[0] - h;
+    o[1] = (c & 2) ? o[1] + h : o[1] - h;
+    o[2] = (c & 1) ? o[2] + h : o[2] - h;
+    size = h;
+  } else {
+    float no[3], ns;
+    child_box(o, size, c, no, &ns);
+    o[0] = no[0]; o[1] = no[1]; o[2] = no[2]; size = ns;
+  }
+  return c;
+}
+
+// Do the keys share their first l octant digits (0 < l <= 42)?
+__device__ __forceinline__ bool same_prefix(unsigned long long ha, unsigned long long la, unsigned long long hb,
+                                            unsigned long long lb, int l) {
+  if (l <= kLevelsPerKey) return (ha >> (3 * (kLevelsPerKey - l))) == (hb >> (3 * (kLevelsPerKey - l)));
+  return ha == hb && (la >> (3 * (kMaxLevels - l))) == (lb >> (3 * (kMaxLevels - l)));
+}
+
+// Octree::ComputeMass of one cell of the compact tree whose children are done (.h:89-95): node m, its word w, level l.
+__device__ __forceinline__ float4 sweep_compact_cell(const float4 *com, const unsigned int *meta, int m, unsigned int w, int l,
+                                                     int div_mode, const float4 *__restrict__ posm, const float *root) {
+#pragma clang fp contract(off)
+  const int end = (int)(w & kLinkMask);
+  float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+  for (int c = m + 1; c != end;) {
+    const float4 ch = com[c];
+    const unsigned int cw = meta[c];
+    M = M + ch.w;
+    cx = cx + ch.w * ch.x; cy = cy + ch.w * ch.y; cz = cz + ch.w * ch.z;
+    c = (cw & kLeafBit) ? c + 1 : (int)(cw & kLinkMask);
+  }
+  if (M != 0.f) {
+    if (div_mode == 0) { const float rv = 1.0f / M; cx = cx * rv; cy = cy * rv; cz = cz * rv; }
+    else { cx = cx / M; cy = cy / M; cz = cz / M; }
+  } else {                                                     // CenterOfMass = Origin (.h:95 else branch): the cell's own box
+    int c = m + 1;
+    while (!(meta[c] & kLeafBit)) ++c;                          // any body of the cell: its path leads through the cell
+    const float4 p = posm[meta[c] & kLinkMask];
+    float o[3] = {root[0], root[1], root[2]};
+    float size = root[3];
+    for (int lev = 0; lev < l; ++lev) (void)descend_level(p, o, size);
+    cx = o[0]; cy = o[1]; cz = o[2];
+  }
+  return make_float4(cx, cy, cz, M);
+}
+
+// What the structure phases of bh_small_build_kernel leave in LDS for the node phases: sorted first key words and bodies,
+// the second key words by body, the first node of every body's group, the shared digits of neighbours (lcpS[i] = lcp(i-1),
+// -1 at both ends) and, when the tree fits in LDS, the body whose group each node belongs to.
+struct SmallScratch {
+  const unsigned long long *hi; const unsigned short *idx; const unsigned long long *lo_by_body;
+  const int *first; const signed char *lcpS; const unsigned short *owner;
+  const float *root; int *maxl; int *lvl;
+};
+
+// One word per node, the leaves' (CoM, M), ComputeMass level by level, and the hand-over to the walk.  IN_LDS: com / meta /
+// cells are LDS arrays (the compiler sees the address space: ds_read, not flat loads); otherwise the tree is too large for
+// LDS and lives in its global arrays from the start (deep chains of single-child cells: slow, correct).
+template <bool IN_LDS>
+__device__ __forceinline__ void small_tree_nodes(const SmallTree &T, float4 *com, unsigned int *meta, unsigned short *cells,
+                                                 const SmallScratch &sc, const float4 *__restrict__ posm, int n, int nodes,
+                                                 int div_mode, int keep_root) {
+  const int t = threadIdx.x;
+  // ---- one word per node: body i's cells (levels lcp(i-1)+1 .. lcp(i)) in preorder, then its leaf
+  for (int m = t; m < nodes; m += kSmT) {
+    int i;
+    if (IN_LDS) {
+      i = sc.owner[m];
+    } else {                                                   // the body whose group holds node m
+      int a = 0, b = n - 1;
+      while (a < b) { const int mid = (a + b + 1) >> 1; if (sc.first[mid] <= m) a = mid; else b = mid - 1; }
+      i = a;
+    }
+    const int q = m - sc.first[i], lp = sc.lcpS[i], ln = sc.lcpS[i + 1];
+    const int open = ln > lp ? ln - lp : 0;
+    if (q == open) {                                           // the leaf: one level below the deepest cell the body shares
+      const int level = (lp > ln ? lp : ln) + 1;
+      meta[m] = kLeafBit | ((unsigned int)level << kLevelShift) | (unsigned int)sc.idx[i];
+      T.leaf_level[i] = (unsigned char)level;
+    } else {                                                   // cell of level l whose first body is i
+      const int l = lp + 1 + q;
+      int upper = n;
+      if (l > 0) {
+        const unsigned long long h0 = sc.hi[i], l0 = l > kLevelsPerKey ? sc.lo_by_body[sc.idx[i]] : 0ull;
+        int x = i + 1, y = n;                                  // first body behind the cell
+        while (x < y) {
+          const int mid = (x + y) >> 1;
+          const unsigned long long hm = sc.hi[mid], lm = l > kLevelsPerKey ? sc.lo_by_body[sc.idx[mid]] : 0ull;
+          if (same_prefix(hm, lm, h0, l0, l)) x = mid + 1; else y = mid;
+        }
+        upper = x;
+      }
+      meta[m] = ((unsigned int)l << kLevelShift) | (unsigned int)sc.first[upper];
+      atomicAdd(&sc.lvl[l], 1);
+      atomicMax(sc.maxl, l);
     }
   }
-  __threadfence();
-  __syncthreads();
-  int levels = 0, cur_off = 0, ncur = s_cnt[0];
-  bool failed = false;
-  while (ncur > 0) {
-    if (levels > kMaxLevels) { failed = true; if (t == 0) s_err = 1; break; }
-    int *cur = frontier + cur_off, *nxt = cur + ncur;
-    for (int g = t; g < 8 * ncur; g += kSmallThreads)      // eight lanes per cell
-      split_cell8(nd, khi, klo, sidx, posm, cur[g >> 3], g & 7, nxt, &s_nodes, &s_next, &s_err, node_cap);
-    __threadfence();
-    __syncthreads();
-    if (s_err != 0) { failed = true; break; }
-    if (t == 0) { s_off[levels] = cur_off; s_cnt[levels] = ncur; }
-    ++levels;
-    cur_off += ncur;
-    ncur = s_next;
-    __syncthreads();
-    if (t == 0) s_next = 0;
+  __syncthreads();                                             // the structure data is dead from here (LDS: the CoMs take it)
+  BH_CLOCK(5);
+  const int maxl = *sc.maxl;
+  if (IN_LDS) {                                                // the cells level by level: lvl[l] := where level l's list starts
+    if (t == 0) { int run = 0; for (int l = 0; l <= maxl; ++l) { const int c = sc.lvl[l]; sc.lvl[l] = run; run += c; } }
     __syncthreads();
   }
-  if (!failed) {
-    for (int l = levels - 1; l >= 0; --l) {                  // ComputeMass: children before parents
-      const int off = s_off[l], cnt = s_cnt[l];
-      for (int f = t; f < cnt; f += kSmallThreads) upsweep_cell(nd, frontier[off + f], div_mode);
+  // ---- leaves: CenterOfMass = Position, TotalMass = Mass (.h:85-88); cells into their level's list
+  for (int m = t; m < nodes; m += kSmT) {
+    const unsigned int w = meta[m];
+    if (w & kLeafBit) com[m] = posm[w & kLinkMask];
+    else if (IN_LDS) cells[atomicAdd(&sc.lvl[(w >> kLevelShift) & 63u], 1)] = (unsigned short)m;
+  }
+  __syncthreads();
+  BH_CLOCK(6);
+  // ---- ComputeMass (.h:89-95), deepest cells first; a cell's children are met by walking its subtree's top level
+  if (IN_LDS) {                                                // after the scatter lvl[l] is the END of level l's list
+    for (int l = maxl; l >= 0; --l) {
+      const int lo_ = l > 0 ? sc.lvl[l - 1] : 0, hi_ = sc.lvl[l];
+      for (int k = lo_ + t; k < hi_; k += kSmT) {
+        const int m = cells[k];
+        com[m] = sweep_compact_cell(com, meta, m, meta[m], l, div_mode, posm, sc.root);
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int l = maxl; l >= 0; --l) {
+      for (int m = t; m < nodes; m += kSmT) {
+        const unsigned int w = meta[m];
+        if ((w & kLeafBit) || (int)((w >> kLevelShift) & 63u) != l) continue;
+        com[m] = sweep_compact_cell(com, meta, m, w, l, div_mode, posm, sc.root);
+      }
       __threadfence();
       __syncthreads();
     }
   }
+  BH_CLOCK(7);
+  // ---- hand the tree to the walk
+  if (IN_LDS)
+    for (int m = t; m < nodes; m += kSmT) { T.com[m] = com[m]; T.meta[m] = meta[m]; }
   if (t == 0) {
-    if (!failed) { const float4 c = nd.com[0]; prev_com[0] = c.x; prev_com[1] = c.y; prev_com[2] = c.z; }   // .cpp:78
-    counters[0] = s_nodes; counters[1] = levels; counters[2] = s_err; counters[3] = 0;
+    if (!keep_root) { const float4 c = com[0]; T.prev_com[0] = c.x; T.prev_com[1] = c.y; T.prev_com[2] = c.z; }   // .cpp:78
+    T.hdr[0] = nodes; T.hdr[1] = nodes - n; T.hdr[2] = n >= 2 ? maxl + 1 : 0; T.hdr[4] = T.hdr[4] + 1;
   }
+  BH_CLOCK(8);
+}
+
+__global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const float4 *__restrict__ posm, int n, int P,
+                                                              int div_mode, int keep_root, float theta) {
+  __shared__ __attribute__((aligned(16))) unsigned char raw[kSmLds];
+  __shared__ int s_scan[kSmT / 64];
+  __shared__ float s_red[kSmT / 64];
+  __shared__ float s_root[4];
+  __shared__ int s_lvl[kMaxLevels + 2];                        // cells per level, then where each level's list ends
+  __shared__ int s_maxl, s_err, s_total;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (T.hdr[3] != 0) return;                                   // an earlier frame of this call was refused: stay there
+  BH_CLOCK(0);
+  unsigned long long *lo_by_body = (unsigned long long *)(raw + 2 * kSmBuf);   // [n] second key word of body i
+  unsigned short *owner = (unsigned short *)(raw + kSmRegionA + kSmNodesLds * 4);   // [nodes] (the cells' lists later)
+
+  // ---- ComputeCubeSize (.cpp:47-56) and the root (.cpp:77-79)
+  float mx = 0.0f;
+  float4 mine[kSmBodies / kSmT];                               // this thread's bodies: t, t + 1024, ...
+#pragma unroll
+  for (int r = 0; r < kSmBodies / kSmT; ++r) {
+    const int i = t + r * kSmT;
+    mine[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) { mine[r] = posm[i]; mx = fmaxf(mx, fmaxf(fmaxf(fabsf(mine[r].x), fabsf(mine[r].y)), fabsf(mine[r].z))); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0) s_red[wave] = mx;
+  if (t == 0) { s_maxl = -1; s_err = 0; }
+  if (t <= kMaxLevels) s_lvl[t] = 0;
+  __syncthreads();
+  if (t == 0) {
+    float m = s_red[0];
+    for (int w = 1; w < kSmT / 64; ++w) m = fmaxf(m, s_red[w]);
+    s_root[0] = T.prev_com[0]; s_root[1] = T.prev_com[1]; s_root[2] = T.prev_com[2]; s_root[3] = m;
+    T.root[0] = s_root[0]; T.root[1] = s_root[1]; T.root[2] = s_root[2]; T.root[3] = m;
+  }
+  __syncthreads();
+  if (t >= kSmT - 64 && t - (kSmT - 64) <= kMaxLevels) {        // the opening rule per level, as a threshold on d2 (the
+    const int l = t - (kSmT - 64);                             // last wave: it owns the fewest bodies)
+    float sz = s_root[3];
+    for (int q = 0; q < l; ++q) sz = (float)(0.5 * (double)sz);   // .h:74
+    T.thr[l] = accept_threshold(sz, theta);
+  }
+  BH_CLOCK(1);
+  // ---- path keys (Octree::Add's descent), into sort buffer 0
+  {
+    unsigned long long *hi0 = (unsigned long long *)raw;
+    unsigned short *idx0 = (unsigned short *)(raw + kSmBodies * 8);
+#pragma unroll
+    for (int r = 0; r < kSmBodies / kSmT; ++r) {
+      const int i = t + r * kSmT;
+      if (i >= P) break;
+      unsigned long long h = ~0ull, l = ~0ull;
+      if (i < n) {
+        float o[3] = {s_root[0], s_root[1], s_root[2]};
+        float size = s_root[3];
+        h = 0; l = 0;
+        for (int lev = 0; lev < kLevelsPerKey; ++lev) h = (h << 3) | (unsigned long long)descend_level(mine[r], o, size);
+        for (int lev = 0; lev < kLevelsPerKey; ++lev) l = (l << 3) | (unsigned long long)descend_level(mine[r], o, size);
+        lo_by_body[i] = l;
+      }
+      hi0[i] = h; idx0[i] = (unsigned short)(i < n ? i : 0xFFFF);
+    }
+  }
+  __syncthreads();
+  BH_CLOCK(2);
+  // ---- merge sort by rank: runs of L become runs of 2L; every element finds its place by a binary search in the partner
+  // run (left run: partner elements strictly before it; right run: partner elements not after it — a stable merge).  One
+  // barrier per round, log2(P) rounds, buffers ping-pong.  Ties in the first key word look the second one up by body.
+  int cur = 0;
+  for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
+    const unsigned long long *shi = (const unsigned long long *)(raw + cur * kSmBuf);
+    const unsigned short *sidx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
+    unsigned long long *dhi = (unsigned long long *)(raw + (cur ^ 1) * kSmBuf);
+    unsigned short *didx = (unsigned short *)(raw + (cur ^ 1) * kSmBuf + kSmBodies * 8);
+    for (int e = t; e < P; e += kSmT) {
+      const int run = e >> lg, pos = e & (L - 1);
+      const bool left = (run & 1) == 0;
+      const int pbase = (run ^ 1) * L;
+      const unsigned long long h = shi[e];
+      const unsigned short b = sidx[e];
+      int x = 0, y = L;
+      while (x < y) {
+        const int mid = (x + y) >> 1;
+        const unsigned long long hp = shi[pbase + mid];
+        bool before = hp < h;                                  // partner element sorts before mine?
+        if (hp == h) {
+          const unsigned short bp = sidx[pbase + mid];
+          const unsigned long long lp = bp == 0xFFFF ? ~0ull : lo_by_body[bp], lm = b == 0xFFFF ? ~0ull : lo_by_body[b];
+          before = left ? lp < lm : lp <= lm;
+        }
+        if (before) x = mid + 1; else y = mid;
+      }
+      const int dest = (run & ~1) * L + pos + x;
+      dhi[dest] = h; didx[dest] = b;
+    }
+    __syncthreads();
+  }
+  const unsigned long long *hi = (const unsigned long long *)(raw + cur * kSmBuf);
+  const unsigned short *idx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
+  int *first = (int *)(raw + (cur ^ 1) * kSmBuf);              // [n + 1], in the buffer the sort left behind
+  signed char *lcpS = (signed char *)(first + kSmBodies + 4);  // [n + 1]
+  static_assert(4 * (kSmBodies + 4) + kSmBodies + 16 <= kSmBuf, "scan and lcp fit in a sort buffer");
+  BH_CLOCK(3);
+  // ---- shared digits of neighbours, the keys and the draw order for later (leaf boxes, DrawOctreeBoxes' order)
+  for (int i = t; i <= n; i += kSmT) {
+    int v = -1;
+    unsigned long long li = 0ull;
+    if (i < n) li = lo_by_body[idx[i]];
+    if (i > 0 && i < n) {
+      const unsigned long long x = hi[i - 1] ^ hi[i];
+      if (x != 0ull) v = (__clzll((long long)x) - 1) / 3;
+      else {
+        const unsigned long long y = lo_by_body[idx[i - 1]] ^ li;
+        if (y != 0ull) v = kLevelsPerKey + (__clzll((long long)y) - 1) / 3;
+        else { v = kMaxLevels; s_err = 1; }                    // same path for 42 levels: the reference would recurse on
+      }
+    }
+    lcpS[i] = (signed char)v;
+    if (i < n) { T.khi[i] = hi[i]; T.klo[i] = li; T.sidx[i] = idx[i]; }
+  }
+  __syncthreads();
+  if (s_err != 0) { if (t == 0) T.hdr[3] = 1; return; }
+  // ---- number the nodes: exclusive scan of (cells opened at body i) + 1, four bodies per thread
+  {
+    int c[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * t + q;
+      c[q] = 0;
+      if (i < n) { const int d = (int)lcpS[i + 1] - (int)lcpS[i]; c[q] = (d > 0 ? d : 0) + 1; }
+      sum += c[q];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_scan[w];
+    int run = base + incl - sum;
+    const int total = [&] { int v = 0; for (int w = 0; w < kSmT / 64; ++w) v += s_scan[w]; return v; }();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * t + q;
+      if (i < n) {
+        first[i] = run;
+        if (total <= kSmNodesLds) for (int k = 0; k < c[q]; ++k) owner[run + k] = (unsigned short)i;
+      }
+      run += c[q];
+    }
+    if (t == kSmT - 1) { s_total = run; first[n] = run; }
+    __syncthreads();
+  }
+  const int nodes = s_total;
+  if (nodes > T.cap) { if (t == 0) T.hdr[3] = 2; return; }
+  BH_CLOCK(4);
+  const SmallScratch sc = {hi, idx, lo_by_body, first, lcpS, owner, s_root, &s_maxl, s_lvl};
+  if (nodes <= kSmNodesLds)   // the tree in LDS: CoMs over the sort's space once the structure is known, words and cell lists behind
+    small_tree_nodes<true>(T, (float4 *)raw, (unsigned int *)(raw + kSmRegionA), owner, sc, posm, n, nodes, div_mode, keep_root);
+  else
+    small_tree_nodes<false>(T, T.com, T.meta, nullptr, sc, posm, n, nodes, div_mode, keep_root);
+}
+
+template <typename T> __device__ __forceinline__ T mul_add_sep(T a, T b, T c) {
+#pragma clang fp contract(off)
+  const T p = a * b;
+  return c + p;
+}
+
+// One accepted node's term of Octree::ComputeForces (.h:104): float(G * M / pow(d, 3)) * (CoM - Pos), d = Dist.
+__device__ __forceinline__ void force_term(float cx, float cy, float cz, float M, const float4 &p, double G, float &tx, float &ty,
+                                           float &tz) {
+#pragma clang fp contract(off)
+  const float ex = p.x - cx, ey = p.y - cy, ez = p.z - cz;
+  float d2 = ex * ex + ey * ey;
+  d2 = d2 + ez * ez;
+  const float d = sqrtf(d2);                                   // FVector::Dist, .h:101 (correctly rounded)
+  const double dd = (double)d;
+  const float s = (float)(G * (double)M / ((dd * dd) * dd));   // (d*d)*d in double = the correctly rounded cube
+  tx = s * (cx - p.x); ty = s * (cy - p.y); tz = s * (cz - p.z);
+}
+
+// value of lane (l + N) mod 16 of the same 16-lane row (v_mov_b32_dpp row_ror:N)
+template <int N> __device__ __forceinline__ int row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_or(int v) { v |= row_ror<8>(v); v |= row_ror<4>(v); v |= row_ror<2>(v); v |= row_ror<1>(v); return v; }
+__device__ __forceinline__ int row_max(int v) {
+  v = max(v, row_ror<8>(v)); v = max(v, row_ror<4>(v)); v = max(v, row_ror<2>(v)); v = max(v, row_ror<1>(v));
+  return v;
+}
+
+// Octree::ComputeForces (.h:99-108) on the compact tree, bodies in key order, one 16-lane row per body.  With dt > 0 the
+// row's first lane goes on to the Tick's update of its body (.cpp:28-31) — nobody else reads that body's position:
+// leaves carry copies.
+// In LDS a node is (CoM, threshold) + a 16-bit "node after the subtree" + M.  The nodes stand in the walk's own order
+// (preorder), so the walk is not followed node by node: the row looks at SIXTEEN consecutive nodes at once, lane j at node
+// w + j.  Each lane decides for its node alone — taken (.h:103: d2 >= threshold; a leaf's is 0), d == 0 (.h:102), or
+// descend — and a node is visited by the reference's recursion exactly when no ancestor of it was taken or had d == 0.
+// The ancestors of a window's nodes that lie before the window are on the path to its first node, hence descended; those
+// inside it announce the nodes they cover as a bit mask, and one OR over the row tells every lane whether its node is
+// visited.  The visited taken nodes' terms (.h:104) are worked out by their lanes side by side and added by the first lane
+// in lane order = the walk's order = the reference's order of additions; the next window starts behind whatever the
+// window's taken nodes cover.
+__global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
+                                                                 float4 *__restrict__ acc, int n, float theta, double G, float dt) {
+#pragma clang fp contract(off)
+  static_assert(kWalkG == 16, "one DPP row per body");
+  constexpr int kGroups = kWalkT / kWalkG;
+  __shared__ float4 s_a[kSmNodesLds];
+  __shared__ float s_m[kSmNodesLds];
+  __shared__ unsigned short s_past[kSmNodesLds];
+  __shared__ float s_thr[kMaxLevels + 2];
+  __shared__ float s_term[kGroups][kWalkG][3];
+  if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
+  BH_WALK_CLOCK(9);
+  BH_WG_STAMP(0);
+  const int t = threadIdx.x;
+  const int nodes = T.hdr[0];
+  const bool in_lds = nodes <= kSmNodesLds;
+  long long dbg_visits = 0, dbg_chunks = 0, dbg_terms = 0;
+  (void)dbg_visits; (void)dbg_chunks; (void)dbg_terms;
+  if (t <= kMaxLevels) s_thr[t] = T.thr[t];
+  __syncthreads();
+  if (in_lds) {
+#pragma unroll 4
+    for (int m = t; m < nodes; m += kWalkT) {
+      const float4 c = T.com[m];
+      const unsigned int w = T.meta[m];
+      const bool leaf = (w & kLeafBit) != 0u;
+      s_a[m] = make_float4(c.x, c.y, c.z, leaf ? 0.0f : s_thr[(w >> kLevelShift) & 63u]);
+      s_m[m] = c.w;
+      s_past[m] = (unsigned short)(leaf ? m + 1 : (int)(w & kLinkMask));
+    }
+    __syncthreads();
+  }
+  const int group = t / kWalkG, g = t % kWalkG;
+  const int k = blockIdx.x * kGroups + group;
+  const bool valid = k < n;
+  const unsigned int body = valid ? T.sidx[k] : 0u;
+  const float4 p = posm[body];
+  float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
+  BH_WALK_CLOCK(10);
+  BH_WG_STAMP(1);
+  if (in_lds) {
+    int w0 = valid ? 0 : nodes;                                // first node of the window (the same in all lanes of the row)
+    while (__any(w0 < nodes)) {
+      const int my = w0 + g;
+      const bool in = my < nodes;
+      const float4 a = s_a[in ? my : 0];
+      const int past = s_past[in ? my : 0];
+      const float ex = p.x - a.x, ey = p.y - a.y, ez = p.z - a.z;
+      float d2 = ex * ex + ey * ey;
+      d2 = d2 + ez * ez;
+      const bool take = in && d2 >= a.w;                       // .h:103: Size / d < Theta, or an occupied leaf
+      const bool zero = in && d2 == 0.f;                       // .h:102: d == 0 adds nothing and ends the subtree
+      const bool ends = take || zero;                          // the recursion does not go below this node
+      // nodes of this window below mine: window offsets g + 1 .. past - w0 - 1
+      const int rel = min(past - w0, kWalkG);
+      const int cover = (ends && rel > g + 1) ? (((1 << rel) - 1) & ~((2 << g) - 1)) : 0;
+      const int dead = row_or(cover);
+      const bool adds = take && !zero && ((dead >> g) & 1) == 0;
+      const unsigned long long am = __ballot(adds);
+      const int row = (int)((am >> ((t & 63) - g)) & 0xFFFFull);   // this row's lanes that add a term
+      if (adds) {
+        float tx, ty, tz;
+        force_term(a.x, a.y, a.z, s_m[my], p, G, tx, ty, tz);
+        const int rank = __popc(row & ((1 << g) - 1));
+        s_term[group][rank][0] = tx; s_term[group][rank][1] = ty; s_term[group][rank][2] = tz;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (g == 0) {                                            // added in lane order = the walk's order
+        const int cnt = __popc(row);
+        for (int e = 0; e < cnt; ++e) { ax = ax + s_term[group][e][0]; ay = ay + s_term[group][e][1]; az = az + s_term[group][e][2]; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      w0 = max(min(w0 + kWalkG, nodes), row_max(ends ? past : 0));
+#ifdef NBODY_BH_PHASE_CLOCKS
+      ++dbg_chunks; dbg_terms += __popc(row); dbg_visits += __popc((~dead) & 0xFFFF);
+#endif
+    }
+  } else if (g == 0 && valid) {                                // a tree too large for LDS: one lane per body, global nodes
+    int node = 0;
+    while (node < nodes) {
+      const float4 cm = T.com[node];
+      const unsigned int w = T.meta[node];
+      const bool leaf = (w & kLeafBit) != 0u;
+      const int past = leaf ? node + 1 : (int)(w & kLinkMask);
+      const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
+      float d2 = ex * ex + ey * ey;
+      d2 = d2 + ez * ez;
+      const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];
+      if (take && d2 != 0.f) {
+        float tx, ty, tz;
+        force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
+        ax = ax + tx; ay = ay + ty; az = az + tz;
+      }
+      node = (take || d2 == 0.f) ? past : node + 1;
+    }
+  }
+  BH_WALK_CLOCK(11);
+  BH_WG_STAMP(2);
+  BH_WALK_COUNT(12, dbg_visits); BH_WALK_COUNT(13, dbg_chunks); BH_WALK_COUNT(14, dbg_terms);
+  if (g != 0 || !valid) return;
+  acc[body] = make_float4(ax, ay, az, 0.f);
+  if (dt > 0.f) {                                              // v += dt*a; x += dt*v, separate multiply and add
+    float4 v = vel[body];
+    float4 x = p;
+    v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
+    x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
+    vel[body] = v;
+    posm[body] = x;
+  }
+}
+
+// What DrawOctreeBoxes hands to DrawDebugBox (.cpp:39-40) from the compact tree: the leaf's box follows from the body's
+// path digits (the keys of the tree that was built, not the body's position now: the update may have moved it since).
+__global__ __launch_bounds__(kB) void bh_small_leaf_boxes_kernel(SmallTree T, int n, float4 *__restrict__ out) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long h = T.khi[i], l = T.klo[i];
+  const int level = T.leaf_level[i];
+  float o[3] = {T.root[0], T.root[1], T.root[2]};
+  float size = T.root[3];
+  for (int lev = 0; lev < level; ++lev) {
+    const int c = lev < kLevelsPerKey ? (int)((h >> (3 * (kLevelsPerKey - 1 - lev))) & 7ull)
+                                      : (int)((l >> (3 * (kMaxLevels - 1 - lev))) & 7ull);
+    float no[3], ns;
+    child_box(o, size, c, no, &ns);
+    o[0] = no[0]; o[1] = no[1]; o[2] = no[2]; size = ns;
+  }
+  out[T.sidx[i]] = make_float4(o[0], o[1], o[2], size);
 }
 
 // Octree::ComputeForces for every body (.h:99-108), bodies taken in key order for coherence.
@@ -418,17 +927,19 @@ __global__ void bh_save_com_kernel(Nodes nd, float *__restrict__ prev_com) {
 }  // namespace
 
 constexpr int kCoopCells = 32768;     // levels with fewer cells than this split with eight lanes per cell
-constexpr int kSmallBodies = 16384;   // up to here one workgroup builds the whole tree (bh_build_small_kernel)
 
 struct BhState {
   int n = 0, node_cap = 0;
+  bool small = false;          // n <= kSmBodies: one-workgroup build of the compact tree (bh_small_build_kernel)
+  SmallTree st{};
+  int frames_seen = 0;         // st.hdr[4] at the last bh_small_collect
   unsigned long long *khi = nullptr, *klo = nullptr, *khi2 = nullptr, *klo2 = nullptr;
   unsigned int *idx = nullptr, *idx2 = nullptr;
   void *sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   Nodes nd{};
   int *frontier = nullptr;     // all levels' internal cells, level after level
-  int *counters = nullptr;     // device: nodes used, next-frontier size, error, current size
+  int *counters = nullptr;     // device: nodes used, next-frontier size, error, current size (small: the SmallTree header)
   int *h_counters = nullptr;   // pinned
   float *root = nullptr;       // ox, oy, oz, size
   float *prev_com = nullptr;   // the previous tree's root CoM (zero before the first frame)
@@ -440,13 +951,36 @@ struct BhState {
 
 hipError_t bh_create(BhState **out, int n) {
   BhState *b = new BhState();
+  *out = b;                    // the caller destroys it whatever happens below
   b->n = n;
-  b->node_cap = 8 * (4 * n + 1024) + 1;
+  b->small = n <= kSmBodies;
   BH_TRY(hipMalloc(&b->khi, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->klo, sizeof(unsigned long long) * n));
+  BH_TRY(hipMalloc(&b->idx, sizeof(unsigned int) * n));
+  BH_TRY(hipMalloc(&b->counters, sizeof(int) * 8));
+  BH_TRY(hipMemset(b->counters, 0, sizeof(int) * 8));
+  BH_TRY(hipHostMalloc(&b->h_counters, sizeof(int) * 8, hipHostMallocDefault));
+  BH_TRY(hipMalloc(&b->root, sizeof(float) * 4));
+  BH_TRY(hipMemset(b->root, 0, sizeof(float) * 4));
+  BH_TRY(hipMalloc(&b->prev_com, sizeof(float) * 3));
+  BH_TRY(hipMemset(b->prev_com, 0, sizeof(float) * 3));    // FVector t = ZeroVector, .cpp:77
+  if (b->small) {
+    // worst case: every body opens a chain of 42 cells of its own (never, but the pool must not be what fails)
+    b->node_cap = ((kMaxLevels + 1) * n + 64 + 3) / 4 * 4;
+    SmallTree &t = b->st;
+    BH_TRY(hipMalloc(&t.com, sizeof(float4) * b->node_cap));
+    BH_TRY(hipMalloc(&t.meta, sizeof(unsigned int) * b->node_cap));
+    BH_TRY(hipMalloc(&t.leaf_level, (size_t)n));
+    BH_TRY(hipMalloc(&t.thr, sizeof(float) * (kMaxLevels + 2)));
+    BH_TRY(hipMalloc(&t.clocks, sizeof(long long) * kDbgClocks));
+    BH_TRY(hipMemset(t.clocks, 0, sizeof(long long) * kDbgClocks));
+    t.khi = b->khi; t.klo = b->klo; t.sidx = b->idx; t.hdr = b->counters; t.root = b->root; t.prev_com = b->prev_com;
+    t.cap = b->node_cap;
+    return hipSuccess;
+  }
+  b->node_cap = 8 * (4 * n + 1024) + 1;
   BH_TRY(hipMalloc(&b->khi2, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->klo2, sizeof(unsigned long long) * n));
-  BH_TRY(hipMalloc(&b->idx, sizeof(unsigned int) * n));
   BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
   size_t bytes = 0;
   BH_TRY(rocprim::radix_sort_pairs(nullptr, bytes, b->klo, b->klo2, b->idx, b->idx2, (unsigned int)n));
@@ -457,22 +991,57 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->nd.link, sizeof(int4) * b->node_cap));
   BH_TRY(hipMalloc(&b->nd.range, sizeof(int2) * b->node_cap));
   BH_TRY(hipMalloc(&b->frontier, sizeof(int) * (b->node_cap / 8 + 8)));
-  BH_TRY(hipMalloc(&b->counters, sizeof(int) * 4));
-  BH_TRY(hipHostMalloc(&b->h_counters, sizeof(int) * 4, hipHostMallocDefault));
-  BH_TRY(hipMalloc(&b->root, sizeof(float) * 4));
-  BH_TRY(hipMalloc(&b->prev_com, sizeof(float) * 3));
-  BH_TRY(hipMemset(b->prev_com, 0, sizeof(float) * 3));    // FVector t = ZeroVector, .cpp:77
-  *out = b;
   return hipSuccess;
 }
 
 void bh_destroy(BhState *b) {
   if (!b) return;
   void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->sort_tmp, b->nd.box, b->nd.com, b->nd.link,
-                  b->nd.range, b->frontier, b->counters, b->root, b->prev_com};
+                  b->nd.range, b->frontier, b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr,
+                  b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
   delete b;
+}
+
+bool bh_is_small(const BhState *b) { return b->small; }
+
+// -DNBODY_BH_PHASE_CLOCKS builds only: the last frame's wall_clock64 stamps (100 MHz) at the kernels' phase boundaries
+hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t s) {
+  if (!b->small) return hipErrorInvalidValue;
+  BH_TRY(hipStreamSynchronize(s));
+  return hipMemcpy(out, b->st.clocks, sizeof(long long) * kDbgClocks, hipMemcpyDeviceToHost);
+}
+const float *bh_root_device(const BhState *b) { return b->root; }
+
+// Small systems: queue one frame — tree, walk and (dt > 0) the update — on the stream; nothing waits for the host.
+// keep_root: the tree is a diagnostic's (nbody_compute_forces), the next frame's root centre stays what it was.
+hipError_t bh_small_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root,
+                          hipStream_t s) {
+  const int n = b->n;
+  int P = 1;
+  while (P < n) P <<= 1;
+  hipLaunchKernelGGL(bh_small_build_kernel, dim3(1), dim3(kSmT), 0, s, b->st, (const float4 *)posm, n, P, b->div_mode, keep_root, theta);
+  hipLaunchKernelGGL(bh_walk_compact_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, (float4 *)posm,
+                     (float4 *)vel, (float4 *)acc, n, theta, G, dt);
+  return hipGetLastError();
+}
+
+// Wait for the stream and read the verdict of the frames queued since the last call: *status 0 ok, 1 depth limit, 2 node
+// pool; *frames = how many of them were built (a refused frame and everything queued behind it leave the state untouched).
+// A refusal is cleared here, so that the next call starts afresh.
+hipError_t bh_small_collect(BhState *b, hipStream_t s, int *status, int *frames) {
+  BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+  BH_TRY(hipStreamSynchronize(s));
+  *status = b->h_counters[3];
+  if (frames) *frames = b->h_counters[4] - b->frames_seen;
+  b->frames_seen = b->h_counters[4];
+  if (b->h_counters[4] > 0) {
+    b->last_nodes = b->n >= 2 ? 1 + 8 * b->h_counters[1] : 1;   // the reference's count: every split makes eight children
+    b->last_levels = b->h_counters[2];
+  }
+  if (*status != 0) BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
+  return hipSuccess;
 }
 
 hipError_t bh_reset_root(BhState *b, hipStream_t s) { return hipMemsetAsync(b->prev_com, 0, sizeof(float) * 3, s); }
@@ -480,7 +1049,8 @@ hipError_t bh_reset_root(BhState *b, hipStream_t s) { return hipMemsetAsync(b->p
 // One CreateOctree (.cpp:74-89) on the device.  size_bits: device word holding Size as left by the bounds kernel.
 // *status: 0 ok, 1 depth limit (bodies closer than Size/2^42 — the reference would keep recursing), 2 node pool full.
 hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned int *size_bits, float theta, double G,
-                     hipStream_t s, int *status) {
+                     int keep_root, hipStream_t s, int *status) {
+  if (b->small) return hipErrorInvalidValue;                  // bh_small_frame is the small systems' pass
   const float4 *posm = (const float4 *)posm_v;
   float4 *acc = (float4 *)acc_v;
   const int n = b->n;
@@ -497,19 +1067,6 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   // b->khi / b->idx are final; bring the low words (b->klo is still in body order) into the same order
   hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->klo, b->idx, b->klo2, n);
 
-  if (n <= kSmallBodies) {
-    // one launch builds and sweeps the tree; the walk follows at once, the verdict is read after it (a refused tree
-    // is still walkable: unsplit cells look like empty leaves)
-    hipLaunchKernelGGL(bh_build_small_kernel, dim3(1), dim3(kSmallThreads), 0, s, b->nd, b->root, posm, b->khi, b->klo2,
-                       b->idx, n, b->frontier, b->counters, b->node_cap, b->prev_com, b->div_mode);
-    hipLaunchKernelGGL(bh_walk_kernel, grd, blk, 0, s, b->nd, posm, b->idx, n, theta, G, acc);
-    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
-    BH_TRY(hipStreamSynchronize(s));
-    b->last_nodes = b->h_counters[0];
-    b->last_levels = b->h_counters[1];
-    *status = b->h_counters[2];
-    return hipGetLastError();
-  }
   hipLaunchKernelGGL(bh_root_kernel, dim3(1), dim3(1), 0, s, b->nd, b->root, posm, b->idx, n, b->counters, b->frontier);
   // level by level; the frontier of level l sits at frontier[off[l] .. off[l] + cnt[l])
   int off[kMaxLevels + 2], cnt[kMaxLevels + 2];
@@ -539,13 +1096,17 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   b->last_levels = levels;
   for (int l = levels - 1; l >= 0; --l)                      // ComputeMass: children before parents
     hipLaunchKernelGGL(bh_upsweep_kernel, dim3((cnt[l] + kB - 1) / kB), blk, 0, s, b->nd, b->frontier + off[l], cnt[l], b->div_mode);
-  hipLaunchKernelGGL(bh_save_com_kernel, dim3(1), dim3(1), 0, s, b->nd, b->prev_com);   // next frame's root centre, .cpp:78
+  if (!keep_root) hipLaunchKernelGGL(bh_save_com_kernel, dim3(1), dim3(1), 0, s, b->nd, b->prev_com);   // next frame's root centre, .cpp:78
   hipLaunchKernelGGL(bh_walk_kernel, grd, blk, 0, s, b->nd, posm, b->idx, n, theta, G, acc);
   return hipGetLastError();
 }
 
 hipError_t bh_leaf_boxes(BhState *b, void *out, hipStream_t s) {
   if (b->last_nodes <= 0) return hipErrorInvalidValue;
+  if (b->small) {
+    hipLaunchKernelGGL(bh_small_leaf_boxes_kernel, dim3((b->n + kB - 1) / kB), dim3(kB), 0, s, b->st, b->n, (float4 *)out);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(bh_leaf_boxes_kernel, dim3((b->last_nodes + kB - 1) / kB), dim3(kB), 0, s, b->nd, b->last_nodes,
                      (float4 *)out);
   return hipGetLastError();
@@ -564,6 +1125,13 @@ hipError_t bh_leaf_order(BhState *b, int *out_host, hipStream_t s) {
 void bh_stats(const BhState *b, int *nodes, int *levels) {
   if (nodes) *nodes = b->last_nodes;
   if (levels) *levels = b->last_levels;
+}
+
+// centre of mass of the root of the last tree built
+hipError_t bh_get_tree_com(BhState *b, float out[3], hipStream_t s) {
+  if (b->last_nodes <= 0) return hipErrorInvalidValue;
+  BH_TRY(hipStreamSynchronize(s));
+  return hipMemcpy(out, b->small ? (const void *)b->st.com : (const void *)b->nd.com, sizeof(float) * 3, hipMemcpyDeviceToHost);
 }
 
 hipError_t bh_get_root_com(BhState *b, float out[3], hipStream_t s) {

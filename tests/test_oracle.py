@@ -384,3 +384,13 @@ def test_simd_cpu_baseline_is_the_same_pair_law(oracle):
     soft = oracle.forces_simd_f32(pos, mass, eps=2.0, i0=100, i1=200, nthreads=2)
     ref = oracle.forces_direct_f64(pos.astype(np.float64), mass.astype(np.float64), eps=2.0, i0=100, i1=200)
     assert (np.linalg.norm(soft - ref, axis=1) / np.linalg.norm(ref, axis=1)).max() < 2e-5
+
+
+def test_child_centre_in_fp32_equals_the_reference_double_expression(tmp_path):
+    # host-side proof by sampling of an arithmetic identity the device's path keys rely on (tests/cpp/child_centre_equiv.c)
+    import subprocess
+    exe = str(tmp_path / "child_centre_equiv")
+    src = os.path.join(os.path.dirname(__file__), "cpp", "child_centre_equiv.c")
+    subprocess.check_call(["gcc", "-O2", "-msse2", "-mfpmath=sse", "-ffp-contract=off", src, "-o", exe])
+    out = subprocess.run([exe, "20000000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "bad 0" in out.stdout, out.stdout

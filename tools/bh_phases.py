@@ -1,0 +1,38 @@
+"""Where one workgroup's tree build spends its time (bh_small_build_kernel, N <= 4096): wall_clock64 stamps at the phase
+boundaries.  Needs a tuning build:   make -C parallelnbody_amd/csrc EXTRA=-DNBODY_BH_PHASE_CLOCKS   (touch kernels_bh.hip first)
+    python3 tools/bh_phases.py [N]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import parallelnbody_amd as nb
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+posm, vel = nb.ic_reference_box(n, 1000.0, seed=1)
+names = ["bounds+root+thresholds", "keys", "sort", "lcp+scan", "node words", "leaves+lists", "upsweep", "hand-over"]
+with nb.NBodyEngine(n, theta=1.0) as e:
+    e.set_state(posm, vel)
+    e.step(0.01, 50)
+    acc = np.zeros(len(names))
+    walk = np.zeros(5)
+    reps = 20
+    for _ in range(reps):
+        e.step(0.01, 1)
+        out = (ctypes.c_longlong * (16 + 3 * 512))()
+        rc = e._L.nbody_debug_bh_clocks(e._h, out)
+        assert rc == 0
+        c = np.array(out[:len(names) + 1], np.float64)
+        acc += np.diff(c) / 100.0                     # 100 MHz -> us
+        w = np.array(out[9:15], np.float64)
+        walk += np.array([(w[1] - w[0]) / 100.0, (w[2] - w[1]) / 100.0, w[3], w[4], w[5]])
+    print(f"N={n}: build kernel phases, us (mean of {reps}):")
+    for nm, v in zip(names, acc / reps):
+        print(f"  {nm:24s} {v:8.2f}")
+    print(f"  {'total':24s} {acc.sum() / reps:8.2f}   {e.bh_stats()}")
+    wg = np.array(out[16:], np.float64).reshape(512, 3)[:(n + 15) // 16]      # the last frame's workgroups: start, fill end, end
+    t0 = wg[:, 0].min()
+    print(f"  walk kernel, all {len(wg)} workgroups of the last frame (us from the first start): starts up to {(wg[:, 0].max() - t0) / 100:.2f}, "
+          f"fill {((wg[:, 1] - wg[:, 0]) / 100).mean():.2f} mean / {((wg[:, 1] - wg[:, 0]) / 100).max():.2f} max, "
+          f"walk {((wg[:, 2] - wg[:, 1]) / 100).mean():.2f} mean / {((wg[:, 2] - wg[:, 1]) / 100).max():.2f} max, last end {(wg[:, 2].max() - t0) / 100:.2f}")
+    walk /= reps
+    print(f"  walk kernel, middle workgroup, first body: LDS fill {walk[0]:.2f} us, walk {walk[1]:.2f} us, nodes visited {walk[2]:.0f}, "
+          f"rounds {walk[3]:.1f}, terms {walk[4]:.0f}")
