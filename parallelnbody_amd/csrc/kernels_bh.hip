@@ -316,6 +316,7 @@ constexpr int kLevelShift = 25;
 constexpr unsigned int kLinkMask = (1u << kLevelShift) - 1u;
 constexpr int kWalkT = 256;                // threads per workgroup of the compact walk
 constexpr int kWalkG = 16;                 // lanes per body there
+constexpr int kWalkK = 48;                 // taken nodes a body lists before their terms are worked out and added
 
 struct SmallTree {
   float4 *com;                  // [cap] preorder nodes: centre of mass, total mass
@@ -744,7 +745,8 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
   __shared__ float s_m[kSmNodesLds];
   __shared__ unsigned short s_past[kSmNodesLds];
   __shared__ float s_thr[kMaxLevels + 2];
-  __shared__ float s_term[kGroups][kWalkG][3];
+  __shared__ unsigned short s_list[kGroups][kWalkK];
+  __shared__ float4 s_term[kGroups][kWalkK];
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   BH_WALK_CLOCK(9);
   BH_WG_STAMP(0);
@@ -775,45 +777,73 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   BH_WALK_CLOCK(10);
   BH_WG_STAMP(1);
+  float sum = 0.f;                                             // lanes 0, 1, 2 of the row: the x, y, z sums (ZeroVector, .cpp:84)
   if (in_lds) {
     int w0 = valid ? 0 : nodes;                                // first node of the window (the same in all lanes of the row)
-    while (__any(w0 < nodes)) {
-      const int my = w0 + g;
-      const bool in = my < nodes;
-      const float4 a = s_a[in ? my : 0];
-      const int past = s_past[in ? my : 0];
-      const float ex = p.x - a.x, ey = p.y - a.y, ez = p.z - a.z;
-      float d2 = ex * ex + ey * ey;
-      d2 = d2 + ez * ez;
-      const bool take = in && d2 >= a.w;                       // .h:103: Size / d < Theta, or an occupied leaf
-      const bool zero = in && d2 == 0.f;                       // .h:102: d == 0 adds nothing and ends the subtree
-      const bool ends = take || zero;                          // the recursion does not go below this node
-      // nodes of this window below mine: window offsets g + 1 .. past - w0 - 1
-      const int rel = min(past - w0, kWalkG);
-      const int cover = (ends && rel > g + 1) ? (((1 << rel) - 1) & ~((2 << g) - 1)) : 0;
-      const int dead = row_or(cover);
-      const bool adds = take && !zero && ((dead >> g) & 1) == 0;
-      const unsigned long long am = __ballot(adds);
-      const int row = (int)((am >> ((t & 63) - g)) & 0xFFFFull);   // this row's lanes that add a term
-      if (adds) {
-        float tx, ty, tz;
-        force_term(a.x, a.y, a.z, s_m[my], p, G, tx, ty, tz);
-        const int rank = __popc(row & ((1 << g) - 1));
-        s_term[group][rank][0] = tx; s_term[group][rank][1] = ty; s_term[group][rank][2] = tz;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      if (g == 0) {                                            // added in lane order = the walk's order
-        const int cnt = __popc(row);
-        for (int e = 0; e < cnt; ++e) { ax = ax + s_term[group][e][0]; ay = ay + s_term[group][e][1]; az = az + s_term[group][e][2]; }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      w0 = max(min(w0 + kWalkG, nodes), row_max(ends ? past : 0));
+    for (;;) {
+      // ---- the walk: windows of sixteen nodes until the row's list cannot take another window's worth
+      int cnt = 0;
+      for (;;) {
+        const bool open = w0 < nodes && cnt + kWalkG <= kWalkK;
+        if (!__any(open)) break;
+        const int my = w0 + g;
+        const bool in = open && my < nodes;
+        const float4 a = s_a[in ? my : 0];
+        const int past = s_past[in ? my : 0];
+        const float ex = p.x - a.x, ey = p.y - a.y, ez = p.z - a.z;
+        float d2 = ex * ex + ey * ey;
+        d2 = d2 + ez * ez;
+        const bool take = in && d2 >= a.w;                     // .h:103: Size / d < Theta, or an occupied leaf
+        const bool zero = in && d2 == 0.f;                     // .h:102: d == 0 adds nothing and ends the subtree
+        const bool ends = take || zero;                        // the recursion does not go below this node
+        // nodes of this window below mine: window offsets g + 1 .. past - w0 - 1
+        const int rel = min(past - w0, kWalkG);
+        const int cover = (ends && rel > g + 1) ? (((1 << rel) - 1) & ~((2 << g) - 1)) : 0;
+        const int dead = row_or(cover);
+        const bool adds = take && !zero && ((dead >> g) & 1) == 0;
+        const unsigned long long am = __ballot(adds);
+        const int row = (int)((am >> ((t & 63) - g)) & 0xFFFFull);   // this row's lanes whose node adds a term
+        if (adds) s_list[group][cnt + __popc(row & ((1 << g) - 1))] = (unsigned short)my;   // lane order = the walk's order
+        cnt += __popc(row);
+        const int next = max(min(w0 + kWalkG, nodes), row_max(ends ? past : 0));
+        w0 = open ? next : w0;
 #ifdef NBODY_BH_PHASE_CLOCKS
-      ++dbg_chunks; dbg_terms += __popc(row); dbg_visits += __popc((~dead) & 0xFFFF);
+        ++dbg_chunks; dbg_visits += in ? __popc((~dead) & 0xFFFF) : 0;
 #endif
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (!__any(cnt > 0)) break;                              // every walk of this wave has ended, nothing left to add
+#ifdef NBODY_BH_PHASE_CLOCKS
+      dbg_terms += cnt;
+#endif
+      // ---- the listed nodes' terms (.h:104), sixteen at a time
+      for (int e = g; e < cnt; e += kWalkG) {
+        const int nd = s_list[group][e];
+        const float4 a = s_a[nd];
+        float tx, ty, tz;
+        force_term(a.x, a.y, a.z, s_m[nd], p, G, tx, ty, tz);
+        s_term[group][e] = make_float4(tx, ty, tz, 0.f);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      // ---- added in the walk's order, one lane per component, eight loads in flight
+      if (g < 3) {
+        const float *col = (const float *)&s_term[group][0] + g;
+        for (int e = 0; e < cnt; e += 8) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = col[4 * min(e + q, kWalkK - 1)];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) sum = (e + q < cnt) ? sum + v[q] : sum;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
+    ay = __builtin_bit_cast(float, row_ror<1>(__builtin_bit_cast(int, sum)));   // lane 0 takes lane 1's and lane 2's sums
+    az = __builtin_bit_cast(float, row_ror<2>(__builtin_bit_cast(int, sum)));
+    ax = sum;
   } else if (g == 0 && valid) {                                // a tree too large for LDS: one lane per body, global nodes
     int node = 0;
     while (node < nodes) {
@@ -836,6 +866,13 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
   BH_WALK_CLOCK(11);
   BH_WG_STAMP(2);
   BH_WALK_COUNT(12, dbg_visits); BH_WALK_COUNT(13, dbg_chunks); BH_WALK_COUNT(14, dbg_terms);
+#ifdef NBODY_BH_PHASE_CLOCKS
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {       // the shader clock under this load: s_sleep 127 = 127 * 64 cycles
+    const long long c0 = wall_clock64();
+    for (int q = 0; q < 16; ++q) __builtin_amdgcn_s_sleep(127);
+    T.clocks[15] = wall_clock64() - c0;
+  }
+#endif
   if (g != 0 || !valid) return;
   acc[body] = make_float4(ax, ay, az, 0.f);
   if (dt > 0.f) {                                              // v += dt*a; x += dt*v, separate multiply and add

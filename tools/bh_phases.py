@@ -33,6 +33,7 @@ with nb.NBodyEngine(n, theta=1.0) as e:
     print(f"  walk kernel, all {len(wg)} workgroups of the last frame (us from the first start): starts up to {(wg[:, 0].max() - t0) / 100:.2f}, "
           f"fill {((wg[:, 1] - wg[:, 0]) / 100).mean():.2f} mean / {((wg[:, 1] - wg[:, 0]) / 100).max():.2f} max, "
           f"walk {((wg[:, 2] - wg[:, 1]) / 100).mean():.2f} mean / {((wg[:, 2] - wg[:, 1]) / 100).max():.2f} max, last end {(wg[:, 2].max() - t0) / 100:.2f}")
+    print(f"  shader clock under this load: {16 * 127 * 64 / (out[15] / 100.0) / 1e3:.2f} GHz (s_sleep probe)")
     walk /= reps
     print(f"  walk kernel, middle workgroup, first body: LDS fill {walk[0]:.2f} us, walk {walk[1]:.2f} us, nodes visited {walk[2]:.0f}, "
           f"rounds {walk[3]:.1f}, terms {walk[4]:.0f}")
