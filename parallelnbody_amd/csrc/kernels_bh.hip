@@ -716,7 +716,7 @@ __device__ __forceinline__ void force_term(float cx, float cy, float cz, float M
   tx = s * (cx - p.x); ty = s * (cy - p.y); tz = s * (cz - p.z);
 }
 
-// value of lane (l + N) mod 16 of the same 16-lane row (v_mov_b32_dpp row_ror:N)
+// value of lane (l - N) mod 16 of the same 16-lane row (v_mov_b32_dpp row_ror:N: the row rotates right)
 template <int N> __device__ __forceinline__ int row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false); }
 __device__ __forceinline__ int row_or(int v) { v |= row_ror<8>(v); v |= row_ror<4>(v); v |= row_ror<2>(v); v |= row_ror<1>(v); return v; }
 __device__ __forceinline__ int row_max(int v) {
@@ -841,8 +841,8 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
     }
-    ay = __builtin_bit_cast(float, row_ror<1>(__builtin_bit_cast(int, sum)));   // lane 0 takes lane 1's and lane 2's sums
-    az = __builtin_bit_cast(float, row_ror<2>(__builtin_bit_cast(int, sum)));
+    ay = __builtin_bit_cast(float, row_ror<15>(__builtin_bit_cast(int, sum)));  // lane 0 takes lane 1's and lane 2's sums
+    az = __builtin_bit_cast(float, row_ror<14>(__builtin_bit_cast(int, sum)));
     ax = sum;
   } else if (g == 0 && valid) {                                // a tree too large for LDS: one lane per body, global nodes
     int node = 0;
