@@ -184,6 +184,20 @@ NBODY_API int nbody_step(nbody_ctx *ctx, float dt, int32_t nsteps);
  */
 NBODY_API int nbody_step_begin(nbody_ctx *ctx);
 NBODY_API int nbody_step_end(nbody_ctx *ctx, float dt);
+/*
+ * nbody_step_begin in two goes, so that the all-gather of the previous step's positions can still be in flight when the
+ * next force pass starts ("compute own-range j-tiles while the gather is in flight"):
+ *   nbody_step_begin_local  : the part of the force pass that needs the OWNED slice of NBODY_BUF_POSM only — on a sharded
+ *                             fp32 NBODY_ALGO_SYMMETRIC context the strips whose j range lies inside the own slice (about
+ *                             1/n_ranks of the rank's work); on any other context nothing
+ *   nbody_step_begin_remote : the rest (everything, where the first go did nothing).  Queue it behind the gather:
+ *                             an event wait on the context's stream is enough, the host need not block.
+ * Same plan, same partial-sum segments, same order of additions as nbody_step_begin: the results are identical in every
+ * bit.  The first go reads the masses of ALL bodies (they are what the last upload left; the gather rewrites them with
+ * the same bits): a host that changes masses in the bound buffer must let the gather finish first.
+ */
+NBODY_API int nbody_step_begin_local(nbody_ctx *ctx);
+NBODY_API int nbody_step_begin_remote(nbody_ctx *ctx);
 NBODY_API int nbody_exchange_info(nbody_ctx *ctx, void **send, void **recv, size_t *bytes_per_rank, int32_t *n_ranks);
 /* Use caller-owned device buffers (e.g. torch tensors) for the exchange: send = n_total x float4, recv = n_ranks x i_count x float4
  * (double4 on an fp64 context). */

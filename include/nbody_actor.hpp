@@ -36,6 +36,7 @@ class OctreeSearchActor {
   uint64_t Seed = 0x4E426F6479ull;      // CreateSpacePoints' generator seed (the reference is unseeded)
   float ActorLocation[3] = {0, 0, 0};   // GetActorLocation(), .cpp:64
   bool MirrorParticles = true;          // refresh `Particles` after every Tick, as the reference's TArray is live
+  bool DrawInTick = true;          // Tick ends with DrawOctreeBoxes() (.cpp:33); a host that draws through its own DrawOctreeBoxes(Octree*) turns it off
   int Device = 0;
   std::vector<int32_t> Devices;         // non-empty: share the bodies over these GPUs (nbody_create_multi; Theta must be 0)
   int Precision = NBODY_PREC_F32;
@@ -121,8 +122,11 @@ class OctreeSearchActor {
         if (LastStatus == NBODY_OK) { dirty_ = true; forces_fresh_ = true; }
       }
     }
-    DrawOctreeBoxes();                                                         // .cpp:33
+    if (DrawInTick) DrawOctreeBoxes();                                         // .cpp:33
   }
+
+  // Has a force pass produced something DrawOctreeBoxes can draw (the reference: ParticleOctree != NULL, .cpp:38)?
+  bool HasTree() const { return Initialized && forces_fresh_; }
 
   // .cpp:36-45 — one DrawDebugPoint per body.
   void DrawOctreeBoxes() {

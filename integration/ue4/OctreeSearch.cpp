@@ -7,8 +7,9 @@
 
 #include <cstring>
 
-AOctreeSearch::AOctreeSearch() : Size(0), Initialized(false), ShowOctree(false), PhDeltaTime(0.01), Theta(1.0f)
+AOctreeSearch::AOctreeSearch() : Size(0), ParticleOctree(NULL), Initialized(false), ShowOctree(false), PhDeltaTime(0.01), Theta(1.0f)
 {
+  Engine.DrawInTick = false;                                  // Tick draws through DrawOctreeBoxes(ParticleOctree), as the reference does
   PrimaryActorTick.bCanEverTick = true;                       // OctreeSearch.cpp:11
 }
 
@@ -38,6 +39,8 @@ void AOctreeSearch::PullMirror()
 {
   Size = Engine.Size;
   Initialized = Engine.Initialized;
+  // the reference's pointer is non-NULL from the first CreateOctree until CleanParticles (OctreeSearch.cpp:79, 94-95)
+  ParticleOctree = Engine.HasTree() ? reinterpret_cast<Octree*>(&Engine) : NULL;
   Particles.SetNumUninitialized((int32)Engine.Particles.size());
   if (Particles.Num() > 0)
     std::memcpy(Particles.GetData(), Engine.Particles.data(), sizeof(FParticle) * (size_t)Particles.Num());
@@ -50,6 +53,16 @@ void AOctreeSearch::Tick(float DeltaSeconds)
   PushKnobs();
   Engine.Tick(DeltaSeconds);                                  // DeltaSeconds is ignored, as in the reference
   PullMirror();
+  DrawOctreeBoxes(ParticleOctree);                            // OctreeSearch.cpp:33 (runs when paused too)
+}
+
+// OctreeSearch.cpp:36-45: per occupied leaf, depth first with children 0..7, the box (if ShowOctree) and the point — drawn
+// by the callbacks BeginPlay installed, from what the device's tree says (nbody_bh_leaf_order / nbody_bh_leaf_boxes).
+void AOctreeSearch::DrawOctreeBoxes(Octree* Oct)
+{
+  if (Oct == NULL) return;                                    // OctreeSearch.cpp:38
+  Engine.ShowOctree = ShowOctree;
+  Engine.DrawOctreeBoxes();
 }
 
 // OctreeSearch.cpp:47-56

@@ -30,6 +30,8 @@ struct FParticle {
 };
 static_assert(sizeof(FParticle) == sizeof(nbody::FParticle), "FParticle must stay 40 bytes: Mass, Position, Velocity, Acceleration");
 
+class Octree;                                // OctreeSearch.h:21-109 — opaque here: see the header comment
+
 UCLASS()
 class NBODY_API AOctreeSearch : public AActor
 {
@@ -39,6 +41,8 @@ public:
   // ---- the reference's members (OctreeSearch.h:117-127) ----
   float Size;                               // half-width of the scene, refreshed by every Tick (ComputeCubeSize)
   TArray<FParticle> Particles;              // mirror of the device state, refreshed by every Tick
+  Octree* ParticleOctree;                   // OctreeSearch.h:119: NULL until the first force pass and after CleanParticles
+                                            // (OctreeSearch.cpp:8, 95); otherwise a token for the device's current tree
   bool Initialized;
 
   UPROPERTY(BlueprintReadWrite)
@@ -60,6 +64,7 @@ public:
   virtual void BeginPlay() override;
   virtual void Tick(float DeltaSeconds) override;
 
+  void DrawOctreeBoxes(Octree* Oct);        // OctreeSearch.h:138, OctreeSearch.cpp:36-45: Oct == NULL draws nothing
   void ComputeCubeSize();
 
   UFUNCTION(BlueprintCallable, Category = "Octree")

@@ -96,6 +96,8 @@ def lib():
     sig("nbody_step", c_int, vp, c_f, c_i32)
     sig("nbody_step_begin", c_int, vp)
     sig("nbody_step_end", c_int, vp, c_f)
+    sig("nbody_step_begin_local", c_int, vp)
+    sig("nbody_step_begin_remote", c_int, vp)
     sig("nbody_exchange_info", c_int, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(c_i32))
     sig("nbody_bind_exchange", c_int, vp, vp, vp)
     sig("nbody_exchange_read_send", c_int, vp, vp)

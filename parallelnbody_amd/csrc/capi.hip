@@ -57,6 +57,7 @@ struct nbody_ctx {
   // symmetric algorithm (kernels_sym.hip, kernels_sym64.hip; plan: sym_plan.h)
   bool sym = false;
   int sym_bi = 0, sym_pad = 0, sym_items_n = 0, sym_nsrc = 1, sym_slots = 0, sym_min_sub = 0;
+  int sym_n_local = 0;                   // items [0, sym_n_local): strips inside the own slice (sym_plan.h)
   double sym_k = 0.0;
   size_t sym_pool_elems = 0;
   nbody::SymPlan *plan = nullptr;                  // host copy, dropped once uploaded
@@ -76,6 +77,7 @@ struct nbody_ctx {
   int masses_equal = -1;
   bool own_send = false, own_recv = false;
   bool step_open = false;      // nbody_step_begin done, nbody_step_end pending
+  bool step_local = false;     // nbody_step_begin_local done, nbody_step_begin_remote pending
   int64_t steps_done = 0;      // updates applied since the state was set (saved in checkpoints)
   // Barnes-Hut mode (kernels_bh.hip)
   float theta = 0.0f;
@@ -259,7 +261,7 @@ void choose_algorithm(nbody_ctx *c) {
   }
   c->plan = plan;
   c->sym_bi = bi; c->sym_np = f64 ? ipt / 2 : np; c->sym_pad = plan->n_pad; c->sym_items_n = (int)plan->items.size();
-  c->sym_nsrc = plan->n_src; c->sym_pool_elems = (size_t)plan->pool_elems;
+  c->sym_nsrc = plan->n_src; c->sym_pool_elems = (size_t)plan->pool_elems; c->sym_n_local = plan->n_local;
   c->sym = true;
   c->wave = 0;            // the small-system one-launch step belongs to the one-sided path
 }
@@ -285,6 +287,7 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
   L.dup_table = c->sym_dup_table; L.dup_slots = c->sym_dup_slots;
   L.general = c->sym_general;
+  L.n_local = c->sym_n_local; L.own_begin = c->p.i_begin; L.own_count = c->p.i_count;
   // the host's own finding is final while nothing but this library writes the position buffer; otherwise "not equal"
   // still is (the device word is sticky), "equal" is only the state of things at the last upload
   // (fp64 always asks the device: its test also looks for bodies out where the padding is)
@@ -438,14 +441,16 @@ int run_forces_bh(nbody_ctx *c, bool diagnostic) {
   return NBODY_OK;
 }
 
-int run_forces(nbody_ctx *c, bool diagnostic = false) {
+// phase (SymLaunch::phase): 0 the whole pass; 1 / 2 the two goes of a sharded fp32 symmetric context (sym_two_goes)
+int run_forces(nbody_ctx *c, bool diagnostic = false, int phase = 0) {
   if (c->theta > 0.0f) return run_forces_bh(c, diagnostic);
   { int rc = ensure_floor(c); if (rc) return rc; }
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
   if (c->sym) {
-    const nbody::SymLaunch L = make_sym_launch(c);
+    nbody::SymLaunch L = make_sym_launch(c);
+    L.phase = phase;
     // a fused context about to run the preparation kernel again (new state): its current table may hold the entries
     // the last update left for positions that are gone
     if (L.fused && !L.skip_prep && L.dup_table && L.eps2 == 0.0)
@@ -962,9 +967,36 @@ int nbody_step_begin(nbody_ctx *c) {
   if (c && c->multi) return multi_unsupported(c, "nbody_step_begin");
   int rc = check_ready(c);
   if (rc) return rc;
-  if (c->step_open) return fail(c, NBODY_ERR_STATE, "nbody_step_begin: previous step not ended");
+  if (c->step_open || c->step_local) return fail(c, NBODY_ERR_STATE, "nbody_step_begin: previous step not ended");
   HIP_TRY(c, hipSetDevice(c->p.device));
   if ((rc = run_forces(c))) return rc;
+  c->step_open = true;
+  return NBODY_OK;
+}
+
+// Can the force pass run in two goes — the strips inside the own slice first, the rest once the other ranks' positions
+// are in?  Sharded fp32 symmetric contexts (all-pairs): their preparation kernel and their plan know the cut.
+static bool sym_two_goes(const nbody_ctx *c) {
+  return c->theta == 0.0f && c->sym && c->sym_nsrc > 1 && c->p.precision != NBODY_PREC_F64;
+}
+
+int nbody_step_begin_local(nbody_ctx *c) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_step_begin_local");
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (c->step_open || c->step_local) return fail(c, NBODY_ERR_STATE, "nbody_step_begin_local: previous step not ended");
+  if (sym_two_goes(c)) { if ((rc = run_forces(c, false, 1))) return rc; }   // otherwise everything happens in the second go
+  c->step_local = true;
+  return NBODY_OK;
+}
+
+int nbody_step_begin_remote(nbody_ctx *c) {
+  if (c && c->multi) return multi_unsupported(c, "nbody_step_begin_remote");
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!c->step_local) return fail(c, NBODY_ERR_STATE, "nbody_step_begin_remote: nbody_step_begin_local first");
+  c->step_local = false;
+  if ((rc = run_forces(c, false, sym_two_goes(c) ? 2 : 0))) return rc;
   c->step_open = true;
   return NBODY_OK;
 }
@@ -1361,7 +1393,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) t
   HIP_TRY(c, hipMemcpy(c->vel, vel.data(), vel.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size(), hipMemcpyHostToDevice));
   { const int rc2 = f64 ? note_masses(c, (const double *)posm.data()) : note_masses(c, (const float *)posm.data()); if (rc2) return rc2; }
-  c->have_state = true; c->floor_eps2 = -1.0; c->step_open = false; c->sym_posg_valid = false;
+  c->have_state = true; c->floor_eps2 = -1.0; c->step_open = false; c->step_local = false; c->sym_posg_valid = false;
   c->steps_done = h.steps_done;
   // Barnes-Hut: the opening angle and the root of the next tree (the previous tree's CoM, OctreeSearch.cpp:77-79) are
   // part of the trajectory.  Only contexts that can run the walk take them over.

@@ -74,6 +74,13 @@ struct SymLaunch {
   // -1 = launch both, each looks at `general`.
   void *general = nullptr;
   int uni_host = 0;
+  // Sharded fp32 contexts can run the pass in two goes, so that the strips inside the own slice need not wait for the other
+  // ranks' positions: phase 1 = prepare the own slice [own_begin, own_begin + own_count) and run items [0, n_local);
+  // phase 2 = prepare the rest, run items [n_local, n_items) and fold the j-side rows; phase 0 = everything at once.
+  // Same plan, same segments, same summation order: the bits do not depend on how the pass is cut.
+  int phase = 0;
+  int n_local = 0;
+  int own_begin = 0, own_count = 0;
 };
 // forces + fold of the j-side rows into L.send
 hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);

@@ -290,9 +290,17 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   if (L.n_total <= 0 || L.n_items <= 0 || L.n_pad < L.n_total || !L.posg || !L.pool || !L.items) return hipErrorInvalidValue;
   if (L.np != 1 && L.np != 2 && L.np != 4 && L.np != 8) return hipErrorInvalidValue;
   if (L.np == 8 && L.kahan) return hipErrorInvalidValue;
-  dim3 grid(L.n_items), block(kBlock), pgrid((L.n_pad + kBlock - 1) / kBlock);
+  if (L.phase < 0 || L.phase > 2 || (L.phase != 0 && (L.fused || L.n_local < 0 || L.n_local > L.n_items))) return hipErrorInvalidValue;
+  // which items this call launches, and which bodies it prepares (SymLaunch::phase)
+  const int item0 = L.phase == 2 ? L.n_local : 0, item1 = L.phase == 1 ? L.n_local : L.n_items;
+  const SymItem *items = (const SymItem *)L.items + item0;
+  dim3 grid(item1 - item0), block(kBlock), pgrid((L.n_pad + kBlock - 1) / kBlock);
   const bool detect = L.eps2 == 0.0 && L.dup_table != nullptr;
-  int *flag = detect ? (int *)((unsigned long long *)L.dup_table + L.dup_slots) : nullptr;
+  int *flag_all = detect ? (int *)((unsigned long long *)L.dup_table + L.dup_slots) : nullptr;
+  int *flag_own = detect ? flag_all + 2 : nullptr;                // the own slice's verdict (phase 1): words 2, 3 behind the table
+  int *flag = L.phase == 1 ? flag_own : flag_all;                 // what this call's force kernels look at
+  const int b0 = L.phase == 0 ? 0 : L.own_begin, b1 = L.phase == 0 ? L.n_pad : L.own_begin + L.own_count;
+  const int inside = L.phase == 2 ? 0 : 1, check_mass = L.phase == 2 ? 0 : 1;
   // positions -> (x, y, z, G m) with far-away zero-mass padding; the coincident-body detector rides along
   // equal masses (L.general: the device's finding, raised by the preparation kernel; L.uni_host: what the host knows —
   // 1 equal and nobody else can write the buffer, 0 not equal / not applicable, -1 ask the device)
@@ -303,14 +311,19 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
     // the previous update_sym_fused_kernel left posg and the detector's verdict for exactly these positions
   } else if (detect) {      // the table and its flag words are zero: cleared at creation and by every pass's fold
     hipLaunchKernelGGL(sym_prep_kernel<true>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
-                       L.n_pad, (float)L.G, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag, general);
+                       L.n_pad, (float)L.G, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag_all, general,
+                       b0, b1, inside, check_mass, L.phase == 1 ? flag_own : (int *)nullptr);
   } else {
     hipLaunchKernelGGL(sym_prep_kernel<false>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
-                       L.n_pad, (float)L.G, (unsigned long long *)nullptr, 0u, (int *)nullptr, general);
+                       L.n_pad, (float)L.G, (unsigned long long *)nullptr, 0u, (int *)nullptr, general, b0, b1, inside,
+                       check_mass, (int *)nullptr);
   }
+  if (grid.x == 0) {                                              // nothing to launch in this go (phase 2 of a plan without remote strips)
+    if (L.phase == 1) return hipGetLastError();
+  } else {
 #define NBODY_SYM_K(NPV, ZM, BARE, KH, UNI, ZP, FLAG, RUNIF)                                                     \
   hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, UNI>), grid, block, 0, s, (const float4 *)L.posg, \
-                     (float4 *)L.pool, (const SymItem *)L.items, (float)(ZP), (const int *)(FLAG), RUNIF, gate, UNI ? 0 : 1)
+                     (float4 *)L.pool, items, (float)(ZP), (const int *)(FLAG), RUNIF, gate, UNI ? 0 : 1)
   bool do_uni = run_uni, do_gen = run_gen;                         // which forms the next NBODY_SYM_NP launches
 #define NBODY_SYM_U(NPV, ZM, BARE, KH, ZP, FLAG, RUNIF)                                                          \
   do {                                                                                                           \
@@ -347,8 +360,9 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
 #undef NBODY_SYM
 #undef NBODY_SYM_U
 #undef NBODY_SYM_K
+  }
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || L.fused) return e;                       // fused: update_sym_fused_kernel folds the j-side rows
+  if (e != hipSuccess || L.fused || L.phase == 1) return e;       // fused: update_sym_fused_kernel folds the j-side rows
   dim3 rgrid((L.n_total + 63) / 64);                               // one workgroup per 64-body granule (sym_common.h, row folds)
   if (L.kahan)
     hipLaunchKernelGGL((reduce_j_kernel<float, true>), rgrid, block, 0, s, (const float4 *)L.pool, (float4 *)L.send,

@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>   // types and enums only: the functions are resolved with dlsym
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace nbody {
@@ -68,6 +69,13 @@ struct Multi {
   std::vector<nbody_ctx *> part;
   std::vector<hipStream_t> stream;
   std::vector<ncclComm_t> comm;
+  // the all-gather has a communicator and a stream of its own per device: it is queued behind the update by an event and
+  // the next step's force pass waits for it only where it needs the other devices' positions (gather_pending)
+  std::vector<ncclComm_t> comm_gather;
+  std::vector<hipStream_t> gather_stream;
+  std::vector<hipEvent_t> ev_updated, ev_gathered;
+  bool gather_pending = false;
+  bool overlap = true;                     // NBODY_MULTI_NO_OVERLAP=1: everything in one stream order (A/B measurements)
   std::vector<void *> posm;                // each device's full position array
   // symmetric algorithm: exchange buffers of every device (null when the step has no exchange)
   std::vector<void *> ex_send, ex_recv;
@@ -92,18 +100,48 @@ int rccl_fail(Multi *m, ncclResult_t r, const char *what) {
 #define PART_TRY(m, k, expr, what) do { int rc_ = (expr); if (rc_) return part_fail((m), (k), rc_, (what)); } while (0)
 #define RCCL_TRY(m, expr, what) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return rccl_fail((m), r_, (what)); } while (0)
 
-// The owned slices -> every device's full position array: one in-place all-gather per device, grouped.
+// The owned slices -> every device's full position array: one in-place all-gather per device, grouped — on the gather
+// streams, behind an event the update has recorded; the devices' own streams go on at once.
 int gather_positions(Multi *m) {
   const ncclDataType_t ty = m->f64 ? ncclDouble : ncclFloat;
+  for (int k = 0; k < m->n_dev; ++k) {
+    (void)hipSetDevice(m->devices[(size_t)k]);
+    if (!m->overlap) continue;
+    if (hipEventRecord(m->ev_updated[(size_t)k], m->stream[(size_t)k]) != hipSuccess ||
+        hipStreamWaitEvent(m->gather_stream[(size_t)k], m->ev_updated[(size_t)k], 0) != hipSuccess)
+      return fail(m, NBODY_ERR_HIP, "hipEventRecord / hipStreamWaitEvent (update -> gather)");
+  }
   RCCL_TRY(m, m->rccl.GroupStart(), "ncclGroupStart");
   for (int k = 0; k < m->n_dev; ++k) {
     char *base = (char *)m->posm[(size_t)k];
     (void)hipSetDevice(m->devices[(size_t)k]);              // one thread, several devices: each call on its communicator's device
-    ncclResult_t r = m->rccl.AllGather(base + (size_t)k * m->slice * m->elem, base, (size_t)m->slice * 4, ty, m->comm[(size_t)k],
-                                       m->stream[(size_t)k]);
+    ncclResult_t r = m->rccl.AllGather(base + (size_t)k * m->slice * m->elem, base, (size_t)m->slice * 4, ty,
+                                       m->overlap ? m->comm_gather[(size_t)k] : m->comm[(size_t)k],
+                                       m->overlap ? m->gather_stream[(size_t)k] : m->stream[(size_t)k]);
     if (r != ncclSuccess) { (void)m->rccl.GroupEnd(); return rccl_fail(m, r, "ncclAllGather(positions)"); }
   }
   RCCL_TRY(m, m->rccl.GroupEnd(), "ncclGroupEnd");
+  if (m->overlap) {
+    for (int k = 0; k < m->n_dev; ++k) {
+      (void)hipSetDevice(m->devices[(size_t)k]);
+      if (hipEventRecord(m->ev_gathered[(size_t)k], m->gather_stream[(size_t)k]) != hipSuccess)
+        return fail(m, NBODY_ERR_HIP, "hipEventRecord (gather)");
+    }
+    m->gather_pending = true;
+  }
+  return NBODY_OK;
+}
+
+// Order every device's own stream behind the last all-gather (no host wait).  Whatever reads the replicated positions
+// outside the force pass's first go comes through here.
+int wait_gather(Multi *m) {
+  if (!m->gather_pending) return NBODY_OK;
+  for (int k = 0; k < m->n_dev; ++k) {
+    (void)hipSetDevice(m->devices[(size_t)k]);
+    if (hipStreamWaitEvent(m->stream[(size_t)k], m->ev_gathered[(size_t)k], 0) != hipSuccess)
+      return fail(m, NBODY_ERR_HIP, "hipStreamWaitEvent (gather -> force pass)");
+  }
+  m->gather_pending = false;
   return NBODY_OK;
 }
 
@@ -182,6 +220,22 @@ int multi_create(const nbody_params *pin, const int32_t *devices, int32_t n_dev,
     m->comm.clear();
     return bail(NBODY_ERR_HIP, std::string("nbody_create_multi: ncclCommInitAll: ") + m->rccl.GetErrorString(r));
   }
+  { const char *e = getenv("NBODY_MULTI_NO_OVERLAP"); m->overlap = !(e && e[0] == '1'); }
+  if (m->overlap) {
+    m->comm_gather.assign((size_t)n_dev, nullptr);
+    const ncclResult_t r2 = m->rccl.CommInitAll(m->comm_gather.data(), n_dev, m->devices.data());
+    if (r2 != ncclSuccess) {
+      m->comm_gather.clear();
+      return bail(NBODY_ERR_HIP, std::string("nbody_create_multi: ncclCommInitAll (gather): ") + m->rccl.GetErrorString(r2));
+    }
+    for (int k = 0; k < n_dev; ++k) {
+      hipStream_t gs = nullptr; hipEvent_t a = nullptr, b = nullptr;
+      if (hipSetDevice(devices[k]) != hipSuccess || hipStreamCreateWithFlags(&gs, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess)
+        return bail(NBODY_ERR_HIP, "nbody_create_multi: cannot create the gather stream / events on device " + std::to_string(devices[k]));
+      m->gather_stream.push_back(gs); m->ev_updated.push_back(a); m->ev_gathered.push_back(b);
+    }
+  }
   *out = m;
   return NBODY_OK;
 }
@@ -189,7 +243,13 @@ int multi_create(const nbody_params *pin, const int32_t *devices, int32_t n_dev,
 void multi_destroy(Multi *m) {
   if (!m) return;
   for (size_t k = 0; k < m->stream.size(); ++k) { (void)hipSetDevice(m->devices[k]); (void)hipStreamSynchronize(m->stream[k]); }
+  for (size_t k = 0; k < m->gather_stream.size(); ++k) { (void)hipSetDevice(m->devices[k]); (void)hipStreamSynchronize(m->gather_stream[k]); }
   for (ncclComm_t c : m->comm) if (c) (void)m->rccl.CommDestroy(c);
+  for (ncclComm_t c : m->comm_gather) if (c) (void)m->rccl.CommDestroy(c);
+  for (size_t k = 0; k < m->gather_stream.size(); ++k) {
+    (void)hipSetDevice(m->devices[k]);
+    (void)hipStreamDestroy(m->gather_stream[k]); (void)hipEventDestroy(m->ev_updated[k]); (void)hipEventDestroy(m->ev_gathered[k]);
+  }
   for (size_t k = 0; k < m->part.size(); ++k) {
     // the context must let go of our stream before the stream dies
     (void)nbody_set_stream(m->part[k], nullptr);
@@ -208,14 +268,17 @@ void multi_slice(const Multi *m, int k, int32_t *i_begin, int32_t *i_count) {
 }
 
 int multi_set_particles(Multi *m, const void *aos, size_t stride, int32_t n) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_set_particles(m->part[(size_t)k], aos, stride, n), "nbody_set_particles");
   return NBODY_OK;
 }
 int multi_set_state_soa(Multi *m, const float *posm4, const float *vel4, int32_t n) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_set_state_soa(m->part[(size_t)k], posm4, vel4, n), "nbody_set_state_soa");
   return NBODY_OK;
 }
 int multi_set_state_soa_f64(Multi *m, const double *posm4, const double *vel4, int32_t n) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_set_state_soa_f64(m->part[(size_t)k], posm4, vel4, n), "nbody_set_state_soa_f64");
   return NBODY_OK;
 }
@@ -223,7 +286,11 @@ int multi_set_state_soa_f64(Multi *m, const double *posm4, const double *vel4, i
 // One Tick body over all devices (OctreeSearch.cpp:27-31): everything is queued on the devices' streams, nothing waits
 // for the host.
 int multi_forces(Multi *m, float dt) {
-  for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_step_begin(m->part[(size_t)k]), "force pass");
+  // the strips inside every device's own slice need no other device's positions: they run while the last step's
+  // all-gather is still in flight; the rest of the pass is ordered behind it (nbody_step_begin_local / _remote)
+  for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_step_begin_local(m->part[(size_t)k]), "force pass (own slice)");
+  { const int rc = wait_gather(m); if (rc) return rc; }
+  for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_step_begin_remote(m->part[(size_t)k]), "force pass");
   { const int rc = exchange_sums(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_step_end(m->part[(size_t)k], dt), "update");
   if (dt > 0.0f) return gather_positions(m);
@@ -231,6 +298,7 @@ int multi_forces(Multi *m, float dt) {
 }
 
 int multi_get_bounds(Multi *m, float *size) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   float best = 0.0f;
   for (int k = 0; k < m->n_dev; ++k) {
     float s = 0.0f;
@@ -242,17 +310,20 @@ int multi_get_bounds(Multi *m, float *size) {
 }
 
 int multi_get_positions(Multi *m, float *xyz, size_t stride, int32_t first, int32_t count) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   PART_TRY(m, 0, nbody_get_positions(m->part[0], xyz, stride, first, count), "nbody_get_positions");   // every device holds all positions
   return NBODY_OK;
 }
 
 int multi_get_particles(Multi *m, void *aos, size_t stride) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k)
     PART_TRY(m, k, nbody_get_particles(m->part[(size_t)k], (char *)aos + (size_t)k * m->slice * stride, stride), "nbody_get_particles");
   return NBODY_OK;
 }
 
 int multi_get_state_soa(Multi *m, float *posm4, float *vel4, float *acc4) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) {
     const size_t o = (size_t)k * m->slice * 4;
     PART_TRY(m, k, nbody_get_state_soa(m->part[(size_t)k], posm4 ? posm4 + o : nullptr, vel4 ? vel4 + o : nullptr, acc4 ? acc4 + o : nullptr),
@@ -261,6 +332,7 @@ int multi_get_state_soa(Multi *m, float *posm4, float *vel4, float *acc4) {
   return NBODY_OK;
 }
 int multi_get_state_soa_f64(Multi *m, double *posm4, double *vel4, double *acc4) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) {
     const size_t o = (size_t)k * m->slice * 4;
     PART_TRY(m, k, nbody_get_state_soa_f64(m->part[(size_t)k], posm4 ? posm4 + o : nullptr, vel4 ? vel4 + o : nullptr, acc4 ? acc4 + o : nullptr),
@@ -270,6 +342,7 @@ int multi_get_state_soa_f64(Multi *m, double *posm4, double *vel4, double *acc4)
 }
 
 int multi_energy(Multi *m, double *ke, double *pe) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   double k_sum = 0.0, p_sum = 0.0;
   for (int k = 0; k < m->n_dev; ++k) {
     double a = 0.0, b = 0.0;
@@ -282,6 +355,7 @@ int multi_energy(Multi *m, double *ke, double *pe) {
 }
 
 int multi_synchronize(Multi *m) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_synchronize(m->part[(size_t)k]), "nbody_synchronize");
   return NBODY_OK;
 }
@@ -304,6 +378,7 @@ int multi_kernel_time_reset(Multi *m) {
 }
 
 int multi_load_checkpoint(Multi *m, const char *path, int64_t *steps_done) {
+  { const int rc = wait_gather(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_load_checkpoint(m->part[(size_t)k], path, steps_done), "nbody_load_checkpoint");
   return NBODY_OK;
 }

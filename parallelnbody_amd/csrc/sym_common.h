@@ -56,16 +56,21 @@ __device__ __forceinline__ unsigned long long coord_bits(double v) { return (uns
 // Do two different bodies share a position?  Every body inserts a 64-bit hash of its three coordinates into an
 // open-addressing table (pre-zeroed, >= 2n slots); meeting its own hash again sets *flag.  A hash collision between
 // different positions also sets it — that only selects the guarded kernel for this pass, never a wrong result.
+// flag2 (optional): a second verdict word that takes every finding of this call too — the verdict on the bodies inserted
+// so far, for a pass that inserts them in two goes (own slice first, the rest once their positions have arrived).
 template <typename T, typename V>
 __device__ __forceinline__ void dup_detect(const V p, unsigned long long *__restrict__ table, unsigned int mask,
-                                           int *__restrict__ flag) {
+                                           int *__restrict__ flag, int *__restrict__ flag2 = nullptr) {
+  auto raise = [&]() { atomicExch(flag, 1); if (flag2) atomicExch(flag2, 1); };
   // d == 0 also happens for DIFFERENT positions when every squared difference underflows: only possible if both
   // bodies sit within ~1e-12 of the origin on all three axes (elsewhere two distinct floats differ by >= 1 ulp of
   // their own size).  Two or more bodies in that cube -> guarded kernel.  flag[1] counts them.
-  if (fabs((double)p.x) < 1e-12 && fabs((double)p.y) < 1e-12 && fabs((double)p.z) < 1e-12)
+  if (fabs((double)p.x) < 1e-12 && fabs((double)p.y) < 1e-12 && fabs((double)p.z) < 1e-12) {
     if (atomicAdd(flag + 1, 1) >= 1) atomicExch(flag, 1);
+    if (flag2 && atomicAdd(flag2 + 1, 1) >= 1) atomicExch(flag2, 1);
+  }
   // the unguarded kernels park their zero-mass padding at pad_far on all three axes: a body exactly there would meet it at d == 0
-  if (p.x == pad_far<T>() && p.y == pad_far<T>() && p.z == pad_far<T>()) atomicExch(flag, 1);
+  if (p.x == pad_far<T>() && p.y == pad_far<T>() && p.z == pad_far<T>()) raise();
   // coord_bits adds +0 first: -0 and +0 are the same position
   unsigned long long h = coord_bits(p.x) * 0x9E3779B97F4A7C15ull;
   h = (h ^ (h >> 29)) + coord_bits(p.y) * 0xBF58476D1CE4E5B9ull;
@@ -76,10 +81,10 @@ __device__ __forceinline__ void dup_detect(const V p, unsigned long long *__rest
   for (unsigned int probe = 0; probe <= mask; ++probe) {
     const unsigned long long old = atomicCAS(&table[slot], 0ull, h);
     if (old == 0ull) return;                                // inserted
-    if (old == h) { atomicExch(flag, 1); return; }          // somebody with the same position (or hash) is already in
+    if (old == h) { raise(); return; }                      // somebody with the same position (or hash) is already in
     slot = (slot + 1) & mask;
   }
-  atomicExch(flag, 1);                                      // table full (cannot happen at >= 2n slots): be safe
+  raise();                                                  // table full (cannot happen at >= 2n slots): be safe
 }
 
 template <typename T>
@@ -109,17 +114,25 @@ __global__ __launch_bounds__(kBlock) void mass_check_kernel(const typename SymVe
 // detector rides along (DETECT), and so does the equal-mass test: a body whose mass differs from body 0's raises
 // *general (sticky until the host resets it on a new state), which selects the general kernels and tells the update not
 // to scale (see forces_sym_pk_kernel, UNI).
+// A sharded context may prepare in two goes (SymLaunch::phase): the bodies of [b0, b1) — its own slice, whose positions its
+// own update has just written — with inside = 1, and the others, once the all-gather has delivered them, with inside = 0.
+// The first go also looks at every mass (masses do not travel: they are what the last upload left) and leaves its
+// coincident-body verdict in flag2 as well: the verdict on the own slice, which is all the strips inside that slice need.
 template <bool DETECT>
 __global__ __launch_bounds__(kBlock) void sym_prep_kernel(const float4 *__restrict__ posm, float4 *__restrict__ posg,
                                                           int n_total, int n_pad, float gscale,
                                                           unsigned long long *__restrict__ table, unsigned int mask,
-                                                          int *__restrict__ flag, int *__restrict__ general) {
+                                                          int *__restrict__ flag, int *__restrict__ general,
+                                                          int b0, int b1, int inside, int check_mass, int *__restrict__ flag2) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_pad) return;
-  if (i >= n_total) { posg[i] = make_float4(kPadFar, kPadFar, kPadFar, 0.f); return; }
+  const bool mine = (i >= b0 && i < b1) == (inside != 0);
+  if (i >= n_total) { if (mine) posg[i] = make_float4(kPadFar, kPadFar, kPadFar, 0.f); return; }
+  if (!mine && !(check_mass && general != nullptr)) return;
   float4 p = posm[i];
-  if (DETECT) dup_detect<float>(p, table, mask, flag);
-  if (general != nullptr && !(p.w == posm[0].w)) *general = 1;     // every writer writes the same value
+  if (check_mass && general != nullptr && !(p.w == posm[0].w)) *general = 1;     // every writer writes the same value
+  if (!mine) return;
+  if (DETECT) dup_detect<float>(p, table, mask, flag, flag2);
   p.w *= gscale;
   posg[i] = p;
 }

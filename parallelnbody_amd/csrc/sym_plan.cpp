@@ -87,8 +87,19 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
     for (const auto &pc : piece) {
       const long long lo = pc[0], hi = std::min<long long>(pc[1], P.n_gran);
       if (hi <= lo) continue;
-      ranges.push_back({a, (int)lo, (int)(hi - lo), 0});
-      total_cost += (hi - lo) * (bi / 256);
+      // a sharded context cuts its ranges where the own slice begins and ends: a strip then lies either wholly inside the
+      // own slice — it needs no other rank's positions and can run while they are still being gathered — or outside it
+      long long cut[4] = {lo, hi, hi, hi};
+      int n_cut = 1;
+      if (!all) {
+        const long long o0 = P.own_gran0, o1 = (long long)P.own_gran0 + P.own_grans;
+        for (long long c : {o0, o1}) if (c > cut[n_cut - 1] && c < hi) cut[n_cut++] = c;
+      }
+      cut[n_cut] = hi;
+      for (int q = 0; q < n_cut; ++q) {
+        ranges.push_back({a, (int)cut[q], (int)(cut[q + 1] - cut[q]), 0});
+        total_cost += (cut[q + 1] - cut[q]) * (bi / 256);
+      }
     }
   }
 
@@ -157,6 +168,15 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
     for (const SymItem &it : P.items)
       if (!(it.flags & kSymNoJSide))
         for (int k = 0; k < it.n_sub; ++k) P.j_off[fill[(size_t)(it.j0 / 64 + k)]++] = it.slot_j + (uint32_t)k * 64u;
+  }
+  // Launch order: the items whose strip lies inside the own slice first (stable).  The lists above name pool segments, not
+  // item numbers, so the order of launch does not touch the order of summation.
+  {
+    const int o0 = P.own_gran0 * 64, o1 = o0 + P.own_grans * 64;
+    auto local = [&](const SymItem &it) { return it.j0 >= o0 && it.j0 + it.n_sub * 64 <= o1; };
+    std::stable_partition(P.items.begin(), P.items.end(), local);
+    P.n_local = 0;
+    while (P.n_local < (int)P.items.size() && local(P.items[(size_t)P.n_local])) ++P.n_local;
   }
   *out = std::move(P);
   return true;

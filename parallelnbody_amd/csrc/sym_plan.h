@@ -43,6 +43,7 @@ struct SymPlan {
   int own_gran0 = 0, own_grans = 0;
   int n_src = 1;          // ranks sharing the bodies
   uint64_t pool_elems = 0;
+  int n_local = 0;        // items [0, n_local): strips inside the own slice (all of them when the context owns all bodies)
   std::vector<SymItem> items;
   std::vector<uint32_t> i_ptr, i_off;   // CSR over OWN granules: i-side segments (+ offset of the granule inside them)
   std::vector<uint32_t> j_ptr, j_off;   // CSR over ALL granules: j-side segments

@@ -156,6 +156,14 @@ class NBodyEngine:
         """Force pass of the owned bodies (first phase of a step driven by a multi-GPU host)."""
         self._check(self._L.nbody_step_begin(self._h))
 
+    def step_begin_local(self):
+        """First go of step_begin: what needs the OWNED slice of the positions only (nbody_step_begin_local)."""
+        self._check(self._L.nbody_step_begin_local(self._h))
+
+    def step_begin_remote(self):
+        """Second go: the rest of the force pass, once all positions are in (nbody_step_begin_remote)."""
+        self._check(self._L.nbody_step_begin_remote(self._h))
+
     def step_end(self, dt=REF_DT):
         """Kick-drift of the owned bodies (dt <= 0: only store the accelerations)."""
         self._check(self._L.nbody_step_end(self._h, dt))

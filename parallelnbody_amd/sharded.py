@@ -9,6 +9,11 @@ Per step (the reference's Tick body, OctreeSearch.cpp:25-31, per slice):
     step_end:   kick-drift(own slice, in place in the full array)
     all_gather_into_tensor(full array, own slice)               # 16 B/body over RCCL/xGMI
 
+The all-gather is issued on a second stream and the next step does not wait for it at once: step_begin_local runs the
+strips of the force pass that lie inside the own slice (about 1/world_size of the rank's work — milliseconds at
+N = 2^20 — against a gather of ~0.1 ms), and only step_begin_remote is ordered behind the gather's event.
+The results are the non-overlapped order's in every bit (`overlap=False` runs that order: same plan, same sums).
+
 No all-reduce anywhere: the force on a body needs every position but no other body's velocity.  With the TILED
 algorithm every rank evaluates its bodies against all others (no all-to-all) and the summation order per body
 does not depend on the partition, so the trajectory is bit-identical for any world size.  With the SYMMETRIC
@@ -56,10 +61,11 @@ class EngineCreationFailed(RuntimeError):
 
 
 class ShardedSimulation:
-    def __init__(self, posm, vel, *, rank=0, world_size=1, device=None, group=None, engine_factory=None,
+    def __init__(self, posm, vel, *, rank=0, world_size=1, device=None, group=None, engine_factory=None, overlap=True,
                  **engine_kw):
         import torch
         self.torch = torch
+        self.overlap = overlap
         posm = np.ascontiguousarray(posm)
         self.n_total = posm.shape[0]
         self.rank, self.world_size, self.group = rank, world_size, group
@@ -72,8 +78,14 @@ class ShardedSimulation:
         factory = engine_factory or hip_engine_factory
         dev_index = self.device.index if self.device.type == "cuda" else -1
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        if self.stream is not None:          # GPU engines launch on the simulation's stream (hip_engine_factory's `stream`)
-            engine_kw = dict(engine_kw, stream=self.stream)
+        # the all-gather's own stream and the event that says "all positions of the last step are in"
+        self.gather_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" and world_size > 1 else None
+        self.gathered = None
+        if self.stream is not None:          # GPU engines launch on the simulation's stream (hip_engine_factory's `stream`);
+            import inspect                   # a caller's own factory gets the keyword only if it takes it
+            params = inspect.signature(factory).parameters
+            if "stream" in params or any(q.kind is inspect.Parameter.VAR_KEYWORD for q in params.values()):
+                engine_kw = dict(engine_kw, stream=self.stream)
         # Engine creation can fail on one rank only (memory, an unsupported geometry).  The ranks agree on the outcome
         # with ONE matched collective, the first this object issues, before anything else can diverge.
         self.engine, failure = None, None
@@ -90,6 +102,8 @@ class ShardedSimulation:
                 if self.engine is not None:
                     self.engine.close()
                 raise EngineCreationFailed(failure or "engine creation failed on another rank")
+        if world_size == 1 and factory is hip_engine_factory:
+            self.posm = None                 # a single HIP rank keeps the positions in the engine's own buffer (fused stepping)
         self.engine.set_state(posm.astype(np.float64 if self.f64 else np.float32, copy=False),
                               np.ascontiguousarray(vel).astype(np.float64 if self.f64 else np.float32, copy=False))
         self.steps_done = 0
@@ -147,10 +161,39 @@ class ShardedSimulation:
             raise RuntimeError(f"ranks disagree on the force-pass geometry (algorithm, bodies per i-set, exchange ranks): "
                                f"this rank {mine}, minimum {lo.tolist()}, maximum {hi.tolist()}")
 
+    def _wait_gather(self):
+        """Order the simulation's stream behind the last all-gather (no host wait)."""
+        if self.gathered is not None:
+            self.stream.wait_event(self.gathered)
+            self.gathered = None
+
     def _forces(self):
-        self.engine.step_begin()
+        two_goes = self.overlap and hasattr(self.engine, "step_begin_local")
+        if two_goes:
+            self.engine.step_begin_local()        # strips inside the own slice: the gather may still be in flight
+            self._wait_gather()
+            self.engine.step_begin_remote()
+        else:
+            self._wait_gather()
+            self.engine.step_begin()
         if self.ex_ranks:
             self.torch.distributed.all_to_all_single(self.ex_recv, self.ex_send, group=self.group)
+
+    def _gather_positions(self):
+        """In-place all-gather of the owned slices.  GPU: on the gather stream, ordered behind the update by an event; the
+        simulation's stream only waits for it where the next force pass needs the other ranks' positions."""
+        dist = self.torch.distributed
+        own = self.posm[self.i_begin:self.i_begin + self.i_count]
+        if self.gather_stream is None or not self.overlap:
+            dist.all_gather_into_tensor(self.posm, own, group=self.group)
+            return
+        updated = self.torch.cuda.Event()
+        updated.record(self.stream)
+        with self.torch.cuda.stream(self.gather_stream):
+            self.gather_stream.wait_event(updated)
+            dist.all_gather_into_tensor(self.posm, own, group=self.group)
+            self.gathered = self.torch.cuda.Event()
+            self.gathered.record(self.gather_stream)
 
     def compute_forces(self):
         """Accelerations of the current positions (the reference's CreateOctree force loop), no update."""
@@ -159,16 +202,20 @@ class ShardedSimulation:
             self.engine.step_end(0.0)
 
     def step(self, dt=REF_DT, nsteps=1):
-        dist = self.torch.distributed
-        own = self.posm[self.i_begin:self.i_begin + self.i_count]
-        with self._on_stream():            # kernels and collectives in one stream order
+        with self._on_stream():            # kernels and collectives ordered by streams and events, never by the host
             for _ in range(nsteps):
                 if dt > 0:                 # OctreeSearch.cpp:25: PhDeltaTime <= 0 freezes the physics
                     self._forces()
                     self.engine.step_end(dt)
                     if self.world_size > 1:
-                        dist.all_gather_into_tensor(self.posm, own, group=self.group)
+                        self._gather_positions()
                 self.steps_done += 1
+
+    def wait_for_positions(self):
+        """Everything that reads the replicated positions outside the stepping loop comes through here first."""
+        if self.stream is not None:
+            with self._on_stream():
+                self._wait_gather()
 
     def settle(self, seconds=0.3):
         """Untimed force passes (state unchanged: nothing is integrated) for about `seconds`, the same number on every
@@ -193,6 +240,7 @@ class ShardedSimulation:
     def gather_state(self):
         """(posm[n_total,4], vel[n_total,4]) on every rank, as numpy (for tests and checkpoints)."""
         torch, dist = self.torch, self.torch.distributed
+        self.wait_for_positions()
         p, v, _ = self.engine.state(np.float64 if self.f64 else np.float32)
         if self.world_size == 1:
             return p, v
@@ -207,6 +255,7 @@ class ShardedSimulation:
 
     def energy(self):
         """System kinetic and potential energy (sum of the ranks' shares)."""
+        self.wait_for_positions()
         ke, pe = self.engine.energy()
         if self.world_size > 1:
             with self._on_stream():
@@ -216,4 +265,6 @@ class ShardedSimulation:
         return ke, pe
 
     def close(self):
+        if self.gather_stream is not None:
+            self.gather_stream.synchronize()      # no collective may still be writing the tensor the engine is bound to
         self.engine.close()

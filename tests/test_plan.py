@@ -99,3 +99,23 @@ def test_unplannable_ranges_are_refused(nb):
         nb.sym_plan(65536, 1000, 3000, 1024, 512, 3, 4)          # slices must be equal multiples of the i-set
     with pytest.raises(nb.NBodyError):
         nb.sym_plan(65536, 0, 32768, 1000, 512, 3, 4)            # i-sets are multiples of 64 bodies
+
+
+@pytest.mark.parametrize("n,ranks,bi", [(65536, 2, 2048), (65536, 8, 4096), (131072, 8, 4096), (49152, 3, 1024), (1 << 20, 8, 4096)])
+def test_sharded_plans_launch_the_strips_inside_the_own_slice_first(nb, n, ranks, bi):
+    # the strips whose j range lies inside the rank's own slice need no other rank's positions; the plan cuts
+    # its ranges at the slice's ends (no strip straddles them) and puts those strips first in launch order, so that they
+    # can run while the all-gather is still in flight (nbody_step_begin_local).  About 1/ranks of a rank's work.
+    ic = n // ranks
+    for r in range(ranks):
+        items, _ = nb.sym_plan(n, r * ic, ic, bi, 512, 3, 4)
+        j0, j1 = items[:, 1], items[:, 1] + 64 * items[:, 2]
+        inside = (j0 >= r * ic) & (j1 <= (r + 1) * ic)
+        outside = (j1 <= r * ic) | (j0 >= (r + 1) * ic)
+        assert np.all(inside | outside)                                   # nobody straddles a slice end
+        k = int(inside.sum())
+        assert k > 0 and inside[:k].all() and not inside[k:].any()        # local strips first
+        share = items[inside, 2].sum() / items[:, 2].sum()
+        assert 0.5 / ranks < share < 2.0 / ranks
+    items, _ = nb.sym_plan(n, 0, 0, bi, 512, 3, 4)                         # one context: everything is local
+    assert np.all(items[:, 1] + 64 * items[:, 2] <= -(-n // 64) * 64)

@@ -136,3 +136,67 @@ def test_all_gather_only_step_eight_slices_equal_one_context_bit_for_bit(nb, ora
     for i in rows[::4]:
         ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1, nthreads=8)
         assert rel_err(a8[i:i + 1, :3], ref).max() < 2e-5, i
+
+
+@pytest.mark.parametrize("precision,eps,n", [("f32", 0.0, 1 << 17), ("f32_kahan", 0.5, 1 << 17), ("f32", 0.0, 1 << 20)])
+def test_force_pass_in_two_goes_equals_the_pass_in_one(nb, oracle, precision, eps, n):
+    # nbody_step_begin_local + nbody_step_begin_remote (what lets the all-gather overlap the force pass) against
+    # nbody_step_begin on the same sharded contexts: same plan, same segments, same sums — every bit, on every rank,
+    # with distinct masses (general form) and with coincident bodies inside one slice and across slices (the own slice's
+    # detector verdict guards the first go, the whole system's the second)
+    posm, vel = nb.ic_plummer(n, seed=77)
+    posm[:, 3] *= np.random.default_rng(3).uniform(0.5, 1.5, n).astype(np.float32)
+    ic = n // RANKS
+    variants = [posm]
+    if n <= 1 << 17:
+        twin = posm.copy(); twin[5, :3] = twin[900, :3]                    # two bodies of rank 0 on one point
+        cross = posm.copy(); cross[7, :3] = cross[ic + 11, :3]             # one of rank 0, one of rank 1
+        variants += [twin, cross]
+    for scene in variants:
+        results = []
+        for goes in (1, 2):
+            engs = [nb.NBodyEngine(n, i_begin=r * ic, i_count=ic, precision=precision, eps=eps) for r in range(RANKS)]
+            try:
+                for e in engs:
+                    assert e.launch_config()["algorithm"] == "symmetric"
+                    e.set_state(scene, vel)
+                    if goes == 1:
+                        e.step_begin()
+                    else:
+                        e.step_begin_local()
+                        with pytest.raises(nb.NBodyError):
+                            e.step_begin_local()                          # one first go per step
+                        e.step_begin_remote()
+                sends = [e.exchange_read_send() for e in engs]
+                out = []
+                for r, e in enumerate(engs):
+                    e.exchange_write_recv(np.concatenate([sd[r * ic:(r + 1) * ic] for sd in sends]))
+                    e.step_end(0.01)
+                    out.append(np.concatenate(e.state(), axis=1))
+                results.append((np.concatenate(out), np.stack(sends)))
+            finally:
+                for e in engs:
+                    e.close()
+        np.testing.assert_array_equal(results[0][1], results[1][1])        # what every rank sends
+        np.testing.assert_array_equal(results[0][0], results[1][0])        # positions, velocities, accelerations
+        a = results[0][0][:, 8:11]
+        assert np.all(np.isfinite(a))
+        if scene is posm:
+            p64 = scene.astype(np.float64)
+            for i in (0, ic - 1, ic, n // 2 + 3, n - 1):
+                ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], eps=eps, i0=i, i1=i + 1, nthreads=8)
+                assert rel_err(a[i:i + 1], ref).max() < (2e-6 if precision == "f32_kahan" else 2e-5), i
+    # contexts without a first go of their own (one device; the one-sided kernel; fp64) accept the two calls as well
+    for kw in (dict(), dict(i_begin=0, i_count=n // 2, algorithm=1), dict(i_begin=0, i_count=n // 2, precision="f64")):
+        if n > 1 << 17:
+            break
+        with nb.NBodyEngine(n, **kw) as a1, nb.NBodyEngine(n, **kw) as a2:
+            for e in (a1, a2):
+                e.set_state(posm, vel)
+            a1.step_begin(); a2.step_begin_local(); a2.step_begin_remote()
+            if a1.exchange_ranks():
+                for e in (a1, a2):
+                    e.exchange_write_recv(np.zeros((e.exchange_ranks() * e.i_count, 4), np.float64 if e.f64 else np.float32))
+            a1.step_end(0.01); a2.step_end(0.01)
+            for x, y in zip(a1.state(), a2.state()):
+                np.testing.assert_array_equal(x, y)

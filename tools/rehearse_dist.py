@@ -30,14 +30,19 @@ posm, vel = nb.ic_plummer(n, seed=1)
 sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device=f"cuda:{lr}", time_kernels=True)
 assert sim.stream is not None and sim.stream.cuda_stream != 0
 sim.step(0.01, 3); torch.cuda.synchronize()
-# stream ordering: what the in-place all-gather of step k ships must be step k's positions.  With one rank the gather
-# is skipped, so issue it by hand on the simulation's stream right behind a step and compare with a synchronised copy.
-with torch.cuda.stream(sim.stream):
-    sim.engine.step_begin(); sim.engine.step_end(0.01)
-    snap = sim.posm.clone()                                  # enqueued behind the update on the same stream
-    dist.all_gather_into_tensor(sim.posm, sim.posm[sim.i_begin:sim.i_begin + sim.i_count])
-torch.cuda.synchronize()
-assert torch.equal(snap, sim.posm) and not torch.equal(snap, torch.from_numpy(posm).to(dev)), "stream ordering broken"
+# stream ordering: what the in-place all-gather of step k ships must be step k's positions: issue one more by hand on the
+# simulation's stream right behind a step and compare with a copy taken on the same stream.  (A single rank keeps the
+# positions inside its engine — sim.posm is None — and gathers nothing.)
+if world > 1:
+    with torch.cuda.stream(sim.stream):
+        sim.wait_for_positions()
+        sim.engine.step_begin(); sim.engine.step_end(0.01)
+        snap = sim.posm.clone()                                  # enqueued behind the update on the same stream
+        dist.all_gather_into_tensor(sim.posm, sim.posm[sim.i_begin:sim.i_begin + sim.i_count])
+    torch.cuda.synchronize()
+    assert torch.equal(snap, sim.posm) and not torch.equal(snap, torch.from_numpy(posm).to(dev)), "stream ordering broken"
+else:
+    assert sim.posm is None
 p, v = sim.gather_state(); ke, pe = sim.energy()
 print("rehearsal ok: rank", rank, "of", world, "algorithm", sim.engine.launch_config()["algorithm"], "finite", bool(np.isfinite(p).all()), "E", ke + pe)
 sim.close(); dist.barrier(); dist.destroy_process_group()

@@ -20,10 +20,18 @@ sim.warm_collectives()
 sim.step(0.001, 3)
 torch.cuda.synchronize()
 p, v = sim.gather_state()
+# the same run with every collective and kernel in ONE stream order (no all-gather under the next force pass): every bit equal
+seq = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device="cuda:0", overlap=False)
+seq.step(0.001, 3)
+ps, vs = seq.gather_state()
+assert sim.overlap and sim.gather_stream is not None and not seq.overlap
+assert np.array_equal(p, ps) and np.array_equal(v, vs), "overlapped and sequential stepping differ"
+seq.close()
 if rank == 0:
     with nb.NBodyEngine(n, algorithm=1) as e:           # one-sided single-context reference run
         e.set_state(posm, vel); e.step(0.001, 3); pr, vr, _ = e.state()
     err = np.abs(p[:, :3] - np.concatenate([pr[:, :3]])).max() / np.abs(pr[:, :3]).max()
-    print(f"two ranks on one GPU over gloo: algorithm {cfg['algorithm']}, exchange ranks {sim.ex_ranks}, max rel position diff vs single context {err:.2e}")
+    print(f"two ranks on one GPU over gloo: algorithm {cfg['algorithm']}, exchange ranks {sim.ex_ranks}, max rel position diff vs single context {err:.2e}; "
+          "all-gather under the next force pass: bits equal to the sequential order")
     assert err < 1e-6
 dist.barrier(); sim.close(); dist.destroy_process_group()
