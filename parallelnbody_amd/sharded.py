@@ -62,10 +62,11 @@ class EngineCreationFailed(RuntimeError):
 
 class ShardedSimulation:
     def __init__(self, posm, vel, *, rank=0, world_size=1, device=None, group=None, engine_factory=None, overlap=True,
-                 **engine_kw):
+                 timeline=False, **engine_kw):
         import torch
         self.torch = torch
         self.overlap = overlap
+        self.marks = [] if timeline else None    # timed events around the gather and the force pass's goes (timeline_ms)
         posm = np.ascontiguousarray(posm)
         self.n_total = posm.shape[0]
         self.rank, self.world_size, self.group = rank, world_size, group
@@ -81,6 +82,7 @@ class ShardedSimulation:
         # the all-gather's own stream and the event that says "all positions of the last step are in"
         self.gather_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" and world_size > 1 else None
         self.gathered = None
+        self.gather_work = None
         if self.stream is not None:          # GPU engines launch on the simulation's stream (hip_engine_factory's `stream`);
             import inspect                   # a caller's own factory gets the keyword only if it takes it
             params = inspect.signature(factory).parameters
@@ -162,17 +164,39 @@ class ShardedSimulation:
                                f"this rank {mine}, minimum {lo.tolist()}, maximum {hi.tolist()}")
 
     def _wait_gather(self):
-        """Order the simulation's stream behind the last all-gather (no host wait)."""
+        """Order the simulation's stream behind the last all-gather.  RCCL: an event wait, the host goes on.  Backends
+        whose collectives complete on the host (gloo, the one-GPU rehearsal) are waited for here, as late as possible."""
+        if self.gather_work is not None:
+            self.gather_work.wait()
+            self.gather_work = None
+            self._mark("all-gather end (seen by the host)", self.gather_stream, step=self.steps_done - 1)
         if self.gathered is not None:
             self.stream.wait_event(self.gathered)
             self.gathered = None
 
+    def _mark(self, name, stream=None, step=None):
+        """timeline=True: a timed event on `stream` (default: the simulation's), read back by `timeline_ms()`."""
+        if self.marks is not None:
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else self.stream)
+            self.marks.append((self.steps_done if step is None else step, name, ev))
+
+    def timeline_ms(self):
+        """[(step, name, milliseconds since the first mark)] — where the all-gather ran relative to the force pass's two goes
+        (tools/overlap_timeline.py).  Synchronises."""
+        self.torch.cuda.synchronize(self.device)
+        t0 = self.marks[0][2]
+        return [(st, name, t0.elapsed_time(ev)) for st, name, ev in self.marks]
+
     def _forces(self):
         two_goes = self.overlap and hasattr(self.engine, "step_begin_local")
         if two_goes:
+            self._mark("local strips begin")
             self.engine.step_begin_local()        # strips inside the own slice: the gather may still be in flight
+            self._mark("local strips end")
             self._wait_gather()
             self.engine.step_begin_remote()
+            self._mark("remote strips end")
         else:
             self._wait_gather()
             self.engine.step_begin()
@@ -191,9 +215,14 @@ class ShardedSimulation:
         updated.record(self.stream)
         with self.torch.cuda.stream(self.gather_stream):
             self.gather_stream.wait_event(updated)
-            dist.all_gather_into_tensor(self.posm, own, group=self.group)
-            self.gathered = self.torch.cuda.Event()
-            self.gathered.record(self.gather_stream)
+            self._mark("all-gather begin", self.gather_stream)
+            if dist.get_backend(self.group) == "nccl":      # RCCL: queued; the gather stream waits for it, the host does not
+                dist.all_gather_into_tensor(self.posm, own, group=self.group)
+                self._mark("all-gather end", self.gather_stream)
+                self.gathered = self.torch.cuda.Event()
+                self.gathered.record(self.gather_stream)
+            else:                                           # completes on the host: started now, waited for in _wait_gather
+                self.gather_work = dist.all_gather_into_tensor(self.posm, own, group=self.group, async_op=True)
 
     def compute_forces(self):
         """Accelerations of the current positions (the reference's CreateOctree force loop), no update."""
@@ -266,5 +295,7 @@ class ShardedSimulation:
 
     def close(self):
         if self.gather_stream is not None:
+            if self.gather_work is not None:
+                self.gather_work.wait()
             self.gather_stream.synchronize()      # no collective may still be writing the tensor the engine is bound to
         self.engine.close()
