@@ -384,7 +384,7 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
     if (L.precision == NBODY_PREC_F64 || i_begin != 0 || i_count != L.n_total || L.n_src != 1) return hipErrorInvalidValue;
     const bool detect = L.eps2 == 0.0 && L.dup_table != nullptr && L.dup_table_next != nullptr;
 #define NBODY_FUSED(KH, DT)                                                                                       \
-    hipLaunchKernelGGL((update_sym_fused_kernel<KH, DT>), grid, block, 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc, \
+    hipLaunchKernelGGL((update_sym_fused_kernel<KH, DT>), grid, dim3(2 * kBlock), 0, s, (float4 *)posm, (float4 *)vel, (float4 *)acc, \
                        (float4 *)L.posg, (const float4 *)L.pool, ip, io, (const unsigned int *)L.j_ptr,             \
                        (const unsigned int *)L.j_off, L.n_total, (float)L.G, dt, dt > 0.0f ? 1 : 0,                  \
                        (unsigned long long *)L.dup_table_next, (unsigned int)(L.dup_slots - 1),                      \

@@ -259,29 +259,40 @@ __global__ __launch_bounds__(kBlock) void update_sym_kernel(typename SymVec<R>::
 // table (`next`; this pass's table `cur`, last read by this pass's force kernels, is cleared for the pass after).  A
 // stepping loop then runs force kernel + this kernel per step: no sym_prep_kernel, no reduce_j_kernel, no memset.
 template <bool KAHAN, bool DETECT>
-__global__ __launch_bounds__(kBlock) void update_sym_fused_kernel(float4 *__restrict__ posm, float4 *__restrict__ vel,
-                                                                  float4 *__restrict__ acc, float4 *__restrict__ posg,
-                                                                  const float4 *__restrict__ pool,
-                                                                  const unsigned int *__restrict__ i_ptr,
-                                                                  const unsigned int *__restrict__ i_off,
-                                                                  const unsigned int *__restrict__ j_ptr,
-                                                                  const unsigned int *__restrict__ j_off, int n_total,
-                                                                  float gscale, float dt, int integrate,
-                                                                  unsigned long long *__restrict__ next, unsigned int mask,
-                                                                  unsigned long long *__restrict__ cur, int cur_words,
-                                                                  const int *__restrict__ general) {
-  __shared__ float sh[kFoldWays][3][64];
-  const int t = threadIdx.x, l = t & 63, way = t >> 6, g = blockIdx.x, bl = g * 64 + l;
-  if (DETECT) for (int w = g * kBlock + t; w < cur_words; w += gridDim.x * kBlock) cur[w] = 0ull;
-  float sx, sy, sz, dx, dy, dz;                                   // the j-side row of this body (reduce_j_kernel's sum)
-  fold_way<float, KAHAN>(pool, j_ptr, j_off, g, l, way, sx, sy, sz);
-  fold_meet<float, KAHAN>(sh, l, way, sx, sy, sz, dx, dy, dz);
-  __syncthreads();                                                // sh is used again
+__global__ __launch_bounds__(2 * kBlock) void update_sym_fused_kernel(float4 *__restrict__ posm, float4 *__restrict__ vel,
+                                                                      float4 *__restrict__ acc, float4 *__restrict__ posg,
+                                                                      const float4 *__restrict__ pool,
+                                                                      const unsigned int *__restrict__ i_ptr,
+                                                                      const unsigned int *__restrict__ i_off,
+                                                                      const unsigned int *__restrict__ j_ptr,
+                                                                      const unsigned int *__restrict__ j_off, int n_total,
+                                                                      float gscale, float dt, int integrate,
+                                                                      unsigned long long *__restrict__ next, unsigned int mask,
+                                                                      unsigned long long *__restrict__ cur, int cur_words,
+                                                                      const int *__restrict__ general) {
+  // Eight waves per granule: waves 0-3 fold the j-side list (reduce_j_kernel's sum, same four ways, same order), waves 4-7
+  // the i-side list at the same time — the two folds are chains of dependent loads, and small systems have few granules.
+  __shared__ float sh[2][kFoldWays][3][64];
+  __shared__ float sj[3][64];
+  const int t = threadIdx.x, l = t & 63, way = (t >> 6) & (kFoldWays - 1), side = t >> 8, g = blockIdx.x, bl = g * 64 + l;
+  if (DETECT) for (int w = g * 2 * kBlock + t; w < cur_words; w += gridDim.x * 2 * kBlock) cur[w] = 0ull;
   float ax, ay, az, cx, cy, cz;
-  fold_way<float, KAHAN>(pool, i_ptr, i_off, g, l, way, ax, ay, az);
-  fold_meet<float, KAHAN>(sh, l, way, ax, ay, az, cx, cy, cz);
-  if (way != 0 || bl >= n_total) return;
-  fold_add<float, KAHAN>(ax, cx, sx); fold_add<float, KAHAN>(ay, cy, sy); fold_add<float, KAHAN>(az, cz, sz);
+  if (side == 0) fold_way<float, KAHAN>(pool, j_ptr, j_off, g, l, way, ax, ay, az);
+  else           fold_way<float, KAHAN>(pool, i_ptr, i_off, g, l, way, ax, ay, az);
+  sh[side][way][0][l] = ax; sh[side][way][1][l] = ay; sh[side][way][2][l] = az;
+  __syncthreads();
+  cx = 0; cy = 0; cz = 0;
+  if (way == 0) {                                                 // ((s0 + s1) + s2) + s3, on both sides (fold_meet)
+#pragma unroll
+    for (int w = 1; w < kFoldWays; ++w) {
+      fold_add<float, KAHAN>(ax, cx, sh[side][w][0][l]); fold_add<float, KAHAN>(ay, cy, sh[side][w][1][l]);
+      fold_add<float, KAHAN>(az, cz, sh[side][w][2][l]);
+    }
+    if (side == 0) { sj[0][l] = ax; sj[1][l] = ay; sj[2][l] = az; }
+  }
+  __syncthreads();
+  if (side != 1 || way != 0 || bl >= n_total) return;
+  fold_add<float, KAHAN>(ax, cx, sj[0][l]); fold_add<float, KAHAN>(ay, cy, sj[1][l]); fold_add<float, KAHAN>(az, cz, sj[2][l]);
   if (general != nullptr && *general == 0) {      // equal-mass kernels: the common G m comes in here (update_sym_kernel)
     const float gm = posm[0].w * gscale;
     ax *= gm; ay *= gm; az *= gm;
