@@ -42,7 +42,6 @@ struct nbody_ctx {
   hipStream_t stream = nullptr;
   void *posm = nullptr, *vel = nullptr, *acc = nullptr, *accp = nullptr;
   void *posm_alt = nullptr;    // small systems: second position buffer of the one-launch step (swapped with posm)
-  void *tile_tickets = nullptr;   // one-launch step of the one-sided packed kernel: an arrival counter per i-block
   bool own_posm = false, own_vel = false, own_acc = false;
   void *d_stage = nullptr, *h_stage = nullptr;   // renderer hand-off staging (device repack target, pinned mirror)
   size_t stage_bytes = 0;
@@ -822,7 +821,6 @@ void nbody_destroy(nbody_ctx *c) {
   }
   if (c->own_posm && c->posm) (void)hipFree(c->posm);
   if (c->posm_alt) (void)hipFree(c->posm_alt);
-  if (c->tile_tickets) (void)hipFree(c->tile_tickets);
   if (c->own_vel && c->vel) (void)hipFree(c->vel);
   if (c->own_acc && c->acc) (void)hipFree(c->acc);
   if (c->accp) (void)hipFree(c->accp);
@@ -1097,30 +1095,8 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
   // (it swaps the two position buffers: not once the caller holds a pointer to one of them)
   const bool one_launch = c->wave != 0 && c->theta == 0.0f && c->own_posm && !c->posm_escaped &&
                           c->p.i_count == c->p.n_total && c->p.precision == NBODY_PREC_F32;
-  // mid-size systems on the one-sided packed kernel: the update rides in the force launch too (the i-block's last chunk adds
-  // the rows and moves the bodies): one launch per step here as well.  NBODY_TILE_NO_FUSE=1 keeps the two launches (A/B).
-  const bool tile_fuse_off = [] { const char *e = getenv("NBODY_TILE_NO_FUSE"); return e && e[0] == '1'; }();   // read per call: tests toggle it
-  const bool one_launch_tile = !tile_fuse_off && !c->sym && c->wave == 0 && c->theta == 0.0f && c->own_posm && !c->posm_escaped &&
-                               c->p.i_count == c->p.n_total && c->p.precision != NBODY_PREC_F64 && c->ipt % 2 == 0 &&
-                               c->p.zero_mode != NBODY_ZERO_SELECT && c->sym_dup_table == nullptr;
-  if ((one_launch || one_launch_tile) && !c->posm_alt) HIP_TRY(c, hipMalloc(&c->posm_alt, (size_t)c->p.n_total * c->elem));
-  if (one_launch_tile && !c->tile_tickets) {
-    const size_t blocks = ((size_t)c->p.n_total + 256u * (size_t)c->ipt - 1) / (256u * (size_t)c->ipt);
-    HIP_TRY(c, hipMalloc(&c->tile_tickets, blocks * sizeof(int)));
-    HIP_TRY(c, hipMemsetAsync(c->tile_tickets, 0, blocks * sizeof(int), c->stream));
-  }
+  if (one_launch && !c->posm_alt) HIP_TRY(c, hipMalloc(&c->posm_alt, (size_t)c->p.n_total * c->elem));
   for (int s = 0; s < nsteps; ++s) {
-    if (one_launch_tile) {
-      if ((rc = ensure_floor(c))) return rc;
-      EventPair ev;
-      const bool timed = c->p.time_kernels != 0;
-      if (timed && (rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev))) return rc;
-      HIP_TRY(c, nbody::launch_step_tile(make_launch(c), c->posm_alt, c->vel, c->acc, c->tile_tickets, dt, c->stream));
-      if (timed && (rc = timer_end(c, NBODY_KERNEL_FORCES, ev))) return rc;
-      if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024 && (rc = timer_drain(c, NBODY_KERNEL_FORCES))) return rc;
-      std::swap(c->posm, c->posm_alt);
-      continue;
-    }
     if (one_launch) {
       if ((rc = ensure_floor(c))) return rc;
       EventPair ev;

@@ -27,9 +27,6 @@ struct ForceLaunch {
   // may have written the buffer since the host last looked).
   void *general = nullptr;
   int check_masses = 0;
-  // launch_step_tile only: the update's operands and one arrival counter per i-block (see TileFuse, kernels.hip)
-  void *fuse_posm_out = nullptr, *fuse_vel = nullptr, *fuse_acc = nullptr, *fuse_tickets = nullptr;
-  float fuse_dt = 0.f;
 };
 
 // All-pairs force partials.  Returns hipSuccess or the launch error.
@@ -37,9 +34,6 @@ hipError_t launch_forces(const ForceLaunch &L, hipStream_t s);
 // Small single-context fp32 systems (L.wave != 0): the whole Tick body — forces, v += dt*a, x += dt*v — in one launch.
 // New positions go to posm_out (a second buffer: the old one is still being read); the caller swaps them afterwards.
 hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s);
-// Mid-size single-context fp32 systems on the one-sided packed kernel (two or four bodies per lane): the same in one launch.
-// tickets: one zeroed int per i-block of 256 * ipt bodies (they are zero again when the launch has finished).
-hipError_t launch_step_tile(const ForceLaunch &L, void *posm_out, void *vel, void *acc, void *tickets, float dt, hipStream_t s);
 // Blocks / threads launch_forces will use for L (for logs).
 void forces_geometry(const ForceLaunch &L, int *blocks, int *threads);
 

@@ -213,22 +213,6 @@ __global__ __launch_bounds__(kBlock) void forces_tile_kernel(const typename V4<T
 // dup_flag (Z_CLAMP only): verdict of dup_detect_kernel on this pass's positions.  With no two bodies on one point
 // (*dup_flag == 0) d == 0 can only be a self pair, so full tiles that do not overlap the workgroup's own i-range run
 // the pair law bare — 5 packed ops + 1 v_rsq_f32 per pair-lane instead of 7 + 1.  The results are the guarded ones.
-// HIP's __fmul_rn/__fadd_rn are plain * and + and get contracted into FMAs under the default
-// -ffp-contract=fast; the pragma keeps the two roundings of the reference's operators (FVector's * and +).
-template <typename T> __device__ __forceinline__ T mul_add_sep(T a, T b, T c) {
-#pragma clang fp contract(off)
-  const T p = a * b;
-  return c + p;
-}
-
-// One launch per step with the one-sided packed kernel (launch_step_tile): where the update's operands are, and one arrival
-// counter per i-block (zero between steps).  tickets == nullptr: a plain force pass, the rows stay for update_kernel.
-struct TileFuse {
-  float4 *posm_out = nullptr, *vel = nullptr, *acc = nullptr;
-  int *tickets = nullptr;
-  float dt = 0.f;
-};
-
 #ifndef NBODY_TILE_UNI
 #define NBODY_TILE_UNI 1      // 0 compiles the equal-mass branch out (A/B builds: tools/ab_tile_uni.sh)
 #endif
@@ -237,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
                                                                 float4 *__restrict__ accp, int n_total, int i_begin,
                                                                 int i_count, int j_chunk, float gscale, float zp,
                                                                 const int *__restrict__ dup_flag,
-                                                                const int *__restrict__ general, TileFuse fuse) {
+                                                                const int *__restrict__ general) {
   constexpr int IPT = 2 * NP;
   // equal-mass form (see forces_sym_pk_kernel, UNI): *general == 0 says every body has body 0's mass — found by the host
   // in the state it uploaded, or by mass_check_kernel before this launch when somebody else can write the buffer.  Then
@@ -337,45 +321,15 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
     if (il0 < i_count) accp[(size_t)c * i_count + il0] = make_float4(sx.x, sy.x, sz.x, 0.f);
     if (il1 < i_count) accp[(size_t)c * i_count + il1] = make_float4(sx.y, sy.y, sz.y, 0.f);
   }
-  if (fuse.tickets == nullptr) return;
-  // ---- one launch per step (launch_step_tile): the workgroup that finishes an i-block's LAST chunk adds the block's rows
-  // in chunk order — update_kernel's order — and applies the Tick's update.  New positions go to the other position buffer:
-  // the rest of the grid still reads this one.
-  __shared__ int s_last;
-  __threadfence();                                             // this workgroup's rows are out before its ticket is
-  __syncthreads();
-  if (t == 0) s_last = atomicAdd(&fuse.tickets[blockIdx.x], 1) == (int)gridDim.y - 1 ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();                                             // the other chunks' rows, as their tickets saw them
-  const int chunks = (int)gridDim.y;
-#pragma unroll
-  for (int q = 0; q < IPT; ++q) {
-    const int il = ibase + t + q * kBlock;
-    if (il >= i_count) continue;
-    float ax = 0.f, ay = 0.f, az = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
-#pragma unroll 8
-    for (int cc = 0; cc < chunks; ++cc) {
-      const float4 pr = accp[(size_t)cc * i_count + il];
-      if (KAHAN) {
-        float yv = pr.x - cx; float tt = ax + yv; cx = (tt - ax) - yv; ax = tt;
-        yv = pr.y - cy; tt = ay + yv; cy = (tt - ay) - yv; ay = tt;
-        yv = pr.z - cz; tt = az + yv; cz = (tt - az) - yv; az = tt;
-      } else {
-        ax = ax + pr.x; ay = ay + pr.y; az = az + pr.z;
-      }
-    }
-    fuse.acc[il] = make_float4(ax, ay, az, 0.f);
-    float4 v = fuse.vel[il];
-    float4 x = posm[i_begin + il];
-    v.x = mul_add_sep(fuse.dt, ax, v.x); v.y = mul_add_sep(fuse.dt, ay, v.y); v.z = mul_add_sep(fuse.dt, az, v.z);
-    x.x = mul_add_sep(fuse.dt, v.x, x.x); x.y = mul_add_sep(fuse.dt, v.y, x.y); x.z = mul_add_sep(fuse.dt, v.z, x.z);
-    fuse.vel[il] = v;
-    fuse.posm_out[i_begin + il] = x;
-  }
-  if (t == 0) fuse.tickets[blockIdx.x] = 0;                     // ready for the next step
 }
 
+// HIP's __fmul_rn/__fadd_rn are plain * and + and get contracted into FMAs under the default
+// -ffp-contract=fast; the pragma keeps the two roundings of the reference's operators (FVector's * and +).
+template <typename T> __device__ __forceinline__ T mul_add_sep(T a, T b, T c) {
+#pragma clang fp contract(off)
+  const T p = a * b;
+  return c + p;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Small-N kernel: one WORKGROUP per register pair of bodies, the j range spread over its 256 lanes.
@@ -594,12 +548,6 @@ __global__ __launch_bounds__(kBlock) void energy_fold_kernel(const double *__res
 template <typename T, int IPT, int TILE, bool KAHAN>
 hipError_t launch_forces_t(const ForceLaunch &L, hipStream_t s) {
   using V = typename V4<T>::type;
-  TileFuse fuse;
-  if (L.fuse_tickets != nullptr) {
-    if (!(sizeof(T) == 4 && IPT % 2 == 0) || !(L.eps2 > 0.0 || L.zero_mode != Z_SELECT)) return hipErrorInvalidValue;
-    fuse.posm_out = (float4 *)L.fuse_posm_out; fuse.vel = (float4 *)L.fuse_vel; fuse.acc = (float4 *)L.fuse_acc;
-    fuse.tickets = (int *)L.fuse_tickets; fuse.dt = L.fuse_dt;
-  }
   const int iblocks = (L.i_count + kBlock * IPT - 1) / (kBlock * IPT);
   dim3 grid(iblocks, L.j_split), block(kBlock);
   const T gscale = (T)L.G;
@@ -609,7 +557,7 @@ hipError_t launch_forces_t(const ForceLaunch &L, hipStream_t s) {
 #define NBODY_LAUNCH_PK(ZM, ZP, FLAG)                                                                            \
   hipLaunchKernelGGL((forces_tile_pk_kernel<IPT / 2, TILE, ZM, KAHAN>), grid, block, 0, s, (const float4 *)L.posm, \
                      (float4 *)L.accp, L.n_total, L.i_begin, L.i_count, L.j_chunk, (float)L.G, (float)(ZP),        \
-                     (const int *)(FLAG), (const int *)L.general, fuse)
+                     (const int *)(FLAG), (const int *)L.general)
       // equal masses?  The host's finding stands while only this library writes the buffer; otherwise the device looks
       if (L.general != nullptr && L.check_masses)
         hipLaunchKernelGGL(mass_check_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
@@ -687,17 +635,6 @@ hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, vo
     hipLaunchKernelGGL((small_pk_kernel<Z_CLAMP, true>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)posm_out,
                        (float4 *)vel, (float4 *)acc, L.n_total, 0, L.i_count, (float)L.G, -0x1p126f, dt);
   return hipGetLastError();
-}
-
-// One whole Tick body with the one-sided packed kernel in ONE launch: the workgroup that finishes an i-block's last j chunk
-// adds the block's rows (chunk order, as update_kernel does) and applies the update; new positions go to posm_out.
-hipError_t launch_step_tile(const ForceLaunch &L0, void *posm_out, void *vel, void *acc, void *tickets, float dt, hipStream_t s) {
-  if (L0.wave != 0 || L0.precision == NBODY_PREC_F64 || L0.i_begin != 0 || L0.i_count != L0.n_total || !(dt > 0.f) ||
-      !posm_out || !tickets || L0.ipt % 2 != 0)
-    return hipErrorInvalidValue;
-  ForceLaunch L = L0;
-  L.fuse_posm_out = posm_out; L.fuse_vel = vel; L.fuse_acc = acc; L.fuse_tickets = tickets; L.fuse_dt = dt;
-  return launch_forces(L, s);
 }
 
 hipError_t launch_forces(const ForceLaunch &L, hipStream_t s) {

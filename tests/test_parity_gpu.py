@@ -1096,36 +1096,3 @@ def test_auto_falls_back_to_the_one_sided_kernel_when_the_pool_would_not_fit(nb)
     assert err.value.code == nb._lib.ERR_UNSUPPORTED and "partial-sum pool" in str(err.value)
     with nb.NBodyEngine(1 << 22) as e:
         assert e.launch_config()["algorithm"] == "symmetric"
-
-
-@pytest.mark.parametrize("n,precision,eps", [(8192, "f32", 0.0), (7000, "f32", 0.0), (10240, "f32_kahan", 0.3), (9001, "f32", 0.5)])
-def test_one_launch_step_of_the_one_sided_kernel_equals_two_launches(nb, oracle, n, precision, eps):
-    # 6656 <= N < 12288: the workgroup that finishes an i-block's last j chunk adds the block's rows (chunk order, as
-    # update_kernel does) and moves the bodies — one launch per step.  Every bit must equal force launch + update launch
-    # (NBODY_TILE_NO_FUSE=1), for equal and for distinct masses, and the step must still be the oracle's
-    for distinct in (False, True):
-        posm, vel = nb.ic_plummer(n, seed=n)
-        if distinct:
-            posm[:, 3] *= np.random.default_rng(n).uniform(0.5, 1.5, n).astype(np.float32)
-        states = []
-        for no_fuse in ("0", "1"):
-            os.environ["NBODY_TILE_NO_FUSE"] = no_fuse
-            try:
-                with nb.NBodyEngine(n, precision=precision, eps=eps) as e:
-                    assert e.launch_config()["kernel"] == "forces_tile_pk_kernel"
-                    e.set_state(posm, vel)
-                    e.step(0.01, 5)
-                    states.append(e.state())
-            finally:
-                del os.environ["NBODY_TILE_NO_FUSE"]
-        for x, y in zip(*states):
-            np.testing.assert_array_equal(x, y)
-    with nb.NBodyEngine(n, precision=precision, eps=eps) as e:     # one step against the oracle (one launch)
-        e.set_state(posm, vel)
-        e.step(0.01, 1)
-        p, v, a = e.state()
-    ref = oracle.forces_direct_f64(posm[:, :3].astype(np.float64), posm[:, 3].astype(np.float64), eps=eps)
-    assert rel_err(a[:, :3], ref).max() < TOL_ACC
-    p1, v1 = oracle.kick_drift_f32(posm[:, :3], vel[:, :3], a[:, :3], 0.01)
-    np.testing.assert_array_equal(p[:, :3], p1)
-    np.testing.assert_array_equal(v[:, :3], v1)
