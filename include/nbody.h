@@ -292,6 +292,10 @@ NBODY_API const char *nbody_force_kernel_name(const nbody_ctx *ctx);
  * (the parameter keeps its round-1 name). */
 NBODY_API int nbody_get_algorithm(nbody_ctx *ctx, int32_t *algorithm, int32_t *super_tile);
 
+/* The symmetric pass's partial-sum pool: its size in bytes (0 for the one-sided kernels) and how many phases share its
+ * j-side area (1 unless the pool of a one-pass plan would exceed a third of the card: N = 2^23 on one 288 GB card). */
+NBODY_API int nbody_sym_pool_info(nbody_ctx *ctx, uint64_t *pool_bytes, int32_t *phases);
+
 /* Symmetric contexts (fp32, Kahan fp32, fp64): did the last force pass run the equal-mass form of the kernel?  When every
  * body has the same mass (the usual Plummer-sphere set-up) the pair loop sums |d|^-3 d with no mass factor — fp32: 14
  * packed instructions per register pair and step instead of 16; fp64: 20 operations per pair instead of 22 — and the
@@ -315,6 +319,14 @@ NBODY_API int nbody_sym_plan_describe(int32_t n_total, int32_t i_begin, int32_t 
 NBODY_API int nbody_sym_plan_describe_tenths(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
                                              int32_t slots, int32_t k_guided_x10, int32_t min_sub, int32_t own_mode,
                                              int32_t *n_items, uint64_t *pool_elems, int32_t *items, int32_t items_cap);
+
+/* A plan whose j-side partial-sum segments must share an area of at most j_budget_elems pool elements: the items run in
+ * phases (consecutive runs of the launch order), each phase's j-side sums are folded before the next reuses the area — how
+ * the library keeps the symmetric pass beyond N = 2^22 on one card.  phases[] receives n_phases + 1 item numbers. */
+NBODY_API int nbody_sym_plan_describe_phased(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
+                                             int32_t slots, int32_t k_guided_x10, int32_t min_sub, uint64_t j_budget_elems,
+                                             int32_t *n_items, uint64_t *pool_elems, int32_t *items, int32_t items_cap,
+                                             int32_t *n_phases, int32_t *phases, int32_t phases_cap);
 
 /* ---- checkpoint / resume (build-defined: the reference keeps its state in a non-serialised TArray) ---------- */
 

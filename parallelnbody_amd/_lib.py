@@ -125,6 +125,7 @@ def lib():
     sig("nbody_force_kernel_name", ctypes.c_char_p, vp)
     sig("nbody_get_algorithm", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32))
     sig("nbody_equal_mass_form", c_int, vp, ctypes.POINTER(c_i32))
+    sig("nbody_sym_pool_info", c_int, vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i32))
     sig("nbody_save_checkpoint", c_int, vp, ctypes.c_char_p)
     sig("nbody_load_checkpoint", c_int, vp, ctypes.c_char_p, ctypes.POINTER(c_i64))
     sig("nbody_steps_done", c_int, vp, ctypes.POINTER(c_i64))
@@ -134,6 +135,8 @@ def lib():
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i32), c_i32)
     sig("nbody_sym_plan_describe_tenths", c_int, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32),
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i32), c_i32)
+    sig("nbody_sym_plan_describe_phased", c_int, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_uint64, ctypes.POINTER(c_i32),
+        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i32), c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_i32)
     # actor mirror (include/nbody_actor.h)
     sig("nbody_actor_create", vp)
     sig("nbody_actor_destroy", None, vp)

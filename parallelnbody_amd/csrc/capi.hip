@@ -3,6 +3,7 @@
 // std::bad_alloc), no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -58,6 +59,8 @@ struct nbody_ctx {
   bool sym = false;
   int sym_bi = 0, sym_pad = 0, sym_items_n = 0, sym_nsrc = 1, sym_slots = 0, sym_min_sub = 0;
   int sym_n_local = 0;                   // items [0, sym_n_local): strips inside the own slice (sym_plan.h)
+  std::vector<int> sym_phase_item0;      // pool phases of the plan: phase p = items [p], [p + 1]) (one phase unless the pool had to be shared)
+  int sym_n_gran = 0;
   double sym_k = 0.0;
   size_t sym_pool_elems = 0;
   nbody::SymPlan *plan = nullptr;                  // host copy, dropped once uploaded
@@ -251,17 +254,36 @@ void choose_algorithm(nbody_ctx *c) {
     delete plan;
     return;
   }
-  // the partial-sum pool must fit comfortably: at most a third of the card's TOTAL memory
+  // the partial-sum pool must fit comfortably: at most a third of the card's TOTAL memory.  Beyond that (N = 2^23 on one
+  // 288 GB card: the j-side segments alone are 137 GB) the fp32 pass runs in phases that share one j-side area, sized so
+  // that the whole pool stays within 32 GB (sym_plan.h); fp64 has no phased form and leaves to the one-sided kernel.
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0 &&
-      (double)plan->pool_elems * (f64 ? 32.0 : 16.0) > (double)total_b / 3.0) {
-    g_create_error = "symmetric plan: the partial-sum pool would exceed a third of the device memory";
-    delete plan;
-    return;
+  const int forced_mb = f64 ? 0 : env_int("NBODY_SYM_POOL_BUDGET_MB", 0);            // tests: pool phases at small sizes
+  if (forced_mb > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0 &&
+                        (double)plan->pool_elems * (f64 ? 32.0 : 16.0) > (double)total_b / 3.0)) {
+    bool ok = false;
+    if (!f64) {
+      const double i_side = (double)plan->items.size() * (double)bi;                  // elements that stay to the end
+      const double budget = forced_mb > 0 ? (double)forced_mb * 1048576.0 / 16.0 : 32.0 * 1073741824.0 / 16.0 - i_side;
+      if (forced_mb > 0 || budget >= 4.0 * 1073741824.0 / 16.0) {
+        try {
+          ok = nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, 1, plan, &why,
+                                     (uint64_t)budget);
+        } catch (const std::bad_alloc &) { why = "out of host memory"; ok = false; }
+      } else {
+        why = "the i-side segments alone leave no room for a shared j-side area";
+      }
+    }
+    if (!ok) {
+      g_create_error = "symmetric plan: the partial-sum pool would exceed a third of the device memory" + (why.empty() ? std::string() : " (" + why + ")");
+      delete plan;
+      return;
+    }
   }
   c->plan = plan;
   c->sym_bi = bi; c->sym_np = f64 ? ipt / 2 : np; c->sym_pad = plan->n_pad; c->sym_items_n = (int)plan->items.size();
   c->sym_nsrc = plan->n_src; c->sym_pool_elems = (size_t)plan->pool_elems; c->sym_n_local = plan->n_local;
+  c->sym_phase_item0 = plan->phase_item0; c->sym_n_gran = plan->n_gran;
   c->sym = true;
   c->wave = 0;            // the small-system one-launch step belongs to the one-sided path
 }
@@ -271,6 +293,7 @@ void choose_algorithm(nbody_ctx *c) {
 bool sym_fused(const nbody_ctx *c) {
   static const bool off = [] { const char *e = getenv("NBODY_SYM_NO_FUSE"); return e && e[0] == '1'; }();   // A/B measurements only
   return !off && c->sym && c->p.precision != NBODY_PREC_F64 && c->sym_nsrc == 1 && c->own_posm && !c->posm_escaped &&
+         c->sym_phase_item0.size() == 2 &&
          (c->sym_dup_table == nullptr || c->sym_dup_table2 != nullptr);
 }
 
@@ -455,7 +478,28 @@ int run_forces(nbody_ctx *c, bool diagnostic = false, int phase = 0) {
     // the last update left for positions that are gone
     if (L.fused && !L.skip_prep && L.dup_table && L.eps2 == 0.0)
       HIP_TRY(c, hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 64, c->stream));
-    HIP_TRY(c, nbody::launch_forces_sym(L, c->stream));
+    if (c->p.precision == NBODY_PREC_F64) {
+      HIP_TRY(c, nbody::launch_forces_sym(L, c->stream));          // the fp64 launcher runs its whole pass
+    } else {
+      // this go's items (phase: 0 all, 1 the strips inside the own slice, 2 the others), pool phase by pool phase: a pool
+      // phase's j-side sums are folded into `send` as soon as its last item has been launched, and the next one reuses
+      // the area (sym_plan.h).  One pool phase and phase 0: a single call, as ever.
+      const int r0 = phase == 2 ? c->sym_n_local : 0, r1 = phase == 1 ? c->sym_n_local : c->sym_items_n;
+      const int n_ph = (int)c->sym_phase_item0.size() - 1;
+      bool first = true;
+      for (int q = 0; q < n_ph; ++q) {
+        const int a = std::max(c->sym_phase_item0[(size_t)q], r0), b = std::min(c->sym_phase_item0[(size_t)q + 1], r1);
+        if (a >= b && !(first && q == n_ph - 1)) continue;           // nothing of this pool phase in this go (but every go prepares)
+        L.item0 = a < b ? a : r0; L.item1 = a < b ? b : r0;
+        L.do_prep = first ? 1 : 0;
+        L.do_fold = (a < b && b == c->sym_phase_item0[(size_t)q + 1]) || (phase != 1 && q == n_ph - 1 && a >= b) ? 1 : 0;
+        L.fold_accumulate = q > 0 ? 1 : 0;
+        L.clear_detector = q == n_ph - 1 ? 1 : 0;
+        L.j_ptr = (const unsigned int *)c->sym_jptr + (size_t)q * ((size_t)c->sym_n_gran + 1);
+        HIP_TRY(c, nbody::launch_forces_sym(L, c->stream));
+        first = false;
+      }
+    }
   } else {
     HIP_TRY(c, nbody::launch_forces(make_launch(c), c->stream));
   }
@@ -1513,6 +1557,14 @@ int nbody_get_algorithm(nbody_ctx *c, int32_t *algorithm, int32_t *super_tile) {
   if (c->multi) return nbody_get_algorithm(nbody::multi_part(c->multi, 0), algorithm, super_tile);
   if (algorithm) *algorithm = c->sym ? NBODY_ALGO_SYMMETRIC : NBODY_ALGO_TILED;
   if (super_tile) *super_tile = c->sym ? c->sym_bi : 0;
+  return NBODY_OK;
+}
+
+int nbody_sym_pool_info(nbody_ctx *c, uint64_t *pool_bytes, int32_t *phases) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return nbody_sym_pool_info(nbody::multi_part(c->multi, 0), pool_bytes, phases);
+  if (pool_bytes) *pool_bytes = c->sym ? (uint64_t)c->sym_pool_elems * c->elem : 0;
+  if (phases) *phases = c->sym ? (int32_t)c->sym_phase_item0.size() - 1 : 0;
   return NBODY_OK;
 }
 

@@ -81,6 +81,13 @@ struct SymLaunch {
   int phase = 0;
   int n_local = 0;
   int own_begin = 0, own_count = 0;
+  // What one call of launch_forces_sym does (fp32; the fp64 launcher runs a whole pass): prepare (phase says which bodies),
+  // launch the items [item0, item1) of the launch order (item1 < 0: phase's own range), fold the j-side lists j_ptr / j_off
+  // into `send` — on top of what is there when fold_accumulate (pool phases after the first, sym_plan.h).
+  int item0 = 0, item1 = -1;
+  int do_prep = 1, do_fold = -1;     // do_fold < 0: as the phase says (phases 0 and 2 fold)
+  int fold_accumulate = 0;
+  int clear_detector = 1;            // the fold also clears the coincident-body table for the next pass (the pass's LAST fold only)
 };
 // forces + fold of the j-side rows into L.send
 hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);

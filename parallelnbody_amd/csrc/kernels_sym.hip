@@ -292,7 +292,10 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   if (L.np == 8 && L.kahan) return hipErrorInvalidValue;
   if (L.phase < 0 || L.phase > 2 || (L.phase != 0 && (L.fused || L.n_local < 0 || L.n_local > L.n_items))) return hipErrorInvalidValue;
   // which items this call launches, and which bodies it prepares (SymLaunch::phase)
-  const int item0 = L.phase == 2 ? L.n_local : 0, item1 = L.phase == 1 ? L.n_local : L.n_items;
+  int item0 = L.phase == 2 ? L.n_local : 0, item1 = L.phase == 1 ? L.n_local : L.n_items;
+  if (L.item1 >= 0) { item0 = L.item0; item1 = L.item1; }
+  if (item0 < 0 || item1 < item0 || item1 > L.n_items) return hipErrorInvalidValue;
+  const bool fold = L.do_fold < 0 ? L.phase != 1 : L.do_fold != 0;
   const SymItem *items = (const SymItem *)L.items + item0;
   dim3 grid(item1 - item0), block(kBlock), pgrid((L.n_pad + kBlock - 1) / kBlock);
   const bool detect = L.eps2 == 0.0 && L.dup_table != nullptr;
@@ -307,8 +310,9 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   int *general = (int *)L.general;
   const bool run_uni = general != nullptr && L.uni_host != 0, run_gen = general == nullptr || L.uni_host != 1;
   const int *gate = (run_uni && run_gen) ? general : nullptr;     // both forms launched: each looks at the finding
-  if (L.skip_prep) {
-    // the previous update_sym_fused_kernel left posg and the detector's verdict for exactly these positions
+  if (L.skip_prep || !L.do_prep) {
+    // the previous update_sym_fused_kernel left posg and the detector's verdict for exactly these positions (skip_prep), or
+    // an earlier call of this pass has prepared (do_prep = 0)
   } else if (detect) {      // the table and its flag words are zero: cleared at creation and by every pass's fold
     hipLaunchKernelGGL(sym_prep_kernel<true>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
                        L.n_pad, (float)L.G, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag_all, general,
@@ -319,7 +323,6 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
                        check_mass, (int *)nullptr);
   }
   if (grid.x == 0) {                                              // nothing to launch in this go (phase 2 of a plan without remote strips)
-    if (L.phase == 1) return hipGetLastError();
   } else {
 #define NBODY_SYM_K(NPV, ZM, BARE, KH, UNI, ZP, FLAG, RUNIF)                                                     \
   hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, UNI>), grid, block, 0, s, (const float4 *)L.posg, \
@@ -362,16 +365,16 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
 #undef NBODY_SYM_K
   }
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || L.fused || L.phase == 1) return e;       // fused: update_sym_fused_kernel folds the j-side rows
+  if (e != hipSuccess || L.fused || !fold) return e;              // fused: update_sym_fused_kernel folds the j-side rows
   dim3 rgrid((L.n_total + 63) / 64);                               // one workgroup per 64-body granule (sym_common.h, row folds)
   if (L.kahan)
     hipLaunchKernelGGL((reduce_j_kernel<float, true>), rgrid, block, 0, s, (const float4 *)L.pool, (float4 *)L.send,
                        (const unsigned int *)L.j_ptr, (const unsigned int *)L.j_off, L.n_total,
-                       (unsigned long long *)L.dup_table, detect ? L.dup_slots + 8 : 0);
+                       (unsigned long long *)L.dup_table, detect && L.clear_detector ? L.dup_slots + 8 : 0, L.fold_accumulate);
   else
     hipLaunchKernelGGL((reduce_j_kernel<float, false>), rgrid, block, 0, s, (const float4 *)L.pool, (float4 *)L.send,
                        (const unsigned int *)L.j_ptr, (const unsigned int *)L.j_off, L.n_total,
-                       (unsigned long long *)L.dup_table, detect ? L.dup_slots + 8 : 0);
+                       (unsigned long long *)L.dup_table, detect && L.clear_detector ? L.dup_slots + 8 : 0, L.fold_accumulate);
   return hipGetLastError();
 }
 

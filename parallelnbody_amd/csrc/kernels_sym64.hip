@@ -200,7 +200,7 @@ hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
   hipLaunchKernelGGL((reduce_j_kernel<double, false>), dim3((L.n_total + 63) / 64), block, 0, s,
                      (const double4 *)L.pool, (double4 *)L.send, (const unsigned int *)L.j_ptr,
                      (const unsigned int *)L.j_off, L.n_total, (unsigned long long *)L.dup_table,
-                     (L.eps2 == 0.0 && L.dup_table != nullptr) ? L.dup_slots + 8 : 0);
+                     (L.eps2 == 0.0 && L.dup_table != nullptr) ? L.dup_slots + 8 : 0, 0);
   return hipGetLastError();
 }
 

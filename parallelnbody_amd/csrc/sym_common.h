@@ -192,7 +192,8 @@ __global__ __launch_bounds__(kBlock) void reduce_j_kernel(const typename SymVec<
                                                           typename SymVec<R>::type *__restrict__ send,
                                                           const unsigned int *__restrict__ j_ptr,
                                                           const unsigned int *__restrict__ j_off, int n_total,
-                                                          unsigned long long *__restrict__ dup_table, int dup_words) {
+                                                          unsigned long long *__restrict__ dup_table, int dup_words,
+                                                          int accumulate) {
   using V = typename SymVec<R>::type;
   __shared__ R sh[kFoldWays][3][64];
   const int t = threadIdx.x, l = t & 63, way = t >> 6, g = blockIdx.x, b = g * 64 + l;
@@ -202,6 +203,10 @@ __global__ __launch_bounds__(kBlock) void reduce_j_kernel(const typename SymVec<
   fold_meet<R, KAHAN>(sh, l, way, sx, sy, sz, cx, cy, cz);
   if (way != 0 || b >= n_total) return;
   V o; o.x = sx; o.y = sy; o.z = sz; o.w = 0;
+  if (accumulate) {      // a later phase of a pass whose j-side segments share one pool area (sym_plan.h): on top of the earlier ones
+    const V prev = send[b];
+    o.x = prev.x + o.x; o.y = prev.y + o.y; o.z = prev.z + o.z;
+  }
   send[b] = o;
 }
 

@@ -45,7 +45,7 @@ bool fail(std::string *err, const char *msg) {
 }  // namespace
 
 bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, double k_guided, int min_sub, int own_mode,
-                    SymPlan *out, std::string *err) {
+                    SymPlan *out, std::string *err, uint64_t j_budget_elems) {
   if (n_total <= 0 || i_count <= 0 || i_begin < 0 || i_begin + i_count > n_total) return fail(err, "bad body range");
   if (bi < 64 || bi % 64 != 0) return fail(err, "bodies per i-set must be a multiple of 64");
   if (slots < 1 || !(k_guided >= 0.5) || min_sub < 1) return fail(err, "bad scheduling parameters");
@@ -128,17 +128,62 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
       it.j0 = (r.j_sub0 + pos) * 64;
       it.n_sub = n;
       it.flags = r.one_sided ? kSymOneSided : 0;
-      const bool j_side = !r.one_sided || own_mode != 0;              // does the item produce j-side sums
-      if (pool + (uint64_t)bi + (uint64_t)n * 64 >= (1ull << 32)) return fail(err, "partial-sum pool exceeds 2^32 elements");
-      it.slot_i = (uint32_t)pool; pool += (uint64_t)bi;
-      if (j_side) { it.slot_j = (uint32_t)pool; pool += (uint64_t)n * 64; }
-      else it.flags |= kSymNoJSide;
+      if (r.one_sided && own_mode == 0) it.flags |= kSymNoJSide;      // does the item produce j-side sums
+      it.reserved1 = (int32_t)P.items.size();                         // place in the canonical order (= the order of summation)
       P.items.push_back(it);
       pos += n;
       remaining -= cost;
     }
   }
+  // Launch order: the items whose strip lies inside the own slice first (stable).  The lists below name pool segments and
+  // are built in the canonical order, so the order of launch does not touch the order of summation.
+  {
+    const int o0 = P.own_gran0 * 64, o1 = o0 + P.own_grans * 64;
+    auto local = [&](const SymItem &it) { return it.j0 >= o0 && it.j0 + it.n_sub * 64 <= o1; };
+    std::stable_partition(P.items.begin(), P.items.end(), local);
+    P.n_local = 0;
+    while (P.n_local < (int)P.items.size() && local(P.items[(size_t)P.n_local])) ++P.n_local;
+  }
+  // Pool segments.  One pass (the usual case): every item owns an i-side and a j-side segment, laid out in canonical order.
+  // A j_budget (very large systems: the j-side segments grow as N^2 / (2 bi)) cuts the launch order into PHASES whose j-side
+  // segments share one area of at most that size: the items of a phase run, their j-side sums are folded into `send`, the
+  // next phase reuses the area.  The i-side segments (N / bi per strip... a few GB) stay to the end.
+  std::vector<size_t> canon(P.items.size());                         // canonical position -> launch position
+  for (size_t k = 0; k < P.items.size(); ++k) canon[(size_t)P.items[k].reserved1] = k;
+  uint64_t total_j = 0;
+  for (const SymItem &it : P.items) if (!(it.flags & kSymNoJSide)) total_j += (uint64_t)it.n_sub * 64;
+  const bool phased = j_budget_elems != 0 && total_j > j_budget_elems;
+  if (!phased) {
+    for (size_t c = 0; c < canon.size(); ++c) {
+      SymItem &it = P.items[canon[c]];
+      if (pool + (uint64_t)bi + (uint64_t)it.n_sub * 64 >= (1ull << 32)) return fail(err, "partial-sum pool exceeds 2^32 elements");
+      it.slot_i = (uint32_t)pool; pool += (uint64_t)bi;
+      if (!(it.flags & kSymNoJSide)) { it.slot_j = (uint32_t)pool; pool += (uint64_t)it.n_sub * 64; }
+      it.reserved0 = 0;
+    }
+    P.phase_item0.assign({0, (int)P.items.size()});
+  } else {
+    for (SymItem &it : P.items) { it.slot_i = (uint32_t)pool; pool += (uint64_t)bi; }
+    if (pool + j_budget_elems >= (1ull << 32)) return fail(err, "partial-sum pool exceeds 2^32 elements");
+    const uint64_t jbase = pool;
+    uint64_t used = 0, area = 0;
+    int phase = 0;
+    P.phase_item0.assign(1, 0);
+    for (size_t k = 0; k < P.items.size(); ++k) {
+      SymItem &it = P.items[k];
+      const uint64_t need = (it.flags & kSymNoJSide) ? 0 : (uint64_t)it.n_sub * 64;
+      if (need > j_budget_elems) return fail(err, "a strip's j-side segment exceeds the pool budget");
+      if (used + need > j_budget_elems) { ++phase; used = 0; P.phase_item0.push_back((int)k); }
+      it.slot_j = (uint32_t)(jbase + used);
+      used += need;
+      area = std::max(area, used);
+      it.reserved0 = phase;
+    }
+    P.phase_item0.push_back((int)P.items.size());
+    pool = jbase + area;
+  }
   P.pool_elems = pool;
+  const int n_phases = (int)P.phase_item0.size() - 1;
 
   // CSR over the own granules: i-side segments, in item order (a row's items are contiguous)
   P.i_ptr.assign((size_t)P.own_grans + 1, 0);
@@ -150,34 +195,41 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
   P.i_off.assign(P.i_ptr.back(), 0);
   {
     std::vector<uint32_t> fill(P.i_ptr.begin(), P.i_ptr.end() - 1);
-    for (const SymItem &it : P.items) {
+    for (size_t c = 0; c < canon.size(); ++c) {
+      const SymItem &it = P.items[canon[c]];
       const int g0 = it.i0 / 64 - P.own_gran0;
       for (int g = g0; g < g0 + sub_per_block && g < P.own_grans; ++g)
         P.i_off[fill[(size_t)g]++] = it.slot_i + (uint32_t)(g - g0) * 64u;
     }
   }
-  // CSR over all granules: j-side segments
-  P.j_ptr.assign((size_t)P.n_gran + 1, 0);
-  for (const SymItem &it : P.items)
-    if (!(it.flags & kSymNoJSide))
-      for (int k = 0; k < it.n_sub; ++k) P.j_ptr[(size_t)(it.j0 / 64 + k) + 1] += 1;
-  for (int g = 0; g < P.n_gran; ++g) P.j_ptr[(size_t)g + 1] += P.j_ptr[(size_t)g];
-  P.j_off.assign(P.j_ptr.back(), 0);
+  // CSR over all granules: j-side segments — one list set per phase, (n_gran + 1) pointers each, offsets into one j_off
   {
-    std::vector<uint32_t> fill(P.j_ptr.begin(), P.j_ptr.end() - 1);
+    const size_t stride = (size_t)P.n_gran + 1;
+    P.j_ptr.assign(stride * (size_t)n_phases, 0);
     for (const SymItem &it : P.items)
       if (!(it.flags & kSymNoJSide))
-        for (int k = 0; k < it.n_sub; ++k) P.j_off[fill[(size_t)(it.j0 / 64 + k)]++] = it.slot_j + (uint32_t)k * 64u;
+        for (int k = 0; k < it.n_sub; ++k) P.j_ptr[stride * (size_t)it.reserved0 + (size_t)(it.j0 / 64 + k) + 1] += 1;
+    uint64_t run = 0;
+    for (int ph = 0; ph < n_phases; ++ph) {                           // counts -> absolute positions in j_off
+      uint32_t *ptr = P.j_ptr.data() + stride * (size_t)ph;
+      uint64_t prev = run;
+      for (int g = 0; g <= P.n_gran; ++g) { const uint64_t c = ptr[g]; prev += c; ptr[g] = (uint32_t)prev; }
+      // ptr[g] now holds the END of granule g - 1's list, i.e. the start of granule g's: ptr[0] = start of the phase
+      run = prev;
+      if (run >= (1ull << 32)) return fail(err, "j-side lists exceed 2^32 entries");
+    }
+    P.j_off.assign((size_t)run, 0);
+    std::vector<uint32_t> fill(P.j_ptr.size());
+    for (int ph = 0; ph < n_phases; ++ph)
+      for (int g = 0; g < P.n_gran; ++g) fill[stride * (size_t)ph + (size_t)g] = P.j_ptr[stride * (size_t)ph + (size_t)g];
+    for (size_t c = 0; c < canon.size(); ++c) {
+      const SymItem &it = P.items[canon[c]];
+      if (it.flags & kSymNoJSide) continue;
+      for (int k = 0; k < it.n_sub; ++k)
+        P.j_off[fill[stride * (size_t)it.reserved0 + (size_t)(it.j0 / 64 + k)]++] = it.slot_j + (uint32_t)k * 64u;
+    }
   }
-  // Launch order: the items whose strip lies inside the own slice first (stable).  The lists above name pool segments, not
-  // item numbers, so the order of launch does not touch the order of summation.
-  {
-    const int o0 = P.own_gran0 * 64, o1 = o0 + P.own_grans * 64;
-    auto local = [&](const SymItem &it) { return it.j0 >= o0 && it.j0 + it.n_sub * 64 <= o1; };
-    std::stable_partition(P.items.begin(), P.items.end(), local);
-    P.n_local = 0;
-    while (P.n_local < (int)P.items.size() && local(P.items[(size_t)P.n_local])) ++P.n_local;
-  }
+  for (SymItem &it : P.items) { it.reserved0 = 0; it.reserved1 = 0; }
   *out = std::move(P);
   return true;
 }
@@ -193,13 +245,44 @@ extern "C" int nbody_sym_plan_describe_tenths(int32_t n_total, int32_t i_begin, 
   std::string why;
   if (i_count == 0) i_count = n_total - i_begin;
   if (k_guided_x10 < 1) return NBODY_ERR_INVALID;
-  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided_x10 / 10.0, min_sub, own_mode, &P, &why))
+  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided_x10 / 10.0, min_sub, own_mode, &P, &why, 0))
     return NBODY_ERR_UNSUPPORTED;
   if (n_items) *n_items = (int32_t)P.items.size();
   if (pool_elems) *pool_elems = P.pool_elems;
   if (items) {
     if (items_cap < (int32_t)P.items.size()) return NBODY_ERR_INVALID;
     static_assert(sizeof(nbody::SymItem) == 32, "SymItem is eight 32-bit words");
+    for (size_t k = 0; k < P.items.size(); ++k) {
+      const nbody::SymItem &it = P.items[k];
+      int32_t *o = items + 8 * k;
+      o[0] = it.i0; o[1] = it.j0; o[2] = it.n_sub; o[3] = it.flags;
+      o[4] = (int32_t)it.slot_i; o[5] = (int32_t)it.slot_j; o[6] = 0; o[7] = 0;
+    }
+  }
+  return NBODY_OK;
+}
+
+// The same for a plan whose j-side segments must share an area of at most j_budget_elems pool elements (phases); phases[]
+// receives the first item of every phase followed by the item count (n_phases + 1 values).
+extern "C" int nbody_sym_plan_describe_phased(int32_t n_total, int32_t i_begin, int32_t i_count, int32_t bodies_per_iset,
+                                              int32_t slots, int32_t k_guided_x10, int32_t min_sub, uint64_t j_budget_elems,
+                                              int32_t *n_items, uint64_t *pool_elems, int32_t *items, int32_t items_cap,
+                                              int32_t *n_phases, int32_t *phases, int32_t phases_cap) {
+  nbody::SymPlan P;
+  std::string why;
+  if (i_count == 0) i_count = n_total - i_begin;
+  if (k_guided_x10 < 1) return NBODY_ERR_INVALID;
+  if (!nbody::build_sym_plan(n_total, i_begin, i_count, bodies_per_iset, slots, k_guided_x10 / 10.0, min_sub, 1, &P, &why, j_budget_elems))
+    return NBODY_ERR_UNSUPPORTED;
+  if (n_items) *n_items = (int32_t)P.items.size();
+  if (pool_elems) *pool_elems = P.pool_elems;
+  if (n_phases) *n_phases = (int32_t)P.phase_item0.size() - 1;
+  if (phases) {
+    if (phases_cap < (int32_t)P.phase_item0.size()) return NBODY_ERR_INVALID;
+    for (size_t k = 0; k < P.phase_item0.size(); ++k) phases[k] = P.phase_item0[k];
+  }
+  if (items) {
+    if (items_cap < (int32_t)P.items.size()) return NBODY_ERR_INVALID;
     for (size_t k = 0; k < P.items.size(); ++k) {
       const nbody::SymItem &it = P.items[k];
       int32_t *o = items + 8 * k;

@@ -29,7 +29,7 @@ struct SymItem {          // 32 bytes, read by the force kernels with scalar loa
   int32_t flags;          // kSymOneSided, kSymNoJSide
   uint32_t slot_i;        // pool element where the i-side sums of bodies [i0, i0 + bi) start
   uint32_t slot_j;        // pool element where the j-side sums of bodies [j0, j0 + 64 n_sub) start (symmetric items)
-  int32_t reserved0, reserved1;
+  int32_t reserved0, reserved1;   // zero (the planner's scratch while it works)
 };
 enum { kSymOneSided = 1,      // the strip lies in the i-set's own block
        kSymNoJSide = 2 };     // the item writes no j-side sums (own_mode 0 only)
@@ -44,6 +44,9 @@ struct SymPlan {
   int n_src = 1;          // ranks sharing the bodies
   uint64_t pool_elems = 0;
   int n_local = 0;        // items [0, n_local): strips inside the own slice (all of them when the context owns all bodies)
+  // pool phases (build_sym_plan's j_budget): phase p = items [phase_item0[p], phase_item0[p + 1]) of the launch order; its
+  // j-side lists are j_ptr[p * (n_gran + 1) ...] (absolute positions in j_off).  One phase unless a budget was given and exceeded.
+  std::vector<int> phase_item0;
   std::vector<SymItem> items;
   std::vector<uint32_t> i_ptr, i_off;   // CSR over OWN granules: i-side segments (+ offset of the granule inside them)
   std::vector<uint32_t> j_ptr, j_off;   // CSR over ALL granules: j-side segments
@@ -53,7 +56,9 @@ struct SymPlan {
 // min_sub: shortest strip, in subtiles; own_mode: how the kernel treats strips inside the i-set's own block — 1 (fp32):
 // register pairs above the subtile's own pair symmetric, that pair one-sided, j-side sums written; 2 (fp64): the same
 // slot by slot; 0: one-sided throughout, no j-side sums (no kernel does that any more; kept for the cost model's tests).  Returns false (and says why) when the owned range does not fit the plan.
+// j_budget_elems: 0 = one pass whatever the pool's size; otherwise the j-side segments of a phase may take at most that many
+// pool elements, and a system whose j-side segments exceed it is run in several phases that share one area (SymPlan).
 bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, double k_guided, int min_sub, int own_mode,
-                    SymPlan *out, std::string *err);
+                    SymPlan *out, std::string *err, uint64_t j_budget_elems = 0);
 
 }  // namespace nbody

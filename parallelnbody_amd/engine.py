@@ -68,6 +68,25 @@ def sym_plan(n_total, i_begin=0, i_count=0, bodies_per_iset=4096, slots=512, k_g
     return items, pe.value
 
 
+def sym_plan_phased(n_total, j_budget_elems, i_begin=0, i_count=0, bodies_per_iset=4096, slots=512, k_guided=3, min_sub=4):
+    """A plan whose j-side segments share a pool area of at most j_budget_elems elements (csrc/sym_plan.h, pool phases).
+    Returns (items[n,8], pool_elems, phase_item0[n_phases + 1])."""
+    L = _lib.lib()
+    n, pe, nph = ctypes.c_int32(), ctypes.c_uint64(), ctypes.c_int32()
+    k10 = int(round(float(k_guided) * 10))
+    args = (n_total, i_begin, i_count, bodies_per_iset, slots, k10, min_sub, int(j_budget_elems))
+    rc = L.nbody_sym_plan_describe_phased(*args, ctypes.byref(n), ctypes.byref(pe), None, 0, ctypes.byref(nph), None, 0)
+    if rc:
+        raise NBodyError(rc, "nbody_sym_plan_describe_phased: this range cannot be planned")
+    items = np.zeros((n.value, 8), np.int32)
+    ph = np.zeros(nph.value + 1, np.int32)
+    rc = L.nbody_sym_plan_describe_phased(*args, ctypes.byref(n), ctypes.byref(pe), items.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                          n.value, ctypes.byref(nph), ph.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), nph.value + 1)
+    if rc:
+        raise NBodyError(rc, "nbody_sym_plan_describe_phased: this range cannot be planned")
+    return items, pe.value, ph
+
+
 def device_count():
     return int(_lib.lib().nbody_device_count())
 
@@ -327,6 +346,12 @@ class NBodyEngine:
         v = ctypes.c_int32()
         self._check(self._L.nbody_equal_mass_form(self._h, ctypes.byref(v)))
         return bool(v.value)
+
+    def sym_pool(self):
+        """(bytes of the symmetric pass's partial-sum pool, phases sharing its j-side area) — (0, 0) on the one-sided kernels."""
+        b, ph = ctypes.c_uint64(), ctypes.c_int32()
+        self._check(self._L.nbody_sym_pool_info(self._h, ctypes.byref(b), ctypes.byref(ph)))
+        return b.value, ph.value
 
     def launch_config(self):
         v = [ctypes.c_int32() for _ in range(5)]

@@ -1086,13 +1086,96 @@ def test_stepping_is_reproducible_and_path_independent(nb):
     assert len(lines) == 5 * 2 * 5
 
 
-def test_auto_falls_back_to_the_one_sided_kernel_when_the_pool_would_not_fit(nb):
-    """The symmetric pass keeps N^2 / (2 x bodies per i-set) partial sums; beyond a third of the card AUTO must not try."""
-    with nb.NBodyEngine(1 << 23) as e:
+def test_pool_phases_at_small_sizes(nb, oracle):
+    """The symmetric pass keeps N^2 / (2 x bodies per i-set) j-side partial sums; when they would not fit the pass runs in
+    PHASES that share one pool area, each phase's sums folded into the rows before the next reuses it (sym_plan.h).  Forced
+    here at sizes the oracle covers (NBODY_SYM_POOL_BUDGET_MB, read when the context is created): single contexts, plain and
+    compensated, and sharded ones in one go and in two (strips inside the own slice first)."""
+    n = 65536
+    posm, vel = nb.ic_plummer(n, seed=41)
+    posm[:, 3] *= np.random.default_rng(8).uniform(0.5, 1.5, n).astype(np.float32)
+    p64 = posm.astype(np.float64)
+    sample = np.arange(17, n, n // 48)
+    ref = np.concatenate([oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1) for i in sample])
+    ref_soft = np.concatenate([oracle.forces_direct_f64(p64[:, :3], p64[:, 3], eps=0.5, i0=int(i), i1=int(i) + 1) for i in sample])
+    with nb.NBodyEngine(n) as one:
+        pool1, ph1 = one.sym_pool()
+        assert ph1 == 1
+        one.set_state(posm, vel); one.step(0.01, 2)
+        s_one = one.state()
+    os.environ["NBODY_SYM_POOL_BUDGET_MB"] = "8"
+    try:
+        with nb.NBodyEngine(n) as e:
+            pool, ph = e.sym_pool()
+            assert ph >= 4 and pool < pool1 and e.launch_config()["algorithm"] == "symmetric"
+            e.set_state(posm, vel)
+            e.compute_forces()
+            assert rel_err(e.accelerations()[sample], ref).max() < TOL_ACC
+            e.step(0.01, 2)                                       # stepping on the phased pass (never the fused update)
+            for x, y in zip(e.state(), s_one):
+                np.testing.assert_allclose(x[:, :3], y[:, :3], rtol=0, atol=2e-5 * np.abs(y[:, :3]).max())
+        with nb.NBodyEngine(n, precision="f32_kahan", eps=0.5) as e:
+            assert e.sym_pool()[1] >= 4
+            e.set_state(posm, vel)
+            e.compute_forces()
+            assert rel_err(e.accelerations()[sample], ref_soft).max() < 2e-6
+        for goes in (1, 2):                                       # four ranks, exchange staged through the host
+            ic = n // 4
+            engs = [nb.NBodyEngine(n, i_begin=r * ic, i_count=ic) for r in range(4)]
+            try:
+                for e in engs:
+                    assert e.sym_pool()[1] >= 2
+                    e.set_state(posm, vel)
+                    if goes == 1:
+                        e.step_begin()
+                    else:
+                        e.step_begin_local(); e.step_begin_remote()
+                sends = [e.exchange_read_send() for e in engs]
+                acc = []
+                for r, e in enumerate(engs):
+                    e.exchange_write_recv(np.concatenate([sd[r * ic:(r + 1) * ic] for sd in sends]))
+                    e.step_end(0.0)
+                    acc.append(e.accelerations())
+            finally:
+                for e in engs:
+                    e.close()
+            a = np.concatenate(acc)
+            assert rel_err(a[sample], ref).max() < TOL_ACC
+            if goes == 1:
+                a_one_go = a
+            else:
+                np.testing.assert_array_equal(a, a_one_go)       # the cut into goes does not touch the sums
+    finally:
+        del os.environ["NBODY_SYM_POOL_BUDGET_MB"]
+
+
+def test_auto_stays_symmetric_at_n_2p23(nb, oracle):
+    """N = 2^23 on one card: the one-pass pool would be 148 GB; in phases it stays within 32 GB and AUTO keeps the symmetric
+    kernel.  One force pass (7e13 interactions), sampled bodies against the fp64 direct sum; fp64 has no phased form and
+    still leaves to the one-sided kernel; N = 2^22 keeps its one-pass plan."""
+    n = 1 << 23
+    posm, vel = nb.ic_plummer(n, seed=23)
+    with nb.NBodyEngine(n, time_kernels=True) as e:
         cfg = e.launch_config()
-        assert cfg["algorithm"] == "tiled" and cfg["kernel"] == "forces_tile_pk_kernel"
-    with pytest.raises(nb.NBodyError) as err:
-        nb.NBodyEngine(1 << 23, algorithm=2)
-    assert err.value.code == nb._lib.ERR_UNSUPPORTED and "partial-sum pool" in str(err.value)
+        pool, ph = e.sym_pool()
+        assert cfg["algorithm"] == "symmetric" and cfg["kernel"] == "forces_sym_pk_kernel" and cfg["i_per_thread"] == 16
+        assert ph >= 4 and pool <= 32 * (1 << 30)
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+        ms, k = e.kernel_time(nb.KERNEL_FORCES)
+    assert np.all(np.isfinite(a))
+    assert float(n) * n / (ms / k * 1e-3) > 5.5e12                # the symmetric pass's rate, not the one-sided kernel's 4.4e12
+    import bench
+    bodies = bench.sample_bodies(0, n, cfg["super_tile"], cfg["i_per_thread"], seed=23)[:20]
+    p64 = posm.astype(np.float64)
+    for i in bodies:
+        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1, nthreads=8)
+        assert rel_err(a[i:i + 1], ref).max() < TOL_ACC, i
+    f = (a.astype(np.float64) * p64[:, 3:4]).sum(0)               # Newton's third law over all bodies
+    assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * p64[:, 3]).sum() < 1e-6
+    del a, p64
     with nb.NBodyEngine(1 << 22) as e:
-        assert e.launch_config()["algorithm"] == "symmetric"
+        assert e.launch_config()["algorithm"] == "symmetric" and e.sym_pool()[1] == 1
+    with nb.NBodyEngine(n, precision="f64") as e:
+        assert e.launch_config()["algorithm"] == "tiled"

@@ -119,3 +119,38 @@ def test_sharded_plans_launch_the_strips_inside_the_own_slice_first(nb, n, ranks
         assert 0.5 / ranks < share < 2.0 / ranks
     items, _ = nb.sym_plan(n, 0, 0, bi, 512, 3, 4)                         # one context: everything is local
     assert np.all(items[:, 1] + 64 * items[:, 2] <= -(-n // 64) * 64)
+
+
+@pytest.mark.parametrize("n,ranks,bi,budget_frac", [(65536, 1, 4096, 0.3), (131072, 1, 4096, 0.11), (65536, 2, 2048, 0.4)])
+def test_pool_phases_share_one_j_side_area(nb, n, ranks, bi, budget_frac):
+    # very large systems: the j-side segments (N^2 / (2 bi) elements) are run in phases that share one pool area.  Same
+    # items, same pairs; inside a phase no two segments overlap, the area is reused from phase to phase, the i-side
+    # segments stay apart to the end, and the pool is what the budget promises.
+    ic = n // ranks
+    for r in range(ranks):
+        ib, icc = (r * ic, ic) if ranks > 1 else (0, 0)
+        base, pool1 = nb.sym_plan(n, ib, icc, bi, 512, 3, 4)
+        total_j = int(64 * base[base[:, 3] & 2 == 0][:, 2].sum())
+        budget = int(total_j * budget_frac)
+        items, pool, ph = nb.sym_plan_phased(n, budget, ib, icc, bi, 512, 3, 4)
+        assert len(ph) - 1 >= int(1 / budget_frac) and ph[0] == 0 and ph[-1] == len(items) and np.all(np.diff(ph) > 0)
+        # the same strips as the one-pass plan, in the same launch order
+        np.testing.assert_array_equal(items[:, :4], base[:, :4])
+        i_end = len(items) * bi                                  # i-side segments first, one per item
+        assert sorted(items[:, 4].astype(np.int64).tolist()) == list(range(0, i_end, bi))
+        area = 0
+        for p in range(len(ph) - 1):
+            seg = items[ph[p]:ph[p + 1]]
+            s0 = seg[:, 5].astype(np.int64)
+            ln = 64 * seg[:, 2].astype(np.int64)
+            order = np.argsort(s0)
+            assert s0[order][0] == i_end                         # every phase starts at the area's first element
+            assert np.all(s0[order][1:] >= (s0 + ln)[order][:-1])   # disjoint inside the phase
+            assert (s0 + ln).max() - i_end <= budget
+            area = max(area, int((s0 + ln).max()) - i_end)
+        assert pool == i_end + area and pool < pool1
+    # a budget that everything fits into: one phase, the one-pass plan exactly (slots included)
+    items, pool, ph = nb.sym_plan_phased(n, 1 << 40, 0, 0, bi, 512, 3, 4)
+    base, pool1 = nb.sym_plan(n, 0, 0, bi, 512, 3, 4)
+    assert len(ph) == 2 and pool == pool1
+    np.testing.assert_array_equal(items, base)
