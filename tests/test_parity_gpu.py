@@ -1103,7 +1103,7 @@ def test_pool_phases_at_small_sizes(nb, oracle):
         assert ph1 == 1
         one.set_state(posm, vel); one.step(0.01, 2)
         s_one = one.state()
-    os.environ["NBODY_SYM_POOL_BUDGET_MB"] = "8"
+    os.environ["NBODY_SYM_POOL_BUDGET_MB"] = "2"
     try:
         with nb.NBodyEngine(n) as e:
             pool, ph = e.sym_pool()
