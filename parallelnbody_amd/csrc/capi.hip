@@ -249,36 +249,35 @@ void choose_algorithm(nbody_ctx *c) {
   } catch (const std::bad_alloc &) {
     why = "out of host memory";
   }
+  // The partial-sum pool must fit comfortably: at most a third of the card's TOTAL memory (and 2^32 elements).  Beyond that
+  // (N = 2^23 on one 288 GB card: the j-side segments alone are 137 GB) the fp32 pass runs in PHASES that share one j-side
+  // area, sized so that the whole pool stays within 32 GB (sym_plan.h); fp64 has no phased form and leaves to the
+  // one-sided kernel.  NBODY_SYM_POOL_BUDGET_MB forces phases at any size (tests).
+  size_t free_b = 0, total_b = 0;
+  const int forced_mb = f64 ? 0 : env_int("NBODY_SYM_POOL_BUDGET_MB", 0);
+  const bool too_big = !planned ? why.find("2^32") != std::string::npos
+                                : (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0 &&
+                                   (double)plan->pool_elems * (f64 ? 32.0 : 16.0) > (double)total_b / 3.0);
+  if (!f64 && (forced_mb > 0 || too_big)) {
+    const double cap = 32.0 * 1073741824.0 / 16.0;                                    // elements
+    double budget = forced_mb > 0 ? (double)forced_mb * 1048576.0 / 16.0 : 20.0 * 1073741824.0 / 16.0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      try {
+        planned = nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, 1, plan, &why,
+                                        (uint64_t)budget);
+      } catch (const std::bad_alloc &) { why = "out of host memory"; planned = false; }
+      if (!planned || forced_mb > 0 || (double)plan->pool_elems <= cap) break;
+      budget -= (double)plan->pool_elems - cap;                                       // the i-side segments took more than 12 GB
+      if (budget < 2.0 * 1073741824.0 / 16.0) { planned = false; why = "the i-side segments leave no room for a shared j-side area"; break; }
+    }
+    if (planned && forced_mb == 0 && (double)plan->pool_elems > cap) { planned = false; why = "the partial-sum pool would exceed 32 GB even in phases"; }
+  } else if (planned && too_big) {
+    planned = false; why = "the partial-sum pool would exceed a third of the device memory";
+  }
   if (!planned) {
     g_create_error = "symmetric plan: " + why;
     delete plan;
     return;
-  }
-  // the partial-sum pool must fit comfortably: at most a third of the card's TOTAL memory.  Beyond that (N = 2^23 on one
-  // 288 GB card: the j-side segments alone are 137 GB) the fp32 pass runs in phases that share one j-side area, sized so
-  // that the whole pool stays within 32 GB (sym_plan.h); fp64 has no phased form and leaves to the one-sided kernel.
-  size_t free_b = 0, total_b = 0;
-  const int forced_mb = f64 ? 0 : env_int("NBODY_SYM_POOL_BUDGET_MB", 0);            // tests: pool phases at small sizes
-  if (forced_mb > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0 &&
-                        (double)plan->pool_elems * (f64 ? 32.0 : 16.0) > (double)total_b / 3.0)) {
-    bool ok = false;
-    if (!f64) {
-      const double i_side = (double)plan->items.size() * (double)bi;                  // elements that stay to the end
-      const double budget = forced_mb > 0 ? (double)forced_mb * 1048576.0 / 16.0 : 32.0 * 1073741824.0 / 16.0 - i_side;
-      if (forced_mb > 0 || budget >= 4.0 * 1073741824.0 / 16.0) {
-        try {
-          ok = nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, 1, plan, &why,
-                                     (uint64_t)budget);
-        } catch (const std::bad_alloc &) { why = "out of host memory"; ok = false; }
-      } else {
-        why = "the i-side segments alone leave no room for a shared j-side area";
-      }
-    }
-    if (!ok) {
-      g_create_error = "symmetric plan: the partial-sum pool would exceed a third of the device memory" + (why.empty() ? std::string() : " (" + why + ")");
-      delete plan;
-      return;
-    }
   }
   c->plan = plan;
   c->sym_bi = bi; c->sym_np = f64 ? ipt / 2 : np; c->sym_pad = plan->n_pad; c->sym_items_n = (int)plan->items.size();
