@@ -103,7 +103,10 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
     }
   }
 
-  // guided self-scheduling: each strip takes 1/(k * slots) of the cost still to hand out
+  // guided self-scheduling: each strip takes 1/(k * slots) of the cost still to hand out.  Plans with a pool budget (systems
+  // beyond N = 2^22) also cap a strip at 1024 subtiles: a lane adds a strip's terms one after the other in fp32, and the
+  // first strips of such a system would otherwise be chains of several hundred thousand terms.
+  const int max_sub = j_budget_elems != 0 ? 1024 : (1 << 30);
   long long remaining = total_cost;
   uint64_t pool = 0;
   const double kp = k_guided * slots;
@@ -113,7 +116,7 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
       const long long target = (long long)((double)remaining / kp);
       long long cost = 0;
       int n = 0;
-      while (pos + n < r.n_sub && (n < min_sub || cost + subtile_cost(r, pos + n, bi, own_mode) <= target)) {
+      while (pos + n < r.n_sub && n < max_sub && (n < min_sub || cost + subtile_cost(r, pos + n, bi, own_mode) <= target)) {
         cost += subtile_cost(r, pos + n, bi, own_mode);
         ++n;
       }
