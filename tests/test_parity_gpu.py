@@ -1173,10 +1173,10 @@ def test_auto_stays_symmetric_at_n_2p23(nb, oracle):
     for i in bodies:
         ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1, nthreads=8)
         worst = max(worst, float(rel_err(a[i:i + 1], ref).max()))
-    # plain fp32 at 8.4 million terms per body: the stated contract (1e-4), not the 2e-5 asserted at N <= 2^21 — the sums are
-    # chains of up to 65536 fp32 additions per strip here (the one-sided kernel's chains of 4 million terms are 1e-2 off on
-    # the same bodies: tools/check_phases.py); the compensated precision is there for this
-    assert worst < TOL_STATED, worst
+    # (phased plans cap a strip at 1024 subtiles: with the guided lengths alone the first strips are chains of several hundred
+    # thousand fp32 additions per lane and the same check reads 8.6e-4; the one-sided kernel, 4 million terms per chain, is
+    # 1.1e-2 off on these bodies — profiles/r03_pool_phases_n2p23.txt)
+    assert worst < TOL_ACC, worst
     f = (a.astype(np.float64) * p64[:, 3:4]).sum(0)               # Newton's third law over all bodies
     assert np.linalg.norm(f) / (np.linalg.norm(a, axis=1) * p64[:, 3]).sum() < 1e-6
     del a, p64
