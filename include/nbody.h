@@ -214,6 +214,8 @@ NBODY_API int nbody_exchange_write_recv(nbody_ctx *ctx, const void *host);
  * fp32 contexts that own all bodies only.  nbody_set_particles / nbody_set_state_* reset the "previous CoM" to zero.
  */
 NBODY_API int nbody_set_theta(nbody_ctx *ctx, float theta);
+/* The opening angle in force (nbody_params.theta, nbody_set_theta, or what nbody_load_checkpoint took over from a file). */
+NBODY_API int nbody_get_theta(nbody_ctx *ctx, float *theta);
 /* Nodes and levels of the last tree built, and its root CoM (= the next frame's root centre). */
 NBODY_API int nbody_bh_stats(nbody_ctx *ctx, int32_t *nodes, int32_t *levels, float root_com[3]);
 /* What DrawOctreeBoxes passes to DrawDebugBox when ShowOctree is set (OctreeSearch.cpp:39-40): for every body the box

@@ -11,6 +11,7 @@ dumped frame int64 frame number + n x 3 float32 positions — `read_trajectory(p
 """
 import argparse
 import json
+import sys
 import time
 
 import numpy as np
@@ -48,11 +49,14 @@ def main(argv=None):
     ap.add_argument("--checkpoint", help="write the final state here")
     ap.add_argument("--resume", help="start from this checkpoint instead of fresh initial conditions")
     ap.add_argument("--dump-positions", help="write the final positions (n x 3 float32, .npy)")
-    ap.add_argument("--theta", type=float, default=0.0,
-                    help="opening angle: 0 = exact all-pairs (default); 1.0 = the reference's shipped Barnes-Hut walk")
+    ap.add_argument("--theta", type=float, default=None,
+                    help="opening angle: 0 = exact all-pairs (default); 1.0 = the reference's shipped Barnes-Hut walk.  With "
+                         "--resume: the file's own opening angle unless this option says otherwise (then it is announced)")
     ap.add_argument("--sync-energy", action="store_true",
                     help="energy lines also carry the total with the staggered velocity pulled to the positions' time "
-                         "(v_n = v_{n-1/2} + dt/2 a_n: one extra force pass per line; the state is not touched)")
+                         "(v_n = v_{n-1/2} + dt/2 a_n: one extra force pass per line.  Positions, velocities and — at theta > 0 — "
+                         "the root of the next tree are not touched, so the trajectory is the same with and without; the stored "
+                         "accelerations are those of the extra pass)")
     ap.add_argument("--leapfrog-start", action="store_true",
                     help="fresh runs only: store v_{-1/2} = v_0 - dt/2 a_0, so the update (v += dt a; x += dt v) is a proper leapfrog")
     ap.add_argument("--trajectory", help="write positions every --trajectory-every frames to this file (read_trajectory reads it back)")
@@ -62,9 +66,13 @@ def main(argv=None):
     posm, vel = (ic_plummer(a.n, G=a.G, seed=a.seed) if a.plummer else ic_reference_box(a.n, a.size, seed=a.seed))
     if a.trajectory_every < 1:
         ap.error("--trajectory-every must be >= 1")
-    with NBodyEngine(a.n, device=a.device, precision=a.precision, G=a.G, eps=a.eps, theta=a.theta) as e:
+    with NBodyEngine(a.n, device=a.device, precision=a.precision, G=a.G, eps=a.eps, theta=a.theta or 0.0) as e:
         e.set_state(posm, vel)
         start = e.load_checkpoint(a.resume) if a.resume else 0
+        if a.resume and a.theta is not None and e.theta() != np.float32(a.theta):
+            print(f"--resume: {a.resume} was written at theta = {e.theta():g}; continuing at --theta {a.theta:g} as asked "
+                  "(not the trajectory the file belongs to)", file=sys.stderr)
+            e.set_theta(a.theta)
         f64 = a.precision == "f64"
         if a.leapfrog_start and not a.resume and a.dt > 0:
             e.compute_forces()

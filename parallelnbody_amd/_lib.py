@@ -103,6 +103,7 @@ def lib():
     sig("nbody_exchange_read_send", c_int, vp, vp)
     sig("nbody_exchange_write_recv", c_int, vp, vp)
     sig("nbody_set_theta", c_int, vp, c_f)
+    sig("nbody_get_theta", c_int, vp, ctypes.POINTER(c_f))
     sig("nbody_bh_stats", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), fp)
     sig("nbody_bh_leaf_boxes", c_int, vp, fp, sz)
     sig("nbody_bh_leaf_order", c_int, vp, ctypes.POINTER(c_i32))

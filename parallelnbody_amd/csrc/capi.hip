@@ -1466,6 +1466,12 @@ int nbody_set_theta(nbody_ctx *c, float theta) {
   return NBODY_OK;
 }
 
+int nbody_get_theta(nbody_ctx *c, float *theta) {
+  if (!c || !theta) return NBODY_ERR_INVALID;
+  *theta = c->multi ? 0.0f : c->theta;
+  return NBODY_OK;
+}
+
 int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com[3]) {
   if (!c) return NBODY_ERR_INVALID;
   if (c->multi) return fail(c, NBODY_ERR_STATE, "nbody_bh_stats: no tree has been built on this context");

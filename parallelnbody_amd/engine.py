@@ -212,6 +212,12 @@ class NBodyEngine:
         """Barnes-Hut opening angle (0 = exact all-pairs; the reference ships 1.0, OctreeSearch.cpp:85)."""
         self._check(self._L.nbody_set_theta(self._h, theta))
 
+    def theta(self):
+        """The opening angle in force (a checkpoint brings its own: nbody_load_checkpoint)."""
+        v = ctypes.c_float()
+        self._check(self._L.nbody_get_theta(self._h, ctypes.byref(v)))
+        return v.value
+
     def bh_stats(self):
         n, l = ctypes.c_int32(), ctypes.c_int32()
         com = np.zeros(3, np.float32)
