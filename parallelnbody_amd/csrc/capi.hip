@@ -1478,7 +1478,7 @@ int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com
   if (!c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_stats: no tree has been built on this context");
   if (int rc = use_device(c)) return rc;
   int n = 0, l = 0;
-  nbody::bh_stats(c->bh, &n, &l);
+  HIP_TRY(c, nbody::bh_stats(c->bh, c->stream, &n, &l));
   if (nodes) *nodes = n;
   if (levels) *levels = l;
   if (root_com) HIP_TRY(c, nbody::bh_get_tree_com(c->bh, root_com, c->stream));
@@ -1549,7 +1549,7 @@ int nbody_kernel_time_reset(nbody_ctx *c) {
 const char *nbody_force_kernel_name(const nbody_ctx *c) {
   if (!c) return "";
   if (c->multi) return nbody_force_kernel_name(nbody::multi_part(c->multi, 0));
-  if (c->theta > 0.0f) return c->p.n_total <= 4096 ? "bh_walk_compact_kernel (+ bh_small_build_kernel)" : "bh_walk_kernel (+ tree build)";
+  if (c->theta > 0.0f) return c->p.n_total <= 4096 ? "bh_walk_compact_kernel (+ bh_small_build_kernel)" : "bh_walk_lane_kernel (+ tree build)";
   if (c->sym) return c->p.precision == NBODY_PREC_F64 ? "forces_sym_f64_kernel" : "forces_sym_pk_kernel";
   if (c->wave) return "small_pk_kernel";
   if (c->p.precision != NBODY_PREC_F64 && c->ipt % 2 == 0 && (c->p.eps > 0.0 || c->p.zero_mode != NBODY_ZERO_SELECT))

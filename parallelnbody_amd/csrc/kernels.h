@@ -118,7 +118,7 @@ hipError_t bh_get_tree_com(BhState *b, float out[3], hipStream_t s);   // root C
 void bh_set_div_mode(BhState *b, int div_mode);            // 0: `/=` in ComputeMass multiplies by the reciprocal; 1: divides
 // order[k] = the body whose leaf a depth-first walk (children 0..7) meets k-th in the last tree built (host array, n ints)
 hipError_t bh_leaf_order(BhState *b, int *out_host, hipStream_t s);
-void bh_stats(const BhState *b, int *nodes, int *levels);
+hipError_t bh_stats(BhState *b, hipStream_t s, int *nodes, int *levels);   // waits for the stream when the last tree's counts are still on their way
 // out[body] = (ox, oy, oz, Size) of the leaf holding the body, for the last tree built
 hipError_t bh_leaf_boxes(BhState *b, void *out, hipStream_t s);
 hipError_t bh_get_root_com(BhState *b, float out[3], hipStream_t s);

@@ -3,19 +3,18 @@
 // Restated on the device, operation by operation in the reference's types (paths relative to
 // /root/reference/Source/NBody/):
 //   class Octree           OctreeSearch.h:21-109   region octree, <= 1 body per leaf, 8 children per split
-//   Octree::Add            .h:60-81    -> bh_keys_kernel + radix sort + bh_split_kernel.  The tree the reference
-//                                          builds depends only on the SET of positions and on the root box, not on
-//                                          the insertion order: a cell is internal iff it holds >= 2 bodies.  A
-//                                          body's path (octant = 4[x>=ox] + 2[y>=oy] + [z>=oz] per level, child
-//                                          centre = centre +- Size*0.5 evaluated as float(double + double)) is
-//                                          computed exactly as Add walks it, packed 3 bits per level into two
-//                                          64-bit keys (42 levels), sorted (rocPRIM radix sort), and cells are split level by level.
-//   Octree::ComputeMass    .h:83-97    -> bh_upsweep_kernel, children 0..7 in order, fp32, /= as reciprocal multiply (or division: div_mode)
-//   Octree::ComputeForces  .h:99-108   -> bh_walk_kernel: depth-first, children 0..7, `Size/d < Theta || leaf`,
-//                                          d == 0 skips (also a whole subtree whose CoM coincides with the body),
-//                                          scale factor 1e4*M/d^3 in double rounded once to float, separate fp32
-//                                          multiply and add.  (d*d)*d in double is the correctly rounded d^3: d*d
-//                                          is exact for a float d.
+//   Octree::Add            .h:60-81    The tree the reference builds depends only on the SET of positions and on the root box,
+//                                          not on the insertion order: a cell is internal iff it holds >= 2 bodies.  A body's
+//                                          path (octant = 4[x>=ox] + 2[y>=oy] + [z>=oz] per level, child centre = centre +-
+//                                          Size*0.5 evaluated as float(double + double)) is computed exactly as Add walks it
+//                                          and packed 3 bits per level into two 64-bit keys (42 levels); the sorted keys say
+//                                          which cells exist, and number them in depth-first order (the compact tree below).
+//   Octree::ComputeMass    .h:83-97    -> sweep_compact_cell, children in octant order, fp32, /= as reciprocal multiply (or division: div_mode)
+//   Octree::ComputeForces  .h:99-108   -> the walks: depth-first, children 0..7, `Size/d < Theta || leaf` (as a threshold on
+//                                          the squared distance: accept_threshold), d == 0 skips (also a whole subtree whose
+//                                          CoM coincides with the body), scale factor 1e4*M/d^3 in double rounded once to
+//                                          float, separate fp32 multiply and add.  (d*d)*d in double is the correctly rounded
+//                                          d^3: d*d is exact for a float d.
 //   CreateOctree root rule .cpp:77-79  root centre = previous tree's CoM (zero the first time), half-width = Size
 //                                          from ComputeCubeSize (.cpp:47-56, about the WORLD origin — bodies may lie
 //                                          outside the root box; octant tests do not care).
@@ -25,7 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 
+#include <algorithm>
+
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "kernels.h"
 
@@ -43,247 +45,6 @@ __device__ __forceinline__ void child_box(const float o[3], float size, int c, f
   out[1] = (float)((double)o[1] + (double)size * ((c & 2) ? 0.5 : -0.5));
   out[2] = (float)((double)o[2] + (double)size * ((c & 1) ? 0.5 : -0.5));
   *csize = (float)(0.5 * (double)size);
-}
-
-__global__ __launch_bounds__(kB) void bh_keys_kernel(const float4 *__restrict__ posm, int n,
-                                                     const float *__restrict__ root /* ox,oy,oz,size */,
-                                                     unsigned long long *__restrict__ key_hi,
-                                                     unsigned long long *__restrict__ key_lo,
-                                                     unsigned int *__restrict__ idx) {
-  const int i = blockIdx.x * kB + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = posm[i];
-  float o[3] = {root[0], root[1], root[2]};
-  float size = root[3];
-  unsigned long long hi = 0, lo = 0;
-  for (int l = 0; l < kMaxLevels; ++l) {
-    int c = 0;                                            // GetOctant, .h:50-56
-    if (p.x >= o[0]) c |= 4;
-    if (p.y >= o[1]) c |= 2;
-    if (p.z >= o[2]) c |= 1;
-    if (l < kLevelsPerKey) hi = (hi << 3) | (unsigned long long)c;
-    else lo = (lo << 3) | (unsigned long long)c;
-    float no[3], ns;
-    child_box(o, size, c, no, &ns);
-    o[0] = no[0]; o[1] = no[1]; o[2] = no[2]; size = ns;
-  }
-  key_hi[i] = hi; key_lo[i] = lo; idx[i] = (unsigned int)i;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kB) void bh_gather_kernel(const T *__restrict__ src, const unsigned int *__restrict__ idx,
-                                                       T *__restrict__ dst, int n) {
-  const int i = blockIdx.x * kB + threadIdx.x;
-  if (i < n) dst[i] = src[idx[i]];
-}
-
-// Node storage (SoA).  link = (first_child or -1, particle or -1, skip, level); range = [lo, hi) in sorted order.
-struct Nodes {
-  float4 *box;     // ox, oy, oz, size
-  float4 *com;     // cx, cy, cz, M
-  int4 *link;
-  int2 *range;
-};
-
-__global__ void bh_root_kernel(Nodes nd, const float *__restrict__ root, const float4 *__restrict__ posm,
-                               const unsigned int *__restrict__ sidx, int n, int *__restrict__ counters,
-                               int *__restrict__ frontier) {
-  // counters: [0] nodes used, [1] next-frontier size, [2] error flag, [3] current frontier size
-  nd.box[0] = make_float4(root[0], root[1], root[2], root[3]);
-  nd.range[0] = make_int2(0, n);
-  counters[0] = 1; counters[1] = 0; counters[2] = 0;
-  if (n >= 2) {
-    nd.link[0] = make_int4(-1, -1, -1, 0);
-    nd.com[0] = make_float4(0.f, 0.f, 0.f, 0.f);          // TotalMass(0), CenterOfMass(ZeroVector): ctor .h:33
-    frontier[0] = 0; counters[3] = 1;
-  } else {
-    const unsigned int b = sidx[0];
-    const float4 p = posm[b];
-    nd.link[0] = make_int4(-1, (int)b, -1, 0);
-    nd.com[0] = p;                                         // leaf: CoM = Position, TotalMass = Mass (.h:85-88)
-    counters[3] = 0;
-  }
-}
-
-// Create the 8 children of cell `me`, which holds >= 2 bodies (.h:68-75) — EIGHT consecutive lanes per cell, lane c
-// makes child c: the eight binary searches (where does key digit > c start?) run side by side instead of one after
-// the other (88 dependent loads for the root of a 2000-body tree), the lower bound comes from the neighbour lane.
-// All eight lanes of a group must call this together.  node_counter / next_counter / err: global memory or LDS.
-__device__ __forceinline__ void split_cell8(const Nodes &nd, const unsigned long long *khi,
-                                            const unsigned long long *__restrict__ klo,
-                                            const unsigned int *__restrict__ sidx, const float4 *__restrict__ posm, int me,
-                                            int c, int *__restrict__ nxt, int *node_counter, int *next_counter, int *err,
-                                            int node_cap) {
-  const int4 lk = nd.link[me];
-  const int level = lk.w;
-  const int2 rg = nd.range[me];
-  if (level >= kMaxLevels) { if (c == 0) atomicExch(err, 1); return; }  // bodies closer than Size/2^42: the reference would recurse on
-  const unsigned long long *kw = level < kLevelsPerKey ? khi : klo;      // only the word that holds this level's digit
-  const int ksh = 3 * (kLevelsPerKey - 1 - (level < kLevelsPerKey ? level : level - kLevelsPerKey));
-  int base = 0;
-  if (c == 0) base = atomicAdd(node_counter, 8);
-  base = __shfl(base, 0, 8);
-  if (base + 8 > node_cap) { if (c == 0) atomicExch(err, 2); return; }
-  const float4 bx = nd.box[me];
-  // bodies of this cell are sorted by key, so those of child c are contiguous: find where digit > c starts
-  int a = rg.x, b = rg.y;
-  while (a < b) {
-    const int m = (a + b) >> 1;
-    if ((int)((kw[m] >> ksh) & 7ull) <= c) a = m + 1; else b = m;
-  }
-  const int hi = a;
-  int lo = __shfl_up(hi, 1, 8);
-  if (c == 0) lo = rg.x;
-  if (c == 0) nd.link[me] = make_int4(base, -1, lk.z, level);
-  const int cnt = hi - lo, id = base + c;
-  const float o[3] = {bx.x, bx.y, bx.z};
-  float co[3], cs;
-  child_box(o, bx.w, c, co, &cs);
-  nd.box[id] = make_float4(co[0], co[1], co[2], cs);
-  nd.range[id] = make_int2(lo, hi);
-  const int skip = (c < 7) ? id + 1 : lk.z;              // next node of a depth-first walk that does not descend
-  if (cnt >= 2) {
-    nd.link[id] = make_int4(-1, -1, skip, level + 1);
-    nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-    nxt[atomicAdd(next_counter, 1)] = id;
-  } else if (cnt == 1) {
-    const unsigned int body = sidx[lo];
-    nd.link[id] = make_int4(-1, (int)body, skip, level + 1);
-    nd.com[id] = posm[body];
-  } else {
-    nd.link[id] = make_int4(-1, -1, skip, level + 1);
-    nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);        // empty leaf: TotalMass 0, CoM ZeroVector
-  }
-}
-
-// Reserve `v` slots for every active lane of the wave with ONE atomicAdd on *counter (hundreds of thousands of cells
-// per level would otherwise queue on a single address); returns this lane's first slot.
-__device__ __forceinline__ int wave_reserve(int *counter, int v) {
-  const unsigned long long active = __ballot(1);
-  const int lane = threadIdx.x & 63;
-  int before = 0, total = 0;
-  for (unsigned long long m = active; m != 0ull; m &= m - 1ull) {      // lanes in ascending order
-    const int l = __ffsll((long long)m) - 1;
-    const int vl = __shfl(v, l, 64);
-    if (l < lane) before += vl;
-    total += vl;
-  }
-  const int leader = __ffsll((long long)active) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(counter, total);
-  return __shfl(base, leader, 64) + before;
-}
-
-// The same for a constant `v` per lane: no scan needed.
-__device__ __forceinline__ int wave_reserve_const(int *counter, int v) {
-  const unsigned long long active = __ballot(1);
-  const int lane = threadIdx.x & 63;
-  const int leader = __ffsll((long long)active) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(counter, v * __popcll(active));
-  return __shfl(base, leader, 64) + v * __popcll(active & ((1ull << lane) - 1ull));
-}
-
-// Create the 8 children of cell `me` by ONE lane (levels with many cells: bandwidth- rather than latency-bound).
-__device__ __forceinline__ void split_cell1(const Nodes &nd, const unsigned long long *__restrict__ khi,
-                                            const unsigned long long *__restrict__ klo,
-                                            const unsigned int *__restrict__ sidx, const float4 *__restrict__ posm, int me,
-                                            int *__restrict__ nxt, int *node_counter, int *next_counter, int *err,
-                                            int node_cap) {
-  const int4 lk = nd.link[me];
-  const int level = lk.w;
-  const int2 rg = nd.range[me];
-  if (level >= kMaxLevels) { atomicExch(err, 1); return; }
-  const unsigned long long *kw = level < kLevelsPerKey ? khi : klo;
-  const int ksh = 3 * (kLevelsPerKey - 1 - (level < kLevelsPerKey ? level : level - kLevelsPerKey));
-  const int base = wave_reserve_const(node_counter, 8);
-  if (base + 8 > node_cap) { atomicExch(err, 2); return; }
-  nd.link[me] = make_int4(base, -1, lk.z, level);
-  const float4 bx = nd.box[me];
-  const float o[3] = {bx.x, bx.y, bx.z};
-  int bound[9];
-  bound[0] = rg.x;
-  int splitting = 0;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    int a = bound[c], b = rg.y;
-    while (a < b) {
-      const int m = (a + b) >> 1;
-      if ((int)((kw[m] >> ksh) & 7ull) <= c) a = m + 1; else b = m;
-    }
-    bound[c + 1] = a;
-    splitting += (a - bound[c] >= 2) ? 1 : 0;
-  }
-  int slot = wave_reserve(next_counter, splitting);
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int lo = bound[c], hi = bound[c + 1], cnt = hi - lo, id = base + c;
-    float co[3], cs;
-    child_box(o, bx.w, c, co, &cs);
-    nd.box[id] = make_float4(co[0], co[1], co[2], cs);
-    nd.range[id] = make_int2(lo, hi);
-    const int skip = (c < 7) ? id + 1 : lk.z;
-    if (cnt >= 2) {
-      nd.link[id] = make_int4(-1, -1, skip, level + 1);
-      nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-      nxt[slot++] = id;
-    } else if (cnt == 1) {
-      const unsigned int body = sidx[lo];
-      nd.link[id] = make_int4(-1, (int)body, skip, level + 1);
-      nd.com[id] = posm[body];
-    } else {
-      nd.link[id] = make_int4(-1, -1, skip, level + 1);
-      nd.com[id] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-}
-
-// Eight threads per cell of the current level that holds >= 2 bodies (LANES = 8), or one (LANES = 1).
-template <int LANES>
-__global__ __launch_bounds__(kB) void bh_split_kernel(Nodes nd, const unsigned long long *__restrict__ khi,
-                                                      const unsigned long long *__restrict__ klo,
-                                                      const unsigned int *__restrict__ sidx,
-                                                      const float4 *__restrict__ posm, const int *__restrict__ cur,
-                                                      int ncur, int *__restrict__ nxt, int *__restrict__ counters,
-                                                      int node_cap) {
-  const int g = blockIdx.x * kB + threadIdx.x;
-  const int f = LANES == 8 ? g >> 3 : g;
-  if (f >= ncur) return;
-  if (LANES == 8) split_cell8(nd, khi, klo, sidx, posm, cur[f], g & 7, nxt, &counters[0], &counters[1], &counters[2], node_cap);
-  else            split_cell1(nd, khi, klo, sidx, posm, cur[f], nxt, &counters[0], &counters[1], &counters[2], node_cap);
-}
-
-// Octree::ComputeMass of one cell whose children are done, .h:89-95.
-// div_mode: the reading of `CenterOfMass /= TotalMass` (.h:95) — 0: FVector::operator/=(float) multiplies by the fp32
-// reciprocal (UE4's implementation as remembered; the engine is not vendored), 1: three divisions.
-__device__ __forceinline__ void upsweep_cell(const Nodes &nd, int me, int div_mode) {
-#pragma clang fp contract(off)
-  const int base = nd.link[me].x;
-  float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
-  for (int c = 0; c < 8; ++c) {
-    const float4 ch = nd.com[base + c];
-    M = M + ch.w;
-    cx = cx + ch.w * ch.x; cy = cy + ch.w * ch.y; cz = cz + ch.w * ch.z;
-  }
-  if (M != 0.f) {
-    if (div_mode == 0) {
-      const float rv = 1.0f / M;                           // FVector::operator/=(float): multiply by the reciprocal
-      cx = cx * rv; cy = cy * rv; cz = cz * rv;
-    } else {
-      cx = cx / M; cy = cy / M; cz = cz / M;               // correctly rounded fp32 divisions
-    }
-  } else {
-    const float4 bx = nd.box[me];
-    cx = bx.x; cy = bx.y; cz = bx.z;
-  }
-  nd.com[me] = make_float4(cx, cy, cz, M);
-}
-
-// The cells of one level (deepest level first).
-__global__ __launch_bounds__(kB) void bh_upsweep_kernel(Nodes nd, const int *__restrict__ cells, int ncells, int div_mode) {
-  const int f = blockIdx.x * kB + threadIdx.x;
-  if (f >= ncells) return;
-  upsweep_cell(nd, cells[f], div_mode);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -904,84 +665,190 @@ __global__ __launch_bounds__(kB) void bh_small_leaf_boxes_kernel(SmallTree T, in
   out[T.sidx[i]] = make_float4(o[0], o[1], o[2], size);
 }
 
-// Octree::ComputeForces for every body (.h:99-108), bodies taken in key order for coherence.
-__global__ __launch_bounds__(kB) void bh_walk_kernel(Nodes nd, const float4 *__restrict__ posm,
-                                                     const unsigned int *__restrict__ sidx, int n, float theta, double G,
-                                                     float4 *__restrict__ acc) {
+template <typename T>
+__global__ __launch_bounds__(kB) void bh_gather_kernel(const T *__restrict__ src, const unsigned int *__restrict__ idx,
+                                                       T *__restrict__ dst, int n) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Larger systems (n > kSmBodies): the same compact preorder tree, built by the whole chip — path keys, two rocPRIM radix
+// sorts over the 126-bit key, the neighbours' shared digits, an exclusive scan that numbers the nodes, one pass that
+// writes the node words and the leaves, ComputeMass level by level (a launch per level over the bodies: body i opens the
+// cell of level l iff lcp(i-1) < l <= lcp(i)), and a walk with one lane per body (enough bodies to hide the loads: the
+// sixteen-lane windows of the small systems' walk buy latency, not throughput).  The host waits ONCE per frame — for the
+// deepest level and the verdict, while the scan and the node pass are already running.
+__global__ __launch_bounds__(64) void bh_root_thr_kernel(SmallTree T, const unsigned int *__restrict__ size_bits, float theta) {
+  __shared__ float s_size;
+  const int t = threadIdx.x;
+  if (t == 0) {
+    const float sz = __uint_as_float(*size_bits);             // Size as the bounds kernel left it (ComputeCubeSize)
+    T.root[0] = T.prev_com[0]; T.root[1] = T.prev_com[1]; T.root[2] = T.prev_com[2]; T.root[3] = sz;
+    s_size = sz;
+    T.hdr[5] = -1;                                            // deepest level with a cell of >= 2 bodies (bh_lcp_kernel)
+  }
+  __syncthreads();
+  if (t <= kMaxLevels) {
+    float sz = s_size;
+    for (int q = 0; q < t; ++q) sz = (float)(0.5 * (double)sz);   // .h:74
+    T.thr[t] = accept_threshold(sz, theta);
+  }
+}
+
+__global__ __launch_bounds__(kB) void bh_keys_kernel(const float4 *__restrict__ posm, int n,
+                                                     const float *__restrict__ root /* ox,oy,oz,size */,
+                                                     unsigned long long *__restrict__ key_hi,
+                                                     unsigned long long *__restrict__ key_lo,
+                                                     unsigned int *__restrict__ idx) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = posm[i];
+  float o[3] = {root[0], root[1], root[2]};
+  float size = root[3];
+  unsigned long long hi = 0, lo = 0;
+  for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
+  for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
+  key_hi[i] = hi; key_lo[i] = lo; idx[i] = (unsigned int)i;
+}
+
+// digits the sorted keys of positions a and a + 1 share (0 .. 42; 42: the same path all the way down)
+__device__ __forceinline__ int shared_digits(const unsigned long long *__restrict__ hi, const unsigned long long *__restrict__ lo, int a) {
+  const unsigned long long x = hi[a] ^ hi[a + 1];
+  if (x != 0ull) return (__clzll((long long)x) - 1) / 3;
+  const unsigned long long y = lo[a] ^ lo[a + 1];
+  if (y != 0ull) return kLevelsPerKey + (__clzll((long long)y) - 1) / 3;
+  return kMaxLevels;
+}
+
+// lcpS[i] = lcp(i - 1) (-1 at both ends); cnt[i] = cells body i opens + 1 (its leaf), cnt[n] = 0 for the scan
+__global__ __launch_bounds__(kB) void bh_lcp_kernel(SmallTree T, int n, signed char *__restrict__ lcpS, int *__restrict__ cnt) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  int ln = -1;
+  if (i < n) {
+    const int lp = i > 0 ? shared_digits(T.khi, T.klo, i - 1) : -1;
+    ln = i + 1 < n ? shared_digits(T.khi, T.klo, i) : -1;
+    lcpS[i] = (signed char)lp;
+    cnt[i] = (ln > lp ? ln - lp : 0) + 1;
+    if (i == n - 1) { lcpS[n] = (signed char)-1; cnt[n] = 0; }
+    if (ln == kMaxLevels) T.hdr[3] = 1;                        // the reference would recurse on: the frame is refused
+  }
+  int m = ln;                                                  // deepest level: one atomic per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(&T.hdr[5], m);
+}
+
+// body i (key order): the words of the cells it opens, its leaf's word, CoM and level
+__global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+                                                      const int *__restrict__ first, const signed char *__restrict__ lcpS) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  if (first[n] > T.cap) {                                      // (a pool sized for 42 cells per body cannot run out below 2^25 nodes)
+    if (i == 0) { T.hdr[0] = 0; T.hdr[3] = 2; }
+    return;
+  }
+  if (i == 0) T.hdr[0] = first[n];
+  const int lp = lcpS[i], ln = lcpS[i + 1], m0 = first[i];
+  const int open = ln > lp ? ln - lp : 0;
+  const unsigned long long h0 = T.khi[i], l0 = T.klo[i];
+  for (int q = 0; q < open; ++q) {                             // cell of level l whose first body is i
+    const int l = lp + 1 + q;
+    int upper = n;
+    if (l > 0) {
+      int x = i + 1, y = n;                                    // first body behind the cell
+      while (x < y) {
+        const int mid = (x + y) >> 1;
+        if (same_prefix(T.khi[mid], l > kLevelsPerKey ? T.klo[mid] : 0ull, h0, l > kLevelsPerKey ? l0 : 0ull, l)) x = mid + 1; else y = mid;
+      }
+      upper = x;
+    }
+    T.meta[m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first[upper];
+  }
+  const int level = (lp > ln ? lp : ln) + 1;                   // the leaf: one level below the deepest cell the body shares
+  const unsigned int body = T.sidx[i];
+  T.meta[m0 + open] = kLeafBit | ((unsigned int)level << kLevelShift) | body;
+  T.com[m0 + open] = posm[body];                               // CenterOfMass = Position, TotalMass = Mass (.h:85-88)
+  T.leaf_level[i] = (unsigned char)level;
+}
+
+// ComputeMass (.h:89-95) of the cells of level l: body i opens one iff lcp(i-1) < l <= lcp(i)
+__global__ __launch_bounds__(kB) void bh_sweep_level_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+                                                            const int *__restrict__ first, const signed char *__restrict__ lcpS,
+                                                            int l, int div_mode) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n || T.hdr[3] != 0) return;
+  const int lp = lcpS[i];
+  if (!(lp < l && l <= (int)lcpS[i + 1])) return;
+  const int m = first[i] + (l - lp - 1);
+  T.com[m] = sweep_compact_cell(T.com, T.meta, m, T.meta[m], l, div_mode, posm, T.root);
+}
+
+__global__ void bh_finish_kernel(SmallTree T, int n, int keep_root) {
+  if (T.hdr[3] != 0) return;
+  if (!keep_root) { const float4 c = T.com[0]; T.prev_com[0] = c.x; T.prev_com[1] = c.y; T.prev_com[2] = c.z; }   // .cpp:78
+  T.hdr[1] = T.hdr[0] - n; T.hdr[2] = T.hdr[5] + 1; T.hdr[4] = T.hdr[4] + 1;
+}
+
+// Octree::ComputeForces (.h:99-108) on the compact tree, one lane per body in key order, node by node: a 16-byte and a
+// 4-byte load, the squared distance and a compare per node (accept_threshold); root, double-precision factor and the three
+// multiply-adds only where a term is added.
+__global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, const float4 *__restrict__ posm, int n, double G,
+                                                          float4 *__restrict__ acc) {
 #pragma clang fp contract(off)
+  __shared__ float s_thr[kMaxLevels + 2];
+  if (threadIdx.x <= kMaxLevels) s_thr[threadIdx.x] = T.thr[threadIdx.x];
+  __syncthreads();
   const int k = blockIdx.x * kB + threadIdx.x;
   if (k >= n) return;
-  const unsigned int body = sidx[k];
+  const int nodes = T.hdr[0];
+  const unsigned int body = T.sidx[k];
   const float4 p = posm[body];
-  float ax = 0.f, ay = 0.f, az = 0.f;                      // Acceleration = ZeroVector, .cpp:84
+  float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   int node = 0;
-  while (node >= 0) {
-    const int4 lk = nd.link[node];
-    const bool leaf = lk.x < 0;
-    if (leaf && lk.y < 0) { node = lk.z; continue; }                      // .h:100
-    const float4 cm = nd.com[node];
+  while (node < nodes) {
+    const float4 cm = T.com[node];
+    const unsigned int w = T.meta[node];
+    const bool leaf = (w & kLeafBit) != 0u;
+    const int past = leaf ? node + 1 : (int)(w & kLinkMask);
     const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
     float d2 = ex * ex + ey * ey;
     d2 = d2 + ez * ez;
-    const float d = sqrtf(d2);   // FVector::Dist, .h:101 — correctly rounded (hipcc default); __fsqrt_rn is the 1-ulp native op
-    if (d == 0.f) { node = lk.z; continue; }                              // .h:102
-    const float size = nd.box[node].w;
-    if (size / d < theta || lk.y >= 0) {                                  // .h:103
-      const double dd = (double)d;
-      const float s = (float)(G * (double)cm.w / ((dd * dd) * dd));       // .h:104
-      ax = ax + s * (cm.x - p.x); ay = ay + s * (cm.y - p.y); az = az + s * (cm.z - p.z);
-      node = lk.z;
-    } else if (!leaf) {
-      node = lk.x;                                                        // children 0..7, .h:105-107
-    } else {
-      node = lk.z;
+    const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];   // .h:103
+    if (take && d2 != 0.f) {                                   // .h:102: d == 0 adds nothing ...
+      float tx, ty, tz;
+      force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
+      ax = ax + tx; ay = ay + ty; az = az + tz;
     }
+    node = (take || d2 == 0.f) ? past : node + 1;              // ... and ends the subtree; children 0..7 otherwise
   }
   acc[body] = make_float4(ax, ay, az, 0.f);
 }
 
-// root = (previous CoM, Size): Size arrives as the bit pattern bounds_kernel leaves; the CoM is the last tree's root.
-__global__ void bh_set_root_kernel(float *__restrict__ root, const float *__restrict__ prev_com,
-                                   const unsigned int *__restrict__ size_bits) {
-  root[0] = prev_com[0]; root[1] = prev_com[1]; root[2] = prev_com[2];
-  root[3] = __uint_as_float(*size_bits);
-}
-
-// What DrawOctreeBoxes hands to DrawDebugBox (OctreeSearch.cpp:39-40): the box (Origin, Size) of the leaf that
-// holds each body, written at the body's index.
-__global__ __launch_bounds__(kB) void bh_leaf_boxes_kernel(Nodes nd, int nodes, float4 *__restrict__ out) {
-  const int k = blockIdx.x * kB + threadIdx.x;
-  if (k >= nodes) return;
-  const int4 lk = nd.link[k];
-  if (lk.x < 0 && lk.y >= 0) out[lk.y] = nd.box[k];
-}
-
-__global__ void bh_save_com_kernel(Nodes nd, float *__restrict__ prev_com) {
-  const float4 c = nd.com[0];
-  prev_com[0] = c.x; prev_com[1] = c.y; prev_com[2] = c.z;
-}
 
 }  // namespace
 
-constexpr int kCoopCells = 32768;     // levels with fewer cells than this split with eight lanes per cell
-
 struct BhState {
   int n = 0, node_cap = 0;
-  bool small = false;          // n <= kSmBodies: one-workgroup build of the compact tree (bh_small_build_kernel)
-  SmallTree st{};
+  bool small = false;          // n <= kSmBodies: one workgroup builds the tree in LDS (bh_small_build_kernel)
+  SmallTree st{};              // the compact tree (either path)
   int frames_seen = 0;         // st.hdr[4] at the last bh_small_collect
+  // path keys: khi / klo in body order, khi2 / klo2 and idx2 the sorts' other buffers (larger systems)
   unsigned long long *khi = nullptr, *klo = nullptr, *khi2 = nullptr, *klo2 = nullptr;
   unsigned int *idx = nullptr, *idx2 = nullptr;
-  void *sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
-  Nodes nd{};
-  int *frontier = nullptr;     // all levels' internal cells, level after level
-  int *counters = nullptr;     // device: nodes used, next-frontier size, error, current size (small: the SmallTree header)
+  void *sort_tmp = nullptr, *scan_tmp = nullptr;
+  size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
+  int *first = nullptr, *cnt = nullptr;    // larger systems: [n + 1] first node of every body's group / its size
+  signed char *lcpS = nullptr;             // [n + 1] shared digits of neighbours
+  hipEvent_t ev = nullptr;                 // larger systems: "the verdict and the deepest level are on the host"
+  int *counters = nullptr;     // device: the tree's header (SmallTree::hdr; [5]: deepest level, larger systems)
   int *h_counters = nullptr;   // pinned
   float *root = nullptr;       // ox, oy, oz, size
   float *prev_com = nullptr;   // the previous tree's root CoM (zero before the first frame)
   int last_nodes = 0, last_levels = 0;
-  int div_mode = 0;            // reading of `/=` in ComputeMass (upsweep_cell)
+  bool stats_pending = false;  // larger systems: h_counters is being refreshed on the stream (bh_stats waits)
+  int div_mode = 0;            // reading of `/=` in ComputeMass (sweep_compact_cell)
 };
 
 #define BH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
@@ -989,6 +856,7 @@ struct BhState {
 hipError_t bh_create(BhState **out, int n) {
   BhState *b = new BhState();
   *out = b;                    // the caller destroys it whatever happens below
+  if (n > (int)kLinkMask) return hipErrorInvalidValue;      // a leaf's word holds its body's index in 25 bits
   b->n = n;
   b->small = n <= kSmBodies;
   BH_TRY(hipMalloc(&b->khi, sizeof(unsigned long long) * n));
@@ -1001,43 +869,44 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMemset(b->root, 0, sizeof(float) * 4));
   BH_TRY(hipMalloc(&b->prev_com, sizeof(float) * 3));
   BH_TRY(hipMemset(b->prev_com, 0, sizeof(float) * 3));    // FVector t = ZeroVector, .cpp:77
-  if (b->small) {
-    // worst case: every body opens a chain of 42 cells of its own (never, but the pool must not be what fails)
-    b->node_cap = ((kMaxLevels + 1) * n + 64 + 3) / 4 * 4;
-    SmallTree &t = b->st;
-    BH_TRY(hipMalloc(&t.com, sizeof(float4) * b->node_cap));
-    BH_TRY(hipMalloc(&t.meta, sizeof(unsigned int) * b->node_cap));
-    BH_TRY(hipMalloc(&t.leaf_level, (size_t)n));
-    BH_TRY(hipMalloc(&t.thr, sizeof(float) * (kMaxLevels + 2)));
-    BH_TRY(hipMalloc(&t.clocks, sizeof(long long) * kDbgClocks));
-    BH_TRY(hipMemset(t.clocks, 0, sizeof(long long) * kDbgClocks));
-    t.khi = b->khi; t.klo = b->klo; t.sidx = b->idx; t.hdr = b->counters; t.root = b->root; t.prev_com = b->prev_com;
-    t.cap = b->node_cap;
-    return hipSuccess;
-  }
-  b->node_cap = 8 * (4 * n + 1024) + 1;
+  // worst case: every body opens a chain of 42 cells of its own (never, but the pool must not be what fails)
+  b->node_cap = (int)std::min<long long>(((long long)(kMaxLevels + 1) * n + 64 + 3) / 4 * 4, (long long)kLinkMask);
+  SmallTree &t = b->st;
+  BH_TRY(hipMalloc(&t.com, sizeof(float4) * (size_t)b->node_cap));
+  BH_TRY(hipMalloc(&t.meta, sizeof(unsigned int) * (size_t)b->node_cap));
+  BH_TRY(hipMalloc(&t.leaf_level, (size_t)n));
+  BH_TRY(hipMalloc(&t.thr, sizeof(float) * (kMaxLevels + 2)));
+  BH_TRY(hipMalloc(&t.clocks, sizeof(long long) * kDbgClocks));
+  BH_TRY(hipMemset(t.clocks, 0, sizeof(long long) * kDbgClocks));
+  t.khi = b->khi; t.klo = b->klo; t.sidx = b->idx; t.hdr = b->counters; t.root = b->root; t.prev_com = b->prev_com;
+  t.cap = b->node_cap;
+  if (b->small) return hipSuccess;
   BH_TRY(hipMalloc(&b->khi2, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->klo2, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
+  t.klo = b->klo2;             // the sorted second key words (khi and idx end up sorted in place: bh_forces)
   size_t bytes = 0;
   BH_TRY(rocprim::radix_sort_pairs(nullptr, bytes, b->klo, b->klo2, b->idx, b->idx2, (unsigned int)n));
   b->sort_tmp_bytes = bytes;
   BH_TRY(hipMalloc(&b->sort_tmp, bytes));
-  BH_TRY(hipMalloc(&b->nd.box, sizeof(float4) * b->node_cap));
-  BH_TRY(hipMalloc(&b->nd.com, sizeof(float4) * b->node_cap));
-  BH_TRY(hipMalloc(&b->nd.link, sizeof(int4) * b->node_cap));
-  BH_TRY(hipMalloc(&b->nd.range, sizeof(int2) * b->node_cap));
-  BH_TRY(hipMalloc(&b->frontier, sizeof(int) * (b->node_cap / 8 + 8)));
+  BH_TRY(hipMalloc(&b->first, sizeof(int) * ((size_t)n + 1)));
+  BH_TRY(hipMalloc(&b->cnt, sizeof(int) * ((size_t)n + 1)));
+  BH_TRY(hipMalloc(&b->lcpS, (size_t)n + 1));
+  bytes = 0;
+  BH_TRY(rocprim::exclusive_scan(nullptr, bytes, b->cnt, b->first, 0, (size_t)n + 1, rocprim::plus<int>()));
+  b->scan_tmp_bytes = bytes;
+  BH_TRY(hipMalloc(&b->scan_tmp, bytes ? bytes : 16));
+  BH_TRY(hipEventCreateWithFlags(&b->ev, hipEventDisableTiming));
   return hipSuccess;
 }
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->sort_tmp, b->nd.box, b->nd.com, b->nd.link,
-                  b->nd.range, b->frontier, b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr,
-                  b->st.clocks};
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->sort_tmp, b->scan_tmp, b->first, b->cnt, b->lcpS,
+                  b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
+  if (b->ev) (void)hipEventDestroy(b->ev);
   delete b;
 }
 
@@ -1083,17 +952,16 @@ hipError_t bh_small_collect(BhState *b, hipStream_t s, int *status, int *frames)
 
 hipError_t bh_reset_root(BhState *b, hipStream_t s) { return hipMemsetAsync(b->prev_com, 0, sizeof(float) * 3, s); }
 
-// One CreateOctree (.cpp:74-89) on the device.  size_bits: device word holding Size as left by the bounds kernel.
-// *status: 0 ok, 1 depth limit (bodies closer than Size/2^42 — the reference would keep recursing), 2 node pool full.
+// One CreateOctree (.cpp:74-89) of a larger system on the device.  size_bits: device word holding Size as left by the
+// bounds kernel.  *status: 0 ok, 1 depth limit (bodies closer than Size/2^42 — the reference would keep recursing), 2 node pool.
 hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned int *size_bits, float theta, double G,
                      int keep_root, hipStream_t s, int *status) {
   if (b->small) return hipErrorInvalidValue;                  // bh_small_frame is the small systems' pass
   const float4 *posm = (const float4 *)posm_v;
-  float4 *acc = (float4 *)acc_v;
   const int n = b->n;
   const dim3 blk(kB), grd((n + kB - 1) / kB);
   *status = 0;
-  hipLaunchKernelGGL(bh_set_root_kernel, dim3(1), dim3(1), 0, s, b->root, b->prev_com, size_bits);
+  hipLaunchKernelGGL(bh_root_thr_kernel, dim3(1), dim3(64), 0, s, b->st, size_bits, theta);
   hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, posm, n, b->root, b->khi, b->klo, b->idx);
   // stable LSD sort over the 126-bit key: low word first, then the high word
   size_t tb = b->sort_tmp_bytes;
@@ -1103,49 +971,34 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->khi2, b->khi, b->idx2, b->idx, (unsigned int)n, 0u, 63u, s));
   // b->khi / b->idx are final; bring the low words (b->klo is still in body order) into the same order
   hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->klo, b->idx, b->klo2, n);
-
-  hipLaunchKernelGGL(bh_root_kernel, dim3(1), dim3(1), 0, s, b->nd, b->root, posm, b->idx, n, b->counters, b->frontier);
-  // level by level; the frontier of level l sits at frontier[off[l] .. off[l] + cnt[l])
-  int off[kMaxLevels + 2], cnt[kMaxLevels + 2];
-  int levels = 0, cur_off = 0;
-  BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
-  BH_TRY(hipStreamSynchronize(s));
-  int ncur = b->h_counters[3];
-  b->last_nodes = 1;
-  while (ncur > 0) {
-    if (levels > kMaxLevels) { *status = 1; return hipSuccess; }
-    off[levels] = cur_off; cnt[levels] = ncur; ++levels;
-    int *cur = b->frontier + cur_off, *nxt = cur + ncur;
-    if (ncur < kCoopCells)     // few cells: latency-bound, eight lanes per cell; many: one lane each
-      hipLaunchKernelGGL(bh_split_kernel<8>, dim3((8 * ncur + kB - 1) / kB), blk, 0, s, b->nd, b->khi, b->klo2, b->idx, posm,
-                         cur, ncur, nxt, b->counters, b->node_cap);
-    else
-      hipLaunchKernelGGL(bh_split_kernel<1>, dim3((ncur + kB - 1) / kB), blk, 0, s, b->nd, b->khi, b->klo2, b->idx, posm,
-                         cur, ncur, nxt, b->counters, b->node_cap);
-    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
-    BH_TRY(hipMemsetAsync(b->counters + 1, 0, sizeof(int), s));
-    BH_TRY(hipStreamSynchronize(s));
-    if (b->h_counters[2] != 0) { *status = b->h_counters[2]; return hipSuccess; }
-    cur_off += ncur;
-    ncur = b->h_counters[1];
-    b->last_nodes = b->h_counters[0];
+  hipLaunchKernelGGL(bh_lcp_kernel, grd, blk, 0, s, b->st, n, b->lcpS, b->cnt);
+  BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+  BH_TRY(hipEventRecord(b->ev, s));
+  // the node numbers and the node words need nothing from the host: they run while it waits for the verdict
+  tb = b->scan_tmp_bytes;
+  BH_TRY(rocprim::exclusive_scan(b->scan_tmp, tb, b->cnt, b->first, 0, (size_t)n + 1, rocprim::plus<int>(), s));
+  hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS);
+  BH_TRY(hipEventSynchronize(b->ev));
+  if (b->h_counters[3] != 0) {
+    *status = b->h_counters[3];
+    BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
+    return hipSuccess;
   }
-  b->last_levels = levels;
-  for (int l = levels - 1; l >= 0; --l)                      // ComputeMass: children before parents
-    hipLaunchKernelGGL(bh_upsweep_kernel, dim3((cnt[l] + kB - 1) / kB), blk, 0, s, b->nd, b->frontier + off[l], cnt[l], b->div_mode);
-  if (!keep_root) hipLaunchKernelGGL(bh_save_com_kernel, dim3(1), dim3(1), 0, s, b->nd, b->prev_com);   // next frame's root centre, .cpp:78
-  hipLaunchKernelGGL(bh_walk_kernel, grd, blk, 0, s, b->nd, posm, b->idx, n, theta, G, acc);
+  const int maxl = b->h_counters[5];
+  for (int l = maxl; l >= 0; --l)                              // ComputeMass: children before parents
+    hipLaunchKernelGGL(bh_sweep_level_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, l, b->div_mode);
+  hipLaunchKernelGGL(bh_finish_kernel, dim3(1), dim3(1), 0, s, b->st, n, keep_root);
+  hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, n, G, (float4 *)acc_v);
+  BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));   // for bh_stats
+  b->stats_pending = true;
+  b->last_levels = maxl + 1;
   return hipGetLastError();
 }
 
+// What DrawOctreeBoxes hands to DrawDebugBox: (Origin, Size) of the leaf holding each body, written at the body's index
 hipError_t bh_leaf_boxes(BhState *b, void *out, hipStream_t s) {
-  if (b->last_nodes <= 0) return hipErrorInvalidValue;
-  if (b->small) {
-    hipLaunchKernelGGL(bh_small_leaf_boxes_kernel, dim3((b->n + kB - 1) / kB), dim3(kB), 0, s, b->st, b->n, (float4 *)out);
-    return hipGetLastError();
-  }
-  hipLaunchKernelGGL(bh_leaf_boxes_kernel, dim3((b->last_nodes + kB - 1) / kB), dim3(kB), 0, s, b->nd, b->last_nodes,
-                     (float4 *)out);
+  if (b->last_levels <= 0 && b->last_nodes <= 0 && !b->stats_pending) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bh_small_leaf_boxes_kernel, dim3((b->n + kB - 1) / kB), dim3(kB), 0, s, b->st, b->n, (float4 *)out);
   return hipGetLastError();
 }
 
@@ -1154,21 +1007,29 @@ void bh_set_div_mode(BhState *b, int div_mode) { b->div_mode = div_mode ? 1 : 0;
 // The bodies in the order DrawOctreeBoxes meets their leaves (OctreeSearch.cpp:36-45: depth first, children 0..7): the
 // path keys are the octant digits root to leaf, so key order IS that order.
 hipError_t bh_leaf_order(BhState *b, int *out_host, hipStream_t s) {
-  if (b->last_nodes <= 0) return hipErrorInvalidValue;
+  if (b->last_levels <= 0 && b->last_nodes <= 0 && !b->stats_pending) return hipErrorInvalidValue;
   BH_TRY(hipStreamSynchronize(s));
   return hipMemcpy(out_host, b->idx, sizeof(unsigned int) * (size_t)b->n, hipMemcpyDeviceToHost);
 }
 
-void bh_stats(const BhState *b, int *nodes, int *levels) {
+// nodes: the reference's count (every cell of >= 2 bodies has eight children, empty ones included); levels with such cells
+hipError_t bh_stats(BhState *b, hipStream_t s, int *nodes, int *levels) {
+  if (b->stats_pending) {
+    BH_TRY(hipStreamSynchronize(s));
+    b->last_nodes = 1 + 8 * b->h_counters[1];
+    b->last_levels = b->h_counters[2];
+    b->stats_pending = false;
+  }
   if (nodes) *nodes = b->last_nodes;
   if (levels) *levels = b->last_levels;
+  return hipSuccess;
 }
 
 // centre of mass of the root of the last tree built
 hipError_t bh_get_tree_com(BhState *b, float out[3], hipStream_t s) {
-  if (b->last_nodes <= 0) return hipErrorInvalidValue;
+  if (b->last_nodes <= 0 && !b->stats_pending) return hipErrorInvalidValue;
   BH_TRY(hipStreamSynchronize(s));
-  return hipMemcpy(out, b->small ? (const void *)b->st.com : (const void *)b->nd.com, sizeof(float) * 3, hipMemcpyDeviceToHost);
+  return hipMemcpy(out, b->st.com, sizeof(float) * 3, hipMemcpyDeviceToHost);
 }
 
 hipError_t bh_get_root_com(BhState *b, float out[3], hipStream_t s) {
