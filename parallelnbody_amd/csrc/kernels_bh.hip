@@ -688,6 +688,7 @@ __global__ __launch_bounds__(64) void bh_root_thr_kernel(SmallTree T, const unsi
     T.root[0] = T.prev_com[0]; T.root[1] = T.prev_com[1]; T.root[2] = T.prev_com[2]; T.root[3] = sz;
     s_size = sz;
     T.hdr[5] = -1;                                            // deepest level with a cell of >= 2 bodies (bh_lcp_kernel)
+    T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
   }
   __syncthreads();
   if (t <= kMaxLevels) {
@@ -733,11 +734,12 @@ __global__ __launch_bounds__(kB) void bh_lcp_kernel(SmallTree T, int n, signed c
     cnt[i] = (ln > lp ? ln - lp : 0) + 1;
     if (i == n - 1) { lcpS[n] = (signed char)-1; cnt[n] = 0; }
     if (ln == kMaxLevels) T.hdr[3] = 1;                        // the reference would recurse on: the frame is refused
+    if (ln >= kLevelsPerKey) T.hdr[6] = 1;                     // neighbours that agree in the whole first key word (bh_forces)
   }
-  int m = ln;                                                  // deepest level: one atomic per wave
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(&T.hdr[5], m);
+  int m = ln;                                                  // deepest level: at most one atomic per wave, and only while
+#pragma unroll                                                 // it would still raise the value (sixteen thousand waves on one
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));   // address would queue for 0.2 ms)
+  if ((threadIdx.x & 63) == 0 && m > *(volatile int *)&T.hdr[5]) atomicMax(&T.hdr[5], m);
 }
 
 // body i (key order): the words of the cells it opens, its leaf's word, CoM and level
@@ -963,22 +965,36 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   *status = 0;
   hipLaunchKernelGGL(bh_root_thr_kernel, dim3(1), dim3(64), 0, s, b->st, size_bits, theta);
   hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, posm, n, b->root, b->khi, b->klo, b->idx);
-  // stable LSD sort over the 126-bit key: low word first, then the high word
-  size_t tb = b->sort_tmp_bytes;
-  BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->klo, b->klo2, b->idx, b->idx2, (unsigned int)n, 0u, 63u, s));
-  hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->khi, b->idx2, b->khi2, n);
-  tb = b->sort_tmp_bytes;
-  BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->khi2, b->khi, b->idx2, b->idx, (unsigned int)n, 0u, 63u, s));
-  // b->khi / b->idx are final; bring the low words (b->klo is still in body order) into the same order
-  hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->klo, b->idx, b->klo2, n);
-  hipLaunchKernelGGL(bh_lcp_kernel, grd, blk, 0, s, b->st, n, b->lcpS, b->cnt);
-  BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
-  BH_TRY(hipEventRecord(b->ev, s));
-  // the node numbers and the node words need nothing from the host: they run while it waits for the verdict
-  tb = b->scan_tmp_bytes;
-  BH_TRY(rocprim::exclusive_scan(b->scan_tmp, tb, b->cnt, b->first, 0, (size_t)n + 1, rocprim::plus<int>(), s));
-  hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS);
-  BH_TRY(hipEventSynchronize(b->ev));
+  // The order of the 126-bit keys.  Almost always the first word (21 levels) decides it: ONE radix sort, and the pass that
+  // looks at the neighbours' shared digits says whether two of them agree in that whole word (bodies closer than
+  // Size / 2^21) — only then is the frame redone with the stable two-pass sort, low word first.
+  for (int full = 0; full < 2; ++full) {
+    size_t tb = b->sort_tmp_bytes;
+    SmallTree &T = b->st;
+    if (!full) {
+      BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->khi, b->khi2, b->idx, b->idx2, (unsigned int)n, 0u, 63u, s));
+      T.khi = b->khi2; T.sidx = b->idx2;
+    } else {
+      BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->klo, b->klo2, b->idx, b->idx2, (unsigned int)n, 0u, 63u, s));
+      hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->khi, b->idx2, b->khi2, n);
+      tb = b->sort_tmp_bytes;
+      BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->khi2, b->khi, b->idx2, b->idx, (unsigned int)n, 0u, 63u, s));
+      T.khi = b->khi; T.sidx = b->idx;
+      BH_TRY(hipMemsetAsync(b->counters + 5, 0xFF, sizeof(int), s));      // deepest level: -1 again
+      BH_TRY(hipMemsetAsync(b->counters + 6, 0, sizeof(int), s));
+    }
+    // the second key words in the same order (b->klo is still in body order)
+    hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->klo, T.sidx, b->klo2, n);
+    hipLaunchKernelGGL(bh_lcp_kernel, grd, blk, 0, s, T, n, b->lcpS, b->cnt);
+    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+    BH_TRY(hipEventRecord(b->ev, s));
+    // the node numbers and the node words need nothing from the host: they run while it waits for the verdict
+    tb = b->scan_tmp_bytes;
+    BH_TRY(rocprim::exclusive_scan(b->scan_tmp, tb, b->cnt, b->first, 0, (size_t)n + 1, rocprim::plus<int>(), s));
+    hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, 0, s, T, posm, n, b->first, b->lcpS);
+    BH_TRY(hipEventSynchronize(b->ev));
+    if (full || b->h_counters[6] == 0) break;
+  }
   if (b->h_counters[3] != 0) {
     *status = b->h_counters[3];
     BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
@@ -1009,7 +1025,7 @@ void bh_set_div_mode(BhState *b, int div_mode) { b->div_mode = div_mode ? 1 : 0;
 hipError_t bh_leaf_order(BhState *b, int *out_host, hipStream_t s) {
   if (b->last_levels <= 0 && b->last_nodes <= 0 && !b->stats_pending) return hipErrorInvalidValue;
   BH_TRY(hipStreamSynchronize(s));
-  return hipMemcpy(out_host, b->idx, sizeof(unsigned int) * (size_t)b->n, hipMemcpyDeviceToHost);
+  return hipMemcpy(out_host, b->st.sidx, sizeof(unsigned int) * (size_t)b->n, hipMemcpyDeviceToHost);
 }
 
 // nodes: the reference's count (every cell of >= 2 bodies has eight children, empty ones included); levels with such cells

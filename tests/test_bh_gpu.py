@@ -211,6 +211,42 @@ def test_switching_the_opening_angle_on_a_fused_all_pairs_context(nb, oracle, n)
     assert rel_err(a[sample, :3], ref).max() < 2e-5
 
 
+@pytest.mark.parametrize("n", [3000, 6000])
+def test_bodies_that_share_twenty_one_levels_and_more(nb, oracle, n):
+    # two pairs of bodies closer than Size / 2^21 (but not on one point): their paths agree in the whole first key word, so
+    # the order comes from the second one — the in-LDS sort's tie path (n <= 4096) and the two-pass radix sort the larger
+    # systems fall back to — and the tree has chains of single-child cells down to level 25 and beyond
+    posm, vel = nb.ic_plummer(n, seed=n)
+    posm[:, 3] *= np.random.default_rng(n).uniform(0.5, 1.5, n).astype(np.float32)
+    size = np.abs(posm[:, :3]).max()
+    posm[7, :3] = posm[900, :3] + np.float32(size * 2.0 ** -24) * np.array([1, 0, 0], np.float32)
+    posm[2001, :3] = posm[15, :3] + np.float32(size * 2.0 ** -30) * np.array([0, -1, 1], np.float32)
+    assert not np.array_equal(posm[7, :3], posm[900, :3]) and not np.array_equal(posm[2001, :3], posm[15, :3])
+    pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+    ref, com, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+    boxes, order = oracle.octree_leaves_f32(pos, m)
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+        st = e.bh_stats()
+        np.testing.assert_array_equal(e.bh_leaf_order(), order)
+        np.testing.assert_array_equal(e.bh_leaf_boxes()[order], boxes)
+    np.testing.assert_array_equal(a, ref)
+    np.testing.assert_array_equal(st["root_com"], com)
+    assert st["nodes"] == nodes and st["levels"] >= 24
+    # the same two bodies ON one point: the reference's Add would never return; the frame is refused on either path
+    posm[7, :3] = posm[900, :3]
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        with pytest.raises(nb.NBodyError) as err:
+            e.step(0.01, 2)
+        assert err.value.code == nb._lib.ERR_UNSUPPORTED and "42 levels" in str(err.value) and e.steps_done() == 0
+        e.set_theta(0.0)                                   # the all-pairs pass takes such a state (d == 0 pairs are skipped)
+        e.step(0.01, 1)
+        assert e.steps_done() == 1
+
+
 def test_bh_limits(nb):
     g = np.load(os.path.join(GOLDEN, "plummer_n1024_seed1.npz"))
     with pytest.raises(nb.NBodyError) as err:
