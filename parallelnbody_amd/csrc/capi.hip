@@ -239,7 +239,9 @@ void choose_algorithm(nbody_ctx *c) {
   if (const char *e = getenv("NBODY_SYM_K")) { const int v = atoi(e); if (v >= 1) c->sym_k = v; }                     // tuning only
   if (const char *e = getenv("NBODY_SYM_K_X10")) { const int v = atoi(e); if (v >= 5) c->sym_k = v / 10.0; }         // tuning only
   // shortest strip, in 64-body subtiles: whole 256-body tiles from N = 131072, half tiles below (same table)
-  c->sym_min_sub = env_int("NBODY_SYM_MIN_SUB", p.n_total < 131072 ? 2 : 4);
+  // (round 3, whole steps without events, four bodies per lane: N = 20480 0.0921 ms with two subtiles, 0.0888 with one; two
+  // bodies per lane — N = 16384 — do not care: 0.0737 / 0.0738)
+  c->sym_min_sub = env_int("NBODY_SYM_MIN_SUB", p.n_total >= 131072 ? 4 : (!f64 && ipt == 4 ? 1 : 2));
   nbody::SymPlan *plan = new (std::nothrow) nbody::SymPlan();
   if (!plan) return;
   std::string why;
