@@ -118,7 +118,17 @@ typedef struct nbody_params {
 /* Fill `p` with the reference-compatible defaults (G=1e4, eps=0, fp32, device 0). */
 NBODY_API int nbody_default_params(nbody_params *p);
 
-/* AOctreeSearch ctor + CreateSpacePoints' allocation (OctreeSearch.cpp:8,62). */
+/* AOctreeSearch ctor + CreateSpacePoints' allocation (OctreeSearch.cpp:8,62).
+ *
+ * Reproducibility.  Every force pass is deterministic (no atomics in any sum): the same context, state and call sequence
+ * give the same bits, run after run.  WHICH sums are formed — the launch geometry — is chosen here, once, from the
+ * parameters and from two facts about the device: its compute-unit count (workgroup slots of the symmetric pass's work
+ * plan) and, beyond N = 2^22, its total memory (whether the partial-sum pool is shared by phases); the strip-length
+ * divisor K of that plan also follows an estimate of the pass's duration from rates measured on MI355X (6.6e12 / 6.0e12 /
+ * 2.7e12 interactions/s: fp32 / compensated / fp64).  Results are therefore reproducible on every MI355X, and across
+ * library versions only where the release notes say so; on a part with another CU count they agree to rounding, not in
+ * every bit.  nbody_get_launch_config, nbody_get_algorithm and nbody_sym_pool_info say what was chosen;
+ * NBODY_ALGO_TILED with explicit tile / i_per_thread / j_split depends on the parameters alone. */
 NBODY_API int nbody_create(const nbody_params *p, nbody_ctx **out);
 
 /*

@@ -93,6 +93,8 @@ struct SmallTree {
   int cap;
 };
 
+constexpr int kHdrDeep = 8, kDeepSlots = 64;   // header words [8, 72): the deepest level, one word per slot (larger systems)
+constexpr int kHdrWords = kHdrDeep + kDeepSlots;
 constexpr int kDbgClocks = 16 + 3 * 512;   // tuning builds: 16 phase stamps + (start, fill end, end) of up to 512 walk workgroups
 #ifdef NBODY_BH_PHASE_CLOCKS
 #define BH_CLOCK(k) do { if (threadIdx.x == 0) T.clocks[k] = wall_clock64(); } while (0)
@@ -687,9 +689,9 @@ __global__ __launch_bounds__(64) void bh_root_thr_kernel(SmallTree T, const unsi
     const float sz = __uint_as_float(*size_bits);             // Size as the bounds kernel left it (ComputeCubeSize)
     T.root[0] = T.prev_com[0]; T.root[1] = T.prev_com[1]; T.root[2] = T.prev_com[2]; T.root[3] = sz;
     s_size = sz;
-    T.hdr[5] = -1;                                            // deepest level with a cell of >= 2 bodies (bh_lcp_kernel)
     T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
   }
+  T.hdr[kHdrDeep + t] = -1;                                   // deepest level with a cell of >= 2 bodies, in kDeepSlots words (bh_lcp_kernel)
   __syncthreads();
   if (t <= kMaxLevels) {
     float sz = s_size;
@@ -736,10 +738,18 @@ __global__ __launch_bounds__(kB) void bh_lcp_kernel(SmallTree T, int n, signed c
     if (ln == kMaxLevels) T.hdr[3] = 1;                        // the reference would recurse on: the frame is refused
     if (ln >= kLevelsPerKey) T.hdr[6] = 1;                     // neighbours that agree in the whole first key word (bh_forces)
   }
-  int m = ln;                                                  // deepest level: at most one atomic per wave, and only while
-#pragma unroll                                                 // it would still raise the value (sixteen thousand waves on one
-  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));   // address would queue for 0.2 ms)
-  if ((threadIdx.x & 63) == 0 && m > *(volatile int *)&T.hdr[5]) atomicMax(&T.hdr[5], m);
+  // deepest level: one atomic per workgroup, spread over kDeepSlots words the host takes the maximum of (sixteen thousand
+  // waves on ONE address queue for 0.2 ms)
+  __shared__ int s_m[kB / 64];
+  int m = ln;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kB / 64; ++w) m = max(m, s_m[w]);
+    if (m >= 0) atomicMax(&T.hdr[kHdrDeep + (blockIdx.x % kDeepSlots)], m);
+  }
 }
 
 // body i (key order): the words of the cells it opens, its leaf's word, CoM and level
@@ -790,7 +800,9 @@ __global__ __launch_bounds__(kB) void bh_sweep_level_kernel(SmallTree T, const f
 __global__ void bh_finish_kernel(SmallTree T, int n, int keep_root) {
   if (T.hdr[3] != 0) return;
   if (!keep_root) { const float4 c = T.com[0]; T.prev_com[0] = c.x; T.prev_com[1] = c.y; T.prev_com[2] = c.z; }   // .cpp:78
-  T.hdr[1] = T.hdr[0] - n; T.hdr[2] = T.hdr[5] + 1; T.hdr[4] = T.hdr[4] + 1;
+  int deep = -1;
+  for (int q = 0; q < kDeepSlots; ++q) deep = max(deep, T.hdr[kHdrDeep + q]);
+  T.hdr[1] = T.hdr[0] - n; T.hdr[2] = deep + 1; T.hdr[4] = T.hdr[4] + 1;
 }
 
 // Octree::ComputeForces (.h:99-108) on the compact tree, one lane per body in key order, node by node: a 16-byte and a
@@ -864,9 +876,9 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->khi, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->klo, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->idx, sizeof(unsigned int) * n));
-  BH_TRY(hipMalloc(&b->counters, sizeof(int) * 8));
-  BH_TRY(hipMemset(b->counters, 0, sizeof(int) * 8));
-  BH_TRY(hipHostMalloc(&b->h_counters, sizeof(int) * 8, hipHostMallocDefault));
+  BH_TRY(hipMalloc(&b->counters, sizeof(int) * kHdrWords));
+  BH_TRY(hipMemset(b->counters, 0, sizeof(int) * kHdrWords));
+  BH_TRY(hipHostMalloc(&b->h_counters, sizeof(int) * kHdrWords, hipHostMallocDefault));
   BH_TRY(hipMalloc(&b->root, sizeof(float) * 4));
   BH_TRY(hipMemset(b->root, 0, sizeof(float) * 4));
   BH_TRY(hipMalloc(&b->prev_com, sizeof(float) * 3));
@@ -980,13 +992,13 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
       tb = b->sort_tmp_bytes;
       BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->khi2, b->khi, b->idx2, b->idx, (unsigned int)n, 0u, 63u, s));
       T.khi = b->khi; T.sidx = b->idx;
-      BH_TRY(hipMemsetAsync(b->counters + 5, 0xFF, sizeof(int), s));      // deepest level: -1 again
+      BH_TRY(hipMemsetAsync(b->counters + kHdrDeep, 0xFF, sizeof(int) * kDeepSlots, s));      // deepest level: -1 again
       BH_TRY(hipMemsetAsync(b->counters + 6, 0, sizeof(int), s));
     }
     // the second key words in the same order (b->klo is still in body order)
     hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->klo, T.sidx, b->klo2, n);
     hipLaunchKernelGGL(bh_lcp_kernel, grd, blk, 0, s, T, n, b->lcpS, b->cnt);
-    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * kHdrWords, hipMemcpyDeviceToHost, s));
     BH_TRY(hipEventRecord(b->ev, s));
     // the node numbers and the node words need nothing from the host: they run while it waits for the verdict
     tb = b->scan_tmp_bytes;
@@ -1000,7 +1012,8 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
     BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
     return hipSuccess;
   }
-  const int maxl = b->h_counters[5];
+  int maxl = -1;
+  for (int q = 0; q < kDeepSlots; ++q) maxl = std::max(maxl, b->h_counters[kHdrDeep + q]);
   for (int l = maxl; l >= 0; --l)                              // ComputeMass: children before parents
     hipLaunchKernelGGL(bh_sweep_level_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, l, b->div_mode);
   hipLaunchKernelGGL(bh_finish_kernel, dim3(1), dim3(1), 0, s, b->st, n, keep_root);
