@@ -215,3 +215,64 @@ def test_engine_creation_failure_on_one_rank_is_seen_by_all(nb, tmp_path):
     assert o0[0].startswith("failed together") and o1[0].startswith("failed together")
     assert "another rank" in o0[0] and "MemoryError" in o1[0]
     assert o0[1] == o1[1]
+
+
+class TwoGoEngine(OracleEngine):
+    """Stand-in with the force pass in two goes (nbody_step_begin_local / _remote): the first go may only read the OWN slice
+    of the positions — it poisons everything else it could see while it runs, so a driver that let it depend on the gathered
+    positions (or started the second go before the gather had landed) would produce NaNs."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.calls = []
+
+    def step_begin_local(self):
+        self.calls.append("local")
+        own = self.posm[self.lo:self.lo + self.cnt]
+        pos = np.ascontiguousarray(own[:, :3]); m = np.ascontiguousarray(own[:, 3])
+        self.acc_local = self.O.forces_direct_f32(pos, m)            # own bodies against own bodies
+
+    def step_begin_remote(self):
+        assert self.calls[-1] == "local"
+        self.calls.append("remote")
+        pos = np.ascontiguousarray(self.posm[:, :3]); m = self.posm[:, 3].copy()
+        m[self.lo:self.lo + self.cnt] = 0                              # the others against the own bodies
+        self.acc[:, :3] = self.acc_local + self.O.forces_direct_f32(pos, m, i0=self.lo, i1=self.lo + self.cnt)
+
+    def step_begin(self):
+        self.calls.append("whole")
+        super().step_begin()
+
+
+def _worker_two_goes(rank, world, port, n, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import parallelnbody_amd as nb
+    posm, vel = nb.ic_plummer(n, seed=4)
+    out = {}
+    for overlap in (True, False):
+        sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device="cpu", engine_factory=TwoGoEngine, overlap=overlap)
+        sim.step(0.01, 3)
+        sim.compute_forces()
+        p, v = sim.gather_state()
+        assert sim.engine.calls == (["local", "remote"] * 4 if overlap else ["whole"] * 4)
+        out["p%d" % overlap], out["v%d" % overlap] = p, v
+        sim.close()
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_driver_runs_the_force_pass_in_two_goes_when_the_engine_has_them(nb, oracle, tmp_path):
+    # ShardedSimulation(overlap=True) drives step_begin_local -> (gather of the previous step) -> step_begin_remote; with
+    # overlap=False the engine's one-go step_begin.  Same physics either way (the stand-in splits the sum differently, so
+    # positions agree to rounding, not in every bit — the HIP engine's two goes are bit-identical: tests/test_rank_geometries_gpu.py)
+    import torch.multiprocessing as mp
+    n = 96
+    mp.spawn(_worker_two_goes, args=(2, _free_port(), n, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "g0.npz"); r1 = np.load(tmp_path / "g1.npz")
+    for k in ("p1", "v1", "p0", "v0"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert np.abs(r0["p1"][:, :3] - r0["p0"][:, :3]).max() / np.abs(r0["p0"][:, :3]).max() < 1e-6
