@@ -247,7 +247,8 @@ void choose_algorithm(nbody_ctx *c) {
   std::string why;
   bool planned = false;
   try {
-    planned = nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, f64 ? 2 : 1, plan, &why);
+    planned = nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, f64 ? 2 : 1, plan, &why,
+                                    0, env_int("NBODY_SYM_MAX_SUB", 0));
   } catch (const std::bad_alloc &) {
     why = "out of host memory";
   }

@@ -45,7 +45,7 @@ bool fail(std::string *err, const char *msg) {
 }  // namespace
 
 bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, double k_guided, int min_sub, int own_mode,
-                    SymPlan *out, std::string *err, uint64_t j_budget_elems) {
+                    SymPlan *out, std::string *err, uint64_t j_budget_elems, int max_sub_arg) {
   if (n_total <= 0 || i_count <= 0 || i_begin < 0 || i_begin + i_count > n_total) return fail(err, "bad body range");
   if (bi < 64 || bi % 64 != 0) return fail(err, "bodies per i-set must be a multiple of 64");
   if (slots < 1 || !(k_guided >= 0.5) || min_sub < 1) return fail(err, "bad scheduling parameters");
@@ -103,10 +103,11 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
     }
   }
 
-  // guided self-scheduling: each strip takes 1/(k * slots) of the cost still to hand out.  Plans with a pool budget (systems
-  // beyond N = 2^22) also cap a strip at 1024 subtiles: a lane adds a strip's terms one after the other in fp32, and the
-  // first strips of such a system would otherwise be chains of several hundred thousand terms.
-  const int max_sub = j_budget_elems != 0 ? 1024 : (1 << 30);
+  // guided self-scheduling: each strip takes 1/(k * slots) of the cost still to hand out, but never more than 1024 subtiles:
+  // a lane adds a strip's terms one after the other in fp32, and the first strips of a system of millions of bodies would
+  // otherwise be chains of several hundred thousand terms (N = 2^23: sampled error 8.6e-4 -> 4.4e-7 with the cap, and the pass
+  // 24 % faster; N = 2^21: 1.6e-6 -> 9e-7, 3.5 % faster — tools/cap_sweep.py).  Up to N = 2^20 no strip is that long.
+  const int max_sub = max_sub_arg > 0 ? max_sub_arg : 1024;
   long long remaining = total_cost;
   uint64_t pool = 0;
   const double kp = k_guided * slots;

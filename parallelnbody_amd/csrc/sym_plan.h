@@ -59,6 +59,6 @@ struct SymPlan {
 // j_budget_elems: 0 = one pass whatever the pool's size; otherwise the j-side segments of a phase may take at most that many
 // pool elements, and a system whose j-side segments exceed it is run in several phases that share one area (SymPlan).
 bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, double k_guided, int min_sub, int own_mode,
-                    SymPlan *out, std::string *err, uint64_t j_budget_elems = 0);
+                    SymPlan *out, std::string *err, uint64_t j_budget_elems = 0, int max_sub_arg = 0);
 
 }  // namespace nbody
