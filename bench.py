@@ -266,6 +266,9 @@ def main():
     ap.add_argument("--no-tiled-row", action="store_true",
                     help="multi-GPU: skip the extra timing of the one-sided kernel + all-gather-only step (config.all_gather_only_row)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length; 0 = skip")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="multi-GPU: every collective in the simulation's one stream order (default: the all-gather of a step's "
+                         "positions runs on a stream of its own, under the next force pass's own-slice strips; same bits)")
     ap.add_argument("--host", default="ranks", choices=["ranks", "single"],
                     help="ranks = one process per GPU under torch.distributed (default; started as a child process when no "
                          "launcher did); single = one process drives all GPUs through nbody_create_multi")
@@ -321,7 +324,7 @@ def main():
     def build(algorithm):
         sim = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device=f"cuda:{local_rank}", engine_factory=factory,
                                    precision=args.precision, eps=args.eps, tile=args.tile, i_per_thread=args.ipt,
-                                   j_split=args.jsplit, time_kernels=True,
+                                   j_split=args.jsplit, time_kernels=True, overlap=not args.no_overlap,
                                    algorithm={"auto": 0, "tiled": 1, "symmetric": 2}[algorithm],
                                    zero_mode={"exact": 0, "floor": 2}[args.zero_mode])
         sim.warm_collectives()
@@ -456,7 +459,9 @@ def main():
             "config": {"workload": f"N={n} all-pairs {args.precision}, seeded Plummer sphere (equal masses), G=1e4, eps={args.eps}, "
                                    f"dt={args.dt}, one force pass + kick-drift per step",
                        "parallelism": (f"range-partition x{world}, per step 1 RCCL all-gather(posm)"
-                                       + (" + 1 all-to-all(j-side sums)" if cfg["algorithm"] == "symmetric" else ""))
+                                       + (" + 1 all-to-all(j-side sums)" if cfg["algorithm"] == "symmetric" else "")
+                                       + ("" if args.no_overlap else "; the all-gather runs on its own stream under the next "
+                                          "force pass's own-slice strips"))
                        if world > 1 else "1 GPU",
                        "algorithm": cfg["algorithm"], "zero_distance": args.zero_mode,
                        "lds_tile_bodies": cfg["tile"], "i_per_lane": cfg["i_per_thread"],

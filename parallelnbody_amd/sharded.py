@@ -25,6 +25,8 @@ torch is plumbing here: device memory, the current stream and torch.distributed.
 injected (`engine_factory`) so that the world_size-2 gloo test can run the host logic on CPU with a stand-in
 defined in tests/; the default factory is the HIP engine and nothing else.
 """
+import os
+
 import numpy as np
 
 from .engine import REF_DT, NBodyEngine
@@ -65,7 +67,7 @@ class ShardedSimulation:
                  timeline=False, **engine_kw):
         import torch
         self.torch = torch
-        self.overlap = overlap
+        self.overlap = overlap and os.environ.get("NBODY_NO_OVERLAP") != "1"    # the environment can put every collective back in one stream order
         self.marks = [] if timeline else None    # timed events around the gather and the force pass's goes (timeline_ms)
         posm = np.ascontiguousarray(posm)
         self.n_total = posm.shape[0]
