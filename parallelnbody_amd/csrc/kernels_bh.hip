@@ -22,6 +22,7 @@
 // lines bit for bit (tests/test_bh_gpu.py).  This is latency/divergence-bound integer+fp work, not the FMA-bound
 // all-pairs path; it is the drop-in for the reference's SHIPPED configuration (theta = 1.0).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 
 #include <algorithm>
@@ -78,6 +79,7 @@ constexpr unsigned int kLinkMask = (1u << kLevelShift) - 1u;
 constexpr int kWalkT = 256;                // threads per workgroup of the compact walk
 constexpr int kWalkG = 16;                 // lanes per body there
 constexpr int kWalkK = 48;                 // taken nodes a body lists before their terms are worked out and added
+constexpr int kRowsMaxN = 32768;           // larger systems up to here walk with sixteen lanes per body on the global tree
 
 struct SmallTree {
   float4 *com;                  // [cap] preorder nodes: centre of mass, total mass
@@ -499,16 +501,95 @@ __device__ __forceinline__ int row_max(int v) {
 // visited.  The visited taken nodes' terms (.h:104) are worked out by their lanes side by side and added by the first lane
 // in lane order = the walk's order = the reference's order of additions; the next window starts behind whatever the
 // window's taken nodes cover.
+// The walk of one row (see the kernels below).  LDS_TREE: the nodes are the LDS arrays s_a / s_past / s_m; otherwise they
+// are read from the tree's global arrays (coalesced: a window is sixteen consecutive nodes) and the threshold comes from the
+// level.  list / term: the row's own LDS slices.  The row's first lane ends up with the acceleration.
+template <bool LDS_TREE, typename LIST_T>
+__device__ __forceinline__ void walk_windows(const SmallTree &T, const float4 *s_a, const float *s_m, const unsigned short *s_past,
+                                             const float *s_thr, LIST_T *list, float4 *term, int nodes, bool valid,
+                                             const float4 &p, double G, int g, int row_shift, float &ax, float &ay, float &az) {
+#pragma clang fp contract(off)
+  float sum = 0.f;                                             // lanes 0, 1, 2 of the row: the x, y, z sums (ZeroVector, .cpp:84)
+  int w0 = valid ? 0 : nodes;                                  // first node of the window (the same in all lanes of the row)
+  for (;;) {
+    // ---- the walk: windows of sixteen nodes until the row's list cannot take another window's worth
+    int cnt = 0;
+    for (;;) {
+      const bool open = w0 < nodes && cnt + kWalkG <= kWalkK;
+      if (!__any(open)) break;
+      const int my = w0 + g;
+      const bool in = open && my < nodes;
+      float4 a;
+      int past;
+      if (LDS_TREE) {
+        a = s_a[in ? my : 0];
+        past = s_past[in ? my : 0];
+      } else {
+        const float4 c = T.com[in ? my : 0];
+        const unsigned int w = T.meta[in ? my : 0];
+        const bool leaf = (w & kLeafBit) != 0u;
+        a = make_float4(c.x, c.y, c.z, leaf ? 0.0f : s_thr[(w >> kLevelShift) & 63u]);
+        past = leaf ? my + 1 : (int)(w & kLinkMask);
+      }
+      const float ex = p.x - a.x, ey = p.y - a.y, ez = p.z - a.z;
+      float d2 = ex * ex + ey * ey;
+      d2 = d2 + ez * ez;
+      const bool take = in && d2 >= a.w;                       // .h:103: Size / d < Theta, or an occupied leaf
+      const bool zero = in && d2 == 0.f;                       // .h:102: d == 0 adds nothing and ends the subtree
+      const bool ends = take || zero;                          // the recursion does not go below this node
+      // nodes of this window below mine: window offsets g + 1 .. past - w0 - 1
+      const int rel = min(past - w0, kWalkG);
+      const int cover = (ends && rel > g + 1) ? (((1 << rel) - 1) & ~((2 << g) - 1)) : 0;
+      const int dead = row_or(cover);
+      const bool adds = take && !zero && ((dead >> g) & 1) == 0;
+      const unsigned long long am = __ballot(adds);
+      const int row = (int)((am >> row_shift) & 0xFFFFull);    // this row's lanes whose node adds a term
+      if (adds) list[cnt + __popc(row & ((1 << g) - 1))] = (LIST_T)my;   // lane order = the walk's order
+      cnt += __popc(row);
+      const int next = max(min(w0 + kWalkG, nodes), row_max(ends ? past : 0));
+      w0 = open ? next : w0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (!__any(cnt > 0)) break;                                // every walk of this wave has ended, nothing left to add
+    // ---- the listed nodes' terms (.h:104), sixteen at a time
+    for (int e = g; e < cnt; e += kWalkG) {
+      const int nd = (int)list[e];
+      float tx, ty, tz;
+      if (LDS_TREE) { const float4 a = s_a[nd]; force_term(a.x, a.y, a.z, s_m[nd], p, G, tx, ty, tz); }
+      else { const float4 c = T.com[nd]; force_term(c.x, c.y, c.z, c.w, p, G, tx, ty, tz); }
+      term[e] = make_float4(tx, ty, tz, 0.f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- added in the walk's order, one lane per component, eight loads in flight
+    if (g < 3) {
+      const float *col = (const float *)term + g;
+      for (int e = 0; e < cnt; e += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = col[4 * min(e + q, kWalkK - 1)];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum = (e + q < cnt) ? sum + v[q] : sum;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  ay = __builtin_bit_cast(float, row_ror<15>(__builtin_bit_cast(int, sum)));    // lane 0 takes lane 1's and lane 2's sums
+  az = __builtin_bit_cast(float, row_ror<14>(__builtin_bit_cast(int, sum)));
+  ax = sum;
+}
+
 __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                                  float4 *__restrict__ acc, int n, float theta, double G, float dt) {
-#pragma clang fp contract(off)
   static_assert(kWalkG == 16, "one DPP row per body");
   constexpr int kGroups = kWalkT / kWalkG;
   __shared__ float4 s_a[kSmNodesLds];
   __shared__ float s_m[kSmNodesLds];
   __shared__ unsigned short s_past[kSmNodesLds];
   __shared__ float s_thr[kMaxLevels + 2];
-  __shared__ unsigned short s_list[kGroups][kWalkK];
+  __shared__ unsigned int s_list[kGroups][kWalkK];
   __shared__ float4 s_term[kGroups][kWalkK];
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   BH_WALK_CLOCK(9);
@@ -516,8 +597,6 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
   const int t = threadIdx.x;
   const int nodes = T.hdr[0];
   const bool in_lds = nodes <= kSmNodesLds;
-  long long dbg_visits = 0, dbg_chunks = 0, dbg_terms = 0;
-  (void)dbg_visits; (void)dbg_chunks; (void)dbg_terms;
   if (t <= kMaxLevels) s_thr[t] = T.thr[t];
   __syncthreads();
   if (in_lds) {
@@ -540,95 +619,12 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   BH_WALK_CLOCK(10);
   BH_WG_STAMP(1);
-  float sum = 0.f;                                             // lanes 0, 1, 2 of the row: the x, y, z sums (ZeroVector, .cpp:84)
-  if (in_lds) {
-    int w0 = valid ? 0 : nodes;                                // first node of the window (the same in all lanes of the row)
-    for (;;) {
-      // ---- the walk: windows of sixteen nodes until the row's list cannot take another window's worth
-      int cnt = 0;
-      for (;;) {
-        const bool open = w0 < nodes && cnt + kWalkG <= kWalkK;
-        if (!__any(open)) break;
-        const int my = w0 + g;
-        const bool in = open && my < nodes;
-        const float4 a = s_a[in ? my : 0];
-        const int past = s_past[in ? my : 0];
-        const float ex = p.x - a.x, ey = p.y - a.y, ez = p.z - a.z;
-        float d2 = ex * ex + ey * ey;
-        d2 = d2 + ez * ez;
-        const bool take = in && d2 >= a.w;                     // .h:103: Size / d < Theta, or an occupied leaf
-        const bool zero = in && d2 == 0.f;                     // .h:102: d == 0 adds nothing and ends the subtree
-        const bool ends = take || zero;                        // the recursion does not go below this node
-        // nodes of this window below mine: window offsets g + 1 .. past - w0 - 1
-        const int rel = min(past - w0, kWalkG);
-        const int cover = (ends && rel > g + 1) ? (((1 << rel) - 1) & ~((2 << g) - 1)) : 0;
-        const int dead = row_or(cover);
-        const bool adds = take && !zero && ((dead >> g) & 1) == 0;
-        const unsigned long long am = __ballot(adds);
-        const int row = (int)((am >> ((t & 63) - g)) & 0xFFFFull);   // this row's lanes whose node adds a term
-        if (adds) s_list[group][cnt + __popc(row & ((1 << g) - 1))] = (unsigned short)my;   // lane order = the walk's order
-        cnt += __popc(row);
-        const int next = max(min(w0 + kWalkG, nodes), row_max(ends ? past : 0));
-        w0 = open ? next : w0;
-#ifdef NBODY_BH_PHASE_CLOCKS
-        ++dbg_chunks; dbg_visits += in ? __popc((~dead) & 0xFFFF) : 0;
-#endif
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      if (!__any(cnt > 0)) break;                              // every walk of this wave has ended, nothing left to add
-#ifdef NBODY_BH_PHASE_CLOCKS
-      dbg_terms += cnt;
-#endif
-      // ---- the listed nodes' terms (.h:104), sixteen at a time
-      for (int e = g; e < cnt; e += kWalkG) {
-        const int nd = s_list[group][e];
-        const float4 a = s_a[nd];
-        float tx, ty, tz;
-        force_term(a.x, a.y, a.z, s_m[nd], p, G, tx, ty, tz);
-        s_term[group][e] = make_float4(tx, ty, tz, 0.f);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      // ---- added in the walk's order, one lane per component, eight loads in flight
-      if (g < 3) {
-        const float *col = (const float *)&s_term[group][0] + g;
-        for (int e = 0; e < cnt; e += 8) {
-          float v[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = col[4 * min(e + q, kWalkK - 1)];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) sum = (e + q < cnt) ? sum + v[q] : sum;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-    }
-    ay = __builtin_bit_cast(float, row_ror<15>(__builtin_bit_cast(int, sum)));  // lane 0 takes lane 1's and lane 2's sums
-    az = __builtin_bit_cast(float, row_ror<14>(__builtin_bit_cast(int, sum)));
-    ax = sum;
-  } else if (g == 0 && valid) {                                // a tree too large for LDS: one lane per body, global nodes
-    int node = 0;
-    while (node < nodes) {
-      const float4 cm = T.com[node];
-      const unsigned int w = T.meta[node];
-      const bool leaf = (w & kLeafBit) != 0u;
-      const int past = leaf ? node + 1 : (int)(w & kLinkMask);
-      const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
-      float d2 = ex * ex + ey * ey;
-      d2 = d2 + ez * ez;
-      const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];
-      if (take && d2 != 0.f) {
-        float tx, ty, tz;
-        force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
-        ax = ax + tx; ay = ay + ty; az = az + tz;
-      }
-      node = (take || d2 == 0.f) ? past : node + 1;
-    }
-  }
+  if (in_lds)
+    walk_windows<true>(T, s_a, s_m, s_past, s_thr, s_list[group], s_term[group], nodes, valid, p, G, g, (t & 63) - g, ax, ay, az);
+  else   // a tree too large for LDS (deep chains of single-child cells): the same windows on the global arrays
+    walk_windows<false>(T, s_a, s_m, s_past, s_thr, s_list[group], s_term[group], nodes, valid, p, G, g, (t & 63) - g, ax, ay, az);
   BH_WALK_CLOCK(11);
   BH_WG_STAMP(2);
-  BH_WALK_COUNT(12, dbg_visits); BH_WALK_COUNT(13, dbg_chunks); BH_WALK_COUNT(14, dbg_terms);
 #ifdef NBODY_BH_PHASE_CLOCKS
   if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {       // the shader clock under this load: s_sleep 127 = 127 * 64 cycles
     const long long c0 = wall_clock64();
@@ -646,6 +642,30 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
     vel[body] = v;
     posm[body] = x;
   }
+}
+
+// The same walk for systems whose tree does not go into LDS but that have too few bodies to keep the chip busy with one lane
+// each (bh_walk_lane_kernel): rows of sixteen lanes on the global arrays, no tree copy.
+__global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, const float4 *__restrict__ posm, int n, double G,
+                                                              float4 *__restrict__ acc) {
+  constexpr int kGroups = kWalkT / kWalkG;
+  __shared__ float s_thr[kMaxLevels + 2];
+  __shared__ unsigned int s_list[kGroups][kWalkK];
+  __shared__ float4 s_term[kGroups][kWalkK];
+  if (T.hdr[3] != 0) return;
+  const int t = threadIdx.x;
+  if (t <= kMaxLevels) s_thr[t] = T.thr[t];
+  __syncthreads();
+  const int nodes = T.hdr[0];
+  const int group = t / kWalkG, g = t % kWalkG;
+  const int k = blockIdx.x * kGroups + group;
+  const bool valid = k < n;
+  const unsigned int body = valid ? T.sidx[k] : 0u;
+  const float4 p = posm[body];
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  walk_windows<false>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[group],
+                      s_term[group], nodes, valid, p, G, g, (t & 63) - g, ax, ay, az);
+  if (g == 0 && valid) acc[body] = make_float4(ax, ay, az, 0.f);
 }
 
 // What DrawOctreeBoxes hands to DrawDebugBox (.cpp:39-40) from the compact tree: the leaf's box follows from the body's
@@ -1017,7 +1037,13 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   for (int l = maxl; l >= 0; --l)                              // ComputeMass: children before parents
     hipLaunchKernelGGL(bh_sweep_level_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, l, b->div_mode);
   hipLaunchKernelGGL(bh_finish_kernel, dim3(1), dim3(1), 0, s, b->st, n, keep_root);
-  hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, n, G, (float4 *)acc_v);
+  // one lane per body needs enough bodies to hide its loads; below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning)
+  static const int rows_max_n = [] { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); return e && *e ? atoi(e) : kRowsMaxN; }();
+  if (n <= rows_max_n)
+    hipLaunchKernelGGL(bh_walk_rows_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, posm, n, G,
+                       (float4 *)acc_v);
+  else
+    hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, n, G, (float4 *)acc_v);
   BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));   // for bh_stats
   b->stats_pending = true;
   b->last_levels = maxl + 1;
