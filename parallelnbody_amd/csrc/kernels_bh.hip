@@ -79,7 +79,8 @@ constexpr unsigned int kLinkMask = (1u << kLevelShift) - 1u;
 constexpr int kWalkT = 256;                // threads per workgroup of the compact walk
 constexpr int kWalkG = 16;                 // lanes per body there
 constexpr int kWalkK = 48;                 // taken nodes a body lists before their terms are worked out and added
-constexpr int kRowsMaxN = 32768;           // larger systems up to here walk with sixteen lanes per body on the global tree
+constexpr int kRowsMaxN = 20480;           // larger systems up to here walk with sixteen lanes per body on the global tree
+                                           // (frames: N = 8192 208 us against 275 with a lane per body, 16384 231 / 270, 32768 321 / 272)
 
 struct SmallTree {
   float4 *com;                  // [cap] preorder nodes: centre of mass, total mass
