@@ -420,12 +420,12 @@ int bh_status_error(nbody_ctx *c, int status) {
 }
 
 // Small systems at theta > 0: queue `nsteps` whole frames (tree, walk, update — two launches each), nothing waits.
-int bh_small_enqueue(nbody_ctx *c, float dt, int nsteps) {
+int bh_small_enqueue(nbody_ctx *c, float dt, int nsteps, float *stage = nullptr) {
   const bool timed = c->p.time_kernels != 0;
   for (int s = 0; s < nsteps; ++s) {
     EventPair ev;
     if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
-    HIP_TRY(c, nbody::bh_small_frame(c->bh, c->posm, c->vel, c->acc, c->theta, c->p.G, dt, 0, c->stream));
+    HIP_TRY(c, nbody::bh_small_frame(c->bh, c->posm, c->vel, c->acc, c->theta, c->p.G, dt, 0, s == nsteps - 1 ? stage : nullptr, c->stream));
     if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
     if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) { int rc = timer_drain(c, NBODY_KERNEL_FORCES); if (rc) return rc; }
   }
@@ -451,7 +451,7 @@ int run_forces_bh(nbody_ctx *c, bool diagnostic) {
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
   int status = 0;
   if (nbody::bh_is_small(c->bh)) {
-    HIP_TRY(c, nbody::bh_small_frame(c->bh, c->posm, nullptr, c->bh_acc, c->theta, c->p.G, 0.0f, diagnostic ? 1 : 0, c->stream));
+    HIP_TRY(c, nbody::bh_small_frame(c->bh, c->posm, nullptr, c->bh_acc, c->theta, c->p.G, 0.0f, diagnostic ? 1 : 0, nullptr, c->stream));
     if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
     HIP_TRY(c, nbody::bh_small_collect(c->bh, c->stream, &status, nullptr));
     return bh_status_error(c, status);
@@ -1281,28 +1281,36 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
     if ((rc = ensure_bh(c))) return rc;
     bh_frame = nbody::bh_is_small(c->bh);
   }
-  if (bh_frame) {
-    if ((rc = bh_small_enqueue(c, dt, 1))) return rc;
-    if (size) HIP_TRY(c, hipMemcpyAsync(c->h_scratch, nbody::bh_root_device(c->bh) + 3, 4, hipMemcpyDeviceToHost, c->stream));
+  const size_t ic = (size_t)c->p.i_count, bytes = ic * sizeof(nbody_particle);
+  if (bh_frame) {                                                // the walk writes the frame's records itself, Size rides with the verdict
+    if (aos && (rc = ensure_stage(c, bytes))) return rc;
+    if ((rc = bh_small_enqueue(c, dt, 1, aos ? (float *)c->d_stage : nullptr))) return rc;
   } else if (live && size) {                                     // .cpp:26, 47-56: bounds of the positions BEFORE the step
     HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
     HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, c->p.i_begin, c->p.i_count, (unsigned int *)c->scratch, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_scratch, c->scratch, 4, hipMemcpyDeviceToHost, c->stream));
   }
   if (live && !bh_frame && (rc = nbody_step(c, dt, 1))) return rc;   // .cpp:27-31
-  const size_t ic = (size_t)c->p.i_count, bytes = ic * sizeof(nbody_particle);
   bool direct = false;
   if (aos) {                                                     // .cpp:33,41: what the frame draws
     if ((rc = ensure_stage(c, bytes))) return rc;
-    HIP_TRY(c, nbody::launch_pack_particles(c->p.precision, c->posm, c->vel, c->acc, (float *)c->d_stage, c->p.i_begin,
-                                            c->p.i_count, c->stream));
+    if (!bh_frame)
+      HIP_TRY(c, nbody::launch_pack_particles(c->p.precision, c->posm, c->vel, c->acc, (float *)c->d_stage, c->p.i_begin,
+                                              c->p.i_count, c->stream));
     direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
     HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
   }
   int frame_rc = NBODY_OK;
   if (bh_frame) frame_rc = bh_small_finish(c);                   // the frame's one wait
   else HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (live && size) memcpy(size, c->h_scratch, 4);
+  if (bh_frame && frame_rc != NBODY_OK && aos) {                 // a refused frame wrote no records: deliver the untouched state
+    HIP_TRY(c, nbody::launch_pack_particles(c->p.precision, c->posm, c->vel, c->acc, (float *)c->d_stage, c->p.i_begin,
+                                            c->p.i_count, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (bh_frame) { if (size) *size = nbody::bh_small_last_size(c->bh); }
+  else if (live && size) memcpy(size, c->h_scratch, 4);
   if (aos && !direct) unstage_particles(c, aos, stride, ic);
   return frame_rc;
 }

@@ -109,8 +109,10 @@ hipError_t bh_forces(BhState *b, const void *posm, void *acc, const unsigned int
 // upsweep by one workgroup, then the walk, which with dt > 0 also applies the Tick's update to (posm, vel) in place.
 // bh_small_collect waits for the stream and reports the frames queued since the last collect.
 bool bh_is_small(const BhState *b);
+// stage (optional): the walk also writes every body's FParticle record (10 floats, body order) there — the frame's mirror
 hipError_t bh_small_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root,
-                          hipStream_t s);
+                          float *stage, hipStream_t s);
+float bh_small_last_size(const BhState *b);                   // Size of the last frame bh_small_collect has seen
 hipError_t bh_small_collect(BhState *b, hipStream_t s, int *status, int *frames);
 hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t s);   // tuning builds only (tools/bh_phases.py)
 const float *bh_root_device(const BhState *b);                // device (ox, oy, oz, Size) of the last tree (small systems)

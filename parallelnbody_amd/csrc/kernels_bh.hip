@@ -334,6 +334,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
     for (int w = 1; w < kSmT / 64; ++w) m = fmaxf(m, s_red[w]);
     s_root[0] = T.prev_com[0]; s_root[1] = T.prev_com[1]; s_root[2] = T.prev_com[2]; s_root[3] = m;
     T.root[0] = s_root[0]; T.root[1] = s_root[1]; T.root[2] = s_root[2]; T.root[3] = m;
+    T.hdr[7] = (int)__float_as_uint(m);                        // Size travels with the verdict (nbody_tick)
   }
   __syncthreads();
   if (t >= kSmT - 64 && t - (kSmT - 64) <= kMaxLevels) {        // the opening rule per level, as a threshold on d2 (the
@@ -583,7 +584,8 @@ __device__ __forceinline__ void walk_windows(const SmallTree &T, const float4 *s
 }
 
 __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
-                                                                 float4 *__restrict__ acc, int n, float theta, double G, float dt) {
+                                                                 float4 *__restrict__ acc, int n, float theta, double G, float dt,
+                                                                 float *__restrict__ stage) {
   static_assert(kWalkG == 16, "one DPP row per body");
   constexpr int kGroups = kWalkT / kWalkG;
   __shared__ float4 s_a[kSmNodesLds];
@@ -635,13 +637,17 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
 #endif
   if (g != 0 || !valid) return;
   acc[body] = make_float4(ax, ay, az, 0.f);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
+  if (dt > 0.f || stage != nullptr) v = vel[body];
   if (dt > 0.f) {                                              // v += dt*a; x += dt*v, separate multiply and add
-    float4 v = vel[body];
-    float4 x = p;
     v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
     x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
     vel[body] = v;
     posm[body] = x;
+  }
+  if (stage != nullptr) {                                      // the frame's FParticle record (.h:8-18), for the renderer hand-off
+    float *o = stage + (size_t)body * 10;
+    o[0] = x.w; o[1] = x.x; o[2] = x.y; o[3] = x.z; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = ax; o[8] = ay; o[9] = az;
   }
 }
 
@@ -958,15 +964,18 @@ const float *bh_root_device(const BhState *b) { return b->root; }
 // Small systems: queue one frame — tree, walk and (dt > 0) the update — on the stream; nothing waits for the host.
 // keep_root: the tree is a diagnostic's (nbody_compute_forces), the next frame's root centre stays what it was.
 hipError_t bh_small_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root,
-                          hipStream_t s) {
+                          float *stage, hipStream_t s) {
   const int n = b->n;
   int P = 1;
   while (P < n) P <<= 1;
   hipLaunchKernelGGL(bh_small_build_kernel, dim3(1), dim3(kSmT), 0, s, b->st, (const float4 *)posm, n, P, b->div_mode, keep_root, theta);
   hipLaunchKernelGGL(bh_walk_compact_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, (float4 *)posm,
-                     (float4 *)vel, (float4 *)acc, n, theta, G, dt);
+                     (float4 *)vel, (float4 *)acc, n, theta, G, dt, stage);
   return hipGetLastError();
 }
+
+// Size (ComputeCubeSize) of the last small-system frame collected by bh_small_collect
+float bh_small_last_size(const BhState *b) { float f; unsigned int u = (unsigned int)b->h_counters[7]; memcpy(&f, &u, 4); return f; }
 
 // Wait for the stream and read the verdict of the frames queued since the last call: *status 0 ok, 1 depth limit, 2 node
 // pool; *frames = how many of them were built (a refused frame and everything queued behind it leave the state untouched).
