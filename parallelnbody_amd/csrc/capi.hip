@@ -24,7 +24,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct EventPair { hipEvent_t a, b; };
+struct EventPair { hipEvent_t a, b; bool counts = true; };   // counts: the interval is a whole pass (not the first go of two)
 
 struct KernelTimer {
   std::vector<EventPair> pending;   // recorded, not yet read
@@ -360,9 +360,10 @@ int timer_begin(nbody_ctx *c, int which, EventPair *ev) {
   return NBODY_OK;
 }
 
-int timer_end(nbody_ctx *c, int which, const EventPair &ev) {
+int timer_end(nbody_ctx *c, int which, const EventPair &ev, bool counts = true) {
   HIP_TRY(c, hipEventRecord(ev.b, c->stream));
   c->timers[which].pending.push_back(ev);
+  c->timers[which].pending.back().counts = counts;
   return NBODY_OK;
 }
 
@@ -373,7 +374,7 @@ int timer_drain(nbody_ctx *c, int which) {
     float ms = 0.f;
     HIP_TRY(c, hipEventElapsedTime(&ms, e.a, e.b));
     t.total_ms += ms;
-    t.launches += 1;
+    t.launches += e.counts ? 1 : 0;
     t.pool.push_back(e);
   }
   t.pending.clear();
@@ -505,7 +506,7 @@ int run_forces(nbody_ctx *c, bool diagnostic = false, int phase = 0) {
   } else {
     HIP_TRY(c, nbody::launch_forces(make_launch(c), c->stream));
   }
-  if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
+  if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev, phase != 1); if (rc) return rc; }   // two goes are ONE pass
   // bound the number of live events on long untimed-drain runs
   if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) return timer_drain(c, NBODY_KERNEL_FORCES);
   return NBODY_OK;

@@ -44,6 +44,9 @@ def test_bench_multi_rank_line_on_one_gpu():
     cf = r["config"]
     assert r["n_gpus"] == 2 and cf["algorithm"] == "symmetric" and "fallback" not in cf
     assert cf["max_rel_err_sampled"] < 2e-5 and cf["bodies_sampled"] >= 48
+    # the force pass runs in two goes here (own-slice strips, then the rest): still ONE pass per step in the kernel timers,
+    # or roofline.achieved would read twice what the hardware did
+    assert r["roofline"]["launches"] == r["steps"] and 0.0 < r["roofline"]["frac"] < 1.0
     row = cf["all_gather_only_row"]
     assert row["algorithm"] == "tiled" and row["value"] > 0 and "all-to-all" not in row["parallelism"]
 
