@@ -64,7 +64,7 @@ enum {
  * both bodies (kernels_sym.hip, kernels_sym64.hip; work plan csrc/sym_plan.h): fp32, Kahan fp32 and fp64 contexts;
  * when the bodies are sharded the slices must be equal multiples of 256 * i_per_thread bodies and the host drives
  * nbody_step_begin / all-to-all / nbody_step_end.  The per-body summation order then depends on the number of ranks
- * (TILED's does not).  AUTO picks SYMMETRIC where it applies and n_total >= 12288 (where its whole step gets faster
+ * (TILED's does not).  AUTO picks SYMMETRIC where it applies and n_total >= 9216 (where its whole step gets faster
  * than the one-sided kernel's), else TILED.
  */
 enum { NBODY_ALGO_AUTO = 0, NBODY_ALGO_TILED = 1, NBODY_ALGO_SYMMETRIC = 2 };

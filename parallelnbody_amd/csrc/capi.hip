@@ -189,7 +189,10 @@ void choose_algorithm(nbody_ctx *c) {
   // whole steps, one box, final kernels (profiles/r02_threshold_symmetric_vs_one_sided.txt): N = 10240 one-sided 0.0597 ms vs
   // symmetric 0.0597, N = 12288 0.0763 vs 0.0700, 14336 0.0934 vs 0.0841, 16384 (the one-sided geometry's best case) 0.0978
   // vs 0.0948, 18432 0.1287 vs 0.1024, 20480 0.147 vs 0.116; Kahan and fp64 likewise from 12288 (0.0735 vs 0.0639, 0.129 vs 0.119)
-  if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < env_int("NBODY_SYM_MIN_N", 12288)) return;
+  // Round 3 (the fused update folds its two lists side by side; whole steps without events, same box: N = 8192 0.0266 ms
+  // one-sided vs 0.0366 symmetric, 9216 0.0351 vs 0.0325, 10240 0.0423 vs 0.0393, 11264 0.0438 vs 0.0413; Kahan 9216 0.0326 vs
+  // 0.0289, fp64 0.0774 vs 0.0658; distinct masses 0.0362 vs 0.0340): the symmetric pass from N = 9216
+  if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < env_int("NBODY_SYM_MIN_N", 9216)) return;
   const bool f64 = p.precision == NBODY_PREC_F64, kahan = p.precision == NBODY_PREC_F32_KAHAN;
   if (f64 && !(p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT)) return;
   // bodies per lane.  fp32: 2 * register pairs; more of them amortise the travelling sums' dpp moves over more
@@ -737,7 +740,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
   if ((p.i_per_thread == 8 || p.i_per_thread == 16) && !(c->sym && c->sym_bi == 256 * p.i_per_thread)) {
     delete c;
     return fail(nullptr, NBODY_ERR_UNSUPPORTED,
-                "nbody_create: i_per_thread %d needs the fp32 symmetric kernel (N >= 12288 or NBODY_ALGO_SYMMETRIC; "
+                "nbody_create: i_per_thread %d needs the fp32 symmetric kernel (N >= 9216 or NBODY_ALGO_SYMMETRIC; "
                 "sharded slices in multiples of %d bodies)", p.i_per_thread, 256 * p.i_per_thread);
   }
   if (p.algorithm == NBODY_ALGO_SYMMETRIC && !c->sym) {
