@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
   __shared__ float s_red[kSmT / 64];
   __shared__ float s_root[4];
   __shared__ int s_lvl[kMaxLevels + 2];                        // cells per level, then where each level's list ends
-  __shared__ int s_maxl, s_err, s_total;
+  __shared__ int s_maxl, s_err, s_total, s_tie;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (T.hdr[3] != 0) return;                                   // an earlier frame of this call was refused: stay there
   BH_CLOCK(0);
@@ -344,82 +344,97 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
     T.thr[l] = accept_threshold(sz, theta);
   }
   BH_CLOCK(1);
-  // ---- path keys (Octree::Add's descent), into sort buffer 0
-  {
-    unsigned long long *hi0 = (unsigned long long *)raw;
-    unsigned short *idx0 = (unsigned short *)(raw + kSmBodies * 8);
+  // ---- path keys, sort, shared digits.  Almost always the first key word (21 levels) decides the order and nobody needs
+  // the second: the first go computes 21 levels per body and sorts on them alone; only when two neighbours turn out to agree in
+  // the whole word (bodies closer than Size / 2^21) is it all done again with both words.
+  const unsigned long long *hi = nullptr;
+  const unsigned short *idx = nullptr;
+  int *first = nullptr;
+  signed char *lcpS = nullptr;
+  static_assert(4 * (kSmBodies + 4) + kSmBodies + 16 <= kSmBuf, "scan and lcp fit in a sort buffer");
+  for (int both = 0; both < 2; ++both) {
+    {
+      unsigned long long *hi0 = (unsigned long long *)raw;
+      unsigned short *idx0 = (unsigned short *)(raw + kSmBodies * 8);
 #pragma unroll
-    for (int r = 0; r < kSmBodies / kSmT; ++r) {
-      const int i = t + r * kSmT;
-      if (i >= P) break;
-      unsigned long long h = ~0ull, l = ~0ull;
-      if (i < n) {
-        float o[3] = {s_root[0], s_root[1], s_root[2]};
-        float size = s_root[3];
-        h = 0; l = 0;
-        for (int lev = 0; lev < kLevelsPerKey; ++lev) h = (h << 3) | (unsigned long long)descend_level(mine[r], o, size);
-        for (int lev = 0; lev < kLevelsPerKey; ++lev) l = (l << 3) | (unsigned long long)descend_level(mine[r], o, size);
-        lo_by_body[i] = l;
-      }
-      hi0[i] = h; idx0[i] = (unsigned short)(i < n ? i : 0xFFFF);
-    }
-  }
-  __syncthreads();
-  BH_CLOCK(2);
-  // ---- merge sort by rank: runs of L become runs of 2L; every element finds its place by a binary search in the partner
-  // run (left run: partner elements strictly before it; right run: partner elements not after it — a stable merge).  One
-  // barrier per round, log2(P) rounds, buffers ping-pong.  Ties in the first key word look the second one up by body.
-  int cur = 0;
-  for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
-    const unsigned long long *shi = (const unsigned long long *)(raw + cur * kSmBuf);
-    const unsigned short *sidx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
-    unsigned long long *dhi = (unsigned long long *)(raw + (cur ^ 1) * kSmBuf);
-    unsigned short *didx = (unsigned short *)(raw + (cur ^ 1) * kSmBuf + kSmBodies * 8);
-    for (int e = t; e < P; e += kSmT) {
-      const int run = e >> lg, pos = e & (L - 1);
-      const bool left = (run & 1) == 0;
-      const int pbase = (run ^ 1) * L;
-      const unsigned long long h = shi[e];
-      const unsigned short b = sidx[e];
-      int x = 0, y = L;
-      while (x < y) {
-        const int mid = (x + y) >> 1;
-        const unsigned long long hp = shi[pbase + mid];
-        bool before = hp < h;                                  // partner element sorts before mine?
-        if (hp == h) {
-          const unsigned short bp = sidx[pbase + mid];
-          const unsigned long long lp = bp == 0xFFFF ? ~0ull : lo_by_body[bp], lm = b == 0xFFFF ? ~0ull : lo_by_body[b];
-          before = left ? lp < lm : lp <= lm;
+      for (int r = 0; r < kSmBodies / kSmT; ++r) {
+        const int i = t + r * kSmT;
+        if (i >= P) break;
+        unsigned long long h = ~0ull, l = 0ull;
+        if (i < n) {
+          float o[3] = {s_root[0], s_root[1], s_root[2]};
+          float size = s_root[3];
+          h = 0;
+          for (int lev = 0; lev < kLevelsPerKey; ++lev) h = (h << 3) | (unsigned long long)descend_level(mine[r], o, size);
+          if (both) for (int lev = 0; lev < kLevelsPerKey; ++lev) l = (l << 3) | (unsigned long long)descend_level(mine[r], o, size);
+          lo_by_body[i] = l;
         }
-        if (before) x = mid + 1; else y = mid;
+        hi0[i] = h; idx0[i] = (unsigned short)(i < n ? i : 0xFFFF);
       }
-      const int dest = (run & ~1) * L + pos + x;
-      dhi[dest] = h; didx[dest] = b;
+    }
+    if (t == 0) s_tie = 0;
+    __syncthreads();
+    if (!both) BH_CLOCK(2);
+    // ---- merge sort by rank: runs of L become runs of 2L; every element finds its place by a binary search in the partner
+    // run (left run: partner elements strictly before it; right run: partner elements not after it — a stable merge).
+    // log2(P) rounds, buffers ping-pong; the rounds whose pairs of runs lie inside a wave's own 64 elements need only that
+    // wave's order, the others a barrier.  Ties in the first key word look the second one up by body (second go only).
+    int cur = 0;
+    for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
+      const unsigned long long *shi = (const unsigned long long *)(raw + cur * kSmBuf);
+      const unsigned short *sidx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
+      unsigned long long *dhi = (unsigned long long *)(raw + (cur ^ 1) * kSmBuf);
+      unsigned short *didx = (unsigned short *)(raw + (cur ^ 1) * kSmBuf + kSmBodies * 8);
+      for (int e = t; e < P; e += kSmT) {
+        const int run = e >> lg, pos = e & (L - 1);
+        const bool left = (run & 1) == 0;
+        const int pbase = (run ^ 1) * L;
+        const unsigned long long h = shi[e];
+        const unsigned short b = sidx[e];
+        int x = 0, y = L;
+        while (x < y) {
+          const int mid = (x + y) >> 1;
+          const unsigned long long hp = shi[pbase + mid];
+          bool before = hp < h;                                // partner element sorts before mine?
+          if (hp == h) {
+            const unsigned short bp = sidx[pbase + mid];
+            const unsigned long long lp = bp == 0xFFFF ? ~0ull : lo_by_body[bp], lm = b == 0xFFFF ? ~0ull : lo_by_body[b];
+            before = left ? lp < lm : lp <= lm;
+          }
+          if (before) x = mid + 1; else y = mid;
+        }
+        const int dest = (run & ~1) * L + pos + x;
+        dhi[dest] = h; didx[dest] = b;
+      }
+      if (2 * L <= 64 && 4 * L <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+      else __syncthreads();
+    }
+    hi = (const unsigned long long *)(raw + cur * kSmBuf);
+    idx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
+    first = (int *)(raw + (cur ^ 1) * kSmBuf);                 // [n + 1], in the buffer the sort left behind
+    lcpS = (signed char *)(first + kSmBodies + 4);             // [n + 1]
+    if (!both) BH_CLOCK(3);
+    // ---- shared digits of neighbours, the keys and the draw order for later (leaf boxes, DrawOctreeBoxes' order)
+    for (int i = t; i <= n; i += kSmT) {
+      int v = -1;
+      unsigned long long li = 0ull;
+      if (i < n) li = lo_by_body[idx[i]];
+      if (i > 0 && i < n) {
+        const unsigned long long x = hi[i - 1] ^ hi[i];
+        if (x != 0ull) v = (__clzll((long long)x) - 1) / 3;
+        else if (!both) { v = kLevelsPerKey; s_tie = 1; }      // agree in the whole first word: the second go will tell
+        else {
+          const unsigned long long y = lo_by_body[idx[i - 1]] ^ li;
+          if (y != 0ull) v = kLevelsPerKey + (__clzll((long long)y) - 1) / 3;
+          else { v = kMaxLevels; s_err = 1; }                  // same path for 42 levels: the reference would recurse on
+        }
+      }
+      lcpS[i] = (signed char)v;
+      if (i < n) { T.khi[i] = hi[i]; T.klo[i] = li; T.sidx[i] = idx[i]; }
     }
     __syncthreads();
-  }
-  const unsigned long long *hi = (const unsigned long long *)(raw + cur * kSmBuf);
-  const unsigned short *idx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
-  int *first = (int *)(raw + (cur ^ 1) * kSmBuf);              // [n + 1], in the buffer the sort left behind
-  signed char *lcpS = (signed char *)(first + kSmBodies + 4);  // [n + 1]
-  static_assert(4 * (kSmBodies + 4) + kSmBodies + 16 <= kSmBuf, "scan and lcp fit in a sort buffer");
-  BH_CLOCK(3);
-  // ---- shared digits of neighbours, the keys and the draw order for later (leaf boxes, DrawOctreeBoxes' order)
-  for (int i = t; i <= n; i += kSmT) {
-    int v = -1;
-    unsigned long long li = 0ull;
-    if (i < n) li = lo_by_body[idx[i]];
-    if (i > 0 && i < n) {
-      const unsigned long long x = hi[i - 1] ^ hi[i];
-      if (x != 0ull) v = (__clzll((long long)x) - 1) / 3;
-      else {
-        const unsigned long long y = lo_by_body[idx[i - 1]] ^ li;
-        if (y != 0ull) v = kLevelsPerKey + (__clzll((long long)y) - 1) / 3;
-        else { v = kMaxLevels; s_err = 1; }                    // same path for 42 levels: the reference would recurse on
-      }
-    }
-    lcpS[i] = (signed char)v;
-    if (i < n) { T.khi[i] = hi[i]; T.klo[i] = li; T.sidx[i] = idx[i]; }
+    if (both || s_tie == 0) break;
+    __syncthreads();                                           // everybody has seen the tie flag before the next go clears it
   }
   __syncthreads();
   if (s_err != 0) { if (t == 0) T.hdr[3] = 1; return; }
