@@ -13,7 +13,6 @@ with nb.NBodyEngine(n, theta=1.0) as e:
     e.set_state(posm, vel)
     e.step(0.01, 50)
     acc = np.zeros(len(names))
-    walk = np.zeros(5)
     reps = 20
     for _ in range(reps):
         e.step(0.01, 1)
@@ -22,8 +21,6 @@ with nb.NBodyEngine(n, theta=1.0) as e:
         assert rc == 0
         c = np.array(out[:len(names) + 1], np.float64)
         acc += np.diff(c) / 100.0                     # 100 MHz -> us
-        w = np.array(out[9:15], np.float64)
-        walk += np.array([(w[1] - w[0]) / 100.0, (w[2] - w[1]) / 100.0, w[3], w[4], w[5]])
     print(f"N={n}: build kernel phases, us (mean of {reps}):")
     for nm, v in zip(names, acc / reps):
         print(f"  {nm:24s} {v:8.2f}")
@@ -34,6 +31,3 @@ with nb.NBodyEngine(n, theta=1.0) as e:
           f"fill {((wg[:, 1] - wg[:, 0]) / 100).mean():.2f} mean / {((wg[:, 1] - wg[:, 0]) / 100).max():.2f} max, "
           f"walk {((wg[:, 2] - wg[:, 1]) / 100).mean():.2f} mean / {((wg[:, 2] - wg[:, 1]) / 100).max():.2f} max, last end {(wg[:, 2].max() - t0) / 100:.2f}")
     print(f"  shader clock under this load: {16 * 127 * 64 / (out[15] / 100.0) / 1e3:.2f} GHz (s_sleep probe)")
-    walk /= reps
-    print(f"  walk kernel, middle workgroup, first body: LDS fill {walk[0]:.2f} us, walk {walk[1]:.2f} us, nodes visited {walk[2]:.0f}, "
-          f"rounds {walk[3]:.1f}, terms {walk[4]:.0f}")
