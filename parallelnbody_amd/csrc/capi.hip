@@ -125,10 +125,39 @@ int use_device(nbody_ctx *c) {
   return NBODY_OK;
 }
 
-// Below this many bodies the one-launch small-system step (small_pk_kernel: a workgroup per pair of bodies, update fused) beats
-// the tile kernel + update: N = 6000 0.0236 vs 0.0275 ms, 7000 0.0318 vs 0.0282, 8000 0.0376 vs 0.0275 (whole steps, no
-// events: profiles/r02_small_system_thresholds.txt).
-constexpr int kSmallSystem = 6656;
+// Up to N = 16384 a workgroup owns a few bodies and spreads the j range over its lanes (forces_block_pk_kernel,
+// kernels_block.hip: one launch per step, no partial rows; 2 ... 8 register pairs of bodies per workgroup).  Above it the
+// symmetric pass (plain fp32; Kahan and fp64 go through the tile kernels up to their own threshold).  Whole steps without
+// events, same box (profiles/r03_block_kernel_by_n.txt): N = 14336 0.0538 ms against the symmetric pass's 0.0630, 16384 —
+// four full workgroups per CU — 0.0674 / 0.0735, 17408 0.0922 / 0.0710; round 2's one-pair-per-workgroup kernel
+// (small_pk_kernel, gone): N = 2000 0.0067 ms against 0.0053 now, 4096 0.0143 / 0.0096, 6000 0.0246 / 0.0150.
+constexpr int kSmallSystem = 6656;      // the threshold of rounds 1-2 (tile kernel above it); still Kahan's and the forced geometries'
+int block_max_n() { static const int v = [] { const char *e = getenv("NBODY_BLOCK_MAX_N"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 16385; }(); return v; }
+
+// Register pairs per workgroup for the block kernel.  A CU works through its workgroups two at a time (2 waves per SIMD at
+// ~200 VGPRs) and a workgroup left alone runs about twice as fast, so a CU's time is its number of workgroups times the
+// pairs each one carries: the bodies are cut so that ceil(workgroups / CUs) * pairs is smallest, larger workgroups first on
+// a tie (fewer prologues).  Measured against all of 2 ... 8 at fifteen sizes (profiles/r03_block_kernel_np_by_n.txt): the
+// rule picks the fastest or within 6 % of it.  A function of n_total and the CU count only.
+int block_pairs(int n_total, int cus) {
+  if (const char *e = getenv("NBODY_BLOCK_NP")) { const int v = atoi(e); if (v >= 1 && v <= 8) return v; }   // tuning only
+  if (cus <= 0) cus = 256;
+  int best = 8;
+  long long best_cost = -1;
+  for (int np = 8; np >= 2; --np) {
+    const long long wgs = (n_total + 2 * np - 1) / (2 * np);
+    const long long cost = (wgs + cus - 1) / cus * np;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = np; }
+  }
+  return best;
+}
+
+int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  if (!e || !*e) return dflt;
+  const int v = atoi(e);
+  return v > 0 ? v : dflt;
+}
 
 int floor_pow2(long long v) { int p = 1; while ((long long)p * 2 <= v) p *= 2; return p; }
 
@@ -164,8 +193,10 @@ void choose_geometry(nbody_ctx *c) {
   // cannot.  Only when the caller left the geometry to us.
   c->wave = 0;
   if (p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && p.algorithm != NBODY_ALGO_SYMMETRIC &&
-      p.tile == 0 && p.i_per_thread == 0 && p.j_split == 0 && p.n_total < kSmallSystem) {
-    c->wave = 1;
+      p.tile == 0 && p.i_per_thread == 0 && p.j_split == 0 && p.n_total < block_max_n()) {
+    int cus = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
+    c->wave = block_pairs(p.n_total, cus);
     c->j_split = 1;
     c->j_chunk = (p.n_total + c->tile - 1) / c->tile * c->tile;
   }
@@ -174,13 +205,6 @@ void choose_geometry(nbody_ctx *c) {
 // Symmetric algorithm: applicability, bodies per lane, and the work plan (sym_plan.h).  Everything here is a function
 // of the parameters and of the device's CU count and total memory — never of what happens to be free — so that equal
 // GPUs arrive at equal plans (the ranks of a sharded job must) and results are reproducible from box to box.
-int env_int(const char *name, int dflt) {
-  const char *e = getenv(name);
-  if (!e || !*e) return dflt;
-  const int v = atoi(e);
-  return v > 0 ? v : dflt;
-}
-
 void choose_algorithm(nbody_ctx *c) {
   const nbody_params &p = c->p;
   c->sym = false;
@@ -192,6 +216,7 @@ void choose_algorithm(nbody_ctx *c) {
   // Round 3 (the fused update folds its two lists side by side; whole steps without events, same box: N = 8192 0.0266 ms
   // one-sided vs 0.0366 symmetric, 9216 0.0351 vs 0.0325, 10240 0.0423 vs 0.0393, 11264 0.0438 vs 0.0413; Kahan 9216 0.0326 vs
   // 0.0289, fp64 0.0774 vs 0.0658; distinct masses 0.0362 vs 0.0340): the symmetric pass from N = 9216
+  if (p.algorithm == NBODY_ALGO_AUTO && c->wave != 0) return;            // the block kernels' one-launch step (choose_geometry)
   if (p.algorithm == NBODY_ALGO_AUTO && p.n_total < env_int("NBODY_SYM_MIN_N", 9216)) return;
   const bool f64 = p.precision == NBODY_PREC_F64, kahan = p.precision == NBODY_PREC_F32_KAHAN;
   if (f64 && !(p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT)) return;
@@ -340,12 +365,15 @@ nbody::ForceLaunch make_launch(const nbody_ctx *c) {
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps; L.precision = c->p.precision;
   L.zero_mode = (c->p.zero_mode == NBODY_ZERO_SELECT) ? 2 : 1;
   L.wave = c->wave;
+  L.guarded = env_int("NBODY_SYM_GUARDED", 0) == 1 ? 1 : 0;        // A/B measurements and tests: no bare pair law anywhere
   L.dup_table = c->sym_dup_table; L.dup_slots = c->sym_dup_slots;
   if (L.eps2 == 0.0 && c->p.zero_mode == NBODY_ZERO_FLOOR && c->floor_eps2 > 0.0) L.eps2 = c->floor_eps2;
   // equal-mass form of the packed one-sided kernel: the host's scan of the uploaded state stands while nothing else writes
   // the position buffer ("not equal" always stands: the device word is sticky); otherwise the device looks before the launch
   L.general = c->sym_general;
   L.check_masses = (c->sym_general && c->masses_equal != 0 && !(c->masses_equal == 1 && c->own_posm && !c->posm_escaped)) ? 1 : 0;
+  // block kernel: which form to launch — the host's finding if it stands, both (each looks at the device word) otherwise
+  L.uni = (!c->sym_general || c->masses_equal == 0) ? 0 : (L.check_masses ? -1 : 1);
   return L;
 }
 
@@ -825,9 +853,9 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
       c->sym_dup_slots = slots;
       if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
     }
-    // equal-mass form of the packed one-sided kernel (not the small-system kernels, whose one launch has no room for a test)
+    // equal-mass form of the packed one-sided kernel and of the block kernel (not small_pk_kernel)
     const char *no_uni = getenv("NBODY_SYM_NO_UNI");
-    if (p.precision != NBODY_PREC_F64 && !c->wave && c->ipt % 2 == 0 && p.zero_mode != NBODY_ZERO_SELECT &&
+    if (p.precision != NBODY_PREC_F64 && (c->wave >= 2 || (!c->wave && c->ipt % 2 == 0)) && p.zero_mode != NBODY_ZERO_SELECT &&
         p.zero_mode != NBODY_ZERO_FLOOR && !(no_uni && no_uni[0] == '1')) {
       if ((e = hipMalloc(&c->sym_general, 64)) != hipSuccess) return bail(e, "hipMalloc equal-mass flag");
       if ((e = hipMemset(c->sym_general, 0, 64)) != hipSuccess) return bail(e, "hipMemset equal-mass flag");
@@ -928,10 +956,9 @@ int nbody_bind_device_state(nbody_ctx *c, void *posm, void *vel, void *acc) {
     if (int rc = posm_escapes(c)) return rc;
     if (c->own_posm) (void)hipFree(c->posm);
     c->posm = posm; c->own_posm = false;
-    if (c->sym_general) {                       // masses nobody here has seen: every pass's preparation kernel looks
-      c->masses_equal = -1;
+    c->masses_equal = -1;                       // masses nobody here has seen
+    if (c->sym_general)                         // ... every pass's preparation kernel looks
       HIP_TRY(c, hipMemsetAsync(c->sym_general, 0, 4, c->stream));
-    }
   }
   if (vel)  { if (c->own_vel) (void)hipFree(c->vel);   c->vel = vel;   c->own_vel = false; }
   if (acc)  { if (c->own_acc) (void)hipFree(c->acc);   c->acc = acc;   c->own_acc = false; }
@@ -1141,10 +1168,10 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
       return bh_small_finish(c);
     }
   }
-  // small single-context fp32 systems: forces + update in ONE launch per step, ping-ponging the position buffer
-  // (it swaps the two position buffers: not once the caller holds a pointer to one of them)
+  // small and mid-size single-context fp32 systems: forces + update in ONE launch per step, ping-ponging the position buffer
+  // (it swaps the two position buffers: not once the caller holds a pointer to one of them; the host must know the masses)
   const bool one_launch = c->wave != 0 && c->theta == 0.0f && c->own_posm && !c->posm_escaped &&
-                          c->p.i_count == c->p.n_total && c->p.precision == NBODY_PREC_F32;
+                          c->p.i_count == c->p.n_total && c->p.precision == NBODY_PREC_F32 && make_launch(c).uni >= 0;
   if (one_launch && !c->posm_alt) HIP_TRY(c, hipMalloc(&c->posm_alt, (size_t)c->p.n_total * c->elem));
   for (int s = 0; s < nsteps; ++s) {
     if (one_launch) {
@@ -1566,7 +1593,7 @@ const char *nbody_force_kernel_name(const nbody_ctx *c) {
   if (c->multi) return nbody_force_kernel_name(nbody::multi_part(c->multi, 0));
   if (c->theta > 0.0f) return c->p.n_total <= 4096 ? "bh_walk_compact_kernel (+ bh_small_build_kernel)" : "bh_walk_lane_kernel (+ tree build)";
   if (c->sym) return c->p.precision == NBODY_PREC_F64 ? "forces_sym_f64_kernel" : "forces_sym_pk_kernel";
-  if (c->wave) return "small_pk_kernel";
+  if (c->wave) return "forces_block_pk_kernel";
   if (c->p.precision != NBODY_PREC_F64 && c->ipt % 2 == 0 && (c->p.eps > 0.0 || c->p.zero_mode != NBODY_ZERO_SELECT))
     return "forces_tile_pk_kernel";
   return "forces_tile_kernel";

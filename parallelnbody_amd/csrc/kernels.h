@@ -19,7 +19,11 @@ struct ForceLaunch {
   double eps2;          // > 0: softened (also the "floor" mode); == 0: exact d == 0 skip
   int zero_mode;        // for eps2 == 0: 1 = clamp trick (default), 2 = compare+select (A/B only)
   int precision;        // NBODY_PREC_*
-  int wave;             // 0: tile kernels; != 0: small-N kernel, one workgroup per pair of bodies (j_split must be 1)
+  int wave;             // 0: tile kernels; 2 ... 8: forces_block_pk_kernel (kernels_block.hip), a workgroup per `wave` register
+                        // pairs of bodies, its lanes split the j range (j_split must be 1)
+  int uni = 0;          // wave >= 2: 1 = the caller knows that every body has body 0's mass (equal-mass form only), 0 = it knows they
+                        // do not (general form only), -1 = launch both, each looks at `general`
+  int guarded = 0;      // wave >= 2: guard every pair (no optimistic bare pass)
   void *dup_table = nullptr;   // packed fp32 kernel, exact mode: coincident-body detector's table [dup_slots] + {flag, count};
   int dup_slots = 0;           // with it, tiles that hold no self pair run without the d == 0 guard when no two bodies coincide
   // packed fp32 kernel: device int that is 0 when every body has body 0's mass (equal-mass form: no mass factor in the
@@ -31,11 +35,30 @@ struct ForceLaunch {
 
 // All-pairs force partials.  Returns hipSuccess or the launch error.
 hipError_t launch_forces(const ForceLaunch &L, hipStream_t s);
-// Small single-context fp32 systems (L.wave != 0): the whole Tick body — forces, v += dt*a, x += dt*v — in one launch.
+// Small and mid-size single-context fp32 systems (L.wave != 0): the whole Tick body — forces, v += dt*a, x += dt*v — in one launch.
 // New positions go to posm_out (a second buffer: the old one is still being read); the caller swaps them afterwards.
 hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s);
 // Blocks / threads launch_forces will use for L (for logs).
 void forces_geometry(const ForceLaunch &L, int *blocks, int *threads);
+
+// Small and mid-size fp32 systems — kernels_block.hip: a workgroup owns `np` register pairs of bodies and its lanes split
+// the j range; a body's whole sum is finished inside its workgroup, so with dt > 0 the Tick's update rides along (new
+// positions into posm_out) and a step is one launch with no partial rows.
+struct BlockLaunch {
+  const void *posm = nullptr;   // [n_total] float4, read only
+  void *posm_out = nullptr;     // dt > 0: [n_total] float4, the owned bodies' new (x, y, z, m); must not be posm
+  void *vel = nullptr;          // dt > 0: [i_count] float4
+  void *acc = nullptr;          // [i_count] float4
+  int n_total = 0, i_begin = 0, i_count = 0;
+  int np = 2;                   // register pairs per workgroup: 2 ... 8
+  double G = 0.0, eps2 = 0.0;   // eps2 > 0 softened (also the floor mode); == 0 exact d == 0 skip
+  float dt = 0.f;               // <= 0: accelerations only
+  int uni = 0;                  // 1: every body has body 0's mass (the caller knows): no mass factor in the pair loop; 0: general form;
+                                // -1: both forms are launched and *general (0 = equal masses) says which one runs
+  const void *general = nullptr;
+  int optimistic = 1;           // eps2 == 0: bare pair law outside the own group first, guarded walk only where a sum came out non-finite
+};
+hipError_t launch_block(const BlockLaunch &L, hipStream_t s);
 
 // acc[i] = sum_c accp[c][i] in chunk order; if dt > 0 also v += dt*a; x += dt*v (owned slice of posm).
 hipError_t launch_update(int precision, void *posm, void *vel, void *acc, const void *accp, int i_begin,

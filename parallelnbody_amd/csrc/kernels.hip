@@ -331,83 +331,6 @@ template <typename T> __device__ __forceinline__ T mul_add_sep(T a, T b, T c) {
   return c + p;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Small-N kernel: one WORKGROUP per register pair of bodies, the j range spread over its 256 lanes.
-//
-// The reference ships N = 2000 (BP_NBodyHUD: CreateSpacePoints(2000, 1000)).  With one lane per i-body that is 8
-// workgroups on a 256-CU chip (72 us per pass, measured); here it is 1000 workgroups.  The two i-bodies sit in a
-// register pair with the same value in every lane (moved out of SGPRs: an SGPR operand halves the issue rate), lane
-// t walks bodies t, t+256, ... with coalesced global loads — eight in flight before the first is used; the positions
-// are L2-resident at this size, so no LDS staging — the packed pair law of pk_common.h does the arithmetic, wavefront
-// shuffles and one LDS hop fold the 256 partial sums in a fixed order.
-// FUSE: thread 0 also applies the reference's update (OctreeSearch.cpp:29-30) to the two bodies and writes the new
-// positions to a SECOND position buffer (other workgroups are still reading the old one); the host swaps the two
-// after the launch.  One launch per Tick instead of two: at this size a launch's fixed cost (~4.5 us) is the step.
-// ---------------------------------------------------------------------------------------------------------
-template <int ZMODE, bool FUSE>
-__global__ __launch_bounds__(kBlock) void small_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ posm_out,
-                                                          float4 *__restrict__ vel, float4 *__restrict__ acc_out,
-                                                          int n_total, int i_begin, int i_count, float gscale, float zp,
-                                                          float dt) {
-  __shared__ float red[kBlock / 64][6];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int ia = 2 * blockIdx.x, ib = ia + 1;                    // owned-slice indices of this workgroup's bodies
-  if (ia >= i_count) return;                                     // uniform per workgroup
-
-  const float4 p0 = posm[i_begin + ia];
-  const float4 p1 = posm[i_begin + min(ib, i_count - 1)];
-  f2 xi[1] = {f2{p0.x, p1.x}}, yi[1] = {f2{p0.y, p1.y}}, zi[1] = {f2{p0.z, p1.z}};
-  asm volatile("" : "+v"(xi[0]), "+v"(yi[0]), "+v"(zi[0]));     // workgroup-uniform values: keep them in VGPRs
-  f2 zp2 = splat2(zp), one2 = splat2(1.0f);
-  asm volatile("" : "+v"(zp2), "+v"(one2));
-  Acc3pk<false> a[1];
-
-  constexpr int JB = 8;
-  const int trips = (n_total + kBlock * JB - 1) / (kBlock * JB);
-  for (int it = 0; it < trips; ++it) {
-    float4 pj[JB];
-#pragma unroll
-    for (int g = 0; g < JB; ++g) {
-      const int j = (it * JB + g) * kBlock + t;
-      pj[g] = (j < n_total) ? posm[j] : make_float4(0.f, 0.f, 0.f, 0.f);   // zero-mass padding
-    }
-#pragma unroll
-    for (int g = 0; g < JB; ++g) pj[g].w *= gscale;
-    pair_group_pk<1, JB, ZMODE, false>(xi, yi, zi, pj, zp2, one2, a);
-  }
-
-  float v[6] = {a[0].x.x, a[0].y.x, a[0].z.x, a[0].x.y, a[0].y.y, a[0].z.y};
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) v[q] += __shfl_xor(v[q], off, 64);
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q) red[wave][q] = v[q];
-  }
-  __syncthreads();
-  if (t == 0) {
-    float s[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) s[q] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int il = ia + h;
-      if (il >= i_count) break;
-      const float ax = s[3 * h], ay = s[3 * h + 1], az = s[3 * h + 2];
-      acc_out[il] = make_float4(ax, ay, az, 0.f);
-      if (FUSE) {
-        float4 vv = vel[il];
-        float4 x = h == 0 ? p0 : p1;
-        vv.x = mul_add_sep(dt, ax, vv.x); vv.y = mul_add_sep(dt, ay, vv.y); vv.z = mul_add_sep(dt, az, vv.z);
-        x.x = mul_add_sep(dt, vv.x, x.x); x.y = mul_add_sep(dt, vv.y, x.y); x.z = mul_add_sep(dt, vv.z, x.z);
-        vel[il] = vv;
-        posm_out[i_begin + il] = x;
-      }
-    }
-  }
-}
-
 // Combine the j-chunk partials in chunk order (deterministic), store the acceleration, and — when
 // integrate != 0 — apply the reference's update with separate multiply and add (no FMA), exactly
 // as FVector's operators do: v = v + dt*a; x = x + dt*v   (OctreeSearch.cpp:29-30).
@@ -612,35 +535,33 @@ hipError_t launch_forces_ipt(const ForceLaunch &L, hipStream_t s) {
 
 }  // namespace
 
-static hipError_t launch_forces_wave(const ForceLaunch &L, hipStream_t s) {
-  dim3 grid((L.i_count + 1) / 2), block(kBlock);
-  if (L.eps2 > 0.0)
-    hipLaunchKernelGGL((small_pk_kernel<Z_SOFT, false>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)nullptr,
-                       (float4 *)nullptr, (float4 *)L.accp, L.n_total, L.i_begin, L.i_count, (float)L.G, (float)L.eps2, 0.f);
-  else
-    hipLaunchKernelGGL((small_pk_kernel<Z_CLAMP, false>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)nullptr,
-                       (float4 *)nullptr, (float4 *)L.accp, L.n_total, L.i_begin, L.i_count, (float)L.G, -0x1p126f, 0.f);
-  return hipGetLastError();
+// L.wave >= 2: the block kernel (kernels_block.hip); dt > 0 makes it the whole Tick body
+static BlockLaunch block_launch(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt) {
+  BlockLaunch b;
+  b.posm = L.posm; b.posm_out = posm_out; b.vel = vel; b.acc = acc;
+  b.n_total = L.n_total; b.i_begin = L.i_begin; b.i_count = L.i_count;
+  b.np = L.wave; b.G = L.G; b.eps2 = L.eps2; b.dt = dt; b.uni = L.uni; b.general = L.general; b.optimistic = L.guarded ? 0 : 1;
+  return b;
 }
 
-// One whole Tick body of a small single-context system in one launch: forces + kick-drift into posm_out.
+static hipError_t launch_forces_wave(const ForceLaunch &L, hipStream_t s) {
+  if (L.general != nullptr && L.check_masses)     // somebody else may have written the buffer: the device looks at the masses
+    hipLaunchKernelGGL(mass_check_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       (const float4 *)L.posm, L.n_total, (int *)L.general);
+  return launch_block(block_launch(L, nullptr, nullptr, L.accp, 0.f), s);
+}
+
+// One whole Tick body of a small or mid-size single-context system in one launch: forces + kick-drift into posm_out.
 hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s) {
-  if (L.wave == 0 || L.precision != NBODY_PREC_F32 || L.i_begin != 0 || L.i_count != L.n_total || !(dt > 0.f))
+  if (L.wave < 2 || L.precision != NBODY_PREC_F32 || L.i_begin != 0 || L.i_count != L.n_total || !(dt > 0.f) || L.uni < 0)
     return hipErrorInvalidValue;
-  dim3 grid((L.i_count + 1) / 2), block(kBlock);
-  if (L.eps2 > 0.0)
-    hipLaunchKernelGGL((small_pk_kernel<Z_SOFT, true>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)posm_out,
-                       (float4 *)vel, (float4 *)acc, L.n_total, 0, L.i_count, (float)L.G, (float)L.eps2, dt);
-  else
-    hipLaunchKernelGGL((small_pk_kernel<Z_CLAMP, true>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)posm_out,
-                       (float4 *)vel, (float4 *)acc, L.n_total, 0, L.i_count, (float)L.G, -0x1p126f, dt);
-  return hipGetLastError();
+  return launch_block(block_launch(L, posm_out, vel, acc, dt), s);
 }
 
 hipError_t launch_forces(const ForceLaunch &L, hipStream_t s) {
   if (L.i_count <= 0 || L.n_total <= 0 || L.j_split <= 0 || L.j_chunk <= 0) return hipErrorInvalidValue;
   if (L.wave != 0) {
-    if (L.precision != NBODY_PREC_F32 || L.j_split != 1) return hipErrorInvalidValue;
+    if (L.precision != NBODY_PREC_F32 || L.j_split != 1 || L.wave < 2) return hipErrorInvalidValue;
     return launch_forces_wave(L, s);
   }
   if (L.j_chunk % L.tile != 0 && L.j_split > 1) return hipErrorInvalidValue;
@@ -654,7 +575,7 @@ hipError_t launch_forces(const ForceLaunch &L, hipStream_t s) {
 
 void forces_geometry(const ForceLaunch &L, int *blocks, int *threads) {
   if (L.wave != 0) {
-    if (blocks) *blocks = (L.i_count + 1) / 2;
+    if (blocks) *blocks = (L.i_count + 2 * L.wave - 1) / (2 * L.wave);
     if (threads) *threads = kBlock;
     return;
   }

@@ -170,9 +170,9 @@ def test_bh_large_n(nb, oracle):
     assert st["nodes"] == nodes and st["levels"] >= 8
 
 
-@pytest.mark.parametrize("n", [16384, 49152])
+@pytest.mark.parametrize("n", [20480, 49152])
 def test_switching_the_opening_angle_on_a_fused_all_pairs_context(nb, oracle, n):
-    # N >= 12288 single-device fp32: the all-pairs step is the symmetric kernel with the fused update, which prepares the
+    # N > 16384 single-device fp32: the all-pairs step is the symmetric kernel with the fused update, which prepares the
     # NEXT pass (scaled positions, coincident-body table) while it moves the bodies.  A Barnes-Hut step in between moves
     # them with the plain update: the next all-pairs pass must prepare again, not reuse what the last fused update left.
     # (The actor hands its public Theta field to nbody_set_theta on every Tick, so this sequence is one checkbox away.)

@@ -1,0 +1,197 @@
+"""forces_block_pk_kernel (csrc/kernels_block.hip): the one-launch step of small and mid-size fp32 systems, through the
+C-ABI, against the CPU oracle (OctreeSearch.h:101-104 summed over all j; OctreeSearch.cpp:28-31 for the update).
+
+Tolerance as in test_parity_gpu.py: per-body |a_gpu - a_oracle| / |a_oracle| <= 2e-5 asserted (1e-4 stated)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACC = 2e-5
+BLOCK = "forces_block_pk_kernel"
+
+
+def scene(n, seed, equal=False, box=500.0):
+    rng = np.random.default_rng(seed)
+    posm = np.concatenate([rng.uniform(-box, box, (n, 3)), rng.uniform(1, 5000, (n, 1))], 1).astype(np.float32)
+    if equal:
+        posm[:, 3] = np.float32(37.5)
+    if n > 3:
+        posm[0, :3] = 0.0                                # the shipped scene pins body 0 at the origin
+    vel = np.concatenate([rng.uniform(-5, 5, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    return posm, vel
+
+
+def sampled(n, rng, k=24):
+    fixed = [0, 1, 255, 256, 257, n // 2, n - 2, n - 1]
+    return sorted(set(int(i) for i in fixed if 0 <= i < n) | set(int(i) for i in rng.choice(n, min(n, k), replace=False)))
+
+
+@pytest.mark.parametrize("eps", [0.0, 0.7])
+@pytest.mark.parametrize("equal", [False, True])
+@pytest.mark.parametrize("n", [2560, 3001, 4096, 5000, 8192, 8200, 12289, 16384])
+def test_block_kernel_forces_match_the_oracle(nb, oracle, n, equal, eps):
+    posm, vel = scene(n, n + 17, equal)
+    with nb.NBodyEngine(n, eps=eps) as e:
+        assert e.launch_config()["kernel"] == BLOCK
+        e.set_state(posm, vel)
+        e.compute_forces()
+        assert bool(e.equal_mass_form()) == equal
+        a = e.accelerations()
+    assert np.all(np.isfinite(a))
+    p64 = posm.astype(np.float64)
+    for i in sampled(n, np.random.default_rng(n)):
+        ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], eps=eps, i0=i, i1=i + 1)[0]
+        assert np.linalg.norm(a[i, :3] - ref) / np.linalg.norm(ref) < TOL_ACC, (n, equal, eps, i)
+
+
+@pytest.mark.parametrize("n", [2560, 6000, 8192, 10000])
+def test_block_kernel_against_the_reference_arithmetic_on_every_body(nb, oracle, n):
+    # every body against the oracle's fp32 direct sum (d in fp32, scale factor in double: OctreeSearch.h:101-104)
+    posm, vel = scene(n, n + 3)
+    with nb.NBodyEngine(n) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+    ref = oracle.forces_direct_f32(posm[:, :3], posm[:, 3])
+    assert rel_err(a, ref).max() < TOL_ACC
+
+
+@pytest.mark.parametrize("equal", [False, True])
+@pytest.mark.parametrize("n", [3000, 8192, 9000])
+def test_coincident_bodies_send_a_workgroup_through_the_guarded_walk(nb, oracle, n, equal):
+    """OctreeSearch.h:102: `if (d == 0) return`.  The kernel first bets that only self pairs have d == 0; a workgroup whose
+    sums come out non-finite walks again with the guard.  The stored bits must be those of a pass that guards every pair."""
+    posm, vel = scene(n, n + 29, equal)
+    posm[17, :3] = posm[n - 400, :3]                     # different groups of j-bodies
+    posm[n - 1, :3] = posm[3, :3]
+    posm[600, :3] = posm[601, :3]                        # neighbours: same workgroup, same group
+    posm[1200, :3] = posm[0, :3]                         # on the origin, with body 0
+    with nb.NBodyEngine(n) as e:
+        assert e.launch_config()["kernel"] == BLOCK
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+        os.environ["NBODY_SYM_GUARDED"] = "1"
+        try:
+            e.compute_forces()
+            g = e.accelerations()
+        finally:
+            del os.environ["NBODY_SYM_GUARDED"]
+    assert np.all(np.isfinite(a))
+    np.testing.assert_array_equal(a, g)
+    ref = oracle.forces_direct_f32(posm[:, :3], posm[:, 3])
+    assert rel_err(a, ref).max() < TOL_ACC
+
+
+def test_underflowing_separations_and_a_body_on_the_padding_point(nb, oracle):
+    # two DIFFERENT positions whose squared distance underflows to 0 in fp32 (only possible next to the origin): the
+    # reference's d == 0 test skips the pair; and a body exactly where the kernel parks its far-away padding
+    n = 5003                                             # ragged: the last group is padded
+    posm, vel = scene(n, 91)
+    posm[0, :3] = 0.0
+    posm[3500, :3] = (1e-30, 0.0, -1e-31)
+    posm[n - 1, :3] = np.float32(1.0e30)
+    posm[n - 1, 3] = 0.0
+    with nb.NBodyEngine(n) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+    assert np.all(np.isfinite(a))
+    ref = oracle.forces_direct_f32(posm[:n - 1, :3], posm[:n - 1, 3])
+    assert rel_err(a[:n - 1], ref).max() < TOL_ACC
+
+
+@pytest.mark.parametrize("equal", [False, True])
+@pytest.mark.parametrize("n", [2560, 8192, 12000])
+def test_one_launch_step_is_the_reference_update_of_its_own_acceleration(nb, oracle, n, equal):
+    # OctreeSearch.cpp:29-30 with separate multiply and add: given the device's own acc, v and x match the oracle's
+    # kick-drift bit for bit; and a second step starts from the swapped buffer
+    posm, vel = scene(n, n + 5, equal)
+    with nb.NBodyEngine(n) as e:
+        e.set_state(posm, vel)
+        e.step(0.01, 1)
+        p, v, a = e.state()
+        p1, v1 = oracle.kick_drift_f32(posm[:, :3], vel[:, :3], a[:, :3], 0.01)
+        np.testing.assert_array_equal(v[:, :3], v1)
+        np.testing.assert_array_equal(p[:, :3], p1)
+        np.testing.assert_array_equal(p[:, 3], posm[:, 3])
+        e.step(0.01, 1)
+        p2, v2, a2 = e.state()
+        q2, w2 = oracle.kick_drift_f32(p[:, :3], v[:, :3], a2[:, :3], 0.01)
+        np.testing.assert_array_equal(v2[:, :3], w2)
+        np.testing.assert_array_equal(p2[:, :3], q2)
+        e.compute_forces()                               # the same positions again, without the update
+        np.testing.assert_array_equal(e.accelerations(), e.accelerations())
+    i = n // 3
+    p64 = p.astype(np.float64)
+    ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=i, i1=i + 1)[0]
+    assert np.linalg.norm(a2[i, :3] - ref) / np.linalg.norm(ref) < TOL_ACC
+
+
+@pytest.mark.parametrize("equal", [False, True])
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_a_position_pointer_handed_out_keeps_the_trajectory(nb, n, equal):
+    """Once nbody_device_ptr(NBODY_BUF_POSM) is out the context may not swap its buffers any more (two launches per step,
+    and the device looks at the masses itself): the trajectory is the one-launch path's, bit for bit."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    posm, vel = scene(n, n + 7, equal)
+    with nb.NBodyEngine(n) as held, nb.NBodyEngine(n) as private:
+        for e in (held, private):
+            e.set_state(posm, vel)
+            e.step(0.01, 3)
+        ptr, nbytes = held.device_ptr(nb.BUF_POSM)
+        for e in (held, private):
+            e.step(0.01, 4)
+        held.synchronize()
+        assert bool(held.equal_mass_form()) == equal and bool(private.equal_mass_form()) == equal
+        seen = np.empty((n, 4), np.float32)
+        assert hip.hipMemcpy(seen.ctypes.data, ptr, nbytes, 2) == 0
+        np.testing.assert_array_equal(seen, held.state()[0])
+        np.testing.assert_array_equal(seen, private.state()[0])
+        np.testing.assert_array_equal(held.state()[1], private.state()[1])
+        # the caller changes a mass through the pointer: the next pass must notice
+        seen[9, 3] *= np.float32(3.0)
+        assert hip.hipMemcpy(ptr, seen.ctypes.data, nbytes, 1) == 0
+        held.compute_forces()
+        assert not held.equal_mass_form()
+        private.set_state(seen, private.state()[1])
+        private.compute_forces()
+        np.testing.assert_array_equal(held.accelerations(), private.accelerations())
+
+
+@pytest.mark.parametrize("equal", [False, True])
+def test_slices_of_a_block_kernel_system_reproduce_the_single_context(nb, equal):
+    # range partition: each context owns a slice and sees all positions; a body's sum does not depend on
+    # which other bodies share its workgroup, so the bits are the single context's
+    n = 6001
+    posm, vel = scene(n, 77, equal)
+    with nb.NBodyEngine(n) as e:
+        assert e.launch_config()["kernel"] == BLOCK
+        e.set_state(posm, vel)
+        e.step(0.01, 1)
+        p_all, v_all, a_all = e.state()
+    cuts = [0, 1999, 4001, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        with nb.NBodyEngine(n, i_begin=lo, i_count=hi - lo) as e:
+            assert e.launch_config()["kernel"] == BLOCK
+            e.set_state(posm, vel)
+            e.step(0.01, 1)
+            p, v, a = e.state()
+        np.testing.assert_array_equal(a, a_all[lo:hi])
+        np.testing.assert_array_equal(p, p_all[lo:hi])
+        np.testing.assert_array_equal(v, v_all[lo:hi])
+
+
+def test_energy_drift_of_the_one_launch_step(nb):
+    # north star: total-energy drift < 1e-4 over 1k steps (softened Plummer sphere), as test_energy_drift_1k_steps
+    from test_parity_gpu import _drift
+    worst, kernel = _drift(nb, 8192, "f32", 1000, 250)
+    assert kernel == BLOCK
+    assert worst < 1e-4, worst

@@ -281,7 +281,7 @@ def test_equal_mass_form_is_not_used_where_it_does_not_apply(nb):
     n = 4096
     posm, vel = scene(n, 5)
     for kw in (dict(algorithm=2, i_per_thread=4, zero_mode=2), dict(algorithm=1, zero_mode=1), dict(algorithm=1, zero_mode=2),
-               dict(algorithm=1, precision="f64"), dict(algorithm=1, i_per_thread=1), dict(theta=1.0), dict()):   # dict(): small_pk_kernel
+               dict(algorithm=1, precision="f64"), dict(algorithm=1, i_per_thread=1), dict(theta=1.0)):
         with nb.NBodyEngine(n, **kw) as e:
             e.set_state(posm, vel)
             e.compute_forces()

@@ -1036,7 +1036,7 @@ def test_geometry_fuzz_sizes_ranks_and_precisions(nb, oracle, equal_masses):
             else:
                 assert np.linalg.norm(a[i] - ref) / scale < tol, (trial, n, ranks, prec, eps, forced, kernels, int(i))
     assert ran >= 100, ran
-    assert {"forces_sym_pk_kernel", "forces_tile_pk_kernel", "small_pk_kernel", "forces_sym_f64_kernel"} <= seen, seen
+    assert {"forces_sym_pk_kernel", "forces_tile_pk_kernel", "forces_block_pk_kernel", "forces_sym_f64_kernel"} <= seen, seen
 
 
 @pytest.mark.parametrize("n", [2000, 40000])
