@@ -847,6 +847,73 @@ __global__ void bh_finish_kernel(SmallTree T, int n, int keep_root) {
   T.hdr[1] = T.hdr[0] - n; T.hdr[2] = deep + 1; T.hdr[4] = T.hdr[4] + 1;
 }
 
+// deepest level with a cell of >= 2 bodies: the maximum over the header's kDeepSlots words (bh_lcp_kernel); every thread of
+// the workgroup gets it (s_tmp: one int of LDS)
+__device__ __forceinline__ int deepest_level(const SmallTree &T, int *s_tmp) {
+  if (threadIdx.x < 64) {
+    int m = threadIdx.x < kDeepSlots ? T.hdr[kHdrDeep + threadIdx.x] : -1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if (threadIdx.x == 0) *s_tmp = m;
+  }
+  __syncthreads();
+  return *s_tmp;
+}
+
+// ComputeMass (.h:89-95) in two launches instead of one per level (systems up to kChunkSweepMaxN bodies).  Body i (key order) opens the cell of level l iff
+// lcp(i-1) < l <= lcp(i), and a cell's descendants are cells opened by bodies of its own range.  So a workgroup that owns
+// the kB bodies [a, b) can finish, deepest level first with a workgroup barrier per level, every cell that ENDS inside its
+// chunk — the cell's first body is in the chunk anyway.  What is left are the cells that reach beyond their chunk's end:
+// at most one per level and chunk (cells of one level are disjoint, and each of these holds body b), noted in
+// straddle[level][chunk] ...
+__global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+                                                             const int *__restrict__ first, const signed char *__restrict__ lcpS,
+                                                             int *__restrict__ straddle, int nchunks, int div_mode) {
+  __shared__ int s_deep;
+  const int chunk = blockIdx.x, i = chunk * kB + threadIdx.x;
+  if (T.hdr[3] != 0) return;                                    // a refused frame (uniform)
+  const int deep = deepest_level(T, &s_deep);
+  if (threadIdx.x <= kMaxLevels) straddle[threadIdx.x * nchunks + chunk] = -1;
+  const int lp = i < n ? (int)lcpS[i] : 0, ln = i < n ? (int)lcpS[i + 1] : -1;
+  const int m0 = i < n ? first[i] : 0;
+  const int chunk_end = first[min((chunk + 1) * kB, n)];       // the first node behind the chunk's bodies
+  __syncthreads();
+  for (int l = deep; l >= 0; --l) {
+    if (lp < l && l <= ln) {
+      const int m = m0 + (l - lp - 1);
+      const unsigned int w = T.meta[m];
+      if ((int)(w & kLinkMask) <= chunk_end) T.com[m] = sweep_compact_cell(T.com, T.meta, m, w, l, div_mode, posm, T.root);
+      else straddle[l * nchunks + chunk] = m;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// ... and finished here by ONE workgroup, again deepest level first: a straddling cell's children are cells that ended
+// inside a chunk (done) or straddling cells one level down (done in the round before).  Then the hand-over (bh_finish).
+constexpr int kTopT = 1024;
+constexpr int kChunkSweepMaxN = 131072;       // larger systems sweep with a launch per level (bh_forces)
+__global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+                                                             const int *__restrict__ straddle, int nchunks, int div_mode,
+                                                             int keep_root) {
+  __shared__ int s_deep;
+  if (T.hdr[3] != 0) return;
+  const int deep = deepest_level(T, &s_deep);
+  for (int l = deep; l >= 0; --l) {
+    for (int c = threadIdx.x; c < nchunks; c += kTopT) {
+      const int m = straddle[l * nchunks + c];
+      if (m >= 0) T.com[m] = sweep_compact_cell(T.com, T.meta, m, T.meta[m], l, div_mode, posm, T.root);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (!keep_root) { const float4 c = T.com[0]; T.prev_com[0] = c.x; T.prev_com[1] = c.y; T.prev_com[2] = c.z; }   // .cpp:78
+    T.hdr[1] = T.hdr[0] - n; T.hdr[2] = deep + 1; T.hdr[4] = T.hdr[4] + 1;
+  }
+}
+
 // Octree::ComputeForces (.h:99-108) on the compact tree, one lane per body in key order, node by node: a 16-byte and a
 // 4-byte load, the squared distance and a compare per node (accept_threshold); root, double-precision factor and the three
 // multiply-adds only where a term is added.
@@ -897,6 +964,7 @@ struct BhState {
   size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
   int *first = nullptr, *cnt = nullptr;    // larger systems: [n + 1] first node of every body's group / its size
   signed char *lcpS = nullptr;             // [n + 1] shared digits of neighbours
+  int *straddle = nullptr;                 // [kMaxLevels + 1][chunks of kB bodies] cells that reach beyond their chunk (bh_sweep_chunks_kernel)
   hipEvent_t ev = nullptr;                 // larger systems: "the verdict and the deepest level are on the host"
   int *counters = nullptr;     // device: the tree's header (SmallTree::hdr; [5]: deepest level, larger systems)
   int *h_counters = nullptr;   // pinned
@@ -948,6 +1016,7 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->first, sizeof(int) * ((size_t)n + 1)));
   BH_TRY(hipMalloc(&b->cnt, sizeof(int) * ((size_t)n + 1)));
   BH_TRY(hipMalloc(&b->lcpS, (size_t)n + 1));
+  BH_TRY(hipMalloc(&b->straddle, sizeof(int) * (size_t)(kMaxLevels + 1) * (size_t)((n + kB - 1) / kB)));
   bytes = 0;
   BH_TRY(rocprim::exclusive_scan(nullptr, bytes, b->cnt, b->first, 0, (size_t)n + 1, rocprim::plus<int>()));
   b->scan_tmp_bytes = bytes;
@@ -958,7 +1027,7 @@ hipError_t bh_create(BhState **out, int n) {
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->sort_tmp, b->scan_tmp, b->first, b->cnt, b->lcpS,
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->sort_tmp, b->scan_tmp, b->first, b->cnt, b->lcpS, b->straddle,
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
@@ -1059,9 +1128,20 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   }
   int maxl = -1;
   for (int q = 0; q < kDeepSlots; ++q) maxl = std::max(maxl, b->h_counters[kHdrDeep + q]);
-  for (int l = maxl; l >= 0; --l)                              // ComputeMass: children before parents
-    hipLaunchKernelGGL(bh_sweep_level_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, l, b->div_mode);
-  hipLaunchKernelGGL(bh_finish_kernel, dim3(1), dim3(1), 0, s, b->st, n, keep_root);
+  // ComputeMass, children before parents.  Up to kChunkSweepMaxN bodies in two launches (the cells that end inside their
+  // chunk of kB bodies, then the few that do not, by one workgroup); above it a launch per level over all bodies — there the
+  // one workgroup of the second launch would have thousands of chunks to look at per level (same-box frames, two launches
+  // against one per level: N = 8192 218 / 240 us, 16384 224 / 243, 65536 276 / 289, 262144 446 / 435, 2^20 1145 / 940).
+  // NBODY_BH_LEVEL_SWEEPS=1: a launch per level at any size (A/B).
+  static const bool level_sweeps = [] { const char *e = getenv("NBODY_BH_LEVEL_SWEEPS"); return e && e[0] == '1'; }();
+  if (level_sweeps || n > kChunkSweepMaxN) {
+    for (int l = maxl; l >= 0; --l)
+      hipLaunchKernelGGL(bh_sweep_level_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, l, b->div_mode);
+    hipLaunchKernelGGL(bh_finish_kernel, dim3(1), dim3(1), 0, s, b->st, n, keep_root);
+  } else {
+    hipLaunchKernelGGL(bh_sweep_chunks_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, (int)grd.x, b->div_mode);
+    hipLaunchKernelGGL(bh_sweep_top_kernel, dim3(1), dim3(kTopT), 0, s, b->st, posm, n, b->straddle, (int)grd.x, b->div_mode, keep_root);
+  }
   // one lane per body needs enough bodies to hide its loads; below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning)
   static const int rows_max_n = [] { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); return e && *e ? atoi(e) : kRowsMaxN; }();
   if (n <= rows_max_n)
