@@ -127,7 +127,9 @@ NBODY_API int nbody_default_params(nbody_params *p);
  * divisor K of that plan also follows an estimate of the pass's duration from rates measured on MI355X (6.6e12 / 6.0e12 /
  * 2.7e12 interactions/s: fp32 / compensated / fp64).  Results are therefore reproducible on every MI355X, and across
  * library versions only where the release notes say so; on a part with another CU count they agree to rounding, not in
- * every bit.  nbody_get_launch_config, nbody_get_algorithm and nbody_sym_pool_info say what was chosen;
+ * every bit.  (Plain fp32 systems of up to 16384 bodies run forces_block_pk_kernel: there the CU count only decides how
+ * many bodies share a workgroup, which no sum depends on — the same bits on any part.)  nbody_get_launch_config,
+ * nbody_get_algorithm and nbody_sym_pool_info say what was chosen;
  * NBODY_ALGO_TILED with explicit tile / i_per_thread / j_split depends on the parameters alone. */
 NBODY_API int nbody_create(const nbody_params *p, nbody_ctx **out);
 
@@ -278,7 +280,8 @@ NBODY_API int nbody_set_stream(nbody_ctx *ctx, void *hip_stream);
 /* Raw device pointer of one state buffer (e.g. as the send/recv buffer of an all-gather).  It stays valid, and keeps
  * naming the live buffer, until nbody_destroy or a nbody_bind_device_state of that buffer.  Asking for NBODY_BUF_POSM
  * tells the context that positions may change behind its back: from then on it re-reads them before every force pass
- * (no fused update + preparation, no buffer-swapping one-launch step on small systems) — same results, a little slower. */
+ * (no fused update + preparation, no buffer-swapping one-launch step on systems of up to 16384 bodies) — same results, a
+ * little slower. */
 NBODY_API int nbody_device_ptr(nbody_ctx *ctx, int32_t which, void **ptr, size_t *bytes);
 
 /* Use caller-owned device memory for the state (any may be NULL = keep the context's own).
