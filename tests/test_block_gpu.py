@@ -195,3 +195,25 @@ def test_energy_drift_of_the_one_launch_step(nb):
     worst, kernel = _drift(nb, 8192, "f32", 1000, 250)
     assert kernel == BLOCK
     assert worst < 1e-4, worst
+
+
+def test_bits_do_not_depend_on_how_many_bodies_share_a_workgroup(nb):
+    # the register pairs per workgroup follow the CU count (block_pairs, csrc/capi.hip); no sum may depend on them
+    n = 7001
+    posm, vel = scene(n, 123)
+    ref = None
+    for np_ in (2, 3, 4, 5, 6, 7, 8):
+        os.environ["NBODY_BLOCK_NP"] = str(np_)
+        try:
+            with nb.NBodyEngine(n) as e:
+                assert e.launch_config()["blocks"] == (n + 2 * np_ - 1) // (2 * np_)
+                e.set_state(posm, vel)
+                e.step(0.01, 2)
+                state = e.state()
+        finally:
+            del os.environ["NBODY_BLOCK_NP"]
+        if ref is None:
+            ref = state
+        else:
+            for a, b in zip(state, ref):
+                np.testing.assert_array_equal(a, b)
