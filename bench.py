@@ -136,6 +136,26 @@ def cpu_baseline(posm, target_seconds):
     return out
 
 
+_RESULT_FD = None
+
+
+def keep_stdout_for_the_result():
+    """The contract: rank 0 prints ONE JSON line.  Libraries under this process write to stdout as well (RCCL prints a
+    version banner there when NCCL_DEBUG says so), so file descriptor 1 is pointed at stderr for the run and the result
+    goes out through a duplicate of the original stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def print_result(out):
+    line = (json.dumps(out) + "\n").encode()
+    sys.stdout.flush()
+    os.write(1 if _RESULT_FD is None else _RESULT_FD, line)
+
+
 def relaunch_under_torchrun(n_gpus):
     """`python bench.py --gpus N` with no launcher around it: run the very same command line under
     `python -m torch.distributed.run` (one rank per GPU) as a CHILD process — started before this process has made any GPU
@@ -242,7 +262,7 @@ def run_single_host(args):
     }
     if args.cpu_seconds > 0 and g == 1:
         out["cpu_baseline"] = cpu_baseline(posm.astype(np.float32), args.cpu_seconds)
-    print(json.dumps(out), flush=True)
+    print_result(out)
 
 
 def main():
@@ -277,10 +297,11 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and args.host != "single" and "WORLD_SIZE" not in os.environ:
+        return relaunch_under_torchrun(args.gpus)
+    keep_stdout_for_the_result()
     if args.host == "single":
         return run_single_host(args)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return relaunch_under_torchrun(args.gpus)
 
     import numpy as np
     import torch
@@ -492,7 +513,7 @@ def main():
         }
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(posm, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        print_result(out)
     sim.close()
     if world > 1:
         dist.barrier()

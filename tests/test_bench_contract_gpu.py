@@ -47,3 +47,17 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     dm = cf["distinct_masses"]
     assert dm["max_rel_err_sampled"] < 2e-5 and 0.2 < dm["roofline_frac"] < rf["frac"] * 1.02
     assert dm["value"] == pytest.approx(65536.0 ** 2 * 3 / (dm["ms_per_step"] * 3e-3), rel=1e-6)
+
+
+def test_stdout_is_the_json_line_alone_when_rccl_prints_its_banner():
+    # NCCL_DEBUG=VERSION makes RCCL write a version banner to the process's stdout at communicator creation: the
+    # single-process multi-GPU leg creates communicators even for one device.  The driver parses stdout.
+    env = dict(os.environ, NCCL_DEBUG="VERSION")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--host", "single", "--steps", "2",
+                          "--warmup", "1", "--n", "32768", "--cpu-seconds", "0", "--settle-seconds", "0.05"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["config"]["host"].startswith("single process") and r["value"] > 0
