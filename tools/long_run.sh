@@ -1,11 +1,11 @@
 #!/bin/bash
 # BASELINE configs[4] in miniature on one GPU: N = 2^20 softened Plummer sphere, Kahan force accumulation, 1000 steps,
 # energy logged every 100, once straight through and once with a checkpoint / resume in the middle; the two final states
-# must be equal in every byte.   bash tools/long_run.sh OUTDIR [N [STEPS]]
+# must be equal in every byte.   bash tools/long_run.sh OUTDIR [N [STEPS [PRECISION [ENERGY_EVERY]]]]
 set -e
-OUT="$1"; N="${2:-1048576}"; STEPS="${3:-1000}"; HALF=$((STEPS / 2))
+OUT="$1"; N="${2:-1048576}"; STEPS="${3:-1000}"; HALF=$((STEPS / 2)); PREC="${4:-f32_kahan}"; EVERY="${5:-100}"
 mkdir -p "$OUT"
-R="python -m parallelnbody_amd --plummer --n $N --eps 0.5 --dt 0.002 --precision f32_kahan --energy-every 100 --sync-energy"
+R="python -m parallelnbody_amd --plummer --n $N --eps 0.5 --dt 0.002 --precision $PREC --energy-every $EVERY --sync-energy"
 echo "# $R --leapfrog-start --steps $STEPS --checkpoint straight.ckpt" > "$OUT/long_run.log"
 $R --leapfrog-start --steps $STEPS --checkpoint "$OUT/straight.ckpt" >> "$OUT/long_run.log"
 echo "# $R --leapfrog-start --steps $HALF --checkpoint half.ckpt" >> "$OUT/long_run.log"
