@@ -52,7 +52,8 @@ struct nbody_ctx {
   int j_split = 1, j_chunk = 0, ipt = 1, tile = 256;
   int sym_np = 1;                        // register pairs per lane of the symmetric kernel
   std::vector<std::pair<char *, size_t>> pinned;   // caller memory page-locked by nbody_pin_host_buffer
-  int wave = 0;                // small-N wave kernel: register pairs per wave (0 = tile kernels)
+  int wave = 0;                // block kernel: register pairs of bodies per workgroup (0 = tile / symmetric kernels)
+  int tick_word = 0;           // nbody_tick on the one-launch step: which of the two Size words (scratch + 32, + 36) is cleared and next
   bool have_state = false;
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
   // symmetric algorithm (kernels_sym.hip, kernels_sym64.hip; plan: sym_plan.h)
@@ -862,6 +863,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
     }
   }
   if ((e = hipMalloc(&c->scratch, 64)) != hipSuccess) return bail(e, "hipMalloc scratch");
+  if ((e = hipMemset(c->scratch, 0, 64)) != hipSuccess) return bail(e, "hipMemset scratch");
   if ((e = hipHostMalloc(&c->h_scratch, 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   g_create_error.clear();   // e.g. the reason AUTO passed over the symmetric plan: not an error of this call
   *out = c;
@@ -1145,6 +1147,28 @@ int nbody_compute_forces(nbody_ctx *c) {
   return NBODY_OK;
 }
 
+// Small and mid-size single-context fp32 systems (forces_block_pk_kernel): forces + update in ONE launch per step, ping-ponging
+// the position buffer — not once the caller holds a pointer to one of the two buffers, and the host must know the masses.
+static bool one_launch_ok(const nbody_ctx *c) {
+  return c->wave != 0 && c->theta == 0.0f && c->own_posm && !c->posm_escaped && c->p.i_count == c->p.n_total &&
+         c->p.precision == NBODY_PREC_F32 && make_launch(c).uni >= 0;
+}
+
+// one such step; stage / size_bits / size_zero: the frame's mirror and ComputeCubeSize from the same launch (nbody_tick)
+static int step_one_launch(nbody_ctx *c, float dt, void *stage, void *size_bits, void *size_zero) {
+  int rc;
+  if (!c->posm_alt) HIP_TRY(c, hipMalloc(&c->posm_alt, (size_t)c->p.n_total * c->elem));
+  if ((rc = ensure_floor(c))) return rc;
+  EventPair ev;
+  const bool timed = c->p.time_kernels != 0;
+  if (timed && (rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev))) return rc;
+  HIP_TRY(c, nbody::launch_step_small(make_launch(c), c->posm_alt, c->vel, c->acc, dt, c->stream, stage, size_bits, size_zero));
+  if (timed && (rc = timer_end(c, NBODY_KERNEL_FORCES, ev))) return rc;
+  if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024 && (rc = timer_drain(c, NBODY_KERNEL_FORCES))) return rc;
+  std::swap(c->posm, c->posm_alt);
+  return NBODY_OK;
+}
+
 int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
   int rc = check_ready(c);
   if (rc) return rc;
@@ -1168,21 +1192,10 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
       return bh_small_finish(c);
     }
   }
-  // small and mid-size single-context fp32 systems: forces + update in ONE launch per step, ping-ponging the position buffer
-  // (it swaps the two position buffers: not once the caller holds a pointer to one of them; the host must know the masses)
-  const bool one_launch = c->wave != 0 && c->theta == 0.0f && c->own_posm && !c->posm_escaped &&
-                          c->p.i_count == c->p.n_total && c->p.precision == NBODY_PREC_F32 && make_launch(c).uni >= 0;
-  if (one_launch && !c->posm_alt) HIP_TRY(c, hipMalloc(&c->posm_alt, (size_t)c->p.n_total * c->elem));
+  const bool one_launch = one_launch_ok(c);
   for (int s = 0; s < nsteps; ++s) {
     if (one_launch) {
-      if ((rc = ensure_floor(c))) return rc;
-      EventPair ev;
-      const bool timed = c->p.time_kernels != 0;
-      if (timed && (rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev))) return rc;
-      HIP_TRY(c, nbody::launch_step_small(make_launch(c), c->posm_alt, c->vel, c->acc, dt, c->stream));
-      if (timed && (rc = timer_end(c, NBODY_KERNEL_FORCES, ev))) return rc;
-      if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024 && (rc = timer_drain(c, NBODY_KERNEL_FORCES))) return rc;
-      std::swap(c->posm, c->posm_alt);
+      if ((rc = step_one_launch(c, dt, nullptr, nullptr, nullptr))) return rc;
       continue;
     }
     if ((rc = run_forces(c))) return rc;
@@ -1313,6 +1326,25 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
     bh_frame = nbody::bh_is_small(c->bh);
   }
   const size_t ic = (size_t)c->p.i_count, bytes = ic * sizeof(nbody_particle);
+  // systems on the one-launch step (theta == 0, up to 16384 bodies): the same launch leaves Size (of the positions before
+  // the update, as .cpp:26 has it) and the frame's FParticle records — one kernel, the copies, one wait
+  if (live && c->theta == 0.0f && (size || aos) && one_launch_ok(c)) {
+    if (aos && (rc = ensure_stage(c, bytes))) return rc;
+    unsigned int *words = (unsigned int *)c->scratch + 8;        // two words that take turns: this frame's (zero), the next one's
+    unsigned int *cur = words + c->tick_word, *nxt = words + (c->tick_word ^ 1);
+    if ((rc = step_one_launch(c, dt, aos ? c->d_stage : nullptr, size ? cur : nullptr, size ? nxt : nullptr))) return rc;
+    c->steps_done += 1;
+    if (size) { c->tick_word ^= 1; HIP_TRY(c, hipMemcpyAsync(c->h_scratch, cur, 4, hipMemcpyDeviceToHost, c->stream)); }
+    bool direct = false;
+    if (aos) {
+      direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
+      HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (size) memcpy(size, c->h_scratch, 4);
+    if (aos && !direct) unstage_particles(c, aos, stride, ic);
+    return NBODY_OK;
+  }
   if (bh_frame) {                                                // the walk writes the frame's records itself, Size rides with the verdict
     if (aos && (rc = ensure_stage(c, bytes))) return rc;
     if ((rc = bh_small_enqueue(c, dt, 1, aos ? (float *)c->d_stage : nullptr))) return rc;

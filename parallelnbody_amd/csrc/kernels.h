@@ -37,7 +37,9 @@ struct ForceLaunch {
 hipError_t launch_forces(const ForceLaunch &L, hipStream_t s);
 // Small and mid-size single-context fp32 systems (L.wave != 0): the whole Tick body — forces, v += dt*a, x += dt*v — in one launch.
 // New positions go to posm_out (a second buffer: the old one is still being read); the caller swaps them afterwards.
-hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s);
+// stage / size_bits / size_zero (optional): see BlockLaunch — the frame's FParticle mirror and ComputeCubeSize from the same launch.
+hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s,
+                             void *stage = nullptr, void *size_bits = nullptr, void *size_zero = nullptr);
 // Blocks / threads launch_forces will use for L (for logs).
 void forces_geometry(const ForceLaunch &L, int *blocks, int *threads);
 
@@ -56,6 +58,11 @@ struct BlockLaunch {
   int uni = 0;                  // 1: every body has body 0's mass (the caller knows): no mass factor in the pair loop; 0: general form;
                                 // -1: both forms are launched and *general (0 = equal masses) says which one runs
   const void *general = nullptr;
+  // dt > 0, optional (the actor's frame in one launch): FParticle records of the owned bodies after the update (10 floats
+  // each); a pre-zeroed word for the bit pattern of ComputeCubeSize over the positions before the update, and a second
+  // word this launch clears for the next frame
+  void *stage = nullptr;
+  void *size_bits = nullptr, *size_zero = nullptr;
   int optimistic = 1;           // eps2 == 0: bare pair law outside the own group first, guarded walk only where a sum came out non-finite
 };
 hipError_t launch_block(const BlockLaunch &L, hipStream_t s);

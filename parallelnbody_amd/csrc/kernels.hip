@@ -552,10 +552,13 @@ static hipError_t launch_forces_wave(const ForceLaunch &L, hipStream_t s) {
 }
 
 // One whole Tick body of a small or mid-size single-context system in one launch: forces + kick-drift into posm_out.
-hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s) {
+hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s, void *stage,
+                             void *size_bits, void *size_zero) {
   if (L.wave < 2 || L.precision != NBODY_PREC_F32 || L.i_begin != 0 || L.i_count != L.n_total || !(dt > 0.f) || L.uni < 0)
     return hipErrorInvalidValue;
-  return launch_block(block_launch(L, posm_out, vel, acc, dt), s);
+  BlockLaunch b = block_launch(L, posm_out, vel, acc, dt);
+  b.stage = stage; b.size_bits = size_bits; b.size_zero = size_zero;
+  return launch_block(b, s);
 }
 
 hipError_t launch_forces(const ForceLaunch &L, hipStream_t s) {

@@ -67,23 +67,31 @@ constexpr int block_jl(int np) { return np >= 5 ? 4 : 8; }
 //   posm_out  integrate != 0: the bodies' new (x, y, z, m) go here (a second buffer — other workgroups still read posm)
 //   acc_out   [i_count] accelerations
 //   gate      optional device word (see below)
+//   stage     integrate != 0, optional: the frame's FParticle records (OctreeSearch.h:8-18: Mass, Position, Velocity,
+//             Acceleration, 10 floats per body) as they stand after the update — what the actor's Tick mirrors
+//   size_bits integrate != 0, optional: pre-zeroed word that takes the bit pattern of max_i max(|x|, |y|, |z|) over the
+//             positions BEFORE the update (ComputeCubeSize, OctreeSearch.cpp:47-56, runs first in the Tick); size_zero: a
+//             second word, cleared for the frame after
 //   optimistic (Z_CLAMP only)  first the bare pair law outside the own group, the guarded walk only if a sum came out non-finite
 template <int NP, int ZMODE, bool UNI>
 __global__ __launch_bounds__(kBlock) void forces_block_pk_kernel(const float4 *__restrict__ posm, float4 *__restrict__ posm_out,
                                                                  float4 *__restrict__ vel, float4 *__restrict__ acc_out,
                                                                  int n_total, int i_begin, int i_count, float gscale, float zp,
                                                                  float dt, int integrate, int optimistic,
-                                                                 const int *__restrict__ gate, int gate_want) {
+                                                                 const int *__restrict__ gate, int gate_want,
+                                                                 float *__restrict__ stage, unsigned int *__restrict__ size_bits,
+                                                                 unsigned int *__restrict__ size_zero) {
   constexpr int B = 2 * NP;                  // bodies of a workgroup
   constexpr int JB = block_jb(NP), JL = block_jl(NP);
   __shared__ float red[kBlock / 64][6 * NP];
   __shared__ int redo;
+  __shared__ unsigned int s_size;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int ia = blockIdx.x * B;
   if (ia >= i_count) return;                 // uniform per workgroup
   // twin launches (the host cannot vouch for the masses): *gate != 0 says "masses differ"; only the form it names runs
   if (gate != nullptr && ((*gate != 0) ? 1 : 0) != gate_want) return;
-  if (t == 0) redo = 0;
+  if (t == 0) { redo = 0; s_size = 0u; }
 
   f2 xi[NP], yi[NP], zi[NP];
 #pragma unroll
@@ -202,10 +210,24 @@ __global__ __launch_bounds__(kBlock) void forces_block_pk_kernel(const float4 *_
   ax *= gm; ay *= gm; az *= gm;
   acc_out[il] = make_float4(ax, ay, az, 0.f);
   if (!integrate) return;
+  const float4 x0 = x;
   vv.x = mul_add_sep2(dt, ax, vv.x); vv.y = mul_add_sep2(dt, ay, vv.y); vv.z = mul_add_sep2(dt, az, vv.z);
   x.x = mul_add_sep2(dt, vv.x, x.x); x.y = mul_add_sep2(dt, vv.y, x.y); x.z = mul_add_sep2(dt, vv.z, x.z);
   vel[il] = vv;
   posm_out[i_begin + il] = x;
+  if (stage != nullptr) {
+    float *o = stage + (size_t)il * 10;
+    o[0] = x.w; o[1] = x.x; o[2] = x.y; o[3] = x.z; o[4] = vv.x; o[5] = vv.y; o[6] = vv.z; o[7] = ax; o[8] = ay; o[9] = az;
+  }
+  if (size_bits != nullptr) {
+    // the finishing threads are lanes of one wave: their LDS maximum is complete when lane 0 reads it back
+    atomicMax(&s_size, __float_as_uint(fmaxf(fmaxf(fabsf(x0.x), fabsf(x0.y)), fabsf(x0.z))));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (t == 0) {
+      atomicMax(size_bits, s_size);            // non-negative floats order as their bit patterns; one atomic per workgroup
+      if (blockIdx.x == 0 && size_zero != nullptr) *size_zero = 0u;
+    }
+  }
 }
 
 template <int NP, bool UNI>
@@ -217,11 +239,11 @@ hipError_t launch_block_np(const BlockLaunch &L, hipStream_t s) {
   if (L.eps2 > 0.0)
     hipLaunchKernelGGL((forces_block_pk_kernel<NP, Z_SOFT, UNI>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posm_out,
                        (float4 *)L.vel, (float4 *)L.acc, L.n_total, L.i_begin, L.i_count, (float)L.G, (float)L.eps2, L.dt, integrate, 0,
-                       gate, UNI ? 0 : 1);
+                       gate, UNI ? 0 : 1, (float *)L.stage, (unsigned int *)L.size_bits, (unsigned int *)L.size_zero);
   else
     hipLaunchKernelGGL((forces_block_pk_kernel<NP, Z_CLAMP, UNI>), grid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posm_out,
                        (float4 *)L.vel, (float4 *)L.acc, L.n_total, L.i_begin, L.i_count, (float)L.G, -0x1p126f, L.dt, integrate,
-                       L.optimistic, gate, UNI ? 0 : 1);
+                       L.optimistic, gate, UNI ? 0 : 1, (float *)L.stage, (unsigned int *)L.size_bits, (unsigned int *)L.size_zero);
   return hipGetLastError();
 }
 
@@ -244,6 +266,7 @@ hipError_t launch_block_uni(const BlockLaunch &L, hipStream_t s) {
 hipError_t launch_block(const BlockLaunch &L, hipStream_t s) {
   if (L.i_count <= 0 || L.n_total <= 0 || L.i_begin < 0 || L.i_begin + L.i_count > L.n_total) return hipErrorInvalidValue;
   if (L.dt > 0.f && (L.posm_out == nullptr || L.vel == nullptr || L.posm_out == L.posm)) return hipErrorInvalidValue;
+  if (!(L.dt > 0.f) && (L.stage != nullptr || L.size_bits != nullptr)) return hipErrorInvalidValue;
   if (L.uni < 0) {                             // both forms; the device word decides which one does the work
     if (L.general == nullptr) return hipErrorInvalidValue;
     const hipError_t e = launch_block_uni<true>(L, s);

@@ -217,3 +217,40 @@ def test_bits_do_not_depend_on_how_many_bodies_share_a_workgroup(nb):
         else:
             for a, b in zip(state, ref):
                 np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("n", [2000, 8192, 12001])
+def test_tick_in_one_launch_is_bounds_plus_step_plus_mirror(nb, n, pinned):
+    """nbody_tick on the one-launch step: Size (of the positions BEFORE the update, OctreeSearch.cpp:26, 47-56) and the
+    frame's FParticle records come out of the same launch — the same bytes as bounds, step, mirror as three calls; mixed
+    with plain steps, with frames that ask for the mirror only, and through the raw C entry point for Size only."""
+    import ctypes
+    posm, vel = scene(n, n + 41)
+    with nb.NBodyEngine(n) as a, nb.NBodyEngine(n) as b:
+        assert b.launch_config()["kernel"] == BLOCK
+        a.set_state(posm, vel); b.set_state(posm, vel)
+        mine = np.zeros(n, nb.PARTICLE_DTYPE)
+        if pinned:
+            b.pin(mine)
+        for frame in range(5):
+            size_a = a.bounds(); a.step(0.01, 1); pa = a.particles()
+            size_b, pb = b.tick(0.01, out=mine)
+            assert size_b == size_a and pb.tobytes() == pa.tobytes(), frame
+            if frame == 2:                                       # plain steps in between leave the two Size words alone
+                a.step(0.01, 3); b.step(0.01, 3)
+        # Size only (no mirror), through the C entry point
+        size_a = a.bounds(); a.step(0.01, 1)
+        size = ctypes.c_float(-1.0)
+        assert b._L.nbody_tick(b._h, ctypes.c_float(0.01), ctypes.byref(size), None, 0) == 0
+        assert size.value == size_a
+        np.testing.assert_array_equal(a.state()[0], b.state()[0])
+        # mirror only
+        a.step(0.01, 1); pa = a.particles()
+        assert b._L.nbody_tick(b._h, ctypes.c_float(0.01), None, mine.ctypes.data, nb.PARTICLE_DTYPE.itemsize) == 0
+        assert mine.tobytes() == pa.tobytes()
+        # and Size again: the word that was cleared two frames ago
+        size_a = a.bounds(); a.step(0.01, 1); pa = a.particles()
+        size_b, pb = b.tick(0.01, out=mine)
+        assert size_b == size_a and pb.tobytes() == pa.tobytes()
+        assert a.steps_done() == b.steps_done() == 11

@@ -1,6 +1,7 @@
 """The reference's shipped frame on the device: K Ticks (OctreeSearch.cpp:25-31) at theta = 1.0 (OctreeSearch.cpp:85).
-    python3 tools/bh_ticks.py N [K [mode]]     mode: step (nbody_step K frames in one call, default) | tick (actor-style
-                                                 nbody_tick per frame: bounds + step + FParticle mirror, one host sync each)
+    python3 tools/bh_ticks.py N [K [mode [theta]]]   mode: step (nbody_step K frames in one call, default) | tick (actor-style
+                                                 nbody_tick per frame: bounds + step + FParticle mirror, one host sync each);
+                                                 theta: 1.0 (default) or e.g. 0 for the all-pairs frame
 Prints wall time per frame; run under `rocprofv3 --kernel-trace --stats` for the per-kernel picture."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,8 +11,9 @@ import parallelnbody_amd as nb
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 mode = sys.argv[3] if len(sys.argv) > 3 else "step"
+theta = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
 posm, vel = nb.ic_reference_box(n, 1000.0, seed=1) if n <= 16384 else nb.ic_plummer(n, seed=1)
-with nb.NBodyEngine(n, theta=1.0) as e:
+with nb.NBodyEngine(n, theta=theta) as e:
     e.set_state(posm, vel)
     e.step(0.01, 3); e.synchronize()
     out = np.zeros(n, nb.PARTICLE_DTYPE)
@@ -26,5 +28,5 @@ with nb.NBodyEngine(n, theta=1.0) as e:
             e.step(0.01, k)
         e.synchronize()
         best = min(best, (time.perf_counter() - t0) / k)
-    st = e.bh_stats()
-print(f"N={n} theta=1.0 mode={mode}: {best * 1e6:.1f} us per frame (best of 3 runs of {k}); nodes {st['nodes']} levels {st['levels']}", flush=True)
+    st = e.bh_stats() if theta > 0 else {'nodes': 0, 'levels': 0}
+print(f"N={n} theta={theta} mode={mode}: {best * 1e6:.1f} us per frame (best of 3 runs of {k}); nodes {st['nodes']} levels {st['levels']}", flush=True)
