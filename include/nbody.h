@@ -343,6 +343,11 @@ NBODY_API int nbody_sym_plan_describe_phased(int32_t n_total, int32_t i_begin, i
                                              int32_t *n_items, uint64_t *pool_elems, int32_t *items, int32_t items_cap,
                                              int32_t *n_phases, int32_t *phases, int32_t phases_cap);
 
+/* Host only: register pairs of bodies (2 ... 8; two bodies each) a workgroup of forces_block_pk_kernel owns for a plain fp32
+ * system of n_total bodies on a device with `compute_units` CUs — the rule of csrc/capi.hip (smallest ceil(workgroups /
+ * CUs) x pairs, larger workgroups on a tie).  No result depends on it; the CPU tests check the rule. */
+NBODY_API int32_t nbody_block_pairs_describe(int32_t n_total, int32_t compute_units);
+
 /* ---- checkpoint / resume (build-defined: the reference keeps its state in a non-serialised TArray) ---------- */
 
 /* Raw little-endian dump of the context's state: header (format NBDYCKP2: sizes, steps, G, eps, theta and — Barnes-Hut —

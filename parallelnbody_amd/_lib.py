@@ -132,6 +132,7 @@ def lib():
     sig("nbody_steps_done", c_int, vp, ctypes.POINTER(c_i64))
     sig("nbody_ic_reference_box", c_int, c_i32, c_f, fp, ctypes.c_uint64, fp, fp)
     sig("nbody_ic_plummer", c_int, c_i32, c_d, c_d, c_d, ctypes.c_uint64, fp, fp)
+    sig("nbody_block_pairs_describe", c_i32, c_i32, c_i32)
     sig("nbody_sym_plan_describe", c_int, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32),
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i32), c_i32)
     sig("nbody_sym_plan_describe_tenths", c_int, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32),

@@ -1631,6 +1631,10 @@ const char *nbody_force_kernel_name(const nbody_ctx *c) {
   return "forces_tile_kernel";
 }
 
+int32_t nbody_block_pairs_describe(int32_t n_total, int32_t compute_units) {
+  return n_total > 0 ? block_pairs(n_total, compute_units) : 0;
+}
+
 int nbody_get_algorithm(nbody_ctx *c, int32_t *algorithm, int32_t *super_tile) {
   if (!c) return NBODY_ERR_INVALID;
   if (c->multi) return nbody_get_algorithm(nbody::multi_part(c->multi, 0), algorithm, super_tile);

@@ -154,3 +154,24 @@ def test_pool_phases_share_one_j_side_area(nb, n, ranks, bi, budget_frac):
     base, pool1 = nb.sym_plan(n, 0, 0, bi, 512, 3, 4)
     assert len(ph) == 2 and pool == pool1
     np.testing.assert_array_equal(items, base)
+
+
+def test_block_kernel_pairs_per_workgroup_rule():
+    """forces_block_pk_kernel: how many register pairs of bodies a workgroup owns (csrc/capi.hip block_pairs).  A CU works
+    through ceil(workgroups / CUs) workgroups of `pairs` pairs each: the rule takes the smallest product, larger workgroups
+    on a tie.  Checked against the choices measured fastest (or within 6 %) in profiles/r03_block_kernel_np_by_n.txt."""
+    import math
+    import parallelnbody_amd as nb
+    L = nb.lib()
+    measured = {2000: 4, 3000: 6, 4096: 8, 5000: 5, 6000: 6, 7000: 7, 8192: 8, 9216: 6, 10240: 5, 12288: 8, 14336: 7,
+                16384: 8, 18432: 6, 20480: 8, 24576: 8}
+    for n, want in measured.items():
+        assert L.nbody_block_pairs_describe(n, 256) == want, n
+    for cus in (64, 120, 256, 304):
+        for n in list(range(1, 300)) + [1000, 2047, 2048, 2049, 8191, 8193, 16383, 16384, 100000]:
+            got = L.nbody_block_pairs_describe(n, cus)
+            assert 2 <= got <= 8
+            cost = lambda k: math.ceil(math.ceil(n / (2 * k)) / cus) * k
+            best = min(cost(k) for k in range(2, 9))
+            assert cost(got) == best and all(cost(k) > best for k in range(got + 1, 9)), (n, cus, got)
+    assert L.nbody_block_pairs_describe(0, 256) == 0
