@@ -153,6 +153,13 @@ int block_pairs(int n_total, int cus) {
   return best;
 }
 
+// forces_block_kernel (Kahan, fp64): 4 or 8 bodies per workgroup by the same rule
+int block_bodies(int n_total, int cus) {
+  if (cus <= 0) cus = 256;
+  const long long c8 = ((n_total + 7) / 8 + cus - 1) / cus * 8, c4 = ((n_total + 3) / 4 + cus - 1) / cus * 4;
+  return c4 < c8 ? 4 : 8;
+}
+
 int env_int(const char *name, int dflt) {
   const char *e = getenv(name);
   if (!e || !*e) return dflt;
@@ -190,14 +197,24 @@ void choose_geometry(nbody_ctx *c) {
   js = (p.n_total + chunk - 1) / chunk;
   c->j_split = js;
   c->j_chunk = chunk;
-  // Small systems (the reference ships N = 2000): one wave per few bodies fills the chip where one lane per body
-  // cannot.  Only when the caller left the geometry to us.
+  // Small and mid-size systems (the reference ships N = 2000): a workgroup owns a few bodies and its lanes split the j range
+  // (forces_block_pk_kernel; forces_block_kernel in the other two precisions) — one lane per body cannot fill the chip
+  // there.  Only when the caller left the geometry to us.  c->wave: register pairs per workgroup (plain fp32), bodies
+  // per workgroup (Kahan, fp64).
   c->wave = 0;
-  if (p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && p.algorithm != NBODY_ALGO_SYMMETRIC &&
-      p.tile == 0 && p.i_per_thread == 0 && p.j_split == 0 && p.n_total < block_max_n()) {
-    int cus = 256;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
+  const bool ours = p.algorithm != NBODY_ALGO_SYMMETRIC && p.tile == 0 && p.i_per_thread == 0 && p.j_split == 0;
+  int cus = 256;
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
+  if (ours && p.precision == NBODY_PREC_F32 && p.zero_mode != NBODY_ZERO_SELECT && p.n_total < block_max_n()) {
     c->wave = block_pairs(p.n_total, cus);
+  } else if (ours && p.precision == NBODY_PREC_F32_KAHAN && p.zero_mode != NBODY_ZERO_SELECT &&
+             p.n_total < env_int("NBODY_BLOCK_MAX_N_KAHAN", kSmallSystem)) {
+    // above kSmallSystem the packed Kahan tile kernel is faster (whole steps: profiles/r03_block_kernel_other_precisions.txt)
+    c->wave = block_bodies(p.n_total, cus);
+  } else if (ours && p.precision == NBODY_PREC_F64 && p.n_total < env_int("NBODY_BLOCK_MAX_N_F64", kSmallSystem)) {
+    c->wave = block_bodies(p.n_total, cus);
+  }
+  if (c->wave != 0) {
     c->j_split = 1;
     c->j_chunk = (p.n_total + c->tile - 1) / c->tile * c->tile;
   }
@@ -856,7 +873,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
     }
     // equal-mass form of the packed one-sided kernel and of the block kernel (not small_pk_kernel)
     const char *no_uni = getenv("NBODY_SYM_NO_UNI");
-    if (p.precision != NBODY_PREC_F64 && (c->wave >= 2 || (!c->wave && c->ipt % 2 == 0)) && p.zero_mode != NBODY_ZERO_SELECT &&
+    if (p.precision != NBODY_PREC_F64 && ((c->wave >= 2 && p.precision == NBODY_PREC_F32) || (!c->wave && c->ipt % 2 == 0)) && p.zero_mode != NBODY_ZERO_SELECT &&
         p.zero_mode != NBODY_ZERO_FLOOR && !(no_uni && no_uni[0] == '1')) {
       if ((e = hipMalloc(&c->sym_general, 64)) != hipSuccess) return bail(e, "hipMalloc equal-mass flag");
       if ((e = hipMemset(c->sym_general, 0, 64)) != hipSuccess) return bail(e, "hipMemset equal-mass flag");
@@ -1151,7 +1168,7 @@ int nbody_compute_forces(nbody_ctx *c) {
 // the position buffer — not once the caller holds a pointer to one of the two buffers, and the host must know the masses.
 static bool one_launch_ok(const nbody_ctx *c) {
   return c->wave != 0 && c->theta == 0.0f && c->own_posm && !c->posm_escaped && c->p.i_count == c->p.n_total &&
-         c->p.precision == NBODY_PREC_F32 && make_launch(c).uni >= 0;
+         (c->p.precision != NBODY_PREC_F32 || make_launch(c).uni >= 0);
 }
 
 // one such step; stage / size_bits / size_zero: the frame's mirror and ComputeCubeSize from the same launch (nbody_tick)
@@ -1328,7 +1345,7 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
   const size_t ic = (size_t)c->p.i_count, bytes = ic * sizeof(nbody_particle);
   // systems on the one-launch step (theta == 0, up to 16384 bodies): the same launch leaves Size (of the positions before
   // the update, as .cpp:26 has it) and the frame's FParticle records — one kernel, the copies, one wait
-  if (live && c->theta == 0.0f && (size || aos) && one_launch_ok(c)) {
+  if (live && c->theta == 0.0f && (size || aos) && c->p.precision == NBODY_PREC_F32 && one_launch_ok(c)) {
     if (aos && (rc = ensure_stage(c, bytes))) return rc;
     unsigned int *words = (unsigned int *)c->scratch + 8;        // two words that take turns: this frame's (zero), the next one's
     unsigned int *cur = words + c->tick_word, *nxt = words + (c->tick_word ^ 1);
@@ -1625,7 +1642,7 @@ const char *nbody_force_kernel_name(const nbody_ctx *c) {
   if (c->multi) return nbody_force_kernel_name(nbody::multi_part(c->multi, 0));
   if (c->theta > 0.0f) return c->p.n_total <= 4096 ? "bh_walk_compact_kernel (+ bh_small_build_kernel)" : "bh_walk_lane_kernel (+ tree build)";
   if (c->sym) return c->p.precision == NBODY_PREC_F64 ? "forces_sym_f64_kernel" : "forces_sym_pk_kernel";
-  if (c->wave) return "forces_block_pk_kernel";
+  if (c->wave) return c->p.precision == NBODY_PREC_F32 ? "forces_block_pk_kernel" : "forces_block_kernel";
   if (c->p.precision != NBODY_PREC_F64 && c->ipt % 2 == 0 && (c->p.eps > 0.0 || c->p.zero_mode != NBODY_ZERO_SELECT))
     return "forces_tile_pk_kernel";
   return "forces_tile_kernel";

@@ -331,6 +331,124 @@ template <typename T> __device__ __forceinline__ T mul_add_sep(T a, T b, T c) {
   return c + p;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The block kernel's idea (kernels_block.hip: a workgroup owns a few bodies, its 256 lanes split the j range, a body's
+// whole sum is finished inside the workgroup, so the update rides along and a step is ONE launch with no partial rows)
+// for the other two precisions, on the scalar staged pair law above: fp64, and fp32 with Kahan-compensated accumulation.
+// Small systems only — there one lane per i-body leaves the chip empty (N = 2000: 27.6 us per step with the tile kernel
+// + update in either precision; the packed fp32 block kernel: 5.3).
+//   per lane    NB running sums over its j-bodies (Acc3: plain for fp64, compensated for KAHAN), LD loads in flight
+//   the sums    every lane's value as a double (KAHAN: sum - compensation), added over the wave by six DPP steps in a fixed
+//               order and over the four waves in order, all in double, rounded ONCE to the working precision: the fp32
+//               result is the correctly rounded sum of the lanes' compensated sums
+//   thread t    finishes body t: acc, and with integrate != 0 the reference's update (OctreeSearch.cpp:29-30, multiply
+//               and add kept apart) into the OTHER position buffer
+// Padding beyond n_total: zero-mass bodies on the origin — every ZMODE here guards d == 0.
+// ---------------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_add64(double v) {
+  const long long i = __builtin_bit_cast(long long, v);
+  const int lo = (int)(i & 0xffffffffll), hi = (int)(i >> 32);
+  const int lo2 = __builtin_amdgcn_update_dpp(ROW_MASK == 0xf ? lo : 0, lo, CTRL, ROW_MASK, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(ROW_MASK == 0xf ? hi : 0, hi, CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(double, ((long long)hi2 << 32) | (long long)(unsigned int)lo2);
+}
+
+// sum over the 64 lanes, left in lane 63 (the order of kernels_block.hip's wave_sum_to_lane63)
+template <int NV> __device__ __forceinline__ void wave_sum64_to_lane63(double (&v)[NV]) {
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = dpp_add64<0xB1, 0xf>(v[q]);    // quad_perm:[1,0,3,2]
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = dpp_add64<0x4E, 0xf>(v[q]);    // quad_perm:[2,3,0,1]
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = dpp_add64<0x141, 0xf>(v[q]);   // row_half_mirror
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = dpp_add64<0x140, 0xf>(v[q]);   // row_mirror
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = dpp_add64<0x142, 0xa>(v[q]);   // row_bcast:15 into rows 1 and 3
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = dpp_add64<0x143, 0xc>(v[q]);   // row_bcast:31 into rows 2 and 3
+}
+
+template <typename T, int NB, int ZMODE, bool KAHAN>
+__global__ __launch_bounds__(kBlock) void forces_block_kernel(const typename V4<T>::type *__restrict__ posm,
+                                                              typename V4<T>::type *__restrict__ posm_out,
+                                                              typename V4<T>::type *__restrict__ vel,
+                                                              typename V4<T>::type *__restrict__ acc_out, int n_total,
+                                                              int i_begin, int i_count, T gscale, T zp, T dt, int integrate) {
+  using V = typename V4<T>::type;
+  constexpr int LD = 4;                      // loads in flight per lane
+  __shared__ double red[kBlock / 64][3 * NB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ia = blockIdx.x * NB;
+  if (ia >= i_count) return;                 // uniform per workgroup
+
+  T xi[NB], yi[NB], zi[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const V p = posm[i_begin + min(ia + k, i_count - 1)];
+    xi[k] = p.x; yi[k] = p.y; zi[k] = p.z;
+  }
+  const int il = ia + t;
+  const bool finisher = t < NB && il < i_count;
+  V vv, x;
+  vv.x = vv.y = vv.z = vv.w = 0; x = vv;
+  if (finisher && integrate) { vv = vel[il]; x = posm[i_begin + il]; }
+#pragma unroll
+  for (int k = 0; k < NB; ++k) asm volatile("" : "+v"(xi[k]), "+v"(yi[k]), "+v"(zi[k]));   // workgroup-uniform: keep them in VGPRs
+  asm volatile("" : "+v"(zp));
+
+  Acc3<T, KAHAN> a[NB];
+  const int trips = (n_total + kBlock - 1) / kBlock;         // lane t meets bodies t, t + 256, ...
+  auto load_one = [&](int trip) {
+    const int j = trip * kBlock + t;
+    V q = posm[min(j, n_total - 1)];
+    if (j >= n_total) { q.x = 0; q.y = 0; q.z = 0; q.w = 0; }
+    return q;
+  };
+  V cur[LD];
+#pragma unroll
+  for (int l = 0; l < LD; ++l) cur[l] = load_one(min(l, trips - 1));
+  for (int g = 0; g < trips; g += LD) {
+#pragma unroll
+    for (int l = 0; l < LD; ++l) {
+      V pj[1] = {cur[l]};
+      const bool live = g + l < trips;       // uniform
+      if (g + LD + l < trips) cur[l] = load_one(g + LD + l);   // the next round's body: in flight under this round's arithmetic
+      if (live) {
+        pj[0].w *= gscale;
+        interact_group<T, NB, 1, ZMODE, KAHAN, V>(xi, yi, zi, pj, zp, a);
+      }
+    }
+  }
+
+  double v[3 * NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    if constexpr (KAHAN) {                   // the running sum minus what it still owes
+      v[3 * k] = (double)a[k].x - (double)a[k].cx; v[3 * k + 1] = (double)a[k].y - (double)a[k].cy; v[3 * k + 2] = (double)a[k].z - (double)a[k].cz;
+    } else {
+      v[3 * k] = (double)a[k].x; v[3 * k + 1] = (double)a[k].y; v[3 * k + 2] = (double)a[k].z;
+    }
+  }
+  wave_sum64_to_lane63(v);
+  if (lane == 63) {
+#pragma unroll
+    for (int q = 0; q < 3 * NB; ++q) red[wave][q] = v[q];
+  }
+  __syncthreads();
+  if (!finisher) return;
+  const T ax = (T)(((red[0][3 * t] + red[1][3 * t]) + red[2][3 * t]) + red[3][3 * t]);
+  const T ay = (T)(((red[0][3 * t + 1] + red[1][3 * t + 1]) + red[2][3 * t + 1]) + red[3][3 * t + 1]);
+  const T az = (T)(((red[0][3 * t + 2] + red[1][3 * t + 2]) + red[2][3 * t + 2]) + red[3][3 * t + 2]);
+  V ao; ao.x = ax; ao.y = ay; ao.z = az; ao.w = 0;
+  acc_out[il] = ao;
+  if (!integrate) return;
+  vv.x = mul_add_sep(dt, ax, vv.x); vv.y = mul_add_sep(dt, ay, vv.y); vv.z = mul_add_sep(dt, az, vv.z);
+  x.x = mul_add_sep(dt, vv.x, x.x); x.y = mul_add_sep(dt, vv.y, x.y); x.z = mul_add_sep(dt, vv.z, x.z);
+  vel[il] = vv;
+  posm_out[i_begin + il] = x;
+}
+
 // Combine the j-chunk partials in chunk order (deterministic), store the acceleration, and — when
 // integrate != 0 — apply the reference's update with separate multiply and add (no FMA), exactly
 // as FVector's operators do: v = v + dt*a; x = x + dt*v   (OctreeSearch.cpp:29-30).
@@ -544,7 +662,27 @@ static BlockLaunch block_launch(const ForceLaunch &L, void *posm_out, void *vel,
   return b;
 }
 
+// L.wave != 0 in the other two precisions: forces_block_kernel, L.wave bodies per workgroup (4 or 8)
+template <typename T, bool KAHAN>
+static hipError_t launch_block_generic(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s) {
+  using V = typename V4<T>::type;
+  if (L.wave != 4 && L.wave != 8) return hipErrorInvalidValue;
+  dim3 grid((L.i_count + L.wave - 1) / L.wave), block(kBlock);
+  const int integrate = dt > 0.f ? 1 : 0;
+#define NBODY_LAUNCH_BLOCK(NB, ZM, ZP)                                                                                    \
+  hipLaunchKernelGGL((forces_block_kernel<T, NB, ZM, KAHAN>), grid, block, 0, s, (const V *)L.posm, (V *)posm_out, (V *)vel, \
+                     (V *)acc, L.n_total, L.i_begin, L.i_count, (T)L.G, (T)(ZP), (T)dt, integrate)
+  if (L.eps2 > 0.0) { if (L.wave == 4) NBODY_LAUNCH_BLOCK(4, Z_SOFT, L.eps2); else NBODY_LAUNCH_BLOCK(8, Z_SOFT, L.eps2); }
+  else if (sizeof(T) == 8) { if (L.wave == 4) NBODY_LAUNCH_BLOCK(4, Z_SELECT, 0.0); else NBODY_LAUNCH_BLOCK(8, Z_SELECT, 0.0); }
+  else { if (L.wave == 4) NBODY_LAUNCH_BLOCK(4, Z_CLAMP, -0x1p126); else NBODY_LAUNCH_BLOCK(8, Z_CLAMP, -0x1p126); }
+#undef NBODY_LAUNCH_BLOCK
+  return hipGetLastError();
+}
+
 static hipError_t launch_forces_wave(const ForceLaunch &L, hipStream_t s) {
+  if (L.precision == NBODY_PREC_F64) return launch_block_generic<double, false>(L, nullptr, nullptr, L.accp, 0.f, s);
+  if (L.precision == NBODY_PREC_F32_KAHAN) return launch_block_generic<float, true>(L, nullptr, nullptr, L.accp, 0.f, s);
+  if (L.wave < 2) return hipErrorInvalidValue;
   if (L.general != nullptr && L.check_masses)     // somebody else may have written the buffer: the device looks at the masses
     hipLaunchKernelGGL(mass_check_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
                        (const float4 *)L.posm, L.n_total, (int *)L.general);
@@ -554,8 +692,13 @@ static hipError_t launch_forces_wave(const ForceLaunch &L, hipStream_t s) {
 // One whole Tick body of a small or mid-size single-context system in one launch: forces + kick-drift into posm_out.
 hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, void *acc, float dt, hipStream_t s, void *stage,
                              void *size_bits, void *size_zero) {
-  if (L.wave < 2 || L.precision != NBODY_PREC_F32 || L.i_begin != 0 || L.i_count != L.n_total || !(dt > 0.f) || L.uni < 0)
-    return hipErrorInvalidValue;
+  if (L.wave == 0 || L.i_begin != 0 || L.i_count != L.n_total || !(dt > 0.f)) return hipErrorInvalidValue;
+  if (L.precision != NBODY_PREC_F32) {
+    if (stage != nullptr || size_bits != nullptr) return hipErrorInvalidValue;       // the mirror rides with the packed kernel only
+    return L.precision == NBODY_PREC_F64 ? launch_block_generic<double, false>(L, posm_out, vel, acc, dt, s)
+                                         : launch_block_generic<float, true>(L, posm_out, vel, acc, dt, s);
+  }
+  if (L.wave < 2 || L.uni < 0) return hipErrorInvalidValue;
   BlockLaunch b = block_launch(L, posm_out, vel, acc, dt);
   b.stage = stage; b.size_bits = size_bits; b.size_zero = size_zero;
   return launch_block(b, s);
@@ -564,7 +707,7 @@ hipError_t launch_step_small(const ForceLaunch &L, void *posm_out, void *vel, vo
 hipError_t launch_forces(const ForceLaunch &L, hipStream_t s) {
   if (L.i_count <= 0 || L.n_total <= 0 || L.j_split <= 0 || L.j_chunk <= 0) return hipErrorInvalidValue;
   if (L.wave != 0) {
-    if (L.precision != NBODY_PREC_F32 || L.j_split != 1 || L.wave < 2) return hipErrorInvalidValue;
+    if (L.j_split != 1) return hipErrorInvalidValue;
     return launch_forces_wave(L, s);
   }
   if (L.j_chunk % L.tile != 0 && L.j_split > 1) return hipErrorInvalidValue;
@@ -578,7 +721,8 @@ hipError_t launch_forces(const ForceLaunch &L, hipStream_t s) {
 
 void forces_geometry(const ForceLaunch &L, int *blocks, int *threads) {
   if (L.wave != 0) {
-    if (blocks) *blocks = (L.i_count + 2 * L.wave - 1) / (2 * L.wave);
+    const int per = L.precision == NBODY_PREC_F32 ? 2 * L.wave : L.wave;   // bodies of a workgroup
+    if (blocks) *blocks = (L.i_count + per - 1) / per;
     if (threads) *threads = kBlock;
     return;
   }

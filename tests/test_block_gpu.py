@@ -254,3 +254,83 @@ def test_tick_in_one_launch_is_bounds_plus_step_plus_mirror(nb, n, pinned):
         size_b, pb = b.tick(0.01, out=mine)
         assert size_b == size_a and pb.tobytes() == pa.tobytes()
         assert a.steps_done() == b.steps_done() == 11
+
+
+# ---- forces_block_kernel: the same idea in the other two precisions (small systems) ------------------------------------
+
+GENERIC = "forces_block_kernel"
+
+
+@pytest.mark.parametrize("eps", [0.0, 0.7])
+@pytest.mark.parametrize("prec", ["f32_kahan", "f64"])
+@pytest.mark.parametrize("n", [1, 2, 255, 1000, 2001, 5000, 6655])
+def test_block_kernel_in_the_other_precisions_matches_the_oracle(nb, oracle, n, prec, eps):
+    dt = np.float64 if prec == "f64" else np.float32
+    posm, vel = scene(n, n + 61)
+    posm, vel = posm.astype(dt), vel.astype(dt)
+    with nb.NBodyEngine(n, precision=prec, eps=eps) as e:
+        assert e.launch_config()["kernel"] == GENERIC
+        e.set_state(posm, vel)
+        e.compute_forces()
+        assert not e.equal_mass_form()
+        a = e.accelerations(np.float64)
+    p64 = posm.astype(np.float64)
+    ref = oracle.forces_direct_f64(p64[:, :3], p64[:, 3], eps=eps)
+    if n == 1:
+        assert np.all(a == 0)
+    else:
+        # fp64: the oracle's own order of additions differs; compensated fp32: the terms themselves are fp32 (v_rsq_f32),
+        # the sum of the lanes' compensated sums is formed in double and rounded once
+        assert rel_err(a[:, :3], ref).max() < (1e-12 if prec == "f64" else 5e-6)
+
+
+@pytest.mark.parametrize("prec", ["f32_kahan", "f64"])
+def test_other_precisions_one_launch_step_update_pointer_slices_and_coincident_bodies(nb, oracle, prec):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    dt = np.float64 if prec == "f64" else np.float32
+    n = 3001
+    posm, vel = scene(n, 71)
+    posm[17, :3] = posm[n - 400, :3]; posm[1200, :3] = posm[0, :3]          # coincident pairs, one on the origin (d == 0 skips)
+    posm, vel = posm.astype(dt), vel.astype(dt)
+    kick = oracle.kick_drift_f64 if prec == "f64" else oracle.kick_drift_f32
+    with nb.NBodyEngine(n, precision=prec) as e, nb.NBodyEngine(n, precision=prec) as held:
+        assert e.launch_config()["kernel"] == GENERIC
+        for c in (e, held):
+            c.set_state(posm, vel)
+        held.device_ptr(nb.BUF_POSM)                                       # two launches per step from here on
+        e.step(0.01, 1)
+        p, v, a = e.state(dt)
+        assert np.all(np.isfinite(a))
+        # the reference's update of the device's own acc (PhDeltaTime is a float: the C-ABI takes dt as float)
+        p1, v1 = kick(posm[:, :3], vel[:, :3], a[:, :3], float(np.float32(0.01)))
+        np.testing.assert_array_equal(v[:, :3], v1)
+        np.testing.assert_array_equal(p[:, :3], p1)
+        ref = oracle.forces_direct_f64(posm[:, :3].astype(np.float64), posm[:, 3].astype(np.float64))
+        assert rel_err(a[:, :3], ref).max() < (1e-12 if prec == "f64" else 5e-6)
+        e.step(0.01, 4); held.step(0.01, 5)
+        for x, y in zip(e.state(dt), held.state(dt)):
+            np.testing.assert_array_equal(x, y)                            # the same trajectory either way
+        p_all, v_all, a_all = e.state(dt)
+    with nb.NBodyEngine(n, precision=prec) as e:                           # slices reproduce the single context
+        e.set_state(posm, vel); e.step(0.01, 1); p_one, v_one, a_one = e.state(dt)
+    for lo, hi in ((0, 1000), (1000, 2999), (2999, n)):
+        with nb.NBodyEngine(n, precision=prec, i_begin=lo, i_count=hi - lo) as e:
+            assert e.launch_config()["kernel"] == GENERIC
+            e.set_state(posm, vel); e.step(0.01, 1)
+            ps, vs, as_ = e.state(dt)
+        np.testing.assert_array_equal(as_, a_one[lo:hi]); np.testing.assert_array_equal(ps, p_one[lo:hi])
+        np.testing.assert_array_equal(vs, v_one[lo:hi])
+
+
+def test_compensated_block_kernel_is_closer_to_fp64_than_the_plain_one(nb, oracle):
+    n = 6000
+    posm, vel = nb.ic_plummer(n, seed=9)
+    ref = oracle.forces_direct_f64(posm[:, :3].astype(np.float64), posm[:, 3].astype(np.float64), eps=0.5)
+    err = {}
+    for prec in ("f32", "f32_kahan"):
+        with nb.NBodyEngine(n, precision=prec, eps=0.5) as e:
+            e.set_state(posm, vel); e.compute_forces()
+            err[prec] = rel_err(e.accelerations(np.float64)[:, :3], ref)
+    assert err["f32_kahan"].max() < 1e-6 and np.median(err["f32_kahan"]) < np.median(err["f32"])
