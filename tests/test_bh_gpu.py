@@ -297,3 +297,57 @@ def test_show_octree_leaf_boxes(nb):
     boxes.clear()
     a.Tick(0.0)
     assert not boxes
+
+
+def _fuzz_scene(rng, n):
+    """A scene with structure at every scale: a few clumps of very different widths (deep, narrow subtrees: chains of
+    single-child cells, cells that reach across many 256-body chunks), a uniform background, masses over three decades."""
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        pos = rng.uniform(-1000, 1000, (n, 3))
+    else:
+        k = int(rng.integers(1, 6))
+        centres = rng.uniform(-800, 800, (k, 3))
+        widths = 10.0 ** rng.uniform(-3, 2.5, k)
+        which = rng.integers(0, k, n)
+        pos = centres[which] + rng.normal(0, 1, (n, 3)) * widths[which, None]
+        if kind == 2:
+            back = rng.random(n) < 0.3
+            pos[back] = rng.uniform(-1000, 1000, (int(back.sum()), 3))
+    posm = np.concatenate([pos, 10.0 ** rng.uniform(0, 3, (n, 1))], 1).astype(np.float32)
+    if n > 3:
+        posm[0, :3] = 0.0
+    return posm
+
+
+def test_bh_fuzz_every_bit_of_the_force_pass_on_random_scenes(nb, oracle):
+    """Sizes on both sides of every switch of the theta > 0 path (one-workgroup build up to 4096, windows on the global tree
+    up to 20480, ComputeMass in two launches up to 131072), random opening angles, clumpy scenes: accelerations, node count
+    and root CoM equal the oracle's tree (correctly rounded cube: pow_mode 3) in every bit.  NBODY_FUZZ_SEED /
+    NBODY_FUZZ_TRIALS run it longer."""
+    rng = np.random.default_rng(int(os.environ.get("NBODY_FUZZ_SEED", "77")))
+    trials = int(os.environ.get("NBODY_FUZZ_TRIALS", "24"))
+    ran = 0
+    for trial in range(trials):
+        u = rng.random()
+        n = int(rng.integers(2, 4097)) if u < 0.35 else (int(rng.integers(4097, 21000)) if u < 0.75 else int(rng.integers(21000, 140000)))
+        theta = float(rng.choice([1.0, 1.0, 0.5, 0.3, 1.7]))
+        div_mode = int(rng.integers(0, 2))
+        posm = _fuzz_scene(rng, n)
+        vel = np.zeros((n, 4), np.float32)
+        pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+        with nb.NBodyEngine(n, theta=theta, bh_div_mode=div_mode) as e:
+            e.set_state(posm, vel)
+            try:
+                e.compute_forces()
+            except nb.NBodyError as err:                          # deeper than 42 levels: the reference would recurse on
+                assert "42" in str(err) or "deep" in str(err).lower(), err
+                continue
+            a = e.accelerations()
+            st = e.bh_stats()
+        ref, com, nodes = oracle.octree_forces_f32(pos, m, theta, pow_mode=3, div_mode=div_mode)
+        np.testing.assert_array_equal(a, ref, err_msg=f"trial {trial}: n={n} theta={theta} div_mode={div_mode}")
+        np.testing.assert_array_equal(st["root_com"], com)
+        assert st["nodes"] == nodes, (trial, n)
+        ran += 1
+    assert ran >= trials * 2 // 3, ran
