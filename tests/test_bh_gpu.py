@@ -351,3 +351,23 @@ def test_bh_fuzz_every_bit_of_the_force_pass_on_random_scenes(nb, oracle):
         assert st["nodes"] == nodes, (trial, n)
         ran += 1
     assert ran >= trials * 2 // 3, ran
+
+
+@pytest.mark.parametrize("n", [5000, 8192, 30000])
+def test_bh_frames_of_larger_systems_equal_the_oracle_in_every_bit(nb, oracle, n):
+    # the whole-chip build (keys, sort, node words, ComputeMass in two launches), both walks of the larger systems, the
+    # update and the cross-frame root (each tree is rooted at the previous tree's CoM, OctreeSearch.cpp:77-79): six whole
+    # Ticks, every byte of the FParticle records, Size and the root centre of every frame
+    rng = np.random.default_rng(n)
+    posm = _fuzz_scene(rng, n)
+    vel = np.concatenate([rng.uniform(-20, 20, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    q = particles_from(nb, posm, vel)
+    com, size = None, 0.0
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        for frame in range(6):
+            size_dev, out = e.tick(0.01)
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+            assert size_dev == size, frame
+            np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
+            assert out.tobytes() == q.tobytes(), frame
