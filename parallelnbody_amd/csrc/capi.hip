@@ -53,6 +53,7 @@ struct nbody_ctx {
   int sym_np = 1;                        // register pairs per lane of the symmetric kernel
   std::vector<std::pair<char *, size_t>> pinned;   // caller memory page-locked by nbody_pin_host_buffer
   int wave = 0;                // block kernel: register pairs of bodies per workgroup (0 = tile / symmetric kernels)
+  int bh_word = 0;             // larger Barnes-Hut systems: which of the two Size words (scratch + 40, + 44) the next frame uses
   int tick_word = 0;           // nbody_tick on the one-launch step: which of the two Size words (scratch + 32, + 36) is cleared and next
   bool have_state = false;
   double floor_eps2 = -1.0;    // NBODY_ZERO_FLOOR: eps^2 floor for the current masses (< 0 = not yet computed)
@@ -506,10 +507,13 @@ int run_forces_bh(nbody_ctx *c, bool diagnostic) {
     HIP_TRY(c, nbody::bh_small_collect(c->bh, c->stream, &status, nullptr));
     return bh_status_error(c, status);
   }
-  HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
-  HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, 0, c->p.n_total, (unsigned int *)c->scratch, c->stream));
-  HIP_TRY(c, nbody::bh_forces(c->bh, c->posm, c->bh_acc, (const unsigned int *)c->scratch, c->theta, c->p.G, diagnostic ? 1 : 0,
-                              c->stream, &status));
+  // ComputeCubeSize into one of two words that take turns (scratch + 40, + 44; zero since creation): the launch clears the
+  // other one for the next frame — no memset launch
+  unsigned int *words = (unsigned int *)c->scratch + 10;
+  unsigned int *cur = words + c->bh_word, *nxt = words + (c->bh_word ^ 1);
+  c->bh_word ^= 1;
+  HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, 0, c->p.n_total, cur, c->stream, nxt));
+  HIP_TRY(c, nbody::bh_forces(c->bh, c->posm, c->bh_acc, cur, c->theta, c->p.G, diagnostic ? 1 : 0, c->stream, &status));
   if (status != 0 && timed) c->timers[NBODY_KERNEL_FORCES].pool.push_back(ev);   // the pair goes back unused
   if (status != 0) return bh_status_error(c, status);
   if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }

@@ -157,8 +157,9 @@ hipError_t bh_get_root_com(BhState *b, float out[3], hipStream_t s);
 hipError_t bh_set_root_com(BhState *b, const float in[3], hipStream_t s);
 
 // out_bits (uint32, pre-zeroed) = bit pattern of max_i max(|x|,|y|,|z|) over the owned slice.
+// zero_word (optional): a second word this launch clears — for callers that alternate between two result words.
 hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_count, unsigned int *out_bits,
-                         hipStream_t s);
+                         hipStream_t s, unsigned int *zero_word = nullptr);
 
 // out_bits (uint32, pre-zeroed) = bit pattern of max_j |m_j| over all n_total bodies.
 hipError_t launch_massmax(int precision, const void *posm, int n_total, unsigned int *out_bits, hipStream_t s);

@@ -488,8 +488,11 @@ __global__ __launch_bounds__(kBlock) void update_kernel(typename V4<T>::type *__
 
 template <typename T, bool MASS>
 __global__ __launch_bounds__(kBlock) void bounds_kernel(const typename V4<T>::type *__restrict__ posm, int i_begin,
-                                                        int i_count, unsigned int *__restrict__ out_bits) {
+                                                        int i_count, unsigned int *__restrict__ out_bits,
+                                                        unsigned int *__restrict__ zero_word) {
   using V = typename V4<T>::type;
+  // callers that alternate between two result words let this launch clear the one the NEXT call will use (no memset launch)
+  if (zero_word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
   float m = 0.0f;
   for (int il = blockIdx.x * kBlock + threadIdx.x; il < i_count; il += gridDim.x * kBlock) {
     const V p = posm[i_begin + il];
@@ -755,16 +758,16 @@ hipError_t launch_update(int precision, void *posm, void *vel, void *acc, const 
 }
 
 hipError_t launch_bounds(int precision, const void *posm, int i_begin, int i_count, unsigned int *out_bits,
-                         hipStream_t s) {
+                         hipStream_t s, unsigned int *zero_word) {
   if (i_count <= 0) return hipErrorInvalidValue;
   int blocks = (i_count + kBlock - 1) / kBlock;
   if (blocks > 512) blocks = 512;
   if (precision == NBODY_PREC_F64)
     hipLaunchKernelGGL((bounds_kernel<double, false>), dim3(blocks), dim3(kBlock), 0, s, (const double4 *)posm, i_begin,
-                       i_count, out_bits);
+                       i_count, out_bits, zero_word);
   else
     hipLaunchKernelGGL((bounds_kernel<float, false>), dim3(blocks), dim3(kBlock), 0, s, (const float4 *)posm, i_begin,
-                       i_count, out_bits);
+                       i_count, out_bits, zero_word);
   return hipGetLastError();
 }
 
@@ -774,10 +777,10 @@ hipError_t launch_massmax(int precision, const void *posm, int n_total, unsigned
   if (blocks > 512) blocks = 512;
   if (precision == NBODY_PREC_F64)
     hipLaunchKernelGGL((bounds_kernel<double, true>), dim3(blocks), dim3(kBlock), 0, s, (const double4 *)posm, 0, n_total,
-                       out_bits);
+                       out_bits, (unsigned int *)nullptr);
   else
     hipLaunchKernelGGL((bounds_kernel<float, true>), dim3(blocks), dim3(kBlock), 0, s, (const float4 *)posm, 0, n_total,
-                       out_bits);
+                       out_bits, (unsigned int *)nullptr);
   return hipGetLastError();
 }
 

@@ -724,34 +724,33 @@ __global__ __launch_bounds__(kB) void bh_gather_kernel(const T *__restrict__ src
 // cell of level l iff lcp(i-1) < l <= lcp(i)), and a walk with one lane per body (enough bodies to hide the loads: the
 // sixteen-lane windows of the small systems' walk buy latency, not throughput).  The host waits ONCE per frame — for the
 // deepest level and the verdict, while the scan and the node pass are already running.
-__global__ __launch_bounds__(64) void bh_root_thr_kernel(SmallTree T, const unsigned int *__restrict__ size_bits, float theta) {
-  __shared__ float s_size;
-  const int t = threadIdx.x;
-  if (t == 0) {
-    const float sz = __uint_as_float(*size_bits);             // Size as the bounds kernel left it (ComputeCubeSize)
-    T.root[0] = T.prev_com[0]; T.root[1] = T.prev_com[1]; T.root[2] = T.prev_com[2]; T.root[3] = sz;
-    s_size = sz;
-    T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
-  }
-  T.hdr[kHdrDeep + t] = -1;                                   // deepest level with a cell of >= 2 bodies, in kDeepSlots words (bh_lcp_kernel)
-  __syncthreads();
-  if (t <= kMaxLevels) {
-    float sz = s_size;
-    for (int q = 0; q < t; ++q) sz = (float)(0.5 * (double)sz);   // .h:74
-    T.thr[t] = accept_threshold(sz, theta);
-  }
-}
-
-__global__ __launch_bounds__(kB) void bh_keys_kernel(const float4 *__restrict__ posm, int n,
-                                                     const float *__restrict__ root /* ox,oy,oz,size */,
+// Path keys of all bodies; the kernel's first workgroup also sets the frame up: the root (centre = the previous tree's CoM,
+// half-width = Size as the bounds kernel left it: ComputeCubeSize), the header words this frame counts in, and the 43
+// acceptance thresholds of the walk.  Every thread reads the root's ingredients itself, so nothing waits for that workgroup.
+__global__ __launch_bounds__(kB) void bh_keys_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+                                                     const unsigned int *__restrict__ size_bits, float theta,
                                                      unsigned long long *__restrict__ key_hi,
                                                      unsigned long long *__restrict__ key_lo,
                                                      unsigned int *__restrict__ idx) {
+  const float sz = __uint_as_float(*size_bits);
+  float o[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
+  if (blockIdx.x == 0) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+      T.root[0] = o[0]; T.root[1] = o[1]; T.root[2] = o[2]; T.root[3] = sz;
+      T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
+    }
+    if (t < kDeepSlots) T.hdr[kHdrDeep + t] = -1;               // deepest level with a cell of >= 2 bodies (bh_lcp_kernel)
+    if (t <= kMaxLevels) {
+      float s_l = sz;
+      for (int q = 0; q < t; ++q) s_l = (float)(0.5 * (double)s_l);   // .h:74
+      T.thr[t] = accept_threshold(s_l, theta);
+    }
+  }
   const int i = blockIdx.x * kB + threadIdx.x;
   if (i >= n) return;
   const float4 p = posm[i];
-  float o[3] = {root[0], root[1], root[2]};
-  float size = root[3];
+  float size = sz;
   unsigned long long hi = 0, lo = 0;
   for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
   for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
@@ -971,7 +970,7 @@ struct BhState {
   float *root = nullptr;       // ox, oy, oz, size
   float *prev_com = nullptr;   // the previous tree's root CoM (zero before the first frame)
   int last_nodes = 0, last_levels = 0;
-  bool stats_pending = false;  // larger systems: h_counters is being refreshed on the stream (bh_stats waits)
+  bool stats_pending = false;  // larger systems: a frame was built since bh_stats last fetched the header
   int div_mode = 0;            // reading of `/=` in ComputeMass (sweep_compact_cell)
 };
 
@@ -1089,8 +1088,7 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   const int n = b->n;
   const dim3 blk(kB), grd((n + kB - 1) / kB);
   *status = 0;
-  hipLaunchKernelGGL(bh_root_thr_kernel, dim3(1), dim3(64), 0, s, b->st, size_bits, theta);
-  hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, posm, n, b->root, b->khi, b->klo, b->idx);
+  hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, b->st, posm, n, size_bits, theta, b->khi, b->klo, b->idx);
   // The order of the 126-bit keys.  Almost always the first word (21 levels) decides it: ONE radix sort, and the pass that
   // looks at the neighbours' shared digits says whether two of them agree in that whole word (bodies closer than
   // Size / 2^21) — only then is the frame redone with the stable two-pass sort, low word first.
@@ -1149,8 +1147,7 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
                        (float4 *)acc_v);
   else
     hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, n, G, (float4 *)acc_v);
-  BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));   // for bh_stats
-  b->stats_pending = true;
+  b->stats_pending = true;                                     // bh_stats fetches the header when somebody asks
   b->last_levels = maxl + 1;
   return hipGetLastError();
 }
@@ -1175,6 +1172,7 @@ hipError_t bh_leaf_order(BhState *b, int *out_host, hipStream_t s) {
 // nodes: the reference's count (every cell of >= 2 bodies has eight children, empty ones included); levels with such cells
 hipError_t bh_stats(BhState *b, hipStream_t s, int *nodes, int *levels) {
   if (b->stats_pending) {
+    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
     BH_TRY(hipStreamSynchronize(s));
     b->last_nodes = 1 + 8 * b->h_counters[1];
     b->last_levels = b->h_counters[2];
