@@ -2,6 +2,7 @@
 // HIP runtime; no torch types, no exceptions across the boundary (the entry points that allocate host memory catch
 // std::bad_alloc), no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <cstdint>
 
 #include <algorithm>
 #include <cmath>
@@ -1350,17 +1351,21 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
   // systems on the one-launch step (theta == 0, up to 16384 bodies): the same launch leaves Size (of the positions before
   // the update, as .cpp:26 has it) and the frame's FParticle records — one kernel, the copies, one wait
   if (live && c->theta == 0.0f && (size || aos) && c->p.precision == NBODY_PREC_F32 && one_launch_ok(c)) {
-    if (aos && (rc = ensure_stage(c, bytes))) return rc;
+    // the records go straight into page-locked host memory — the caller's own mirror if it pinned it (nbody_pin_host_buffer),
+    // the context's staging buffer otherwise: no copy to wait for (profiles/r03_tick_parts_n2000.txt: the 80 KB copy of the
+    // shipped scene's mirror cost 12.7 us of a 32.7 us frame)
+    bool direct = false;
+    void *stage = nullptr;
+    if (aos) {
+      if ((rc = ensure_stage(c, bytes))) return rc;
+      direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes) && ((uintptr_t)aos & 15u) == 0;
+      HIP_TRY(c, hipHostGetDevicePointer(&stage, direct ? aos : c->h_stage, 0));
+    }
     unsigned int *words = (unsigned int *)c->scratch + 8;        // two words that take turns: this frame's (zero), the next one's
     unsigned int *cur = words + c->tick_word, *nxt = words + (c->tick_word ^ 1);
-    if ((rc = step_one_launch(c, dt, aos ? c->d_stage : nullptr, size ? cur : nullptr, size ? nxt : nullptr))) return rc;
+    if ((rc = step_one_launch(c, dt, stage, size ? cur : nullptr, size ? nxt : nullptr))) return rc;
     c->steps_done += 1;
     if (size) { c->tick_word ^= 1; HIP_TRY(c, hipMemcpyAsync(c->h_scratch, cur, 4, hipMemcpyDeviceToHost, c->stream)); }
-    bool direct = false;
-    if (aos) {
-      direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
-      HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
-    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (size) memcpy(size, c->h_scratch, 4);
     if (aos && !direct) unstage_particles(c, aos, stride, ic);

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(kBlock) void forces_block_pk_kernel(const float4 *_
   __shared__ float red[kBlock / 64][6 * NP];
   __shared__ int redo;
   __shared__ unsigned int s_size;
+  __shared__ __attribute__((aligned(16))) float s_rec[10 * B];   // the workgroup's FParticle records, contiguous (stage)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int ia = blockIdx.x * B;
   if (ia >= i_count) return;                 // uniform per workgroup
@@ -204,21 +205,34 @@ __global__ __launch_bounds__(kBlock) void forces_block_pk_kernel(const float4 *_
     pass(std::false_type{});
   }
 
-  if (!finisher) return;
+  if (wave != 0) return;                       // what is left is the first wave's (the finishing threads are its lanes 0 .. B-1)
   // the loop summed m_j |d|^-3 d (equal masses: |d|^-3 d): G (and the common m) come in here
   const float gm = UNI ? posm[0].w * gscale : gscale;
   ax *= gm; ay *= gm; az *= gm;
-  acc_out[il] = make_float4(ax, ay, az, 0.f);
+  if (finisher) acc_out[il] = make_float4(ax, ay, az, 0.f);
   if (!integrate) return;
   const float4 x0 = x;
   vv.x = mul_add_sep2(dt, ax, vv.x); vv.y = mul_add_sep2(dt, ay, vv.y); vv.z = mul_add_sep2(dt, az, vv.z);
   x.x = mul_add_sep2(dt, vv.x, x.x); x.y = mul_add_sep2(dt, vv.y, x.y); x.z = mul_add_sep2(dt, vv.z, x.z);
-  vel[il] = vv;
-  posm_out[i_begin + il] = x;
-  if (stage != nullptr) {
-    float *o = stage + (size_t)il * 10;
-    o[0] = x.w; o[1] = x.x; o[2] = x.y; o[3] = x.z; o[4] = vv.x; o[5] = vv.y; o[6] = vv.z; o[7] = ax; o[8] = ay; o[9] = az;
+  if (finisher) {
+    vel[il] = vv;
+    posm_out[i_begin + il] = x;
   }
+  if (stage != nullptr) {
+    // the records leave as one contiguous piece per workgroup (40 B x bodies, 16-byte stores): `stage` may be host memory —
+    // the caller's pinned mirror — where ten scattered 4-byte stores per body would each be a transaction of their own
+    if (finisher) {
+      float *o = s_rec + 10 * t;
+      o[0] = x.w; o[1] = x.x; o[2] = x.y; o[3] = x.z; o[4] = vv.x; o[5] = vv.y; o[6] = vv.z; o[7] = ax; o[8] = ay; o[9] = az;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int nrec = min(B, i_count - ia), nfl = 10 * nrec;                 // floats of this workgroup's records
+    float *dst = stage + (size_t)ia * 10;                                   // ia is even: 16-byte aligned
+    if (4 * lane + 3 < nfl) *(float4 *)(dst + 4 * lane) = *(const float4 *)(s_rec + 4 * lane);
+    else if (4 * lane < nfl) { for (int q = 4 * lane; q < nfl; ++q) dst[q] = s_rec[q]; }
+  }
+  if (!finisher) return;
   if (size_bits != nullptr) {
     // the finishing threads are lanes of one wave: their LDS maximum is complete when lane 0 reads it back
     atomicMax(&s_size, __float_as_uint(fmaxf(fmaxf(fabsf(x0.x), fabsf(x0.y)), fabsf(x0.z))));
