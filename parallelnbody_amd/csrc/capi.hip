@@ -1371,9 +1371,16 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
     if (aos && !direct) unstage_particles(c, aos, stride, ic);
     return NBODY_OK;
   }
+  bool bh_direct = false;
   if (bh_frame) {                                                // the walk writes the frame's records itself, Size rides with the verdict
-    if (aos && (rc = ensure_stage(c, bytes))) return rc;
-    if ((rc = bh_small_enqueue(c, dt, 1, aos ? (float *)c->d_stage : nullptr))) return rc;
+    // ... straight into page-locked host memory: the caller's mirror if it is pinned, the staging buffer otherwise
+    void *stage = nullptr;
+    if (aos) {
+      if ((rc = ensure_stage(c, bytes))) return rc;
+      bh_direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
+      HIP_TRY(c, hipHostGetDevicePointer(&stage, bh_direct ? aos : c->h_stage, 0));
+    }
+    if ((rc = bh_small_enqueue(c, dt, 1, (float *)stage))) return rc;
   } else if (live && size) {                                     // .cpp:26, 47-56: bounds of the positions BEFORE the step
     HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
     HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, c->p.i_begin, c->p.i_count, (unsigned int *)c->scratch, c->stream));
@@ -1387,7 +1394,7 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
       HIP_TRY(c, nbody::launch_pack_particles(c->p.precision, c->posm, c->vel, c->acc, (float *)c->d_stage, c->p.i_begin,
                                               c->p.i_count, c->stream));
     direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
-    HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (!bh_frame) HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
   }
   int frame_rc = NBODY_OK;
   if (bh_frame) frame_rc = bh_small_finish(c);                   // the frame's one wait

@@ -650,19 +650,27 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
     T.clocks[15] = wall_clock64() - c0;
   }
 #endif
-  if (g != 0 || !valid) return;
-  acc[body] = make_float4(ax, ay, az, 0.f);
+  if (!valid || (g != 0 && stage == nullptr)) return;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
-  if (dt > 0.f || stage != nullptr) v = vel[body];
-  if (dt > 0.f) {                                              // v += dt*a; x += dt*v, separate multiply and add
-    v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
-    x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
-    vel[body] = v;
-    posm[body] = x;
+  if (g == 0) {
+    acc[body] = make_float4(ax, ay, az, 0.f);
+    if (dt > 0.f || stage != nullptr) v = vel[body];
+    if (dt > 0.f) {                                            // v += dt*a; x += dt*v, separate multiply and add
+      v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
+      x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
+      vel[body] = v;
+      posm[body] = x;
+    }
   }
-  if (stage != nullptr) {                                      // the frame's FParticle record (.h:8-18), for the renderer hand-off
-    float *o = stage + (size_t)body * 10;
-    o[0] = x.w; o[1] = x.x; o[2] = x.y; o[3] = x.z; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = ax; o[8] = ay; o[9] = az;
+  if (stage != nullptr) {
+    // The frame's FParticle record (.h:8-18), for the renderer hand-off.  `stage` may be page-locked HOST memory (nbody_tick
+    // hands the caller's pinned mirror over): the row's first lane lays the ten floats out in the row's LDS slice and ten lanes
+    // store them with ONE instruction — 40 contiguous bytes per body — instead of ten scattered 4-byte stores.
+    float *rec = (float *)s_term[group];
+    if (g == 0) { rec[0] = x.w; rec[1] = x.x; rec[2] = x.y; rec[3] = x.z; rec[4] = v.x; rec[5] = v.y; rec[6] = v.z; rec[7] = ax; rec[8] = ay; rec[9] = az; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (g < 10) stage[(size_t)body * 10 + g] = rec[g];
   }
 }
 
