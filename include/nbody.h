@@ -252,7 +252,10 @@ NBODY_API int nbody_get_particles(nbody_ctx *ctx, void *aos, size_t stride);
 /* One frame of AOctreeSearch::Tick (OctreeSearch.cpp:21-34) with a single host synchronisation: if dt > 0, *size =
  * ComputeCubeSize of the current positions (.cpp:26) and one Tick body (.cpp:27-31); then the owned FParticle records
  * as nbody_get_particles delivers them (what .cpp:33,41 draws).  size and aos may each be NULL.  Same results as
- * nbody_get_bounds + nbody_step(dt, 1) + nbody_get_particles; not for sharded symmetric contexts (phased step). */
+ * nbody_get_bounds + nbody_step(dt, 1) + nbody_get_particles; not for sharded symmetric contexts (phased step).
+ * Systems whose step is a kernel or two (theta = 0 up to 16384 bodies; theta > 0 up to 4096) write the records from that
+ * kernel straight into page-locked host memory — into `aos` itself when it lies in a range pinned with
+ * nbody_pin_host_buffer (stride 40), so that the frame queues no copy of the mirror at all. */
 NBODY_API int nbody_tick(nbody_ctx *ctx, float dt, float *size, void *aos, size_t stride);
 
 /* Renderer hand-off straight into the caller's buffer (what OctreeSearch.cpp:41 reads every frame):
