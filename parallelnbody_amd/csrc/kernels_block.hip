@@ -58,9 +58,13 @@ template <int NV> __device__ __forceinline__ void wave_sum_to_lane63(float (&v)[
   for (int q = 0; q < NV; ++q) v[q] = dpp_add<0x143, 0xc>(v[q]);   // row_bcast:31 into rows 2 and 3
 }
 
+#ifndef NBODY_BLOCK_JL_BIG
+#define NBODY_BLOCK_JL_BIG 4      // loads in flight per lane at five and more register pairs; 6 and 8 measured no better
+                                  // (profiles/r03_ab_block_kernel_loads_in_flight.txt: N = 16384 68.3 / 70.4 / 80.0 us)
+#endif
 // j-bodies per staged group of the pair law (NP * JB independent chains) and loads in flight per lane (a multiple of JB)
 constexpr int block_jb(int np) { return np >= 5 ? 1 : (np >= 3 ? 2 : 4); }
-constexpr int block_jl(int np) { return np >= 5 ? 4 : 8; }
+constexpr int block_jl(int np) { return np >= 5 ? NBODY_BLOCK_JL_BIG : 8; }
 
 // grid.x = ceil(i_count / (2 NP)) workgroups of 256 lanes.
 //   posm      all n_total bodies (x, y, z, m), read only
