@@ -43,20 +43,27 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add(float
 // Sum of a value over the 64 lanes, left in lane 63, always in this order: neighbours, pairs of neighbours, the two
 // quads of a half row, the two halves of a row (quad_perm, quad_perm, row_half_mirror, row_mirror: every lane of a row
 // then holds the row's sum), row 0 into row 1 and row 2 into row 3 (row_bcast:15), rows 0+1 into rows 2, 3 (row_bcast:31).
+// The first step goes through the builtin (hipcc turns it into a copy, a v_mov_b32_dpp and an add, and pads the hazard
+// between whatever wrote the value and the DPP read); the other five are ONE v_add_f32_dpp each, written out: their
+// operand was produced NV instructions earlier by the step before, far beyond the two wait states a DPP read needs.
+// (Rows a row_mask leaves out keep their value; nobody reads them afterwards.)
+#define NBODY_DPP_ADD(v, ctrl) asm("v_add_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
 template <int NV> __device__ __forceinline__ void wave_sum_to_lane63(float (&v)[NV]) {
+  static_assert(NV >= 8, "the written-out steps rely on NV instructions between a value's steps");
 #pragma unroll
   for (int q = 0; q < NV; ++q) v[q] = dpp_add<0xB1, 0xf>(v[q]);    // quad_perm:[1,0,3,2]
 #pragma unroll
-  for (int q = 0; q < NV; ++q) v[q] = dpp_add<0x4E, 0xf>(v[q]);    // quad_perm:[2,3,0,1]
+  for (int q = 0; q < NV; ++q) NBODY_DPP_ADD(v[q], "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
 #pragma unroll
-  for (int q = 0; q < NV; ++q) v[q] = dpp_add<0x141, 0xf>(v[q]);   // row_half_mirror
+  for (int q = 0; q < NV; ++q) NBODY_DPP_ADD(v[q], "row_half_mirror row_mask:0xf bank_mask:0xf");
 #pragma unroll
-  for (int q = 0; q < NV; ++q) v[q] = dpp_add<0x140, 0xf>(v[q]);   // row_mirror
+  for (int q = 0; q < NV; ++q) NBODY_DPP_ADD(v[q], "row_mirror row_mask:0xf bank_mask:0xf");
 #pragma unroll
-  for (int q = 0; q < NV; ++q) v[q] = dpp_add<0x142, 0xa>(v[q]);   // row_bcast:15 into rows 1 and 3
+  for (int q = 0; q < NV; ++q) NBODY_DPP_ADD(v[q], "row_bcast:15 row_mask:0xa bank_mask:0xf");
 #pragma unroll
-  for (int q = 0; q < NV; ++q) v[q] = dpp_add<0x143, 0xc>(v[q]);   // row_bcast:31 into rows 2 and 3
+  for (int q = 0; q < NV; ++q) NBODY_DPP_ADD(v[q], "row_bcast:31 row_mask:0xc bank_mask:0xf");
 }
+#undef NBODY_DPP_ADD
 
 #ifndef NBODY_BLOCK_JL_BIG
 #define NBODY_BLOCK_JL_BIG 4      // loads in flight per lane at five and more register pairs; 6 and 8 measured no better
