@@ -334,3 +334,29 @@ def test_compensated_block_kernel_is_closer_to_fp64_than_the_plain_one(nb, oracl
             e.set_state(posm, vel); e.compute_forces()
             err[prec] = rel_err(e.accelerations(np.float64)[:, :3], ref)
     assert err["f32_kahan"].max() < 1e-6 and np.median(err["f32_kahan"]) < np.median(err["f32"])
+
+
+@pytest.mark.parametrize("theta", [0.0, 1.0])
+def test_tick_into_strided_and_misaligned_caller_records(nb, theta):
+    # FParticle records 48 bytes apart, starting 8 bytes into a pinned buffer: the kernels' direct path (stride 40, 16-byte
+    # aligned for the block kernel) does not apply; the records must arrive all the same
+    import ctypes
+    n = 2000
+    posm, vel = scene(n, 5)
+    with nb.NBodyEngine(n, theta=theta) as a, nb.NBodyEngine(n, theta=theta) as b:
+        a.set_state(posm, vel); b.set_state(posm, vel)
+        raw = np.zeros(n * 48 + 64, np.uint8)
+        b.pin(raw)
+        base = raw.ctypes.data + 8
+        for frame in range(3):
+            size_a = a.bounds(); a.step(0.01, 1); pa = a.particles()
+            size = ctypes.c_float(-1.0)
+            assert b._L.nbody_tick(b._h, ctypes.c_float(0.01), ctypes.byref(size), ctypes.c_void_p(base), 48) == 0
+            assert size.value == size_a
+            got = np.lib.stride_tricks.as_strided(raw[8:8 + 40].view(np.uint8), shape=(n, 40), strides=(48, 1))
+            assert got.tobytes() == pa.tobytes(), frame
+        # and 40-byte records at a 4-byte-aligned address inside the pinned range
+        base2 = raw.ctypes.data + 4
+        a.step(0.01, 1); pa = a.particles()
+        assert b._L.nbody_tick(b._h, ctypes.c_float(0.01), None, ctypes.c_void_p(base2), 40) == 0
+        assert raw[4:4 + n * 40].tobytes() == pa.tobytes()
