@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the one-launch small-system step (small_pk_kernel) stops paying: whole steps without events, library default against
+"""Round 2 (small_pk_kernel, since replaced by forces_block_pk_kernel — tools/block_by_n.sh is the current measurement): where the one-launch small-system step stops paying: whole steps without events, library default against
 the one-sided tile kernel forced (i_per_thread = 4) and the symmetric pass forced.   python tools/small_threshold.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
