@@ -4,14 +4,15 @@
 //   forces_block_pk_kernel <- the pair law OctreeSearch.h:101-104 summed over all j (the loop OctreeSearch.cpp:83-86 at
 //                             theta = 0) and, when integrating, the Tick's update OctreeSearch.cpp:28-31 for the same bodies
 //
-// small_pk_kernel (kernels.hip) gives a workgroup ONE register pair of bodies: right for the shipped N = 2000 (1000
-// workgroups on 256 CUs), but every lane then loads 16 bytes per two pair evaluations and a few thousand bodies more
-// are bound by the L1/L2 paths, not by the arithmetic.  Here a workgroup owns NP register pairs (2 NP bodies, the same
-// values in every lane), its 256 lanes still split the j range with coalesced loads — one 16-byte load per 2 NP pair
-// evaluations —, the wave sums are six DPP adds per value and one LDS hop joins the four waves.  Because a body's whole
-// sum is finished inside its workgroup, the update rides along (as in small_pk_kernel: new positions into a second buffer)
-// and a step is ONE launch with no partial rows — where the tile kernels need a second launch of >= 4.7 us just to add
-// their j chunks.
+// One lane per i-body gives the shipped N = 2000 eight workgroups on a 256-CU chip, and the tile kernels fill the chip only by
+// cutting the j range into chunks whose partial rows a second launch has to add.  Round 2 had a kernel for the smallest
+// systems in which a workgroup owned ONE register pair of bodies and its lanes split the j range: right at N = 2000, but
+// every lane then loads 16 bytes per two pair evaluations and a few thousand bodies more are bound by the L1/L2 paths, not
+// by the arithmetic.  Here a workgroup owns NP register pairs (2 NP bodies, the same values in every lane), its 256 lanes
+// still split the j range with coalesced loads — one 16-byte load per 2 NP pair evaluations —, the wave sums are six DPP
+// adds per value and one LDS hop joins the four waves.  Because a body's whole sum is finished inside its workgroup, the
+// update rides along (new positions into a second buffer: other workgroups still read the first) and a step is ONE launch
+// with no partial rows — where the tile kernels need a second launch just to add their j chunks.
 //
 // Exact d == 0 (OctreeSearch.h:102) without a detector: the guard (Z_CLAMP, pk_common.h) changes nothing for a normal
 // r^2 > 0, so the kernel first runs the BARE pair law on every group of j-bodies that does not hold the workgroup's own
