@@ -174,19 +174,11 @@ __device__ __forceinline__ bool same_prefix(unsigned long long ha, unsigned long
   return ha == hb && (la >> (3 * (kMaxLevels - l))) == (lb >> (3 * (kMaxLevels - l)));
 }
 
-// Octree::ComputeMass of one cell of the compact tree whose children are done (.h:89-95): node m, its word w, level l.
-__device__ __forceinline__ float4 sweep_compact_cell(const float4 *com, const unsigned int *meta, int m, unsigned int w, int l,
+// The end of Octree::ComputeMass for one cell (.h:94-95): CenterOfMass /= TotalMass, or the cell's own box origin when it
+// holds no mass.  (M, cx, cy, cz): the children's masses and mass-weighted centres, summed in octant order.
+__device__ __forceinline__ float4 cell_com_from_sums(float M, float cx, float cy, float cz, const unsigned int *meta, int m, int l,
                                                      int div_mode, const float4 *__restrict__ posm, const float *root) {
 #pragma clang fp contract(off)
-  const int end = (int)(w & kLinkMask);
-  float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
-  for (int c = m + 1; c != end;) {
-    const float4 ch = com[c];
-    const unsigned int cw = meta[c];
-    M = M + ch.w;
-    cx = cx + ch.w * ch.x; cy = cy + ch.w * ch.y; cz = cz + ch.w * ch.z;
-    c = (cw & kLeafBit) ? c + 1 : (int)(cw & kLinkMask);
-  }
   if (M != 0.f) {
     if (div_mode == 0) { const float rv = 1.0f / M; cx = cx * rv; cy = cy * rv; cz = cz * rv; }
     else { cx = cx / M; cy = cy / M; cz = cz / M; }
@@ -200,6 +192,22 @@ __device__ __forceinline__ float4 sweep_compact_cell(const float4 *com, const un
     cx = o[0]; cy = o[1]; cz = o[2];
   }
   return make_float4(cx, cy, cz, M);
+}
+
+// Octree::ComputeMass of one cell of the compact tree whose children are done (.h:89-95): node m, its word w, level l.
+__device__ __forceinline__ float4 sweep_compact_cell(const float4 *com, const unsigned int *meta, int m, unsigned int w, int l,
+                                                     int div_mode, const float4 *__restrict__ posm, const float *root) {
+#pragma clang fp contract(off)
+  const int end = (int)(w & kLinkMask);
+  float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+  for (int c = m + 1; c != end;) {
+    const float4 ch = com[c];
+    const unsigned int cw = meta[c];
+    M = M + ch.w;
+    cx = cx + ch.w * ch.x; cy = cy + ch.w * ch.y; cz = cz + ch.w * ch.z;
+    c = (cw & kLeafBit) ? c + 1 : (int)(cw & kLinkMask);
+  }
+  return cell_com_from_sums(M, cx, cy, cz, meta, m, l, div_mode, posm, root);
 }
 
 // What the structure phases of bh_small_build_kernel leave in LDS for the node phases: sorted first key words and bodies,
@@ -875,22 +883,49 @@ __device__ __forceinline__ int deepest_level(const SmallTree &T, int *s_tmp) {
 // straddle[level][chunk] ...
 __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                              const int *__restrict__ first, const signed char *__restrict__ lcpS,
-                                                             int *__restrict__ straddle, int nchunks, int div_mode) {
+                                                             int *__restrict__ straddle, int *__restrict__ kids, int nchunks,
+                                                             int div_mode) {
   __shared__ int s_deep;
+  __shared__ int s_strad[kMaxLevels + 1];
   const int chunk = blockIdx.x, i = chunk * kB + threadIdx.x;
   if (T.hdr[3] != 0) return;                                    // a refused frame (uniform)
   const int deep = deepest_level(T, &s_deep);
-  if (threadIdx.x <= kMaxLevels) straddle[threadIdx.x * nchunks + chunk] = -1;
+  if (threadIdx.x <= kMaxLevels) s_strad[threadIdx.x] = -1;
   const int lp = i < n ? (int)lcpS[i] : 0, ln = i < n ? (int)lcpS[i + 1] : -1;
   const int m0 = i < n ? first[i] : 0;
   const int chunk_end = first[min((chunk + 1) * kB, n)];       // the first node behind the chunk's bodies
   __syncthreads();
+  // The cells this chunk's bodies open that reach beyond the chunk — at most one per level — are noted for the second launch
+  // together with their children.  A cell's children are met by following the skip links from node m + 1: a chain of
+  // dependent loads that needs none of the sums.  So the chains are walked HERE, by all chunks at once and one lane per
+  // level (the first bodies of a chunk open whole ladders of such cells: one thread walking them all would be the
+  // kernel's critical path), and the one workgroup of the second launch finds up to eight node numbers per cell and
+  // loads their sums side by side.
+  for (int l = lp + 1; l <= ln; ++l) {
+    const int m = m0 + (l - lp - 1);
+    if ((int)(T.meta[m] & kLinkMask) > chunk_end) s_strad[l] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x <= kMaxLevels) {
+    const int l = threadIdx.x, m = s_strad[l];
+    straddle[l * nchunks + chunk] = m;
+    if (m >= 0) {
+      const int end = (int)(T.meta[m] & kLinkMask);
+      int *k8 = kids + ((size_t)l * nchunks + chunk) * 8;
+      int k = 0;
+      for (int c = m + 1; c != end;) {
+        const unsigned int cw = T.meta[c];
+        k8[k++] = c;
+        c = (cw & kLeafBit) ? c + 1 : (int)(cw & kLinkMask);
+      }
+      for (; k < 8; ++k) k8[k] = -1;
+    }
+  }
   for (int l = deep; l >= 0; --l) {
     if (lp < l && l <= ln) {
       const int m = m0 + (l - lp - 1);
       const unsigned int w = T.meta[m];
       if ((int)(w & kLinkMask) <= chunk_end) T.com[m] = sweep_compact_cell(T.com, T.meta, m, w, l, div_mode, posm, T.root);
-      else straddle[l * nchunks + chunk] = m;
     }
     __threadfence_block();
     __syncthreads();
@@ -901,16 +936,41 @@ __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const 
 // inside a chunk (done) or straddling cells one level down (done in the round before).  Then the hand-over (bh_finish).
 constexpr int kTopT = 1024;
 constexpr int kChunkSweepMaxN = 131072;       // larger systems sweep with a launch per level (bh_forces)
+static_assert((kChunkSweepMaxN + kB - 1) / kB <= kTopT, "bh_sweep_top_kernel: one chunk per thread");
 __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
-                                                             const int *__restrict__ straddle, int nchunks, int div_mode,
-                                                             int keep_root) {
+                                                             const int *__restrict__ straddle, const int *__restrict__ kids,
+                                                             int nchunks, int div_mode, int keep_root) {
+#pragma clang fp contract(off)
   __shared__ int s_deep;
   if (T.hdr[3] != 0) return;
   const int deep = deepest_level(T, &s_deep);
+  // one chunk per thread (nchunks <= kTopT up to kChunkSweepMaxN bodies); the cell of the NEXT level and its children's
+  // node numbers — which depend on none of the sums — are fetched while this level's sums are formed
+  const int c = threadIdx.x;
+  const bool mine = c < nchunks;
+  int m_nx = -1;
+  int4 ka_nx = make_int4(-1, -1, -1, -1), kb_nx = ka_nx;
+  auto fetch = [&](int l) {
+    m_nx = (mine && l >= 0) ? straddle[l * nchunks + c] : -1;
+    if (m_nx >= 0) {
+      const int4 *k8 = (const int4 *)(kids + ((size_t)l * nchunks + c) * 8);
+      ka_nx = k8[0]; kb_nx = k8[1];
+    }
+  };
+  fetch(deep);
   for (int l = deep; l >= 0; --l) {
-    for (int c = threadIdx.x; c < nchunks; c += kTopT) {
-      const int m = straddle[l * nchunks + c];
-      if (m >= 0) T.com[m] = sweep_compact_cell(T.com, T.meta, m, T.meta[m], l, div_mode, posm, T.root);
+    const int m = m_nx;
+    const int kid[8] = {ka_nx.x, ka_nx.y, ka_nx.z, ka_nx.w, kb_nx.x, kb_nx.y, kb_nx.z, kb_nx.w};
+    fetch(l - 1);
+    if (m >= 0) {
+      float4 ch[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ch[k] = T.com[kid[k] >= 0 ? kid[k] : m];   // eight loads in flight (absent children: any address)
+      float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)                                // the children in octant order, as sweep_compact_cell adds them
+        if (kid[k] >= 0) { M = M + ch[k].w; cx = cx + ch[k].w * ch[k].x; cy = cy + ch[k].w * ch[k].y; cz = cz + ch[k].w * ch[k].z; }
+      T.com[m] = cell_com_from_sums(M, cx, cy, cz, T.meta, m, l, div_mode, posm, T.root);
     }
     __threadfence_block();
     __syncthreads();
@@ -972,6 +1032,7 @@ struct BhState {
   int *first = nullptr, *cnt = nullptr;    // larger systems: [n + 1] first node of every body's group / its size
   signed char *lcpS = nullptr;             // [n + 1] shared digits of neighbours
   int *straddle = nullptr;                 // [kMaxLevels + 1][chunks of kB bodies] cells that reach beyond their chunk (bh_sweep_chunks_kernel)
+  int *kids = nullptr;                     // ... and the (up to eight) children of each, [kMaxLevels + 1][chunks][8]
   hipEvent_t ev = nullptr;                 // larger systems: "the verdict and the deepest level are on the host"
   int *counters = nullptr;     // device: the tree's header (SmallTree::hdr; [5]: deepest level, larger systems)
   int *h_counters = nullptr;   // pinned
@@ -1024,6 +1085,7 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->cnt, sizeof(int) * ((size_t)n + 1)));
   BH_TRY(hipMalloc(&b->lcpS, (size_t)n + 1));
   BH_TRY(hipMalloc(&b->straddle, sizeof(int) * (size_t)(kMaxLevels + 1) * (size_t)((n + kB - 1) / kB)));
+  if (n <= kChunkSweepMaxN) BH_TRY(hipMalloc(&b->kids, sizeof(int) * 8 * (size_t)(kMaxLevels + 1) * (size_t)((n + kB - 1) / kB)));
   bytes = 0;
   BH_TRY(rocprim::exclusive_scan(nullptr, bytes, b->cnt, b->first, 0, (size_t)n + 1, rocprim::plus<int>()));
   b->scan_tmp_bytes = bytes;
@@ -1034,7 +1096,7 @@ hipError_t bh_create(BhState **out, int n) {
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->sort_tmp, b->scan_tmp, b->first, b->cnt, b->lcpS, b->straddle,
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->sort_tmp, b->scan_tmp, b->first, b->cnt, b->lcpS, b->straddle, b->kids,
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
@@ -1145,8 +1207,9 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
       hipLaunchKernelGGL(bh_sweep_level_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, l, b->div_mode);
     hipLaunchKernelGGL(bh_finish_kernel, dim3(1), dim3(1), 0, s, b->st, n, keep_root);
   } else {
-    hipLaunchKernelGGL(bh_sweep_chunks_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, (int)grd.x, b->div_mode);
-    hipLaunchKernelGGL(bh_sweep_top_kernel, dim3(1), dim3(kTopT), 0, s, b->st, posm, n, b->straddle, (int)grd.x, b->div_mode, keep_root);
+    hipLaunchKernelGGL(bh_sweep_chunks_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, (int)grd.x, b->div_mode);
+    hipLaunchKernelGGL(bh_sweep_top_kernel, dim3(1), dim3(std::min(kTopT, ((int)grd.x + 63) / 64 * 64)), 0, s, b->st, posm, n, b->straddle, b->kids,
+                       (int)grd.x, b->div_mode, keep_root);   // a thread per chunk: few waves, cheap barriers
   }
   // one lane per body needs enough bodies to hide its loads; below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning)
   static const int rows_max_n = [] { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); return e && *e ? atoi(e) : kRowsMaxN; }();
