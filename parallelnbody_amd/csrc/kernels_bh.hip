@@ -734,12 +734,15 @@ __global__ __launch_bounds__(kB) void bh_gather_kernel(const T *__restrict__ src
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Larger systems (n > kSmBodies): the same compact preorder tree, built by the whole chip — path keys, two rocPRIM radix
-// sorts over the 126-bit key, the neighbours' shared digits, an exclusive scan that numbers the nodes, one pass that
-// writes the node words and the leaves, ComputeMass level by level (a launch per level over the bodies: body i opens the
-// cell of level l iff lcp(i-1) < l <= lcp(i)), and a walk with one lane per body (enough bodies to hide the loads: the
-// sixteen-lane windows of the small systems' walk buy latency, not throughput).  The host waits ONCE per frame — for the
-// deepest level and the verdict, while the scan and the node pass are already running.
+// Larger systems (n > kSmBodies): the same compact preorder tree, built by the whole chip — path keys, ONE rocPRIM radix
+// sort on the first key word (two, over the whole 126-bit key, only when neighbours tie in that word), the neighbours' shared
+// digits, an exclusive scan that numbers the nodes, one pass that writes the node words and the leaves, ComputeMass (two
+// launches up to kChunkSweepMaxN bodies, a launch per level above: body i opens the cell of level l iff
+// lcp(i-1) < l <= lcp(i)), and a walk — sixteen lanes per body on the global arrays up to kRowsMaxN bodies, one lane per
+// body above (enough bodies to hide the loads: the windows buy latency, not throughput).  The host waits ONCE per frame —
+// for the verdict (and the deepest level, which only the launch-per-level form needs on the host), while the scan and the
+// node pass are already running.
+//
 // Path keys of all bodies; the kernel's first workgroup also sets the frame up: the root (centre = the previous tree's CoM,
 // half-width = Size as the bounds kernel left it: ComputeCubeSize), the header words this frame counts in, and the 43
 // acceptance thresholds of the walk.  Every thread reads the root's ingredients itself, so nothing waits for that workgroup.
@@ -933,7 +936,7 @@ __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const 
 }
 
 // ... and finished here by ONE workgroup, again deepest level first: a straddling cell's children are cells that ended
-// inside a chunk (done) or straddling cells one level down (done in the round before).  Then the hand-over (bh_finish).
+// inside a chunk (done) or straddling cells one level down (done in the round before).  Then the hand-over: the next frame's root centre, the header's counts.
 constexpr int kTopT = 1024;
 constexpr int kChunkSweepMaxN = 131072;       // larger systems sweep with a launch per level (bh_forces)
 static_assert((kChunkSweepMaxN + kB - 1) / kB <= kTopT, "bh_sweep_top_kernel: one chunk per thread");
