@@ -776,22 +776,26 @@ __global__ __launch_bounds__(kB) void bh_keys_kernel(SmallTree T, const float4 *
   key_hi[i] = hi; key_lo[i] = lo; idx[i] = (unsigned int)i;
 }
 
-// digits the sorted keys of positions a and a + 1 share (0 .. 42; 42: the same path all the way down)
-__device__ __forceinline__ int shared_digits(const unsigned long long *__restrict__ hi, const unsigned long long *__restrict__ lo, int a) {
-  const unsigned long long x = hi[a] ^ hi[a + 1];
+// digits two path keys share (0 .. 42; 42: the same path all the way down)
+__device__ __forceinline__ int shared_digits(unsigned long long ha, unsigned long long la, unsigned long long hb, unsigned long long lb) {
+  const unsigned long long x = ha ^ hb;
   if (x != 0ull) return (__clzll((long long)x) - 1) / 3;
-  const unsigned long long y = lo[a] ^ lo[a + 1];
+  const unsigned long long y = la ^ lb;
   if (y != 0ull) return kLevelsPerKey + (__clzll((long long)y) - 1) / 3;
   return kMaxLevels;
 }
 
-// lcpS[i] = lcp(i - 1) (-1 at both ends); cnt[i] = cells body i opens + 1 (its leaf), cnt[n] = 0 for the scan
-__global__ __launch_bounds__(kB) void bh_lcp_kernel(SmallTree T, int n, signed char *__restrict__ lcpS, int *__restrict__ cnt) {
+// lcpS[i] = lcp(i - 1) (-1 at both ends); cnt[i] = cells body i opens + 1 (its leaf), cnt[n] = 0 for the scan.  The second
+// key words arrive in body order (klo_body: only the first words went through the sort) and leave in key order (T.klo).
+__global__ __launch_bounds__(kB) void bh_lcp_kernel(SmallTree T, int n, const unsigned long long *__restrict__ klo_body,
+                                                    signed char *__restrict__ lcpS, int *__restrict__ cnt) {
   const int i = blockIdx.x * kB + threadIdx.x;
   int ln = -1;
   if (i < n) {
-    const int lp = i > 0 ? shared_digits(T.khi, T.klo, i - 1) : -1;
-    ln = i + 1 < n ? shared_digits(T.khi, T.klo, i) : -1;
+    const unsigned long long h = T.khi[i], l = klo_body[T.sidx[i]];
+    T.klo[i] = l;
+    const int lp = i > 0 ? shared_digits(T.khi[i - 1], klo_body[T.sidx[i - 1]], h, l) : -1;
+    ln = i + 1 < n ? shared_digits(h, l, T.khi[i + 1], klo_body[T.sidx[i + 1]]) : -1;
     lcpS[i] = (signed char)lp;
     cnt[i] = (ln > lp ? ln - lp : 0) + 1;
     if (i == n - 1) { lcpS[n] = (signed char)-1; cnt[n] = 0; }
@@ -1180,9 +1184,8 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
       BH_TRY(hipMemsetAsync(b->counters + kHdrDeep, 0xFF, sizeof(int) * kDeepSlots, s));      // deepest level: -1 again
       BH_TRY(hipMemsetAsync(b->counters + 6, 0, sizeof(int), s));
     }
-    // the second key words in the same order (b->klo is still in body order)
-    hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->klo, T.sidx, b->klo2, n);
-    hipLaunchKernelGGL(bh_lcp_kernel, grd, blk, 0, s, T, n, b->lcpS, b->cnt);
+    // (the second key words follow in the same order inside bh_lcp_kernel: b->klo is still in body order)
+    hipLaunchKernelGGL(bh_lcp_kernel, grd, blk, 0, s, T, n, b->klo, b->lcpS, b->cnt);
     BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * kHdrWords, hipMemcpyDeviceToHost, s));
     BH_TRY(hipEventRecord(b->ev, s));
     // the node numbers and the node words need nothing from the host: they run while it waits for the verdict
