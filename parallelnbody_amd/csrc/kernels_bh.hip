@@ -96,7 +96,8 @@ struct SmallTree {
   int cap;
 };
 
-constexpr int kHdrDeep = 8, kDeepSlots = 64;   // header words [8, 72): the deepest level, one word per slot (larger systems)
+constexpr int kHdrDeep = 8, kDeepSlots = 1024;   // header words [8, 1032): the deepest level, one word per slot (larger systems):
+                                                 // same-address atomics queue up (N = 2^20, 4096 workgroups: bh_lcp_kernel 71 us with 64 slots)
 constexpr int kHdrWords = kHdrDeep + kDeepSlots;
 constexpr int kDbgClocks = 16 + 3 * 512;   // tuning builds: 16 phase stamps + (start, fill end, end) of up to 512 walk workgroups
 #ifdef NBODY_BH_PHASE_CLOCKS
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(kB) void bh_keys_kernel(SmallTree T, const float4 *
       T.root[0] = o[0]; T.root[1] = o[1]; T.root[2] = o[2]; T.root[3] = sz;
       T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
     }
-    if (t < kDeepSlots) T.hdr[kHdrDeep + t] = -1;               // deepest level with a cell of >= 2 bodies (bh_lcp_kernel)
+    for (int q = t; q < kDeepSlots; q += kB) T.hdr[kHdrDeep + q] = -1;   // deepest level with a cell of >= 2 bodies (bh_lcp_kernel)
     if (t <= kMaxLevels) {
       float s_l = sz;
       for (int q = 0; q < t; ++q) s_l = (float)(0.5 * (double)s_l);   // .h:74
@@ -873,7 +874,8 @@ __global__ void bh_finish_kernel(SmallTree T, int n, int keep_root) {
 // the workgroup gets it (s_tmp: one int of LDS)
 __device__ __forceinline__ int deepest_level(const SmallTree &T, int *s_tmp) {
   if (threadIdx.x < 64) {
-    int m = threadIdx.x < kDeepSlots ? T.hdr[kHdrDeep + threadIdx.x] : -1;
+    int m = -1;
+    for (int q = threadIdx.x; q < kDeepSlots; q += 64) m = max(m, T.hdr[kHdrDeep + q]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
     if (threadIdx.x == 0) *s_tmp = m;
