@@ -890,19 +890,24 @@ __device__ __forceinline__ int deepest_level(const SmallTree &T, int *s_tmp) {
 // chunk — the cell's first body is in the chunk anyway.  What is left are the cells that reach beyond their chunk's end:
 // at most one per level and chunk (cells of one level are disjoint, and each of these holds body b), noted in
 // straddle[level][chunk] ...
+template <int BPT>      // bodies per thread: a chunk is kB * BPT consecutive bodies (thread t owns bodies t, t + kB, ... of it)
 __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                              const int *__restrict__ first, const signed char *__restrict__ lcpS,
                                                              int *__restrict__ straddle, int *__restrict__ kids, int nchunks,
                                                              int div_mode) {
   __shared__ int s_deep;
   __shared__ int s_strad[kMaxLevels + 1];
-  const int chunk = blockIdx.x, i = chunk * kB + threadIdx.x;
+  const int chunk = blockIdx.x, base = chunk * (kB * BPT);
   if (T.hdr[3] != 0) return;                                    // a refused frame (uniform)
   const int deep = deepest_level(T, &s_deep);
   if (threadIdx.x <= kMaxLevels) s_strad[threadIdx.x] = -1;
-  const int lp = i < n ? (int)lcpS[i] : 0, ln = i < n ? (int)lcpS[i + 1] : -1;
-  const int m0 = i < n ? first[i] : 0;
-  const int chunk_end = first[min((chunk + 1) * kB, n)];       // the first node behind the chunk's bodies
+  int lp[BPT], ln[BPT], m0[BPT];
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) {
+    const int i = base + q * kB + threadIdx.x;
+    lp[q] = i < n ? (int)lcpS[i] : 0; ln[q] = i < n ? (int)lcpS[i + 1] : -1; m0[q] = i < n ? first[i] : 0;
+  }
+  const int chunk_end = first[min(base + kB * BPT, n)];        // the first node behind the chunk's bodies
   __syncthreads();
   // The cells this chunk's bodies open that reach beyond the chunk — at most one per level — are noted for the second launch
   // together with their children.  A cell's children are met by following the skip links from node m + 1: a chain of
@@ -910,10 +915,12 @@ __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const 
   // level (the first bodies of a chunk open whole ladders of such cells: one thread walking them all would be the
   // kernel's critical path), and the one workgroup of the second launch finds up to eight node numbers per cell and
   // loads their sums side by side.
-  for (int l = lp + 1; l <= ln; ++l) {
-    const int m = m0 + (l - lp - 1);
-    if ((int)(T.meta[m] & kLinkMask) > chunk_end) s_strad[l] = m;
-  }
+#pragma unroll
+  for (int q = 0; q < BPT; ++q)
+    for (int l = lp[q] + 1; l <= ln[q]; ++l) {
+      const int m = m0[q] + (l - lp[q] - 1);
+      if ((int)(T.meta[m] & kLinkMask) > chunk_end) s_strad[l] = m;
+    }
   __syncthreads();
   if (threadIdx.x <= kMaxLevels) {
     const int l = threadIdx.x, m = s_strad[l];
@@ -931,11 +938,13 @@ __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const 
     }
   }
   for (int l = deep; l >= 0; --l) {
-    if (lp < l && l <= ln) {
-      const int m = m0 + (l - lp - 1);
-      const unsigned int w = T.meta[m];
-      if ((int)(w & kLinkMask) <= chunk_end) T.com[m] = sweep_compact_cell(T.com, T.meta, m, w, l, div_mode, posm, T.root);
-    }
+#pragma unroll
+    for (int q = 0; q < BPT; ++q)
+      if (lp[q] < l && l <= ln[q]) {
+        const int m = m0[q] + (l - lp[q] - 1);
+        const unsigned int w = T.meta[m];
+        if ((int)(w & kLinkMask) <= chunk_end) T.com[m] = sweep_compact_cell(T.com, T.meta, m, w, l, div_mode, posm, T.root);
+      }
     __threadfence_block();
     __syncthreads();
   }
@@ -944,8 +953,10 @@ __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const 
 // ... and finished here by ONE workgroup, again deepest level first: a straddling cell's children are cells that ended
 // inside a chunk (done) or straddling cells one level down (done in the round before).  Then the hand-over: the next frame's root centre, the header's counts.
 constexpr int kTopT = 1024;
-constexpr int kChunkSweepMaxN = 131072;       // larger systems sweep with a launch per level (bh_forces)
-static_assert((kChunkSweepMaxN + kB - 1) / kB <= kTopT, "bh_sweep_top_kernel: one chunk per thread");
+constexpr int kChunkSweepMaxN = 1 << 20;      // larger systems sweep with a launch per level (bh_forces)
+// bodies per thread of the first launch: as few as keep the chunks within one per thread of the second launch's workgroup
+constexpr int sweep_bpt(int n) { return n <= kTopT * kB ? 1 : 4; }
+static_assert((kChunkSweepMaxN + 4 * kB - 1) / (4 * kB) <= kTopT, "bh_sweep_top_kernel: one chunk per thread");
 __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                              const int *__restrict__ straddle, const int *__restrict__ kids,
                                                              int nchunks, int div_mode, int keep_root) {
@@ -1093,8 +1104,11 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->first, sizeof(int) * ((size_t)n + 1)));
   BH_TRY(hipMalloc(&b->cnt, sizeof(int) * ((size_t)n + 1)));
   BH_TRY(hipMalloc(&b->lcpS, (size_t)n + 1));
-  BH_TRY(hipMalloc(&b->straddle, sizeof(int) * (size_t)(kMaxLevels + 1) * (size_t)((n + kB - 1) / kB)));
-  if (n <= kChunkSweepMaxN) BH_TRY(hipMalloc(&b->kids, sizeof(int) * 8 * (size_t)(kMaxLevels + 1) * (size_t)((n + kB - 1) / kB)));
+  if (n <= kChunkSweepMaxN) {
+    const size_t nchunks = (size_t)((n + kB * sweep_bpt(n) - 1) / (kB * sweep_bpt(n)));
+    BH_TRY(hipMalloc(&b->straddle, sizeof(int) * (size_t)(kMaxLevels + 1) * nchunks));
+    BH_TRY(hipMalloc(&b->kids, sizeof(int) * 8 * (size_t)(kMaxLevels + 1) * nchunks));
+  }
   bytes = 0;
   BH_TRY(rocprim::exclusive_scan(nullptr, bytes, b->cnt, b->first, 0, (size_t)n + 1, rocprim::plus<int>()));
   b->scan_tmp_bytes = bytes;
@@ -1206,8 +1220,8 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   for (int q = 0; q < kDeepSlots; ++q) maxl = std::max(maxl, b->h_counters[kHdrDeep + q]);
   // ComputeMass, children before parents.  Up to kChunkSweepMaxN bodies in two launches (the cells that end inside their
   // chunk of kB bodies, then the few that do not, by one workgroup); above it a launch per level over all bodies — there the
-  // one workgroup of the second launch would have thousands of chunks to look at per level (same-box frames, two launches
-  // against one per level: N = 8192 218 / 240 us, 16384 224 / 243, 65536 276 / 289, 262144 446 / 435, 2^20 1145 / 940).
+  // one workgroup of the second launch would have more than a chunk per thread to look at per level (chunks are 256 bodies up to
+  // N = 262144, 1024 bodies above).
   // NBODY_BH_LEVEL_SWEEPS=1: a launch per level at any size (A/B).
   static const bool level_sweeps = [] { const char *e = getenv("NBODY_BH_LEVEL_SWEEPS"); return e && e[0] == '1'; }();
   if (level_sweeps || n > kChunkSweepMaxN) {
@@ -1215,9 +1229,13 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
       hipLaunchKernelGGL(bh_sweep_level_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, l, b->div_mode);
     hipLaunchKernelGGL(bh_finish_kernel, dim3(1), dim3(1), 0, s, b->st, n, keep_root);
   } else {
-    hipLaunchKernelGGL(bh_sweep_chunks_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, (int)grd.x, b->div_mode);
-    hipLaunchKernelGGL(bh_sweep_top_kernel, dim3(1), dim3(std::min(kTopT, ((int)grd.x + 63) / 64 * 64)), 0, s, b->st, posm, n, b->straddle, b->kids,
-                       (int)grd.x, b->div_mode, keep_root);   // a thread per chunk: few waves, cheap barriers
+    const int bpt = sweep_bpt(n), nchunks = (n + kB * bpt - 1) / (kB * bpt);
+    if (bpt == 1)
+      hipLaunchKernelGGL(bh_sweep_chunks_kernel<1>, dim3(nchunks), blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
+    else
+      hipLaunchKernelGGL(bh_sweep_chunks_kernel<4>, dim3(nchunks), blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
+    hipLaunchKernelGGL(bh_sweep_top_kernel, dim3(1), dim3(std::min(kTopT, (nchunks + 63) / 64 * 64)), 0, s, b->st, posm, n, b->straddle, b->kids,
+                       nchunks, b->div_mode, keep_root);   // a thread per chunk: few waves, cheap barriers
   }
   // one lane per body needs enough bodies to hide its loads; below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning)
   static const int rows_max_n = [] { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); return e && *e ? atoi(e) : kRowsMaxN; }();

@@ -322,7 +322,7 @@ def _fuzz_scene(rng, n):
 
 def test_bh_fuzz_every_bit_of_the_force_pass_on_random_scenes(nb, oracle):
     """Sizes on both sides of every switch of the theta > 0 path (one-workgroup build up to 4096, windows on the global tree
-    up to 20480, ComputeMass in two launches up to 131072), random opening angles, clumpy scenes: accelerations, node count
+    up to 20480, ComputeMass over chunks of 256 bodies up to 262144 and of 1024 above), random opening angles, clumpy scenes: accelerations, node count
     and root CoM equal the oracle's tree (correctly rounded cube: pow_mode 3) in every bit.  NBODY_FUZZ_SEED /
     NBODY_FUZZ_TRIALS run it longer."""
     rng = np.random.default_rng(int(os.environ.get("NBODY_FUZZ_SEED", "77")))
@@ -330,7 +330,8 @@ def test_bh_fuzz_every_bit_of_the_force_pass_on_random_scenes(nb, oracle):
     ran = 0
     for trial in range(trials):
         u = rng.random()
-        n = int(rng.integers(2, 4097)) if u < 0.35 else (int(rng.integers(4097, 21000)) if u < 0.75 else int(rng.integers(21000, 140000)))
+        n = (int(rng.integers(2, 4097)) if u < 0.35 else int(rng.integers(4097, 21000)) if u < 0.7 else
+             int(rng.integers(21000, 140000)) if u < 0.92 else int(rng.integers(262145, 400000)))
         theta = float(rng.choice([1.0, 1.0, 0.5, 0.3, 1.7]))
         div_mode = int(rng.integers(0, 2))
         posm = _fuzz_scene(rng, n)
