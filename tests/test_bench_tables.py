@@ -4,6 +4,7 @@ FETCH_SIZE / WRITE_SIZE figures it is computed from)."""
 import importlib.util
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -36,3 +37,15 @@ def test_flop_conventions_are_what_design_states():
     b = _bench()
     assert (b.FLOP_PER_PAIR, b.FLOP_PER_EVAL_SYM, b.FLOP_PER_EVAL_SYM_EQUAL) == (20, 25, 23)
     assert b.PEAK_FP32_TFLOPS == 157.3
+
+
+def test_result_line_has_stdout_to_itself():
+    """bench.py's contract is ONE JSON line on stdout; libraries under it (RCCL's version banner) write to file descriptor 1
+    as well.  keep_stdout_for_the_result() points fd 1 at stderr for the run; print_result() goes out through the original."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.keep_stdout_for_the_result(); "
+            "os.write(1, b'a library banner on fd 1\\n'); print('a python print'); bench.print_result({'value': 1.5})") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout == '{"value": 1.5}\n'
+    assert "a library banner on fd 1" in out.stderr and "a python print" in out.stderr
