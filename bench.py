@@ -156,19 +156,244 @@ def print_result(out):
     os.write(1 if _RESULT_FD is None else _RESULT_FD, line)
 
 
-def relaunch_under_torchrun(n_gpus):
-    """`python bench.py --gpus N` with no launcher around it: run the very same command line under
-    `python -m torch.distributed.run` (one rank per GPU) as a CHILD process — started before this process has made any GPU
-    call, never an exec after one — relay what it prints and leave with its exit code."""
+def _kill_group(proc, grace=5.0):
+    """End a child this process started (and only that: its own session / process group, never a pattern): SIGTERM, then
+    SIGKILL after `grace` seconds."""
+    import signal
+    if proc.poll() is not None:
+        return
+    for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 30.0)):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        t_end = time.monotonic() + wait
+        while time.monotonic() < t_end and proc.poll() is None:
+            time.sleep(0.05)
+        if proc.poll() is not None:
+            return
+
+
+def _die_with_parent():
+    """preexec of every child: if the watchdog itself is killed, the kernel ends the child too (PR_SET_PDEATHSIG)."""
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)
+    except Exception:  # noqa: BLE001
+        pass
+
+
+class _Child:
+    """A worker process in its own session, stdout collected, stderr relayed line by line (the last lines kept)."""
+
+    def __init__(self, cmd, env, tag):
+        import collections
+        import subprocess
+        import threading
+        self.proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True,
+                                     preexec_fn=_die_with_parent)
+        self.out, self.tail, self.tag = [], collections.deque(maxlen=12), tag
+        self.threads = [threading.Thread(target=self._pump_out, daemon=True), threading.Thread(target=self._pump_err, daemon=True)]
+        for t in self.threads:
+            t.start()
+
+    def _pump_out(self):
+        for raw in self.proc.stdout:
+            self.out.append(raw.decode(errors="replace"))
+
+    def _pump_err(self):
+        for raw in self.proc.stderr:
+            line = raw.decode(errors="replace")
+            self.tail.append(line.rstrip())
+            sys.stderr.write(line)
+            sys.stderr.flush()
+
+    def finish(self):
+        for t in self.threads:
+            t.join(timeout=5.0)
+
+    def json_line(self):
+        for ln in reversed("".join(self.out).splitlines()):
+            if ln.startswith("{"):
+                try:
+                    return json.loads(ln)
+                except ValueError:
+                    pass
+        return None
+
+
+def _write_atomically(path, text):
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def _free_port():
     import socket
-    import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+        return sk.getsockname()[1]
+
+
+FALLBACK_ARGS = ["--algorithm", "tiled", "--no-overlap"]
+
+
+def rank_watchdog(args, argv):
+    """What every rank of `bench.py --gpus N` (N > 1) is before any GPU call: a watchdog that never touches the GPU itself.
+
+    The default multi-rank step (symmetric pass + all-to-all + all-gather under the next pass's own-slice strips) has more
+    moving parts than north_star's literal one (one-sided kernel, per-step all-gather, nothing else).  A failure or a hang in
+    the first must not cost the whole measurement, and ranks inside a job cannot agree on a failure without risking
+    mismatched collectives — so each attempt is a FRESH set of worker processes:
+
+      attempt 1: this command line as given, as a child process with a time limit (--child-timeout);
+      attempt 2: only if attempt 1 failed on any rank or ran out of time (and --algorithm was left on auto): the children's
+                 process groups are killed and a new child is started with `--algorithm tiled --no-overlap`, on a rendezvous
+                 port of its own.  Its line carries config.fallback: what failed, where, and the last lines of stderr.
+
+    The watchdogs of one job agree through small files in a directory only they know (rank 0 decides: `done`, or `retry` with
+    the next attempt's port); nothing here is a collective and nothing re-execs a process that has used the GPU.  Exit code 0
+    iff a contract-complete line went out."""
+    import shutil
+    import signal
+    import tempfile
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
+    run_dir = os.environ.get("NBODY_BENCH_RUN_DIR") or os.path.join(
+        tempfile.gettempdir(), "nbody_bench_%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                                          os.getppid() if "TORCHELASTIC_RUN_ID" in os.environ else "x"))
+    os.makedirs(run_dir, exist_ok=True)
+    for name in os.listdir(run_dir):                      # leftovers of an earlier job under the same name: this rank's own files only
+        if name.endswith(f".rank{rank}") or (rank == 0 and ".verdict" in name):
+            try:
+                os.unlink(os.path.join(run_dir, name))
+            except OSError:
+                pass
+    attempts = [("as given", [])]
+    if args.algorithm == "auto" and not args.no_fallback:
+        attempts.append(("all-gather-only step (one-sided kernel, every collective in stream order)", FALLBACK_ARGS))
+    worker_cmd = os.environ.get("NBODY_BENCH_WORKER_CMD")     # tests/test_bench_watchdog.py: a stand-in worker, no GPU
+    base = (worker_cmd.split() if worker_cmd else [sys.executable, os.path.abspath(__file__)]) + list(argv) + ["--worker"]
+    live = {"child": None}
+
+    def on_signal(signum, _frame):
+        if live["child"] is not None:
+            _kill_group(live["child"].proc, grace=2.0)
+        sys.exit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, on_signal)
+
+    say = lambda msg: print(f"[bench watchdog rank {rank}] {msg}", file=sys.stderr, flush=True)
+    failures, port, line = [], None, None
+    for k, (what, extra) in enumerate(attempts, start=1):
+        env = dict(os.environ, NBODY_BENCH_ATTEMPT=str(k))
+        if k > 1:                                         # a rendezvous of its own: rank 0's worker hosts the store on the new port
+            env["MASTER_PORT"] = str(port)
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        child = _Child(base + extra, env, f"attempt {k}")
+        live["child"] = child
+        t_limit = time.monotonic() + args.child_timeout
+        status_path = os.path.join(run_dir, f"a{k}.rank{rank}")
+        verdict_path = os.path.join(run_dir, f"a{k}.verdict")
+        status, verdict = None, None
+        while verdict is None:
+            rc = child.proc.poll()
+            if status is None and rc is not None:
+                child.finish()
+                status = "ok" if rc == 0 else f"fail worker exit code {rc}"
+            elif status is None and time.monotonic() > t_limit:
+                say(f"attempt {k} ({what}): no result after {args.child_timeout:.0f} s: killing the worker's process group")
+                _kill_group(child.proc)
+                child.finish()
+                status = f"fail time limit of {args.child_timeout:.0f} s"
+            if status is not None and not os.path.exists(status_path):
+                _write_atomically(status_path, json.dumps({"status": status, "stderr_tail": list(child.tail)}))
+            if rank == 0:
+                peers = {q: json.loads(_read(os.path.join(run_dir, f"a{k}.rank{q}")) or "null") for q in range(world)}
+                bad = {q: s for q, s in peers.items() if s and s["status"] != "ok"}
+                # a line that is already out counts even if some rank then stumbles in its teardown
+                got = child.json_line() if status == "ok" or (status is None and bad) else None
+                if got is not None:
+                    line, verdict = got, "done"
+                elif status is not None or bad:
+                    # the own worker failed, or another rank's did (this one may sit in a collective the other never enters)
+                    if status is None:
+                        say(f"attempt {k}: rank(s) {sorted(bad)} failed: killing the own worker")
+                        _kill_group(child.proc)
+                        child.finish()
+                        bad[0] = {"status": "fail killed: another rank failed first", "stderr_tail": list(child.tail)}
+                    elif status == "ok":
+                        bad[0] = {"status": "fail no JSON line on stdout", "stderr_tail": list(child.tail)}
+                    elif 0 not in bad:
+                        bad[0] = {"status": status, "stderr_tail": list(child.tail)}
+                    first = min(bad, key=lambda q: (bad[q]["status"].startswith("fail killed"), q))
+                    failures.append({"attempt": k, "ran": what, "rank": first, "reason": bad[first]["status"][5:],
+                                     "ranks_failed": sorted(bad), "stderr_tail": bad[first]["stderr_tail"]})
+                    port = _free_port()
+                    verdict = f"retry {port}" if k < len(attempts) else "give up"
+                if verdict is not None:
+                    _write_atomically(verdict_path, verdict)
+            else:
+                verdict = _read(verdict_path)
+                if verdict is None and time.monotonic() > t_limit + 90.0:
+                    verdict = "give up"               # rank 0's watchdog is gone
+            if verdict is None:
+                time.sleep(0.1)
+        _kill_group(child.proc)                           # no-op when the worker has left by itself
+        child.finish()
+        live["child"] = None
+        if verdict == "done":
+            if rank == 0:
+                if failures:
+                    line.setdefault("config", {})["fallback"] = {
+                        "ran": what, "instead_of": failures[0]["ran"] + " (the default multi-rank step: symmetric pass + all-to-all)",
+                        "because": f"rank {failures[0]['rank']}: {failures[0]['reason']}", "ranks_failed": failures[0]["ranks_failed"],
+                        "stderr_tail": failures[0]["stderr_tail"]}
+                print_result(line)
+                t_end = time.monotonic() + 10.0           # the other watchdogs say when they have read the verdict
+                while time.monotonic() < t_end and not all(os.path.exists(os.path.join(run_dir, f"a{k}.seen.rank{q}")) for q in range(1, world)):
+                    time.sleep(0.05)
+                shutil.rmtree(run_dir, ignore_errors=True)
+            else:
+                _write_atomically(os.path.join(run_dir, f"a{k}.seen.rank{rank}"), "")
+            return 0
+        if verdict.startswith("retry"):
+            port = int(verdict.split()[1])
+            say(f"attempt {k} ({what}) failed; starting a fresh worker: {attempts[k][0]}")
+            continue
+        say(f"attempt {k} ({what}) failed and there is nothing left to try")
+        return 1
+    return 1
+
+
+def relaunch_under_torchrun(n_gpus, limit_s):
+    """`python bench.py --gpus N` with no launcher around it: run the very same command line under
+    `python -m torch.distributed.run` (one rank per GPU) as a CHILD process — started before this process has made any GPU
+    call, never an exec after one — relay what it prints and leave with its exit code.  Every rank it starts is a
+    rank_watchdog; `limit_s` bounds the whole job from out here as well (a launcher that never returns)."""
+    import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     print("[bench] no launcher around --gpus %d: starting %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
-    sys.exit(subprocess.call(cmd))
+    proc = subprocess.Popen(cmd, start_new_session=True, preexec_fn=_die_with_parent)
+    try:
+        return proc.wait(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] the launcher has not returned after {limit_s:.0f} s: killing its process group", file=sys.stderr, flush=True)
+        _kill_group(proc)
+        return 1
+    except KeyboardInterrupt:
+        _kill_group(proc)
+        raise
 
 
 def run_single_host(args):
@@ -294,11 +519,18 @@ def main():
                          "launcher did); single = one process drives all GPUs through nbody_create_multi")
     ap.add_argument("--settle-seconds", type=float, default=0.3,
                     help="untimed force passes before the warm-up steps (state unchanged): lets the GPU clock settle")
+    ap.add_argument("--child-timeout", type=float, default=300.0,
+                    help="multi-GPU: seconds a rank's worker process may take before its watchdog kills it and the job falls "
+                         "back to the all-gather-only step in fresh workers (rank_watchdog)")
+    ap.add_argument("--no-fallback", action="store_true", help="multi-GPU: one attempt only, exit non-zero if it fails")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)      # set by rank_watchdog on the processes that do the work
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and args.host != "single" and "WORLD_SIZE" not in os.environ:
-        return relaunch_under_torchrun(args.gpus)
+        sys.exit(relaunch_under_torchrun(args.gpus, 2 * (args.child_timeout + 120.0)))
+    if args.gpus > 1 and args.host != "single" and not args.worker:
+        sys.exit(rank_watchdog(args, sys.argv[1:]))
     keep_stdout_for_the_result()
     if args.host == "single":
         return run_single_host(args)
@@ -322,6 +554,16 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = torch.distributed
+    # rehearsals of rank_watchdog (tests/test_two_rank_gpu.py): on the named rank the all-to-all of the symmetric step raises,
+    # or never returns.  The all-gather-only step has no all-to-all, so the fallback's workers are unaffected.
+    a2a_fail, a2a_hang = os.environ.get("NBODY_REHEARSE_A2A_FAILURE"), os.environ.get("NBODY_REHEARSE_A2A_HANG")
+    if str(rank) in (a2a_fail, a2a_hang):
+        def rehearsed_all_to_all(*_a, **_kw):
+            if a2a_hang == str(rank):
+                print(f"[bench rank {rank}] NBODY_REHEARSE_A2A_HANG: this rank never returns from the all-to-all", file=sys.stderr, flush=True)
+                time.sleep(1e6)
+            raise RuntimeError("NBODY_REHEARSE_A2A_FAILURE: injected failure inside the all-to-all")
+        dist.all_to_all_single = rehearsed_all_to_all
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

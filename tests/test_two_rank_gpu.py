@@ -22,18 +22,32 @@ def test_two_processes_one_gpu_end_to_end():
     assert "two ranks on one GPU over gloo: algorithm symmetric, exchange ranks 2" in out.stdout
 
 
-def _bench_two_ranks(extra_env):
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline")
+
+
+def _bench_two_ranks(extra_env, extra_args=(), launcher=True):
+    """bench.py --gpus 2 with both ranks on this box's one GPU (collectives over gloo).  launcher=True: the driver's own command
+    line for N > 1 (torch.distributed.run around it); False: the bare `python bench.py --gpus 2`."""
     import json
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--bodies", "65536", "--settle-seconds", "0.02"]
-    env = dict(os.environ, NBODY_DIST_BACKEND="gloo", **extra_env)
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--bodies", "65536", "--settle-seconds", "0.02",
+            *extra_args]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NBODY_DIST_BACKEND="gloo", **extra_env)
+    if launcher:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
-    return json.loads(lines[0]), out.stderr
+    r = json.loads(lines[0])
+    for key in CONTRACT_KEYS:
+        assert key in r, key
+    return r, out.stderr
 
 
 def test_bench_multi_rank_line_on_one_gpu():
@@ -57,6 +71,33 @@ def test_bench_falls_back_together_when_one_rank_cannot_build_the_symmetric_engi
     r, err = _bench_two_ranks({"NBODY_REHEARSE_CREATE_FAILURE": "1"})
     assert r["config"]["algorithm"] == "tiled" and "symmetric engines could not be created" in r["config"]["fallback"]
     assert "every rank rebuilds" in err
+
+
+@pytest.mark.parametrize("launcher", [True, False])
+def test_bench_survives_a_failure_inside_the_all_to_all(launcher):
+    # rank 1 raises inside the symmetric step's all-to-all (its first one: the warm-up of the collectives); rank 0 is left inside
+    # that collective.  The watchdogs end both workers and start fresh ones on north_star's literal step — one-sided kernel,
+    # per-step all-gather, every collective in stream order — whose line goes out with config.fallback saying what happened
+    r, err = _bench_two_ranks({"NBODY_REHEARSE_A2A_FAILURE": "1"}, extra_args=["--child-timeout", "240"], launcher=launcher)
+    cf = r["config"]
+    assert r["n_gpus"] == 2 and cf["algorithm"] == "tiled" and r["value"] > 0 and cf["max_rel_err_sampled"] < 2e-5
+    assert "all-to-all" not in cf["parallelism"] and "own stream" not in cf["parallelism"]
+    fb = cf["fallback"]
+    assert fb["because"].startswith("rank 1: worker exit code") and 1 in fb["ranks_failed"]
+    assert any("NBODY_REHEARSE_A2A_FAILURE" in ln for ln in fb["stderr_tail"])
+    assert "starting a fresh worker" in err
+    assert 0.0 < r["roofline"]["frac"] < 1.0 and r["roofline"]["launches"] == r["steps"]
+
+
+@pytest.mark.parametrize("launcher", [True, False])
+def test_bench_survives_a_rank_that_never_returns_from_the_all_to_all(launcher):
+    # the hang: rank 1 sleeps inside the all-to-all; nothing fails, nothing returns.  At the time limit the watchdogs kill the
+    # workers' process groups (their own children, by process group id) and the fresh workers deliver the all-gather-only line
+    r, err = _bench_two_ranks({"NBODY_REHEARSE_A2A_HANG": "1"}, extra_args=["--child-timeout", "75"], launcher=launcher)
+    cf = r["config"]
+    assert cf["algorithm"] == "tiled" and r["value"] > 0 and cf["max_rel_err_sampled"] < 2e-5
+    assert "time limit of 75 s" in cf["fallback"]["because"]
+    assert "killing the worker's process group" in err
 
 
 def test_bench_without_a_launcher_starts_its_own_ranks():
