@@ -136,6 +136,22 @@ def cpu_baseline(posm, target_seconds):
     return out
 
 
+def clock_fields(engine, avg_launch_s, launch_pairs):
+    """roofline.clock_ghz / cycles_per_interaction: the shader clock the timed force kernels ran at (read inside the kernels:
+    nbody_kernel_clock) and launch time x clock x SIMD lanes / interactions — SIMD cycles per interaction and lane if every SIMD
+    of the device was busy for the whole launch.  The force loops are power-limited and boxes hold different clocks under them;
+    the cycles do not depend on the box: ~20 in the equal-mass form of the symmetric kernel, ~22 in its general form, ~37 one-sided
+    (DESIGN.md 4.1, 4.1b).  None for kernels without the stamps (fp64)."""
+    try:
+        mhz, cus = engine.kernel_clock()
+    except Exception:  # noqa: BLE001
+        return {"clock_ghz": None, "cycles_per_interaction": None}
+    if not mhz > 0.0:
+        return {"clock_ghz": None, "cycles_per_interaction": None}
+    return {"clock_ghz": mhz * 1e-3, "compute_units": cus,
+            "cycles_per_interaction": avg_launch_s * mhz * 1e6 * (cus * 4 * 64) / launch_pairs}
+
+
 _RESULT_FD = None
 
 
@@ -304,7 +320,7 @@ def rank_watchdog(args, argv):
         t_limit = time.monotonic() + args.child_timeout
         status_path = os.path.join(run_dir, f"a{k}.rank{rank}")
         verdict_path = os.path.join(run_dir, f"a{k}.verdict")
-        status, verdict = None, None
+        status, verdict, t_status = None, None, 0.0
         while verdict is None:
             rc = child.proc.poll()
             if status is None and rc is not None:
@@ -316,7 +332,8 @@ def rank_watchdog(args, argv):
                 child.finish()
                 status = f"fail time limit of {args.child_timeout:.0f} s"
             if status is not None and not os.path.exists(status_path):
-                _write_atomically(status_path, json.dumps({"status": status, "stderr_tail": list(child.tail)}))
+                t_status = time.time()
+                _write_atomically(status_path, json.dumps({"status": status, "t": t_status, "stderr_tail": list(child.tail)}))
             if rank == 0:
                 peers = {q: json.loads(_read(os.path.join(run_dir, f"a{k}.rank{q}")) or "null") for q in range(world)}
                 bad = {q: s for q, s in peers.items() if s and s["status"] != "ok"}
@@ -324,20 +341,25 @@ def rank_watchdog(args, argv):
                 got = child.json_line() if status == "ok" or (status is None and bad) else None
                 if got is not None:
                     line, verdict = got, "done"
+                elif status is not None and status != "ok" and len(peers) - list(peers.values()).count(None) < world and time.time() < t_status + 3.0:
+                    pass          # the own worker failed: a moment for the others to say when theirs did (the first failure is the cause)
                 elif status is not None or bad:
                     # the own worker failed, or another rank's did (this one may sit in a collective the other never enters)
                     if status is None:
                         say(f"attempt {k}: rank(s) {sorted(bad)} failed: killing the own worker")
                         _kill_group(child.proc)
                         child.finish()
-                        bad[0] = {"status": "fail killed: another rank failed first", "stderr_tail": list(child.tail)}
+                        bad[0] = {"status": "fail killed: another rank failed first", "t": time.time(), "stderr_tail": list(child.tail)}
                     elif status == "ok":
-                        bad[0] = {"status": "fail no JSON line on stdout", "stderr_tail": list(child.tail)}
+                        bad[0] = {"status": "fail no JSON line on stdout", "t": time.time(), "stderr_tail": list(child.tail)}
                     elif 0 not in bad:
-                        bad[0] = {"status": status, "stderr_tail": list(child.tail)}
-                    first = min(bad, key=lambda q: (bad[q]["status"].startswith("fail killed"), q))
+                        bad[0] = {"status": status, "t": t_status, "stderr_tail": list(child.tail)}
+                    first = min(bad, key=lambda q: (bad[q]["status"].startswith("fail killed"), bad[q].get("t", 0.0), q))
+                    order = sorted(bad, key=lambda q: (bad[q]["status"].startswith("fail killed"), bad[q].get("t", 0.0), q))
                     failures.append({"attempt": k, "ran": what, "rank": first, "reason": bad[first]["status"][5:],
-                                     "ranks_failed": sorted(bad), "stderr_tail": bad[first]["stderr_tail"]})
+                                     "ranks_failed": sorted(bad), "stderr_tail": bad[first]["stderr_tail"],
+                                     "others": [{"rank": q, "reason": bad[q]["status"][5:], "stderr_tail": bad[q]["stderr_tail"][-4:]}
+                                                for q in order[1:4]]})
                     port = _free_port()
                     verdict = f"retry {port}" if k < len(attempts) else "give up"
                 if verdict is not None:
@@ -357,7 +379,7 @@ def rank_watchdog(args, argv):
                     line.setdefault("config", {})["fallback"] = {
                         "ran": what, "instead_of": failures[0]["ran"] + " (the default multi-rank step: symmetric pass + all-to-all)",
                         "because": f"rank {failures[0]['rank']}: {failures[0]['reason']}", "ranks_failed": failures[0]["ranks_failed"],
-                        "stderr_tail": failures[0]["stderr_tail"]}
+                        "stderr_tail": failures[0]["stderr_tail"], "other_failures": failures[0]["others"]}
                 print_result(line)
                 t_end = time.monotonic() + 10.0           # the other watchdogs say when they have read the verdict
                 while time.monotonic() < t_end and not all(os.path.exists(os.path.join(run_dir, f"a{k}.seen.rank{q}")) for q in range(1, world)):
@@ -439,6 +461,7 @@ def run_single_host(args):
         elapsed = time.perf_counter() - t0
         f_ms, f_n = e.kernel_time(nb.KERNEL_FORCES)   # the slowest device's total
         u_ms, u_n = e.kernel_time(nb.KERNEL_UPDATE)
+        clk = clock_fields(e, f_ms / max(f_n, 1) * 1e-3, float(n // g) * float(n))
         equal_mass = e.equal_mass_form()
         p_end = e.state(np.float64 if args.precision == "f64" else np.float32)[0]
         finite = bool(np.isfinite(p_end).all())
@@ -480,7 +503,7 @@ def run_single_host(args):
         "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak,
                      "achieved_is": "algorithmic: N_i x N ordered interactions x 20 flop (SURVEY 8d) / the slowest device's launch time",
-                     "executed": executed, "executed_frac": executed / peak,
+                     "executed": executed, "executed_frac": executed / peak, **clk,
                      "traffic": traffic[0], "traffic_source": traffic[1], "kernel": cfg["kernel"],
                      "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n, "flop_per_pair": FLOP_PER_PAIR,
                      "pairs_per_launch": launch_pairs, "update_kernel_avg_ms": u_ms / max(u_n, 1)},
@@ -624,6 +647,7 @@ def main():
 
     f_ms, f_n = sim.engine.kernel_time(nb.KERNEL_FORCES)
     u_ms, u_n = sim.engine.kernel_time(nb.KERNEL_UPDATE)
+    clk = clock_fields(sim.engine, f_ms / max(f_n, 1) * 1e-3, float(sim.i_count) * float(n))
     pairs_per_step = float(n) * float(n)
     value = pairs_per_step * args.steps / elapsed
     # dominant kernel: the force pass of this rank = i_count x n_total pair interactions per launch (the symmetric
@@ -636,6 +660,10 @@ def main():
         t = torch.tensor([-avg_launch_s * 1e3, avg_launch_s * 1e3], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         launch_ms_minmax = [-float(t[0]), float(t[1])]
+        g_ = clk["clock_ghz"] or 0.0
+        t = torch.tensor([-g_, g_], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        clk["clock_ghz_min_max_over_ranks"] = [-float(t[0]), float(t[1])]
     achieved_tflops = launch_pairs * FLOP_PER_PAIR / avg_launch_s * 1e-12
     # what the hardware executed: the symmetric kernel evaluates each unordered pair once (25 flop) and credits both
     # bodies; the one-sided kernel evaluates every ordered pair (20 flop)
@@ -684,6 +712,7 @@ def main():
         fence()
         el2 = time.perf_counter() - t0
         f2_ms, f2_n = sim2.engine.kernel_time(nb.KERNEL_FORCES)
+        clk2 = clock_fields(sim2.engine, f2_ms / max(f2_n, 1) * 1e-3, launch_pairs)
         p2, _ = sim2.gather_state()
         sim2.compute_forces()
         err2 = sampled_force_error(p2, sim2.engine.accelerations(np.float64 if args.precision == "f64" else np.float32), 0, bodies, 1.0e4, args.eps)
@@ -695,6 +724,7 @@ def main():
                     "value": pairs_per_step * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3,
                     "force_pass_avg_ms": f2_ms / max(f2_n, 1),
                     "roofline_frac": launch_pairs * FLOP_PER_PAIR / (f2_ms / max(f2_n, 1) * 1e-3) * 1e-12 / peak,
+                    "clock_ghz": clk2["clock_ghz"], "cycles_per_interaction": clk2["cycles_per_interaction"],
                     "max_rel_err_sampled": err2}
 
     # Multi-GPU only: north_star's literal step — one-sided kernel, per-step all-gather of positions, no other collective —
@@ -739,7 +769,7 @@ def main():
             "roofline": {"bound": "valu_fp32" if args.precision != "f64" else "valu_fp64",
                          "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
                          "achieved_is": "algorithmic: N_i x N ordered interactions x 20 flop (SURVEY 8d) / launch time",
-                         "executed": executed_tflops, "executed_frac": executed_tflops / peak,
+                         "executed": executed_tflops, "executed_frac": executed_tflops / peak, **clk,
                          "executed_is": (f"VALU flops issued: each unordered pair evaluated once, {flop_eval} flop"
                                          + (" (equal-mass form: no mass factors inside the loop)" if equal_mass else "")
                                          if cfg["algorithm"] == "symmetric" else "every ordered pair evaluated, 20 flop"),

@@ -162,6 +162,13 @@ NBODY_API int nbody_device_count(void);
 /* TArray<FParticle> contents (OctreeSearch.h:8-18,118): all n_total records, `stride` bytes apart (>= 40). */
 NBODY_API int nbody_set_particles(nbody_ctx *ctx, const void *aos, size_t stride, int32_t n);
 
+/* The host has EDITED records of a running simulation.  In the reference `Particles` is the state itself (OctreeSearch.h:118;
+ * the Tick reads and writes it in place, OctreeSearch.cpp:28-31): code that changes Particles[i] between two Ticks changes the
+ * simulation, and nothing else restarts — the next tree is still rooted at the previous tree's CoM (OctreeSearch.cpp:77-79).
+ * Same upload as nbody_set_particles (Mass, Position, Velocity, Acceleration of all n_total records), but the history stays:
+ * nbody_steps_done goes on counting and the Barnes-Hut root centre is kept. */
+NBODY_API int nbody_push_particles(nbody_ctx *ctx, const void *aos, size_t stride, int32_t n);
+
 /* Native layout: posm4 = n_total x {x,y,z,m}, vel4 = n_total x {vx,vy,vz,unused}, fp32. */
 NBODY_API int nbody_set_state_soa(nbody_ctx *ctx, const float *posm4, const float *vel4, int32_t n);
 
@@ -298,6 +305,14 @@ NBODY_API int nbody_synchronize(nbody_ctx *ctx);
  * events recorded on the launch stream (needs params.time_kernels).  Synchronises. */
 NBODY_API int nbody_kernel_time(nbody_ctx *ctx, int32_t which, double *total_ms, int64_t *launches);
 NBODY_API int nbody_kernel_time_reset(nbody_ctx *ctx);
+
+/* The shader clock the timed force kernels actually ran at since the last nbody_kernel_time_reset, in MHz (needs
+ * params.time_kernels): every workgroup of forces_sym_pk_kernel / forces_tile_pk_kernel reads the shader-clock counter and the
+ * fixed reference counter at both ends and the ratio of the sums is reported — the power-limited force loops hold a different
+ * clock on different boxes (2.13 - 2.33 GHz seen), and time x clock is what tells a slower box from slower code.  0 when no
+ * instrumented kernel has run (fp64, block and Barnes-Hut kernels are not instrumented).  compute_units: of the context's device.
+ * A multi-device context reports its slowest device.  Synchronises. */
+NBODY_API int nbody_kernel_clock(nbody_ctx *ctx, double *shader_mhz, int32_t *compute_units);
 
 /* Launch geometry actually chosen (for logs and DESIGN.md tables). */
 NBODY_API int nbody_get_launch_config(nbody_ctx *ctx, int32_t *tile, int32_t *i_per_thread, int32_t *j_split,

@@ -51,6 +51,13 @@ NBODY_API void nbody_actor_set_devices(nbody_actor *a, const int32_t *devices, i
 NBODY_API int32_t nbody_actor_last_status(const nbody_actor *a);
 /* Copy the (synchronised) Particles array out; returns the number of records written. */
 NBODY_API int32_t nbody_actor_get_particles(nbody_actor *a, nbody_particle *out, int32_t capacity);
+/* The live (synchronised) records themselves — the counterpart of the reference's `Particles` member (OctreeSearch.h:118).  The
+ * device writes every frame's records here; what the host edits here reaches the simulation with nbody_actor_push_particles. */
+NBODY_API nbody_particle *nbody_actor_particle_data(nbody_actor *a);
+/* The host has edited records between two Ticks (in the reference that alone changes the simulation: `Particles` is the state,
+ * OctreeSearch.cpp:28-31).  p == NULL: push the live records as they stand; otherwise n records (n = the actor's count) are
+ * copied in first.  History is kept (step count, the next tree's root centre): nbody_push_particles. */
+NBODY_API void nbody_actor_push_particles(nbody_actor *a, const nbody_particle *p, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,8 @@ class OctreeSearchActor {
  public:
   // ---- reference members (OctreeSearch.h:117-127) ----
   float Size = 0.0f;                    // .h:117
-  std::vector<FParticle> Particles;     // .h:118  (host mirror of the device state, see MirrorParticles)
+  std::vector<FParticle> Particles;     // .h:118  (host mirror of the device state, see MirrorParticles; empty when the
+                                        //          records live in the host's own array: AllocateParticles)
   bool Initialized = false;             // .h:121
   bool ShowOctree = false;              // .h:124  BlueprintReadWrite
   float PhDeltaTime = 0.01f;            // .h:127  BlueprintReadWrite; default from the ctor, .cpp:8
@@ -44,6 +45,14 @@ class OctreeSearchActor {
   double Eps = 0.0;
   int LastStatus = NBODY_OK;            // last C-ABI return code (the reference's methods are void)
 
+  // Where the records live.  Unset: in `Particles` above.  Set: the host's own array — a UE4 adapter hands out its
+  // TArray<FParticle>'s storage (`Particles.SetNumUninitialized(n); return Particles.GetData();`), the device then writes every
+  // frame's records straight into THAT memory (it is page-locked for the context: nbody_pin_host_buffer) and nothing is copied
+  // on the host.  Called with the number of records whenever the actor needs storage for a new scene; the array must keep its
+  // address until the next call (or CleanParticles).  A host that resizes or reallocates its array tells the actor with
+  // SetParticles(data, n); one that only edits records with PushParticles().
+  std::function<FParticle *(size_t n)> AllocateParticles;
+
   // Renderer hand-off (OctreeSearch.cpp:24,40-41): FlushPersistentDebugLines, DrawDebugPoint(Position, 10.0, Black),
   // DrawDebugBox(Origin, (Size,Size,Size), Red) per occupied leaf when ShowOctree (only with Theta > 0: at theta = 0
   // no tree exists).
@@ -65,10 +74,11 @@ class OctreeSearchActor {
     std::vector<float> posm(4 * (size_t)N), vel(4 * (size_t)N);
     LastStatus = nbody_ic_reference_box(N, SizeArg, ActorLocation, Seed, posm.data(), vel.data());
     if (LastStatus) return;
-    Release();                          // before `Particles` gives up its (pinned) storage
-    Particles.assign((size_t)N, FParticle{});
+    Release();                          // before the records give up their (pinned) storage
+    if (!Storage((size_t)N)) return;
     for (int32_t i = 0; i < N; ++i) {
-      FParticle &p = Particles[(size_t)i];
+      FParticle &p = data_[(size_t)i];
+      p = FParticle{};
       p.Mass = posm[4 * (size_t)i + 3];
       for (int k = 0; k < 3; ++k) { p.Position[k] = posm[4 * (size_t)i + k]; p.Velocity[k] = vel[4 * (size_t)i + k]; }
     }
@@ -76,18 +86,31 @@ class OctreeSearchActor {
   }
 
   // Build-defined: explicit initial state instead of the random one (same post-conditions as CreateSpacePoints).
+  // With AllocateParticles set and `p` the host's own array (same address as the hook returns for N records) nothing is
+  // copied: the array IS the record storage from here on.
   void SetParticles(const FParticle *p, int32_t N) {
     if (!p || N <= 0) { LastStatus = NBODY_ERR_INVALID; return; }
-    if (p >= Particles.data() && p < Particles.data() + Particles.size()) {   // re-upload of (part of) the own array
-      std::vector<FParticle> copy(p, p + N);
-      Release();
-      Particles.swap(copy);
-    } else {
-      Release();
-      Particles.assign(p, p + N);
-    }
+    std::vector<FParticle> copy(p, p + N);   // `p` may point into the storage that is about to be released / reallocated
+    Release();
+    if (!Storage((size_t)N)) return;
+    if (data_ != p) std::copy(copy.begin(), copy.end(), data_);
     Upload();
   }
+
+  // The host has edited records in place (the reference's `Particles` IS the state, .h:118: whatever code changes
+  // Particles[i] between two Ticks changes the simulation, .cpp:28-31).  Here the state lives on the device and the array is
+  // its mirror: an edit is overwritten by the next frame unless it is pushed.  Keeps the history (step count, the next
+  // tree's root centre = the previous tree's CoM, .cpp:77-79): nbody_push_particles.
+  void PushParticles() {
+    if (!Initialized) return;
+    LastStatus = nbody_push_particles(ctx_, data_, sizeof(FParticle), (int32_t)num_);
+    if (LastStatus == NBODY_OK) dirty_ = false;
+  }
+
+  // The records (`Particles`, or the host's array behind AllocateParticles) and their number
+  FParticle *ParticleData() { return data_; }
+  const FParticle *ParticleData() const { return data_; }
+  size_t NumParticles() const { return num_; }
 
   // .cpp:47-56
   void ComputeCubeSize() {
@@ -114,7 +137,7 @@ class OctreeSearchActor {
       if (LastStatus == NBODY_OK && MirrorParticles) {
         // .cpp:26-31 and the mirror DrawOctreeBoxes reads, in one call with one host synchronisation
         float s = Size;
-        LastStatus = nbody_tick(ctx_, PhDeltaTime, &s, Particles.data(), sizeof(FParticle));
+        LastStatus = nbody_tick(ctx_, PhDeltaTime, &s, data_, sizeof(FParticle));
         if (LastStatus == NBODY_OK) { Size = s; dirty_ = false; forces_fresh_ = true; }
       } else if (LastStatus == NBODY_OK) {
         ComputeCubeSize();                                                     // .cpp:26
@@ -137,22 +160,22 @@ class OctreeSearchActor {
       // ShowOctree) and then the point (.cpp:39-41): same order, same interleaving
       const bool boxes = ShowOctree && OnDrawDebugBox;
       if (!boxes && !OnDrawDebugPoint) return;
-      order_.resize(Particles.size());
+      order_.resize(num_);
       if (nbody_bh_leaf_order(ctx_, order_.data()) == NBODY_OK) {
         if (boxes) {
-          boxes_.resize(4 * Particles.size());
+          boxes_.resize(4 * num_);
           if (nbody_bh_leaf_boxes(ctx_, boxes_.data(), 16) != NBODY_OK) boxes_.clear();
         }
         for (int32_t i : order_) {
           if (boxes && !boxes_.empty()) OnDrawDebugBox(&boxes_[4 * (size_t)i], boxes_[4 * (size_t)i + 3]);          // .cpp:40
-          if (OnDrawDebugPoint) OnDrawDebugPoint(Particles[(size_t)i].Position, 10.0f);                                // .cpp:41
+          if (OnDrawDebugPoint) OnDrawDebugPoint(data_[(size_t)i].Position, 10.0f);                                    // .cpp:41
         }
         return;
       }
     }
     // theta = 0: there is no tree; bodies in index order, no boxes
     if (OnDrawDebugPoint)
-      for (const FParticle &p : Particles) OnDrawDebugPoint(p.Position, 10.0f);
+      for (size_t i = 0; i < num_; ++i) OnDrawDebugPoint(data_[i].Position, 10.0f);
   }
 
   // .cpp:91-97
@@ -163,12 +186,13 @@ class OctreeSearchActor {
     forces_fresh_ = false;
     dirty_ = false;
     Particles.clear();
+    data_ = nullptr; num_ = 0;          // (a host array behind AllocateParticles is the host's to empty)
   }
 
-  // Pull the whole device state into `Particles`.
+  // Pull the whole device state into the records.
   void SyncParticles() {
     if (!ctx_ || !dirty_) return;
-    LastStatus = nbody_get_particles(ctx_, Particles.data(), sizeof(FParticle));
+    LastStatus = nbody_get_particles(ctx_, data_, sizeof(FParticle));
     if (LastStatus == NBODY_OK) dirty_ = false;
   }
 
@@ -177,7 +201,21 @@ class OctreeSearchActor {
  private:
   void SyncPositions() {
     if (!ctx_ || !dirty_) return;
-    LastStatus = nbody_get_positions(ctx_, Particles.data()->Position, sizeof(FParticle), 0, (int32_t)Particles.size());
+    LastStatus = nbody_get_positions(ctx_, data_->Position, sizeof(FParticle), 0, (int32_t)num_);
+  }
+
+  // storage for n records: the host's array if it hands one out, `Particles` otherwise
+  bool Storage(size_t n) {
+    if (AllocateParticles) {
+      Particles.clear();
+      data_ = AllocateParticles(n);
+      if (!data_) { num_ = 0; LastStatus = NBODY_ERR_NOMEM; return false; }
+    } else {
+      Particles.assign(n, FParticle{});
+      data_ = Particles.data();
+    }
+    num_ = n;
+    return true;
   }
 
   void Release() {
@@ -190,7 +228,7 @@ class OctreeSearchActor {
     Release();
     nbody_params p;
     nbody_default_params(&p);
-    p.n_total = (int32_t)Particles.size();
+    p.n_total = (int32_t)num_;
     p.device = Device;
     p.precision = Precision;
     p.G = G;
@@ -198,18 +236,20 @@ class OctreeSearchActor {
     LastStatus = Devices.empty() ? nbody_create(&p, &ctx_)
                                  : nbody_create_multi(&p, Devices.data(), (int32_t)Devices.size(), &ctx_);
     if (LastStatus) return;
-    LastStatus = nbody_set_particles(ctx_, Particles.data(), sizeof(FParticle), (int32_t)Particles.size());
+    LastStatus = nbody_set_particles(ctx_, data_, sizeof(FParticle), (int32_t)num_);
     if (LastStatus) return;
-    // the per-frame mirror lands in `Particles` by one DMA (an optimisation only: unpinned memory works the same).
-    // `Particles` must keep its storage while the actor is initialised, as the reference's TArray does between
+    // the per-frame records land in the storage straight from the device (an optimisation only: unpinned memory works the
+    // same).  The storage must keep its address while the actor is initialised, as the reference's TArray does between
     // CreateSpacePoints and CleanParticles.
-    (void)nbody_pin_host_buffer(ctx_, Particles.data(), Particles.size() * sizeof(FParticle));
+    (void)nbody_pin_host_buffer(ctx_, data_, num_ * sizeof(FParticle));
     Initialized = true;                                                        // .cpp:71
     forces_fresh_ = false;
     dirty_ = false;
   }
 
   nbody_ctx *ctx_ = nullptr;
+  FParticle *data_ = nullptr;           // the records: Particles.data() or the host's array
+  size_t num_ = 0;
   std::vector<float> boxes_;
   std::vector<int32_t> order_;
   bool forces_fresh_ = false;

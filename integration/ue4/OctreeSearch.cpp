@@ -10,6 +10,12 @@
 AOctreeSearch::AOctreeSearch() : Size(0), ParticleOctree(NULL), Initialized(false), ShowOctree(false), PhDeltaTime(0.01), Theta(1.0f)
 {
   Engine.DrawInTick = false;                                  // Tick draws through DrawOctreeBoxes(ParticleOctree), as the reference does
+  // The records live in THIS actor's TArray (OctreeSearch.h:118): the engine asks for storage here, page-locks it for its
+  // context and lets the device write every frame's FParticle records straight into it.
+  Engine.AllocateParticles = [this](size_t N) {
+    Particles.SetNumUninitialized((int32)N);
+    return reinterpret_cast<nbody::FParticle*>(Particles.GetData());
+  };
   PrimaryActorTick.bCanEverTick = true;                       // OctreeSearch.cpp:11
 }
 
@@ -41,9 +47,23 @@ void AOctreeSearch::PullMirror()
   Initialized = Engine.Initialized;
   // the reference's pointer is non-NULL from the first CreateOctree until CleanParticles (OctreeSearch.cpp:79, 94-95)
   ParticleOctree = Engine.HasTree() ? reinterpret_cast<Octree*>(&Engine) : NULL;
-  Particles.SetNumUninitialized((int32)Engine.Particles.size());
-  if (Particles.Num() > 0)
-    std::memcpy(Particles.GetData(), Engine.Particles.data(), sizeof(FParticle) * (size_t)Particles.Num());
+  // nothing to copy: the frame's records are in Particles already (Engine.AllocateParticles)
+}
+
+// The host resized or reallocated `Particles` (Add / SetNum / Empty + refill ...): what is in the array now is the scene.
+void AOctreeSearch::AdoptStorage()
+{
+  if (!Engine.Initialized) return;
+  const nbody::FParticle* Data = reinterpret_cast<const nbody::FParticle*>(Particles.GetData());
+  if (Data == Engine.ParticleData() && (size_t)Particles.Num() == Engine.NumParticles()) return;
+  if (Particles.Num() == 0) { Engine.CleanParticles(); return; }
+  Engine.SetParticles(Data, Particles.Num());                 // re-creates the context on (and re-pins) the new storage
+}
+
+void AOctreeSearch::PushParticles()
+{
+  AdoptStorage();
+  Engine.PushParticles();
 }
 
 // OctreeSearch.cpp:21-34: flush, (if PhDeltaTime > 0) bounds + force pass + kick-drift, draw.
@@ -51,6 +71,7 @@ void AOctreeSearch::Tick(float DeltaSeconds)
 {
   Super::Tick(DeltaSeconds);
   PushKnobs();
+  AdoptStorage();
   Engine.Tick(DeltaSeconds);                                  // DeltaSeconds is ignored, as in the reference
   PullMirror();
   DrawOctreeBoxes(ParticleOctree);                            // OctreeSearch.cpp:33 (runs when paused too)
@@ -95,6 +116,7 @@ void AOctreeSearch::CreateOctree()
 // OctreeSearch.cpp:91-97
 void AOctreeSearch::CleanParticles()
 {
-  Engine.CleanParticles();
+  Engine.CleanParticles();                                    // destroys the context (and unpins the array) first ...
+  Particles.Empty();                                          // ... then OctreeSearch.cpp:96
   PullMirror();
 }

@@ -40,7 +40,11 @@ class NBODY_API AOctreeSearch : public AActor
 public:
   // ---- the reference's members (OctreeSearch.h:117-127) ----
   float Size;                               // half-width of the scene, refreshed by every Tick (ComputeCubeSize)
-  TArray<FParticle> Particles;              // mirror of the device state, refreshed by every Tick
+  TArray<FParticle> Particles;              // OctreeSearch.h:118.  The array's own storage is where the device writes every frame's
+                                            // records (it is page-locked for the context; nothing is copied on the host).  The
+                                            // simulation state lives on the device: code that EDITS Particles[i] calls
+                                            // PushParticles() afterwards, code that resizes the array needs nothing more —
+                                            // the next Tick sees the new storage and re-creates the engine on it.
   Octree* ParticleOctree;                   // OctreeSearch.h:119: NULL until the first force pass and after CleanParticles
                                             // (OctreeSearch.cpp:8, 95); otherwise a token for the device's current tree
   bool Initialized;
@@ -76,8 +80,15 @@ public:
   UFUNCTION(BlueprintCallable, Category = "Octree")
   void CleanParticles();
 
+  // new: records of `Particles` edited by the host since the last Tick -> the device (in the reference the edit alone would
+  // do: the Tick integrates the array in place, OctreeSearch.cpp:28-31).  Keeps the history: the next tree is still rooted at the
+  // previous tree's centre of mass (OctreeSearch.cpp:77-79).
+  UFUNCTION(BlueprintCallable, Category = "Octree")
+  void PushParticles();
+
 private:
   nbody::OctreeSearchActor Engine;          // owns the nbody_ctx; never touched from Blueprints
-  void PullMirror();                        // Engine.Particles / Size / Initialized -> the members above
+  void PullMirror();                        // Engine's Size / Initialized / tree token -> the members above (no record is copied)
   void PushKnobs();                         // PhDeltaTime / ShowOctree / Theta / Devices -> Engine
+  void AdoptStorage();                      // the TArray was resized or reallocated by the host: the engine moves to the new storage
 };

@@ -7,7 +7,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnbody_amd.so")
+# NBODY_AMD_LIB: another build of the same library (a tuning build from `make variant`, csrc/Makefile) — for A/B measurements;
+# the shipped file is never replaced by one
+LIB_PATH = os.environ.get("NBODY_AMD_LIB") or os.path.join(_HERE, "libnbody_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 OK = 0
@@ -90,6 +92,7 @@ def lib():
     sig("nbody_destroy", None, vp)
     sig("nbody_last_error", ctypes.c_char_p, vp)
     sig("nbody_set_particles", c_int, vp, vp, sz, c_i32)
+    sig("nbody_push_particles", c_int, vp, vp, sz, c_i32)
     sig("nbody_set_state_soa", c_int, vp, fp, fp, c_i32)
     sig("nbody_set_state_soa_f64", c_int, vp, dp, dp, c_i32)
     sig("nbody_compute_forces", c_int, vp)
@@ -122,6 +125,7 @@ def lib():
     sig("nbody_synchronize", c_int, vp)
     sig("nbody_kernel_time", c_int, vp, c_i32, dp, ctypes.POINTER(c_i64))
     sig("nbody_kernel_time_reset", c_int, vp)
+    sig("nbody_kernel_clock", c_int, vp, dp, ctypes.POINTER(c_i32))
     sig("nbody_get_launch_config", c_int, vp, *([ctypes.POINTER(c_i32)] * 5))
     sig("nbody_force_kernel_name", ctypes.c_char_p, vp)
     sig("nbody_get_algorithm", c_int, vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32))
@@ -163,5 +167,7 @@ def lib():
     sig("nbody_actor_set_devices", None, vp, ctypes.POINTER(c_i32), c_i32)
     sig("nbody_actor_last_status", c_i32, vp)
     sig("nbody_actor_get_particles", c_i32, vp, vp, c_i32)
+    sig("nbody_actor_particle_data", vp, vp)
+    sig("nbody_actor_push_particles", None, vp, vp, c_i32)
     _lib = L
     return L

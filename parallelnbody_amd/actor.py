@@ -94,6 +94,25 @@ class OctreeSearch:
         a = np.ascontiguousarray(particles, PARTICLE_DTYPE)
         self._L.nbody_actor_set_particles(self._h, a.ctypes.data, a.shape[0])
 
+    def PushParticles(self, particles=None):
+        """The host has edited records between two Ticks (in the reference `Particles` IS the state: OctreeSearch.h:118,
+        OctreeSearch.cpp:28-31).  particles=None pushes the actor's live records as they stand (edit them through
+        `live_particles()`); otherwise the given records are copied in first.  History is kept (nbody_push_particles)."""
+        if particles is None:
+            self._L.nbody_actor_push_particles(self._h, None, 0)
+        else:
+            a = np.ascontiguousarray(particles, PARTICLE_DTYPE)
+            self._L.nbody_actor_push_particles(self._h, a.ctypes.data, a.shape[0])
+
+    def live_particles(self):
+        """The actor's own records as a numpy VIEW (no copy): what the device writes every frame, and what PushParticles() uploads."""
+        n = self._L.nbody_actor_num_particles(self._h)
+        ptr = self._L.nbody_actor_particle_data(self._h)
+        if not n or not ptr:
+            return np.zeros(0, PARTICLE_DTYPE)
+        buf = (ctypes.c_char * (n * PARTICLE_DTYPE.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=PARTICLE_DTYPE, count=n)
+
     def set_box_callback(self, on_box=None):
         """on_box((ox,oy,oz), size) <- DrawDebugBox of an occupied leaf (ShowOctree and theta > 0)."""
         b = _lib.DRAW_BOX_FN((lambda user, o, sz: on_box((o[0], o[1], o[2]), sz)) if on_box else 0)

@@ -37,7 +37,7 @@ void nbody_actor_set_box_callback(nbody_actor *a, nbody_draw_box_fn box, void *u
 
 float nbody_actor_get_size(const nbody_actor *a) { return a ? a->impl.Size : 0.0f; }
 int32_t nbody_actor_get_initialized(const nbody_actor *a) { return a && a->impl.Initialized ? 1 : 0; }
-int32_t nbody_actor_num_particles(const nbody_actor *a) { return a ? (int32_t)a->impl.Particles.size() : 0; }
+int32_t nbody_actor_num_particles(const nbody_actor *a) { return a ? (int32_t)a->impl.NumParticles() : 0; }
 float nbody_actor_get_ph_delta_time(const nbody_actor *a) { return a ? a->impl.PhDeltaTime : 0.0f; }
 void nbody_actor_set_ph_delta_time(nbody_actor *a, float dt) { if (a) a->impl.PhDeltaTime = dt; }
 int32_t nbody_actor_get_show_octree(const nbody_actor *a) { return a && a->impl.ShowOctree ? 1 : 0; }
@@ -58,9 +58,24 @@ int32_t nbody_actor_last_status(const nbody_actor *a) { return a ? a->impl.LastS
 int32_t nbody_actor_get_particles(nbody_actor *a, nbody_particle *out, int32_t capacity) {
   if (!a || !out || capacity < 0) return 0;
   a->impl.SyncParticles();
-  const int32_t n = std::min<int32_t>(capacity, (int32_t)a->impl.Particles.size());
-  std::copy(a->impl.Particles.begin(), a->impl.Particles.begin() + n, out);
+  const int32_t n = std::min<int32_t>(capacity, (int32_t)a->impl.NumParticles());
+  std::copy(a->impl.ParticleData(), a->impl.ParticleData() + n, out);
   return n;
+}
+
+nbody_particle *nbody_actor_particle_data(nbody_actor *a) {
+  if (!a) return nullptr;
+  a->impl.SyncParticles();
+  return a->impl.ParticleData();
+}
+
+void nbody_actor_push_particles(nbody_actor *a, const nbody_particle *p, int32_t n) {
+  if (!a) return;
+  if (p) {
+    if (n != (int32_t)a->impl.NumParticles()) { a->impl.LastStatus = NBODY_ERR_INVALID; return; }
+    if (p != a->impl.ParticleData()) std::copy(p, p + n, a->impl.ParticleData());
+  }
+  a->impl.PushParticles();
 }
 
 }  // extern "C"

@@ -90,6 +90,8 @@ struct nbody_ctx {
   nbody::BhState *bh = nullptr;
   void *bh_acc = nullptr;      // [n_total] float4: the walk's output, summed (j_split = 1) by update_kernel
   KernelTimer timers[2];
+  unsigned long long *clk = nullptr;   // time_kernels: {shader-clock cycles, reference-clock ticks} summed over the force kernels' workgroups (pk_common.h)
+  int wall_khz = 0, cus = 0;           // hipDeviceAttributeWallClockRate, compute units
   std::string err;
 };
 
@@ -377,6 +379,7 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
       L.dup_table_next = c->sym_dup_cur ? c->sym_dup_table : c->sym_dup_table2;
     }
   }
+  L.clk = c->clk;
   return L;
 }
 
@@ -397,6 +400,7 @@ nbody::ForceLaunch make_launch(const nbody_ctx *c) {
   L.check_masses = (c->sym_general && c->masses_equal != 0 && !(c->masses_equal == 1 && c->own_posm && !c->posm_escaped)) ? 1 : 0;
   // block kernel: which form to launch — the host's finding if it stands, both (each looks at the device word) otherwise
   L.uni = (!c->sym_general || c->masses_equal == 0) ? 0 : (L.check_masses ? -1 : 1);
+  L.clk = c->clk;
   return L;
 }
 
@@ -617,8 +621,10 @@ int note_masses(nbody_ctx *c, const T *posm4) {
 }
 
 // Upload host SoA state given as T (float or double); converts to the context's precision.
+// keep_history: the records of a running simulation edited by the host (nbody_push_particles) — the step count and the
+// Barnes-Hut root centre (the previous tree's CoM) stay what they are.
 template <typename T>
-int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
+int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4, bool keep_history = false) {
   if (int rc = use_device(c)) return rc;
   const int n = c->p.n_total, ib = c->p.i_begin, ic = c->p.i_count;
   const bool ctx64 = c->p.precision == NBODY_PREC_F64;
@@ -645,8 +651,9 @@ int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_state = true;
   c->floor_eps2 = -1.0;
-  c->steps_done = 0;
   c->sym_posg_valid = false;
+  if (keep_history) return NBODY_OK;
+  c->steps_done = 0;
   if (c->bh) HIP_TRY(c, nbody::bh_reset_root(c->bh, c->stream));   // a new scene: root centre starts at zero again
   return NBODY_OK;
 }
@@ -889,6 +896,12 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
   }
   if ((e = hipMalloc(&c->scratch, 64)) != hipSuccess) return bail(e, "hipMalloc scratch");
   if ((e = hipMemset(c->scratch, 0, 64)) != hipSuccess) return bail(e, "hipMemset scratch");
+  if (p.time_kernels) {
+    if ((e = hipMalloc(&c->clk, 64)) != hipSuccess) return bail(e, "hipMalloc clock words");
+    if ((e = hipMemset(c->clk, 0, 64)) != hipSuccess) return bail(e, "hipMemset clock words");
+    (void)hipDeviceGetAttribute(&c->wall_khz, hipDeviceAttributeWallClockRate, p.device);
+    (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, p.device);
+  }
   if ((e = hipHostMalloc(&c->h_scratch, 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   g_create_error.clear();   // e.g. the reason AUTO passed over the symmetric plan: not an error of this call
   *out = c;
@@ -942,6 +955,7 @@ void nbody_destroy(nbody_ctx *c) {
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->clk) (void)hipFree(c->clk);
   if (c->energy_part) (void)hipFree(c->energy_part);
   if (c->h_scratch) (void)hipHostFree(c->h_scratch);
   for (const auto &r : c->pinned) (void)hipHostUnregister(r.first);   // the memory itself stays the caller's
@@ -1021,11 +1035,19 @@ int nbody_set_state_soa_f64(nbody_ctx *c, const double *posm4, const double *vel
   return fail(c, NBODY_ERR_NOMEM, "nbody_set_state_soa_f64: out of host memory");
 }
 
-int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n) try {
-  if (!c || !aos) return c ? fail(c, NBODY_ERR_INVALID, "nbody_set_particles: null buffer") : NBODY_ERR_INVALID;
-  if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "nbody_set_particles: n = %d but the context holds %d bodies", n, c->p.n_total);
-  if (stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "nbody_set_particles: stride %zu < %zu", stride, sizeof(nbody_particle));
-  if (c->multi) { const int rc = multi_rc(c, nbody::multi_set_particles(c->multi, aos, stride, n)); if (!rc) { c->have_state = true; c->steps_done = 0; } return rc; }
+}  // extern "C"
+
+namespace {
+int set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n, bool keep_history, const char *who) {
+  if (!c || !aos) return c ? fail(c, NBODY_ERR_INVALID, "%s: null buffer", who) : NBODY_ERR_INVALID;
+  if (n != c->p.n_total) return fail(c, NBODY_ERR_INVALID, "%s: n = %d but the context holds %d bodies", who, n, c->p.n_total);
+  if (stride < sizeof(nbody_particle)) return fail(c, NBODY_ERR_INVALID, "%s: stride %zu < %zu", who, stride, sizeof(nbody_particle));
+  if (keep_history && !c->have_state) return fail(c, NBODY_ERR_STATE, "%s: no state has been set yet (nbody_set_particles first)", who);
+  if (c->multi) {
+    const int rc = multi_rc(c, nbody::multi_set_particles(c->multi, aos, stride, n, keep_history));
+    if (!rc) { c->have_state = true; if (!keep_history) c->steps_done = 0; }
+    return rc;
+  }
   std::vector<float> posm((size_t)n * 4), vel((size_t)n * 4);
   const char *base = (const char *)aos;
   for (int i = 0; i < n; ++i) {
@@ -1036,7 +1058,7 @@ int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n)
     vel[4 * (size_t)i + 0] = q.Velocity[0]; vel[4 * (size_t)i + 1] = q.Velocity[1];
     vel[4 * (size_t)i + 2] = q.Velocity[2]; vel[4 * (size_t)i + 3] = 0.f;
   }
-  int rc = upload_soa<float>(c, posm.data(), vel.data());
+  int rc = upload_soa<float>(c, posm.data(), vel.data(), keep_history);
   if (rc) return rc;
   // carry the records' Acceleration field over too (the reference keeps whatever was there until the next force pass)
   std::vector<float> acc((size_t)c->p.i_count * 4);
@@ -1053,8 +1075,21 @@ int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n)
     HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size() * 4, hipMemcpyHostToDevice));
   }
   return NBODY_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int nbody_set_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n) try {
+  return set_particles(c, aos, stride, n, false, "nbody_set_particles");
 } catch (const std::bad_alloc &) {
   return fail(c, NBODY_ERR_NOMEM, "nbody_set_particles: out of host memory");
+}
+
+int nbody_push_particles(nbody_ctx *c, const void *aos, size_t stride, int32_t n) try {
+  return set_particles(c, aos, stride, n, true, "nbody_push_particles");
+} catch (const std::bad_alloc &) {
+  return fail(c, NBODY_ERR_NOMEM, "nbody_push_particles: out of host memory");
 }
 
 // A sharded symmetric context has an exchange between the force pass and the update: the caller must drive
@@ -1653,6 +1688,21 @@ int nbody_kernel_time_reset(nbody_ctx *c) {
     c->timers[w].total_ms = 0.0;
     c->timers[w].launches = 0;
   }
+  if (c->clk) { HIP_TRY(c, hipMemsetAsync(c->clk, 0, 16, c->stream)); HIP_TRY(c, hipStreamSynchronize(c->stream)); }
+  return NBODY_OK;
+}
+
+int nbody_kernel_clock(nbody_ctx *c, double *shader_mhz, int32_t *compute_units) {
+  if (!c) return NBODY_ERR_INVALID;
+  if (c->multi) return multi_rc(c, nbody::multi_kernel_clock(c->multi, shader_mhz, compute_units));
+  if (int rc0 = use_device(c)) return rc0;
+  if (shader_mhz) *shader_mhz = 0.0;
+  if (compute_units) *compute_units = c->cus;
+  if (!c->clk) return fail(c, NBODY_ERR_STATE, "nbody_kernel_clock: the context was created without time_kernels");
+  unsigned long long w[2] = {0, 0};
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(w, c->clk, sizeof w, hipMemcpyDeviceToHost));
+  if (shader_mhz && w[1] != 0ull) *shader_mhz = (double)w[0] / (double)w[1] * (double)c->wall_khz * 1e-3;
   return NBODY_OK;
 }
 

@@ -31,6 +31,7 @@ struct ForceLaunch {
   // may have written the buffer since the host last looked).
   void *general = nullptr;
   int check_masses = 0;
+  void *clk = nullptr;  // packed fp32 tile kernel: two device uint64 the workgroups add their shader-clock / reference-clock intervals to (pk_common.h)
 };
 
 // All-pairs force partials.  Returns hipSuccess or the launch error.
@@ -118,6 +119,7 @@ struct SymLaunch {
   int do_prep = 1, do_fold = -1;     // do_fold < 0: as the phase says (phases 0 and 2 fold)
   int fold_accumulate = 0;
   int clear_detector = 1;            // the fold also clears the coincident-body table for the next pass (the pass's LAST fold only)
+  void *clk = nullptr;               // fp32: two device uint64 the force kernel's workgroups add their clock intervals to (pk_common.h)
 };
 // forces + fold of the j-side rows into L.send
 hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);

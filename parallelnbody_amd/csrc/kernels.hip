@@ -221,8 +221,10 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
                                                                 float4 *__restrict__ accp, int n_total, int i_begin,
                                                                 int i_count, int j_chunk, float gscale, float zp,
                                                                 const int *__restrict__ dup_flag,
-                                                                const int *__restrict__ general) {
+                                                                const int *__restrict__ general,
+                                                                unsigned long long *__restrict__ clk) {
   constexpr int IPT = 2 * NP;
+  const ClockStamp stamp = clock_begin(clk);
   // equal-mass form (see forces_sym_pk_kernel, UNI): *general == 0 says every body has body 0's mass — found by the host
   // in the state it uploaded, or by mass_check_kernel before this launch when somebody else can write the buffer.  Then
   // the pair loop carries no mass factor (11 packed ops per register pair and j instead of 12), the padding of ragged tiles
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(kBlock) void forces_tile_pk_kernel(const float4 *__
     if (il0 < i_count) accp[(size_t)c * i_count + il0] = make_float4(sx.x, sy.x, sz.x, 0.f);
     if (il1 < i_count) accp[(size_t)c * i_count + il1] = make_float4(sx.y, sy.y, sz.y, 0.f);
   }
+  clock_end(clk, stamp);
 }
 
 // HIP's __fmul_rn/__fadd_rn are plain * and + and get contracted into FMAs under the default
@@ -601,7 +604,7 @@ hipError_t launch_forces_t(const ForceLaunch &L, hipStream_t s) {
 #define NBODY_LAUNCH_PK(ZM, ZP, FLAG)                                                                            \
   hipLaunchKernelGGL((forces_tile_pk_kernel<IPT / 2, TILE, ZM, KAHAN>), grid, block, 0, s, (const float4 *)L.posm, \
                      (float4 *)L.accp, L.n_total, L.i_begin, L.i_count, L.j_chunk, (float)L.G, (float)(ZP),        \
-                     (const int *)(FLAG), (const int *)L.general)
+                     (const int *)(FLAG), (const int *)L.general, (unsigned long long *)L.clk)
       // equal masses?  The host's finding stands while only this library writes the buffer; otherwise the device looks
       if (L.general != nullptr && L.check_masses)
         hipLaunchKernelGGL(mass_check_kernel<float>, dim3((L.n_total + kBlock - 1) / kBlock), dim3(kBlock), 0, s,

@@ -45,14 +45,25 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add(float
 // quads of a half row, the two halves of a row (quad_perm, quad_perm, row_half_mirror, row_mirror: every lane of a row
 // then holds the row's sum), row 0 into row 1 and row 2 into row 3 (row_bcast:15), rows 0+1 into rows 2, 3 (row_bcast:31).
 // The first step goes through the builtin (hipcc turns it into a copy, a v_mov_b32_dpp and an add, and pads the hazard
-// between whatever wrote the value and the DPP read); the other five are ONE v_add_f32_dpp each, written out: their
-// operand was produced NV instructions earlier by the step before, far beyond the two wait states a DPP read needs.
+// between whatever wrote the value and the DPP read); the other five are ONE v_add_f32_dpp each, written out.
+// A DPP read needs two wait states after the VALU write of its operand, and LLVM's hazard recogniser does not look inside
+// inline asm, so the distance is built in rather than left to the scheduler: the asms are `volatile` (they keep their source
+// order among themselves — a value's steps are then NV >= 8 instructions apart), every first-step result is consumed by an
+// empty volatile asm before ONE `s_nop 1`, and only then do the written-out steps begin.  tools/isa_hazards.py checks the
+// built object's disassembly for exactly this (tests/test_isa_hazards.py).
 // (Rows a row_mask leaves out keep their value; nobody reads them afterwards.)
+#ifdef NBODY_BLOCK_DPP_UNORDERED   // round 3's form, for the A/B timing only (tools/ab_dpp_order.sh): order left to the scheduler
 #define NBODY_DPP_ADD(v, ctrl) asm("v_add_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
+#define NBODY_DPP_SETTLE(v, nv) do { } while (0)
+#else
+#define NBODY_DPP_ADD(v, ctrl) asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl : "+v"(v))
+#define NBODY_DPP_SETTLE(v, nv) do { _Pragma("unroll") for (int q_ = 0; q_ < (nv); ++q_) asm volatile("" : "+v"((v)[q_])); asm volatile("s_nop 1"); } while (0)
+#endif
 template <int NV> __device__ __forceinline__ void wave_sum_to_lane63(float (&v)[NV]) {
   static_assert(NV >= 8, "the written-out steps rely on NV instructions between a value's steps");
 #pragma unroll
   for (int q = 0; q < NV; ++q) v[q] = dpp_add<0xB1, 0xf>(v[q]);    // quad_perm:[1,0,3,2]
+  NBODY_DPP_SETTLE(v, NV);   // all first-step results exist (an empty volatile asm has consumed each) and are two wait states old
 #pragma unroll
   for (int q = 0; q < NV; ++q) NBODY_DPP_ADD(v[q], "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
 #pragma unroll
@@ -65,6 +76,7 @@ template <int NV> __device__ __forceinline__ void wave_sum_to_lane63(float (&v)[
   for (int q = 0; q < NV; ++q) NBODY_DPP_ADD(v[q], "row_bcast:31 row_mask:0xc bank_mask:0xf");
 }
 #undef NBODY_DPP_ADD
+#undef NBODY_DPP_SETTLE
 
 #ifndef NBODY_BLOCK_JL_BIG
 #define NBODY_BLOCK_JL_BIG 4      // loads in flight per lane at five and more register pairs; 6 and 8 measured no better

@@ -164,12 +164,13 @@ __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu(sym_waves(NP, KAHAN), sym_waves(NP, KAHAN))))
 void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ pool, const SymItem *__restrict__ items,
                           float zp, const int *__restrict__ dup_flag, int run_if_dup, const int *__restrict__ general,
-                          int run_if_general) {
+                          int run_if_general, unsigned long long *__restrict__ clk) {
   constexpr bool kCanMerge = BARE && (NP <= 4 || UNI);           // the general form at NP = 8 would spill (52 B of scratch)
   const bool merged = kCanMerge && run_if_dup < 0;
   if (!merged && dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
   if (general != nullptr && ((*general != 0) ? 1 : 0) != run_if_general) return;
   const bool guard_all = merged && *dup_flag != 0;               // merged launch, coincident bodies: the guarded loops
+  const ClockStamp stamp = clock_begin(clk);
   __shared__ float4 sh_pos[2][4][128];   // double-buffered subtile images, doubled: entries l and l+64 hold body l
   __shared__ float sh_acc[4][3][kJT];    // per-WAVE j-side sums of the tile (private: no ordering between waves needed)
 
@@ -279,6 +280,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
     Pi[(2 * p) * kBlock] = make_float4(sx.x, sy.x, sz.x, 0.f);
     Pi[(2 * p + 1) * kBlock] = make_float4(sx.y, sy.y, sz.y, 0.f);
   }
+  clock_end(clk, stamp);
 }
 
 }  // namespace
@@ -326,7 +328,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   } else {
 #define NBODY_SYM_K(NPV, ZM, BARE, KH, UNI, ZP, FLAG, RUNIF)                                                     \
   hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, UNI>), grid, block, 0, s, (const float4 *)L.posg, \
-                     (float4 *)L.pool, items, (float)(ZP), (const int *)(FLAG), RUNIF, gate, UNI ? 0 : 1)
+                     (float4 *)L.pool, items, (float)(ZP), (const int *)(FLAG), RUNIF, gate, UNI ? 0 : 1, (unsigned long long *)L.clk)
   bool do_uni = run_uni, do_gen = run_gen;                         // which forms the next NBODY_SYM_NP launches
 #define NBODY_SYM_U(NPV, ZM, BARE, KH, ZP, FLAG, RUNIF)                                                          \
   do {                                                                                                           \

@@ -21,7 +21,7 @@ int multi_parts(const Multi *m);
 nbody_ctx *multi_part(const Multi *m, int k);                     // the k-th device's context (owned by the Multi)
 void multi_slice(const Multi *m, int k, int32_t *i_begin, int32_t *i_count);
 
-int multi_set_particles(Multi *m, const void *aos, size_t stride, int32_t n);
+int multi_set_particles(Multi *m, const void *aos, size_t stride, int32_t n, bool keep_history = false);
 int multi_set_state_soa(Multi *m, const float *posm4, const float *vel4, int32_t n);
 int multi_set_state_soa_f64(Multi *m, const double *posm4, const double *vel4, int32_t n);
 int multi_forces(Multi *m, float dt);                             // one force pass + update (dt <= 0: accelerations only)
@@ -34,6 +34,7 @@ int multi_energy(Multi *m, double *ke, double *pe);
 int multi_synchronize(Multi *m);
 int multi_kernel_time(Multi *m, int32_t which, double *total_ms, int64_t *launches);   // slowest device's total
 int multi_kernel_time_reset(Multi *m);
+int multi_kernel_clock(Multi *m, double *shader_mhz, int32_t *compute_units);   // the slowest clock among the devices
 int multi_load_checkpoint(Multi *m, const char *path, int64_t *steps_done);
 
 }  // namespace nbody

@@ -7,6 +7,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <string>
 #include <vector>
 
 namespace nbody {
@@ -25,22 +27,32 @@ struct Rccl {
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-// One process-wide handle; the library stays loaded (RCCL does not like being unloaded under live communicators).
+// One handle per library name, process-wide; a library stays loaded (RCCL does not like being unloaded under live
+// communicators).  NBODY_RCCL_LIB names another library with the same eight entry points: the test suite's stand-in
+// (tests/cpp/fake_rccl.c), which lets one GPU play several devices — see NBODY_MULTI_SHARE_DEVICE in multi_create.
 bool load_rccl(Rccl *r, std::string *err) {
-  static Rccl g;
-  static bool tried = false, ok = false;
-  static std::string why;
-  if (!tried) {
-    tried = true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      g.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (g.handle) break;
+  struct Loaded { Rccl api; bool ok = false; std::string why; };
+  static std::map<std::string, Loaded> cache;
+  const char *named = getenv("NBODY_RCCL_LIB");
+  const std::string key = named && named[0] ? named : "";
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    Loaded l;
+    Rccl &g = l.api;
+    if (!key.empty()) {
+      g.handle = dlopen(key.c_str(), RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g.handle) break;
+      }
     }
     if (!g.handle) {
-      why = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+      const char *de = dlerror();
+      l.why = std::string("cannot load RCCL (") + (key.empty() ? "librccl.so.1" : key.c_str()) + "): " + (de ? de : "not found");
     } else {
       bool all = true;
-      auto sym = [&](const char *n) { void *p = dlsym(g.handle, n); if (!p) { all = false; why = std::string("RCCL lacks ") + n; } return p; };
+      auto sym = [&](const char *n) { void *p = dlsym(g.handle, n); if (!p) { all = false; l.why = std::string("RCCL lacks ") + n; } return p; };
       g.CommInitAll = (decltype(g.CommInitAll))sym("ncclCommInitAll");
       g.CommDestroy = (decltype(g.CommDestroy))sym("ncclCommDestroy");
       g.GroupStart = (decltype(g.GroupStart))sym("ncclGroupStart");
@@ -49,11 +61,12 @@ bool load_rccl(Rccl *r, std::string *err) {
       g.Send = (decltype(g.Send))sym("ncclSend");
       g.Recv = (decltype(g.Recv))sym("ncclRecv");
       g.GetErrorString = (decltype(g.GetErrorString))sym("ncclGetErrorString");
-      ok = all;
+      l.ok = all;
     }
+    it = cache.emplace(key, l).first;
   }
-  if (!ok) { if (err) *err = why; return false; }
-  *r = g;
+  if (!it->second.ok) { if (err) *err = it->second.why; return false; }
+  *r = it->second.api;
   return true;
 }
 
@@ -175,9 +188,13 @@ int multi_create(const nbody_params *pin, const int32_t *devices, int32_t n_dev,
   if (pin->n_total <= 0 || pin->n_total % n_dev != 0)
     return bad(NBODY_ERR_INVALID, "nbody_create_multi: n_total must be a positive multiple of n_dev (equal slices)");
   if (pin->theta > 0.0f) return bad(NBODY_ERR_UNSUPPORTED, "nbody_create_multi: Barnes-Hut (theta > 0) runs on a single-device context");
-  for (int a = 0; a < n_dev; ++a)
-    for (int b = a + 1; b < n_dev; ++b)
-      if (devices[a] == devices[b]) return bad(NBODY_ERR_INVALID, "nbody_create_multi: a device is listed twice");
+  // NBODY_MULTI_SHARE_DEVICE=1 (test suites only, together with NBODY_RCCL_LIB: real RCCL refuses two ranks on one device):
+  // a device may be listed several times, so that one GPU runs every index of this file that a node of eight would
+  const char *share = getenv("NBODY_MULTI_SHARE_DEVICE");
+  if (!(share && share[0] == '1'))
+    for (int a = 0; a < n_dev; ++a)
+      for (int b = a + 1; b < n_dev; ++b)
+        if (devices[a] == devices[b]) return bad(NBODY_ERR_INVALID, "nbody_create_multi: a device is listed twice");
   Multi *m = new (std::nothrow) Multi();
   if (!m) return bad(NBODY_ERR_NOMEM, "nbody_create_multi: out of host memory");
   std::string why;
@@ -267,9 +284,11 @@ void multi_slice(const Multi *m, int k, int32_t *i_begin, int32_t *i_count) {
   if (i_count) *i_count = m->slice;
 }
 
-int multi_set_particles(Multi *m, const void *aos, size_t stride, int32_t n) {
+int multi_set_particles(Multi *m, const void *aos, size_t stride, int32_t n, bool keep_history) {
   { const int rc = wait_gather(m); if (rc) return rc; }
-  for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_set_particles(m->part[(size_t)k], aos, stride, n), "nbody_set_particles");
+  for (int k = 0; k < m->n_dev; ++k)
+    PART_TRY(m, k, keep_history ? nbody_push_particles(m->part[(size_t)k], aos, stride, n) : nbody_set_particles(m->part[(size_t)k], aos, stride, n),
+             keep_history ? "nbody_push_particles" : "nbody_set_particles");
   return NBODY_OK;
 }
 int multi_set_state_soa(Multi *m, const float *posm4, const float *vel4, int32_t n) {
@@ -374,6 +393,18 @@ int multi_kernel_time(Multi *m, int32_t which, double *total_ms, int64_t *launch
 }
 int multi_kernel_time_reset(Multi *m) {
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_kernel_time_reset(m->part[(size_t)k]), "nbody_kernel_time_reset");
+  return NBODY_OK;
+}
+
+int multi_kernel_clock(Multi *m, double *shader_mhz, int32_t *compute_units) {
+  double slowest = 0.0;
+  for (int k = 0; k < m->n_dev; ++k) {
+    double mhz = 0.0; int32_t cus = 0;
+    PART_TRY(m, k, nbody_kernel_clock(m->part[(size_t)k], &mhz, &cus), "nbody_kernel_clock");
+    if (k == 0 || (mhz > 0.0 && mhz < slowest)) slowest = mhz;
+    if (compute_units && k == 0) *compute_units = cus;
+  }
+  if (shader_mhz) *shader_mhz = slowest;
   return NBODY_OK;
 }
 

@@ -19,6 +19,26 @@ enum { Z_SOFT = 0, Z_CLAMP = 1, Z_SELECT = 2, Z_BARE = 3 };
 
 __device__ __forceinline__ float rsq_dev(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
 
+// Which clock did the kernel run at?  The force loops are power-limited: the clock a box holds under them differs by several
+// per cent from box to box (2.13 - 2.33 GHz seen), so a time alone cannot tell a slower box from slower code.  A wave can read two
+// counters: s_memtime counts SHADER-clock cycles, s_memrealtime a fixed reference (100 MHz: hipDeviceAttributeWallClockRate) —
+// profiles/r04_microbench_clock_counters.txt shows the first following the load, the second not.  With clk != nullptr
+// (nbody_params.time_kernels) every workgroup adds its own two intervals to clk[0] / clk[1]; their ratio is the clock the
+// kernel's workgroups saw, weighted by how long each ran (nbody_kernel_clock).  Two scalar reads at either end of a workgroup
+// that runs for tens of microseconds to milliseconds, two atomics per workgroup; nothing when clk is null.
+struct ClockStamp { unsigned long long t, r; };
+__device__ __forceinline__ ClockStamp clock_begin(const unsigned long long *clk) {
+  ClockStamp s{0ull, 0ull};
+  if (clk != nullptr) { s.t = __builtin_amdgcn_s_memtime(); s.r = __builtin_amdgcn_s_memrealtime(); }
+  return s;
+}
+__device__ __forceinline__ void clock_end(unsigned long long *clk, const ClockStamp &s) {
+  if (clk != nullptr) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime() - s.t, r = __builtin_amdgcn_s_memrealtime() - s.r;
+    if (threadIdx.x == 0) { atomicAdd(clk, t); atomicAdd(clk + 1, r); }
+  }
+}
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }

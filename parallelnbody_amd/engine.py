@@ -347,6 +347,20 @@ class NBodyEngine:
     def kernel_time_reset(self):
         self._check(self._L.nbody_kernel_time_reset(self._h))
 
+    def kernel_clock(self):
+        """(shader clock in MHz the timed force kernels ran at since the last reset — 0.0 if none of them is instrumented —,
+        compute units of the device): nbody_kernel_clock.  Needs time_kernels."""
+        mhz, cus = ctypes.c_double(), ctypes.c_int32()
+        self._check(self._L.nbody_kernel_clock(self._h, ctypes.byref(mhz), ctypes.byref(cus)))
+        return mhz.value, cus.value
+
+    def push_particles(self, particles):
+        """Records of the RUNNING simulation edited by the host (nbody_push_particles): like set_particles, but the step count
+        and the Barnes-Hut root centre stay."""
+        a = np.ascontiguousarray(particles)
+        assert a.dtype.itemsize >= 40
+        self._check(self._L.nbody_push_particles(self._h, a.ctypes.data, a.dtype.itemsize, a.shape[0]))
+
     def equal_mass_form(self):
         """Did the last force pass run the equal-mass form of the fp32 symmetric kernel (nbody.h)?"""
         v = ctypes.c_int32()

@@ -90,6 +90,63 @@ int main() {
     if (frame == 0) std::printf("theta = 1.0 frame 0: %d/2000 accelerations bit-equal to the oracle's tree walk (max rel %.1e)\n", same, e);
   }
   CHECK(boxes == 3 * 2000, "ShowOctree boxes %d", boxes);
+
+  // ---- the host edits a body between two Ticks (the reference's Particles IS the state, OctreeSearch.h:118, .cpp:28-31) ----
+  // without a push the device state wins: the next frame overwrites the edit ...
+  const nbody::FParticle before = actor.Particles[7];
+  actor.Particles[7].Velocity[0] += 1000.0f;
+  actor.Tick(0.016f);
+  oracle_tick_aos_f32(2000, ref.data(), 0.01f, 1.0f, 1.0e4, 0, com, &size);
+  CHECK(std::fabs(actor.Particles[7].Velocity[0] - ref[7].Velocity[0]) < 1.0f && before.Mass == actor.Particles[7].Mass,
+        "an edit that is not pushed does not reach the simulation");
+  // ... with PushParticles it is the simulation's state from the next Tick on, history kept: the oracle's Tick on the same
+  // edited records, with the SAME root centre (the previous tree's CoM, .cpp:77-79) and Size carried over
+  for (std::vector<oracle_particle> *dst : {&ref}) {
+    (*dst)[7].Velocity[0] += 1000.0f; (*dst)[7].Position[2] -= 25.0f; (*dst)[7].Mass = 4000.0f;
+    (*dst)[1999].Position[0] = 3.0f * size;                       // a body moved outside the old bounds: Size must follow
+  }
+  actor.Particles[7].Velocity[0] += 1000.0f; actor.Particles[7].Position[2] -= 25.0f; actor.Particles[7].Mass = 4000.0f;
+  actor.Particles[1999].Position[0] = ref[1999].Position[0];
+  actor.PushParticles();
+  CHECK(actor.LastStatus == NBODY_OK, "PushParticles status %d", actor.LastStatus);
+  for (int frame = 0; frame < 2; ++frame) {
+    actor.Tick(0.016f);
+    oracle_tick_aos_f32(2000, ref.data(), 0.01f, 1.0f, 1.0e4, 0, com, &size);
+    int same = 0;
+    const double e = max_rel_acc(actor.Particles, ref, &same);
+    CHECK(actor.LastStatus == NBODY_OK && e < 1e-6 && same >= 1998, "after PushParticles, frame %d: rel err %.3e, %d/2000 bit-equal", frame, e, same);
+    CHECK(actor.Size == size, "Size after the edit %g vs %g", actor.Size, size);
+    CHECK(actor.Particles[7].Mass == 4000.0f && std::fabs(actor.Particles[7].Position[2] - ref[7].Position[2]) <= 1e-4f * std::fabs(ref[7].Position[2]) + 1e-4f &&
+          std::fabs(actor.Particles[7].Velocity[0] - ref[7].Velocity[0]) <= 1e-4f * std::fabs(ref[7].Velocity[0]), "the edited body");
+    if (frame == 0) std::printf("PushParticles: edited bodies simulated on, %d/2000 accelerations bit-equal to the oracle's Tick of the edited state\n", same);
+  }
+  int64_t steps = 0;
+  CHECK(nbody_steps_done(actor.Context(), &steps) == NBODY_OK && steps == 6, "history kept across the push: %lld steps", (long long)steps);
+
+  // ---- the records in the HOST's own array (what the UE4 adapter does with its TArray<FParticle>): no host copy ----
+  {
+    std::vector<nbody::FParticle> mine;                 // stands in for AOctreeSearch::Particles
+    int allocations = 0;
+    nbody::OctreeSearchActor hosted, plain;
+    hosted.AllocateParticles = [&](size_t n) { ++allocations; mine.resize(n); return mine.data(); };
+    for (nbody::OctreeSearchActor *a : {&hosted, &plain}) { a->Seed = 3; a->CreateSpacePoints(2000, 1000.0f); }
+    CHECK(hosted.Initialized && hosted.Particles.empty() && hosted.ParticleData() == mine.data() && mine.size() == 2000 && allocations == 1,
+          "AllocateParticles: the records live in the host's array");
+    for (int frame = 0; frame < 3; ++frame) { hosted.Tick(0.016f); plain.Tick(0.016f); }
+    CHECK(hosted.LastStatus == NBODY_OK && std::memcmp(mine.data(), plain.Particles.data(), 2000 * 40) == 0 && hosted.Size == plain.Size,
+          "frames delivered into the host's array equal the plain actor's");
+    // the host grows its array (TArray::Add reallocates): the adapter hands the new storage over with SetParticles
+    std::vector<nbody::FParticle> grown(mine);
+    grown.push_back(grown[5]); grown.back().Position[0] += 17.0f;
+    mine.clear(); mine.shrink_to_fit();
+    hosted.SetParticles(grown.data(), (int32_t)grown.size());
+    plain.SetParticles(grown.data(), (int32_t)grown.size());
+    hosted.Tick(0.016f); plain.Tick(0.016f);
+    CHECK(allocations == 2 && mine.size() == 2001 && hosted.NumParticles() == 2001 &&
+          std::memcmp(mine.data(), plain.Particles.data(), 2001 * 40) == 0, "a resized host array is adopted");
+    hosted.CleanParticles();
+    CHECK(!hosted.Initialized && hosted.NumParticles() == 0 && mine.size() == 2001, "CleanParticles leaves the host's array to the host");
+  }
   std::printf(g_fail ? "actor parity: %d FAILED\n" : "actor parity: ok\n", g_fail);
   return g_fail ? 1 : 0;
 }

@@ -17,9 +17,14 @@ static nbody_ctx *ctx_for_err = NULL;
 static int run(int32_t n, int precision, double eps, int steps) {
   int32_t devs[64];
   int n_dev = nbody_device_count();
+  /* NBODY_TEST_PARTS=<n> (with NBODY_RCCL_LIB = the suite's stand-in library and NBODY_MULTI_SHARE_DEVICE=1): device 0 listed n
+   * times, so that a one-GPU box runs this host's n_dev > 1 branch (tests/test_multi_parts_gpu.py) */
+  const char *parts = getenv("NBODY_TEST_PARTS");
+  const int shared = parts && atoi(parts) > 1;
+  if (shared) n_dev = atoi(parts);
   if (n_dev > 64) n_dev = 64;
   while (n_dev > 1 && n % (4096 * n_dev) != 0) --n_dev;      /* equal slices of whole i-sets */
-  for (int k = 0; k < n_dev; ++k) devs[k] = k;
+  for (int k = 0; k < n_dev; ++k) devs[k] = shared ? 0 : k;
 
   float *posm = malloc(sizeof(float) * 4 * (size_t)n), *vel = malloc(sizeof(float) * 4 * (size_t)n);
   if (nbody_ic_plummer(n, 1000.0, 100.0, 1.0e4, 42u, posm, vel)) return 1;

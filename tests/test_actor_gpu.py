@@ -112,3 +112,61 @@ def test_pause_reset_and_theta(nb):
     assert a.Initialized and a.Particles.shape == (300,)
     a.ShowOctree = True
     assert a.ShowOctree
+
+
+def test_push_particles_keeps_the_history(nb, oracle):
+    # the reference's Particles IS the state (OctreeSearch.h:118): an edit between two Ticks changes the simulation and nothing
+    # restarts.  Here: the edit reaches the device with PushParticles and the next frames equal the oracle's Ticks of the edited
+    # records with the SAME root centre carried over (the previous tree's CoM, OctreeSearch.cpp:77-79) — every byte, theta = 1
+    act = nb.OctreeSearch()
+    act.set_seed(11)
+    act.CreateSpacePoints(2000, 1000.0)
+    q = act.Particles.copy()
+    com, size = None, 0.0
+    for _ in range(3):
+        act.Tick(1.0 / 60)
+        com, size = oracle.tick_aos_f32(q, 0.01, theta=1.0, root_com=com, size=size, pow_mode=3)
+    assert act.Particles.tobytes() == q.tobytes()
+    live = act.live_particles()
+    for rec in (live, q):
+        rec["Velocity"][7, 0] += 1000.0
+        rec["Position"][7, 2] -= 25.0
+        rec["Mass"][11] = 4321.0
+    act.PushParticles()
+    assert act.LastStatus == 0
+    for _ in range(3):
+        act.Tick(1.0 / 60)
+        com, size = oracle.tick_aos_f32(q, 0.01, theta=1.0, root_com=com, size=size, pow_mode=3)
+        assert act.Size == size and act.Particles.tobytes() == q.tobytes()
+    # an edit that is NOT pushed is overwritten by the next frame (the one-way mirror INTEGRATION.md lists)
+    live = act.live_particles()
+    live["Velocity"][7, 0] += 1000.0
+    act.Tick(1.0 / 60)
+    com, size = oracle.tick_aos_f32(q, 0.01, theta=1.0, root_com=com, size=size, pow_mode=3)
+    assert act.Particles.tobytes() == q.tobytes()
+    # records handed over by value work the same
+    q["Position"][3, 1] += 5.0
+    act.PushParticles(q)
+    act.Tick(1.0 / 60)
+    com, size = oracle.tick_aos_f32(q, 0.01, theta=1.0, root_com=com, size=size, pow_mode=3)
+    assert act.Particles.tobytes() == q.tobytes()
+
+
+def test_engine_push_particles_at_theta_zero(nb):
+    n = 8192
+    posm, vel = nb.ic_plummer(n, seed=2)
+    from conftest import particles_from
+    with nb.NBodyEngine(n) as a, nb.NBodyEngine(n) as b:
+        with pytest.raises(nb.NBodyError):
+            a.push_particles(particles_from(nb, posm, vel))      # nothing to edit yet
+        a.set_state(posm, vel); b.set_state(posm, vel)
+        a.step(0.01, 2); b.step(0.01, 2)
+        rec = a.particles()
+        rec["Velocity"][5] = (1.0, 2.0, 3.0)
+        a.push_particles(rec)
+        assert a.steps_done() == 2                               # history kept
+        b.set_particles(rec)                                     # a new scene with the same records: step count starts again
+        assert b.steps_done() == 0
+        a.step(0.01, 2); b.step(0.01, 2)
+        for x, y in zip(a.state(), b.state()):
+            np.testing.assert_array_equal(x, y)

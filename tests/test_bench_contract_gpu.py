@@ -30,6 +30,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert key in rf, key
     assert rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     assert 0.2 < rf["frac"] < 1.0, rf           # a real measurement of the HIP kernel (N = 65536: about two thirds of peak)
+    # the clock the timed kernels ran at, read inside the kernels, and what time x clock says about the code alone: SIMD cycles
+    # per interaction (equal-mass form at N = 65536: 21.9 by PMC; the launch also holds ramp-up, tail and the fold)
+    assert 1.2 < rf["clock_ghz"] <= 2.45 and rf["compute_units"] == 256, rf
+    assert 19.0 < rf["cycles_per_interaction"] < 32.0, rf
+    assert rf["cycles_per_interaction"] == pytest.approx(rf["avg_launch_ms"] * 1e-3 * rf["clock_ghz"] * 1e9 * 256 * 4 * 64 / rf["pairs_per_launch"])
     cb = r["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
@@ -47,6 +52,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     dm = cf["distinct_masses"]
     assert dm["max_rel_err_sampled"] < 2e-5 and 0.2 < dm["roofline_frac"] < rf["frac"] * 1.02
     assert dm["value"] == pytest.approx(65536.0 ** 2 * 3 / (dm["ms_per_step"] * 3e-3), rel=1e-6)
+    assert 1.2 < dm["clock_ghz"] <= 2.45 and rf["cycles_per_interaction"] < dm["cycles_per_interaction"] < 36.0   # two more packed ops per register pair
 
 
 def test_stdout_is_the_json_line_alone_when_rccl_prints_its_banner():

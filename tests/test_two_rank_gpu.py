@@ -83,8 +83,10 @@ def test_bench_survives_a_failure_inside_the_all_to_all(launcher):
     assert r["n_gpus"] == 2 and cf["algorithm"] == "tiled" and r["value"] > 0 and cf["max_rel_err_sampled"] < 2e-5
     assert "all-to-all" not in cf["parallelism"] and "own stream" not in cf["parallelism"]
     fb = cf["fallback"]
-    assert fb["because"].startswith("rank 1: worker exit code") and 1 in fb["ranks_failed"]
-    assert any("NBODY_REHEARSE_A2A_FAILURE" in ln for ln in fb["stderr_tail"])
+    # (rank 0's worker fails as well, as soon as gloo sees its peer go: whichever exit was noticed first is named, both are listed)
+    assert "worker exit code" in fb["because"] and 1 in fb["ranks_failed"]
+    tails = fb["stderr_tail"] + [ln for o in fb["other_failures"] for ln in o["stderr_tail"]]
+    assert any("NBODY_REHEARSE_A2A_FAILURE" in ln for ln in tails)
     assert "starting a fresh worker" in err
     assert 0.0 < r["roofline"]["frac"] < 1.0 and r["roofline"]["launches"] == r["steps"]
 
