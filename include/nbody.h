@@ -130,7 +130,13 @@ NBODY_API int nbody_default_params(nbody_params *p);
  * every bit.  (Plain fp32 systems of up to 16384 bodies run forces_block_pk_kernel: there the CU count only decides how
  * many bodies share a workgroup, which no sum depends on — the same bits on any part.)  nbody_get_launch_config,
  * nbody_get_algorithm and nbody_sym_pool_info say what was chosen;
- * NBODY_ALGO_TILED with explicit tile / i_per_thread / j_split depends on the parameters alone. */
+ * NBODY_ALGO_TILED with explicit tile / i_per_thread / j_split depends on the parameters alone.
+ *
+ * Masses.  A context that owns all bodies re-reads every mass before every pass: a mass changed through a bound or handed-out
+ * device buffer is seen at once.  SHARDED contexts (i_count < n_total) treat masses as immutable between uploads
+ * (nbody_set_* / nbody_push_particles / nbody_load_checkpoint): the first go of a pass looks only at the own slice — the other
+ * ranks' records may still be arriving — so a mass another rank changes in its buffer selects the general form of the kernels one
+ * pass late. */
 NBODY_API int nbody_create(const nbody_params *p, nbody_ctx **out);
 
 /*

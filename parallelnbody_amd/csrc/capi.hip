@@ -556,11 +556,17 @@ int run_forces(nbody_ctx *c, bool diagnostic = false, int phase = 0) {
         if (a >= b && !(first && q == n_ph - 1)) continue;           // nothing of this pool phase in this go (but every go prepares)
         L.item0 = a < b ? a : r0; L.item1 = a < b ? b : r0;
         L.do_prep = first ? 1 : 0;
-        L.do_fold = (a < b && b == c->sym_phase_item0[(size_t)q + 1]) || (phase != 1 && q == n_ph - 1 && a >= b) ? 1 : 0;
+        // a go with nothing to launch (a plan without remote strips: every item — and with its last item every pool phase's
+        // fold — went out in the first go) prepares and folds NOTHING again: a second fold of the last pool phase would add its
+        // j-side sums to `send` twice.  What the go's preparation entered into the coincident-body table is cleared by hand.
+        const bool folded_in_first_go = phase == 2 && c->sym_n_local >= c->sym_phase_item0[(size_t)q + 1];
+        L.do_fold = (a < b && b == c->sym_phase_item0[(size_t)q + 1]) || (phase != 1 && q == n_ph - 1 && a >= b && !folded_in_first_go) ? 1 : 0;
         L.fold_accumulate = q > 0 ? 1 : 0;
         L.clear_detector = q == n_ph - 1 ? 1 : 0;
         L.j_ptr = (const unsigned int *)c->sym_jptr + (size_t)q * ((size_t)c->sym_n_gran + 1);
         HIP_TRY(c, nbody::launch_forces_sym(L, c->stream));
+        if (a >= b && folded_in_first_go && L.dup_table && L.eps2 == 0.0)
+          HIP_TRY(c, hipMemsetAsync(L.dup_table, 0, (size_t)L.dup_slots * 8 + 64, c->stream));
         first = false;
       }
     }

@@ -27,9 +27,6 @@
 
 #include <algorithm>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-
 #include "kernels.h"
 
 namespace nbody {
@@ -97,7 +94,7 @@ struct SmallTree {
 };
 
 constexpr int kHdrDeep = 8, kDeepSlots = 1024;   // header words [8, 1032): the deepest level, one word per slot (larger systems):
-                                                 // same-address atomics queue up (N = 2^20, 4096 workgroups: bh_lcp_kernel 71 us with 64 slots)
+                                                 // same-address atomics queue up (N = 2^20, 4096 workgroups: the lcp kernel: 71 us with 64 slots)
 constexpr int kHdrWords = kHdrDeep + kDeepSlots;
 constexpr int kDbgClocks = 16 + 3 * 512;   // tuning builds: 16 phase stamps + (start, fill end, end) of up to 512 walk workgroups
 #ifdef NBODY_BH_PHASE_CLOCKS
@@ -726,13 +723,6 @@ __global__ __launch_bounds__(kB) void bh_small_leaf_boxes_kernel(SmallTree T, in
   out[T.sidx[i]] = make_float4(o[0], o[1], o[2], size);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kB) void bh_gather_kernel(const T *__restrict__ src, const unsigned int *__restrict__ idx,
-                                                       T *__restrict__ dst, int n) {
-  const int i = blockIdx.x * kB + threadIdx.x;
-  if (i < n) dst[i] = src[idx[i]];
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Larger systems (n > kSmBodies): the same compact preorder tree, built by the whole chip — path keys, ONE rocPRIM radix
@@ -744,37 +734,334 @@ __global__ __launch_bounds__(kB) void bh_gather_kernel(const T *__restrict__ src
 // for the verdict (and the deepest level, which only the launch-per-level form needs on the host), while the scan and the
 // node pass are already running.
 //
-// Path keys of all bodies; the kernel's first workgroup also sets the frame up: the root (centre = the previous tree's CoM,
-// half-width = Size as the bounds kernel left it: ComputeCubeSize), the header words this frame counts in, and the 43
-// acceptance thresholds of the walk.  Every thread reads the root's ingredients itself, so nothing waits for that workgroup.
-__global__ __launch_bounds__(kB) void bh_keys_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
-                                                     const unsigned int *__restrict__ size_bits, float theta,
-                                                     unsigned long long *__restrict__ key_hi,
-                                                     unsigned long long *__restrict__ key_lo,
-                                                     unsigned int *__restrict__ idx) {
+// ---------------------------------------------------------------------------------------------------------------------
+// The larger systems' own sort of the path keys (Octree::Add's order, OctreeSearch.h:60-81): 8-byte first key word + 4-byte
+// body index.  Two forms, both hand-written for gfx950 — no library kernel on the path:
+//   tiles + merge   up to kMergeMaxN bodies, TWO launches: every workgroup computes the keys of kTs bodies and sorts them in
+//                   LDS (the small systems' merge by rank); then every element finds its place among ALL tiles by one
+//                   binary search per other tile, several searches in flight.  Bodies that agree in the whole first key
+//                   word are ordered by the second one on the spot (it is looked up only then).
+//   radix           above: least-significant-digit radix sort, 8 bits a pass, ONE launch per pass ("onesweep"): a tile's
+//                   keys are ranked inside the workgroup (per-wave match by ballots, LDS counters), where the tile's keys of
+//                   a digit go is found by decoupled look-back over the earlier tiles' counters, and the keys leave through
+//                   LDS in bin order.  The global digit histograms come from the key kernel (partial histograms per
+//                   workgroup, no global atomics: contended device-scope atomics cost ~0.8 us each here), ties in the whole
+//                   first key word are put right afterwards (bh_ties_kernel).
+constexpr int kTsT = 1024;                 // threads of a tile-sort workgroup
+constexpr int kTs = 4096;                  // bodies per tile
+constexpr int kMergeMaxN = 131072;         // tiles + merge up to here (32 tiles), radix above
+
+// What the first workgroup of a frame's first kernel sets up: the root (centre = the previous tree's CoM, half-width = Size as
+// the bounds kernel left it: ComputeCubeSize), the header words this frame counts in, the 43 acceptance thresholds of the walk.
+__device__ __forceinline__ void bh_frame_setup(const SmallTree &T, const float o[3], float sz, float theta, int nthreads) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    T.root[0] = o[0]; T.root[1] = o[1]; T.root[2] = o[2]; T.root[3] = sz;
+    T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
+  }
+  for (int q = t; q < kDeepSlots; q += nthreads) T.hdr[kHdrDeep + q] = -1;   // deepest level with a cell of >= 2 bodies (bh_lcp_scan_kernel)
+  if (t <= kMaxLevels) {
+    float s_l = sz;
+    for (int q = 0; q < t; ++q) s_l = (float)(0.5 * (double)s_l);   // .h:74
+    T.thr[t] = accept_threshold(s_l, theta);
+  }
+}
+
+// Keys of kTs bodies, sorted in LDS by (first word, second word on a tie, position): tile_hi / tile_idx hold the tiles one after
+// the other; klo_body the second key words by body.
+__global__ __launch_bounds__(kTsT) void bh_tile_sort_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+                                                            const unsigned int *__restrict__ size_bits, float theta,
+                                                            unsigned long long *__restrict__ klo_body,
+                                                            unsigned long long *__restrict__ tile_hi,
+                                                            unsigned int *__restrict__ tile_idx) {
+  constexpr int kBuf = kTs * (8 + 2);                          // one sort buffer: hi[kTs], idx[kTs] (local index)
+  __shared__ __attribute__((aligned(16))) unsigned char raw[2 * kBuf + kTs * 8];
+  unsigned long long *lo_l = (unsigned long long *)(raw + 2 * kBuf);   // second key word by local index
+  const int t = threadIdx.x;
   const float sz = __uint_as_float(*size_bits);
-  float o[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
-  if (blockIdx.x == 0) {
-    const int t = threadIdx.x;
-    if (t == 0) {
-      T.root[0] = o[0]; T.root[1] = o[1]; T.root[2] = o[2]; T.root[3] = sz;
-      T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
-    }
-    for (int q = t; q < kDeepSlots; q += kB) T.hdr[kHdrDeep + q] = -1;   // deepest level with a cell of >= 2 bodies (bh_lcp_kernel)
-    if (t <= kMaxLevels) {
-      float s_l = sz;
-      for (int q = 0; q < t; ++q) s_l = (float)(0.5 * (double)s_l);   // .h:74
-      T.thr[t] = accept_threshold(s_l, theta);
+  const float o0[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
+  if (blockIdx.x == 0) bh_frame_setup(T, o0, sz, theta, kTsT);
+  const int base = blockIdx.x * kTs, cnt = min(kTs, n - base);
+  int P = 64;
+  while (P < cnt) P <<= 1;
+  {
+    unsigned long long *hi0 = (unsigned long long *)raw;
+    unsigned short *idx0 = (unsigned short *)(raw + kTs * 8);
+#pragma unroll
+    for (int r = 0; r < kTs / kTsT; ++r) {
+      const int i = t + r * kTsT;
+      if (i >= P) break;
+      unsigned long long h = ~0ull, l = ~0ull;
+      if (i < cnt) {
+        const float4 p = posm[base + i];
+        float o[3] = {o0[0], o0[1], o0[2]};
+        float size = sz;
+        h = 0; l = 0;
+        for (int lev = 0; lev < kLevelsPerKey; ++lev) h = (h << 3) | (unsigned long long)descend_level(p, o, size);
+        for (int lev = 0; lev < kLevelsPerKey; ++lev) l = (l << 3) | (unsigned long long)descend_level(p, o, size);
+        klo_body[base + i] = l;
+      }
+      lo_l[i] = l;
+      hi0[i] = h; idx0[i] = (unsigned short)i;
     }
   }
+  __syncthreads();
+  // merge sort by rank (bh_small_build_kernel): runs of L become runs of 2L, every element finds its place by a binary search
+  // in the partner run — left run: partner elements strictly before it; right run: partner elements not after it (stable)
+  int cur = 0;
+  for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
+    const unsigned long long *shi = (const unsigned long long *)(raw + cur * kBuf);
+    const unsigned short *sidx = (const unsigned short *)(raw + cur * kBuf + kTs * 8);
+    unsigned long long *dhi = (unsigned long long *)(raw + (cur ^ 1) * kBuf);
+    unsigned short *didx = (unsigned short *)(raw + (cur ^ 1) * kBuf + kTs * 8);
+    for (int e = t; e < P; e += kTsT) {
+      const int run = e >> lg, pos = e & (L - 1);
+      const bool left = (run & 1) == 0;
+      const int pbase = (run ^ 1) * L;
+      const unsigned long long h = shi[e];
+      const unsigned short b = sidx[e];
+      int x = 0, y = L;
+      while (x < y) {
+        const int mid = (x + y) >> 1;
+        const unsigned long long hp = shi[pbase + mid];
+        bool before = hp < h;
+        if (hp == h) { const unsigned long long lp = lo_l[sidx[pbase + mid]], lm = lo_l[b]; before = left ? lp < lm : lp <= lm; }
+        if (before) x = mid + 1; else y = mid;
+      }
+      const int dest = (run & ~1) * L + pos + x;
+      dhi[dest] = h; didx[dest] = b;
+    }
+    if (2 * L <= 64 && 4 * L <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+  }
+  const unsigned long long *hi = (const unsigned long long *)(raw + cur * kBuf);
+  const unsigned short *idx = (const unsigned short *)(raw + cur * kBuf + kTs * 8);
+  for (int e = t; e < cnt; e += kTsT) { tile_hi[base + e] = hi[e]; tile_idx[base + e] = (unsigned int)(base + idx[e]); }
+}
+
+// Every element's place among all tiles: its place in its own tile + for every other tile the number of that tile's elements
+// that sort before it (an earlier tile's equal keys come first: the order is (key, tile, place) — stable).  kMergeW searches run
+// side by side: each is a chain of dependent loads from L2.
+constexpr int kMergeW = 8;
+__global__ __launch_bounds__(kB) void bh_tile_merge_kernel(int n, const unsigned long long *__restrict__ tile_hi,
+                                                           const unsigned int *__restrict__ tile_idx,
+                                                           const unsigned long long *__restrict__ klo_body,
+                                                           unsigned long long *__restrict__ out_hi, unsigned int *__restrict__ out_idx) {
+  const int e = blockIdx.x * kB + threadIdx.x;
+  if (e >= n) return;
+  const int a = e / kTs, ntiles = (n + kTs - 1) / kTs;
+  const unsigned long long h = tile_hi[e];
+  const unsigned int b = tile_idx[e];
+  int rank = e - a * kTs;
+  for (int tb = 0; tb < ntiles; tb += kMergeW) {
+    int x[kMergeW], y[kMergeW];
+#pragma unroll
+    for (int q = 0; q < kMergeW; ++q) {
+      const int tile = tb + q;
+      x[q] = 0;
+      y[q] = (tile < ntiles && tile != a) ? min(kTs, n - tile * kTs) : 0;
+    }
+    for (int step = 0; step < 13; ++step) {                    // a range of 4096 closes in 13 halvings
+#pragma unroll
+      for (int q = 0; q < kMergeW; ++q)
+        if (x[q] < y[q]) {
+          const int tile = tb + q, mid = (x[q] + y[q]) >> 1;
+          const unsigned long long hp = tile_hi[(size_t)tile * kTs + mid];
+          bool before = hp < h;
+          if (hp == h) {                                         // the whole first key word agrees (bodies closer than Size / 2^21)
+            const unsigned long long lp = klo_body[tile_idx[(size_t)tile * kTs + mid]], lm = klo_body[b];
+            before = tile < a ? lp <= lm : lp < lm;
+          }
+          if (before) x[q] = mid + 1; else y[q] = mid;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kMergeW; ++q) rank += x[q];
+  }
+  out_hi[rank] = h; out_idx[rank] = b;
+}
+
+// ---- radix sort (onesweep), 8 bits a pass
+constexpr int kRxT = 256;                  // threads of a pass's workgroup
+constexpr int kRxKpt = 16;                 // keys per thread
+constexpr int kRxTile = kRxT * kRxKpt;     // 4096 keys per tile
+constexpr int kRxBins = 256;
+constexpr int kRxPasses = 8;               // 63 key bits
+constexpr unsigned int kRxAgg = 1u << 30, kRxIncl = 2u << 30, kRxVal = (1u << 30) - 1u;
+
+// Path keys of all bodies (both words, body order) and, per workgroup of kRxTile bodies, how many of its keys carry each value
+// of each of the first word's eight digits: part_hist[workgroup][digit][value].
+__global__ __launch_bounds__(kRxT) void bh_keys_hist_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+                                                            const unsigned int *__restrict__ size_bits, float theta,
+                                                            unsigned long long *__restrict__ key_hi,
+                                                            unsigned long long *__restrict__ key_lo, unsigned int *__restrict__ idx,
+                                                            unsigned int *__restrict__ part_hist) {
+  __shared__ unsigned int s_h[kRxPasses][kRxBins];
+  const int t = threadIdx.x;
+  const float sz = __uint_as_float(*size_bits);
+  const float o0[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
+  if (blockIdx.x == 0) bh_frame_setup(T, o0, sz, theta, kRxT);
+  for (int q = t; q < kRxPasses * kRxBins; q += kRxT) (&s_h[0][0])[q] = 0u;
+  __syncthreads();
+  for (int r = 0; r < kRxKpt; ++r) {
+    const int i = blockIdx.x * kRxTile + r * kRxT + t;
+    if (i >= n) break;
+    const float4 p = posm[i];
+    float o[3] = {o0[0], o0[1], o0[2]};
+    float size = sz;
+    unsigned long long hi = 0, lo = 0;
+    for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
+    for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
+    key_hi[i] = hi; key_lo[i] = lo; idx[i] = (unsigned int)i;
+#pragma unroll
+    for (int d = 0; d < kRxPasses; ++d) atomicAdd(&s_h[d][(hi >> (8 * d)) & 0xFFull], 1u);
+  }
+  __syncthreads();
+  unsigned int *out = part_hist + (size_t)blockIdx.x * (kRxPasses * kRxBins);
+  for (int q = t; q < kRxPasses * kRxBins; q += kRxT) out[q] = (&s_h[0][0])[q];
+}
+
+// bin_base[digit][value] = number of keys whose digit is smaller: the sum of the workgroups' counts, scanned.  One workgroup
+// per digit, thread v owns value v.
+__global__ __launch_bounds__(kRxBins) void bh_hist_reduce_kernel(const unsigned int *__restrict__ part_hist, int nparts,
+                                                                  unsigned int *__restrict__ bin_base) {
+  __shared__ unsigned int s_w[kRxBins / 64];
+  const int d = blockIdx.x, v = threadIdx.x, lane = v & 63, wave = v >> 6;
+  unsigned int c = 0;
+  for (int w = 0; w < nparts; ++w) c += part_hist[((size_t)w * kRxPasses + d) * kRxBins + v];
+  unsigned int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned int u = __shfl_up(incl, off, 64); if (lane >= off) incl += u; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  unsigned int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_w[w];
+  bin_base[d * kRxBins + v] = base + incl - c;
+}
+
+struct RadixPass {
+  const unsigned long long *kin; const unsigned int *vin;
+  unsigned long long *kout; unsigned int *vout;
+  const unsigned int *bin_base;            // [256] of this pass's digit
+  unsigned int *desc;                      // [tiles][256] look-back words of this pass, zero before the launch
+  unsigned int *ticket;                    // zero before the launch
+  int shift, n;
+};
+
+__global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
+  __shared__ unsigned int s_cnt[kRxT / 64][kRxBins];          // per wave: keys of each digit value seen so far, then where the wave's keys of it start in the tile
+  __shared__ unsigned int s_start[kRxBins];                   // where a value's keys start in the tile's sorted order
+  __shared__ unsigned int s_goes[kRxBins];                    // ... and where they start in the output
+  __shared__ unsigned int s_scan[kRxT / 64];
+  __shared__ unsigned long long s_k[kRxTile];
+  __shared__ unsigned int s_v[kRxTile];
+  __shared__ int s_tile;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) s_tile = (int)atomicAdd(P.ticket, 1u);          // tiles in the order the workgroups START: a tile's predecessors are running or done
+  for (int q = t; q < (kRxT / 64) * kRxBins; q += kRxT) (&s_cnt[0][0])[q] = 0u;
+  __syncthreads();
+  const int tile = s_tile;
+  const int tbase = tile * kRxTile, tcount = min(kRxTile, P.n - tbase);
+  // wave w owns the tile's keys [1024 w, 1024 (w + 1)), sixty-four consecutive ones a round: a key's place among the keys of its
+  // digit value is (keys of the value in earlier waves) + (in earlier rounds of this wave) + (in lower lanes of this round)
+  unsigned long long k[kRxKpt];
+  unsigned int v[kRxKpt];
+  unsigned short rk[kRxKpt];
+#pragma unroll
+  for (int r = 0; r < kRxKpt; ++r) {
+    const int e = wave * (64 * kRxKpt) + r * 64 + lane;
+    const bool valid = e < tcount;
+    k[r] = valid ? P.kin[tbase + e] : ~0ull;
+    v[r] = valid ? P.vin[tbase + e] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < kRxKpt; ++r) {
+    const int e = wave * (64 * kRxKpt) + r * 64 + lane;
+    const bool valid = e < tcount;
+    const unsigned int d = (unsigned int)(k[r] >> P.shift) & 0xFFu;
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const unsigned long long vote = __ballot(one);
+      same &= one ? vote : ~vote;
+    }
+    const unsigned int before = (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
+    const unsigned int seen = valid ? s_cnt[wave][d] : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (valid && before == 0u) s_cnt[wave][d] = seen + (unsigned int)__popcll(same);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    rk[r] = (unsigned short)(seen + before);
+  }
+  __syncthreads();
+  // thread t owns digit value t: the waves' counts -> where each wave's keys of the value start; the tile's count
+  unsigned int total = 0;
+#pragma unroll
+  for (int w = 0; w < kRxT / 64; ++w) { const unsigned int c = s_cnt[w][t]; s_cnt[w][t] = total; total += c; }
+  // where the tile's keys of value t go: decoupled look-back over the earlier tiles' counts of the value
+  unsigned int *mine = P.desc + (size_t)tile * kRxBins + t;
+  __hip_atomic_store(mine, (tile == 0 ? kRxIncl : kRxAgg) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned int earlier = 0;
+  for (int p = tile - 1; p >= 0; --p) {
+    unsigned int w;
+    do {
+      w = __hip_atomic_load(P.desc + (size_t)p * kRxBins + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((w >> 30) == 0u) __builtin_amdgcn_s_sleep(1);
+    } while ((w >> 30) == 0u);
+    earlier += w & kRxVal;
+    if ((w >> 30) == 2u) break;
+  }
+  if (tile > 0) __hip_atomic_store(mine, kRxIncl | (earlier + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // exclusive scan of the tile's counts over the values: where a value's keys start in the tile's sorted order
+  unsigned int incl = total;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned int u = __shfl_up(incl, off, 64); if (lane >= off) incl += u; }
+  if (lane == 63) s_scan[wave] = incl;
+  __syncthreads();
+  unsigned int sbase = 0;
+  for (int w = 0; w < wave; ++w) sbase += s_scan[w];
+  const unsigned int start = sbase + incl - total;
+  s_start[t] = start;
+  s_goes[t] = P.bin_base[t] + earlier - start;                 // output index = s_goes[value] + place in the tile's sorted order
+  __syncthreads();
+  // the keys into LDS in sorted order, then out: consecutive threads write consecutive addresses within a value's run
+#pragma unroll
+  for (int r = 0; r < kRxKpt; ++r) {
+    const int e = wave * (64 * kRxKpt) + r * 64 + lane;
+    if (e < tcount) {
+      const unsigned int d = (unsigned int)(k[r] >> P.shift) & 0xFFu;
+      const unsigned int pos = s_start[d] + s_cnt[wave][d] + rk[r];
+      s_k[pos] = k[r]; s_v[pos] = v[r];
+    }
+  }
+  __syncthreads();
+  for (int pos = t; pos < tcount; pos += kRxT) {
+    const unsigned long long key = s_k[pos];
+    const unsigned int d = (unsigned int)(key >> P.shift) & 0xFFu;
+    const unsigned int dst = s_goes[d] + (unsigned int)pos;
+    P.kout[dst] = key; P.vout[dst] = s_v[pos];
+  }
+}
+
+// After the radix sort on the first key word: runs of bodies that agree in that whole word (closer than Size / 2^21; almost
+// never any) are put in the order of their second words.  The thread at the start of a run sorts it by insertion.
+__global__ __launch_bounds__(kB) void bh_ties_kernel(int n, const unsigned long long *__restrict__ khi, unsigned int *__restrict__ sidx,
+                                                     const unsigned long long *__restrict__ klo_body) {
   const int i = blockIdx.x * kB + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = posm[i];
-  float size = sz;
-  unsigned long long hi = 0, lo = 0;
-  for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
-  for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
-  key_hi[i] = hi; key_lo[i] = lo; idx[i] = (unsigned int)i;
+  if (i + 1 >= n) return;
+  const unsigned long long h = khi[i];
+  if (khi[i + 1] != h || (i > 0 && khi[i - 1] == h)) return;
+  int end = i + 2;
+  while (end < n && khi[end] == h) ++end;
+  for (int a = i + 1; a < end; ++a) {
+    const unsigned int body = sidx[a];
+    const unsigned long long l = klo_body[body];
+    int q = a - 1;
+    while (q >= i && klo_body[sidx[q]] > l) { sidx[q + 1] = sidx[q]; --q; }
+    sidx[q + 1] = body;
+  }
 }
 
 // digits two path keys share (0 .. 42; 42: the same path all the way down)
@@ -786,48 +1073,111 @@ __device__ __forceinline__ int shared_digits(unsigned long long ha, unsigned lon
   return kMaxLevels;
 }
 
-// lcpS[i] = lcp(i - 1) (-1 at both ends); cnt[i] = cells body i opens + 1 (its leaf), cnt[n] = 0 for the scan.  The second
-// key words arrive in body order (klo_body: only the first words went through the sort) and leave in key order (T.klo).
-__global__ __launch_bounds__(kB) void bh_lcp_kernel(SmallTree T, int n, const unsigned long long *__restrict__ klo_body,
-                                                    signed char *__restrict__ lcpS, int *__restrict__ cnt) {
-  const int i = blockIdx.x * kB + threadIdx.x;
-  int ln = -1;
-  if (i < n) {
-    const unsigned long long h = T.khi[i], l = klo_body[T.sidx[i]];
-    T.klo[i] = l;
-    const int lp = i > 0 ? shared_digits(T.khi[i - 1], klo_body[T.sidx[i - 1]], h, l) : -1;
-    ln = i + 1 < n ? shared_digits(h, l, T.khi[i + 1], klo_body[T.sidx[i + 1]]) : -1;
-    lcpS[i] = (signed char)lp;
-    cnt[i] = (ln > lp ? ln - lp : 0) + 1;
-    if (i == n - 1) { lcpS[n] = (signed char)-1; cnt[n] = 0; }
-    if (ln == kMaxLevels) T.hdr[3] = 1;                        // the reference would recurse on: the frame is refused
-    if (ln >= kLevelsPerKey) T.hdr[6] = 1;                     // neighbours that agree in the whole first key word (bh_forces)
-  }
-  // deepest level: one atomic per workgroup, spread over kDeepSlots words the host takes the maximum of (sixteen thousand
-  // waves on ONE address queue for 0.2 ms)
+// lcpS[i] = lcp(i - 1) (-1 at both ends), and the numbering of the nodes: body i (key order) opens max(lcp(i) - lcp(i-1), 0)
+// cells and has one leaf; the exclusive scan of these counts numbers all nodes in preorder.  The scan is done HERE, in the same
+// launch — no scan library, no second pass over the data: a workgroup scans its block of kB * bpt consecutive bodies
+// (first_local[i] = nodes of the block's earlier bodies) and leaves the block's total in block_sum; the few block totals
+// (at most kScanBlocks) are scanned again by every workgroup of the next kernel as it starts (bh_nodes_kernel).
+// The second key words arrive in body order (klo_body: only the first words went through the sort) and leave in key order (T.klo).
+constexpr int kScanBlocks = 1024;          // block totals the consumers scan in LDS; a block is kB * bpt bodies (bpt: a power of two)
+__global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int bpt, const unsigned long long *__restrict__ klo_body,
+                                                         signed char *__restrict__ lcpS, int *__restrict__ first_local,
+                                                         int *__restrict__ block_sum) {
+  __shared__ int s_w[kB / 64];
   __shared__ int s_m[kB / 64];
-  int m = ln;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i0 = (blockIdx.x * kB + t) * bpt;                  // this thread's bodies: i0 .. i0 + bpt - 1, in key order
+  int sum = 0, deep = -1;
+  if (i0 < n) {
+    unsigned long long hp = 0, lp_w = 0, h = T.khi[i0], l = klo_body[T.sidx[i0]];
+    int lp = -1;
+    if (i0 > 0) { hp = T.khi[i0 - 1]; lp_w = klo_body[T.sidx[i0 - 1]]; lp = shared_digits(hp, lp_w, h, l); }
+    for (int q = 0; q < bpt; ++q) {
+      const int i = i0 + q;
+      if (i >= n) break;
+      T.klo[i] = l;
+      int ln = -1;
+      unsigned long long hn = 0, l_n = 0;
+      if (i + 1 < n) { hn = T.khi[i + 1]; l_n = klo_body[T.sidx[i + 1]]; ln = shared_digits(h, l, hn, l_n); }
+      lcpS[i] = (signed char)lp;
+      const int c = (ln > lp ? ln - lp : 0) + 1;
+      first_local[i] = c;                                      // the count for now; the scan below turns it into the prefix
+      sum += c;
+      if (i == n - 1) lcpS[n] = (signed char)-1;
+      if (ln == kMaxLevels) T.hdr[3] = 1;                      // the reference would recurse on: the frame is refused
+      if (ln >= kLevelsPerKey) T.hdr[6] = 1;                   // neighbours that agree in the whole first key word
+      deep = max(deep, ln);
+      lp = ln; h = hn; l = l_n;
+    }
+  }
+  // exclusive scan of the threads' sums over the block
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off, 64); if (lane >= off) incl += u; }
+  int m = deep;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  if (lane == 63) s_w[wave] = incl;
+  if (lane == 0) s_m[wave] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  int run = incl - sum;
+  for (int w = 0; w < wave; ++w) run += s_w[w];
+  for (int q = 0; q < bpt; ++q) {
+    const int i = i0 + q;
+    if (i >= n) break;
+    const int c = first_local[i];
+    first_local[i] = run;
+    run += c;
+  }
+  if (t == kB - 1) block_sum[blockIdx.x] = run;
+  // deepest level: one atomic per workgroup, spread over kDeepSlots words (sixteen thousand waves on ONE address queue for 0.2 ms)
+  if (t == 0) {
     for (int w = 1; w < kB / 64; ++w) m = max(m, s_m[w]);
     if (m >= 0) atomicMax(&T.hdr[kHdrDeep + (blockIdx.x % kDeepSlots)], m);
   }
 }
 
+// The block totals of bh_lcp_scan_kernel, scanned: s_base[b] = nodes of the blocks before b, s_base[nblocks] = all nodes.
+template <int NT>   // threads of the calling workgroup
+__device__ __forceinline__ void scan_block_sums(const int *__restrict__ block_sum, int nblocks, int *s_base, int *s_tmp) {
+  constexpr int per = (kScanBlocks + NT - 1) / NT;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int v[per], sum = 0;
+#pragma unroll
+  for (int q = 0; q < per; ++q) { const int b = t * per + q; v[q] = b < nblocks ? block_sum[b] : 0; sum += v[q]; }
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off, 64); if (lane >= off) incl += u; }
+  if (lane == 63) s_tmp[wave] = incl;
+  __syncthreads();
+  int run = incl - sum;
+  for (int w = 0; w < wave; ++w) run += s_tmp[w];
+#pragma unroll
+  for (int q = 0; q < per; ++q) { const int b = t * per + q; if (b <= nblocks) s_base[b] = run; run += v[q]; }
+  if (t == NT - 1 && NT * per <= nblocks) s_base[nblocks] = run;   // (nblocks == kScanBlocks: the total sits one past the last thread's blocks)
+  __syncthreads();
+}
+
 // body i (key order): the words of the cells it opens, its leaf's word, CoM and level
 __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
-                                                      const int *__restrict__ first, const signed char *__restrict__ lcpS) {
+                                                      const int *__restrict__ first_local, const int *__restrict__ block_sum,
+                                                      int block_shift, int *__restrict__ first, const signed char *__restrict__ lcpS) {
+  __shared__ int s_base[kScanBlocks + 1];
+  __shared__ int s_tmp[kB / 64];
+  const int nblocks = (n + (1 << block_shift) - 1) >> block_shift;
+  scan_block_sums<kB>(block_sum, nblocks, s_base, s_tmp);
+  const int total = s_base[nblocks];
+  auto first_of = [&](int j) { return j < n ? s_base[j >> block_shift] + first_local[j] : total; };   // first node of body j's group
   const int i = blockIdx.x * kB + threadIdx.x;
   if (i >= n) return;
-  if (first[n] > T.cap) {                                      // (a pool sized for 42 cells per body cannot run out below 2^25 nodes)
+  if (total > T.cap) {                                         // (a pool sized for 42 cells per body cannot run out below 2^25 nodes)
     if (i == 0) { T.hdr[0] = 0; T.hdr[3] = 2; }
     return;
   }
-  if (i == 0) T.hdr[0] = first[n];
-  const int lp = lcpS[i], ln = lcpS[i + 1], m0 = first[i];
+  if (i == 0) T.hdr[0] = total;
+  const int lp = lcpS[i], ln = lcpS[i + 1], m0 = first_of(i);
+  first[i] = m0;                                               // absolute node numbers for the kernels that follow
+  if (i == n - 1) first[n] = total;
   const int open = ln > lp ? ln - lp : 0;
   const unsigned long long h0 = T.khi[i], l0 = T.klo[i];
   for (int q = 0; q < open; ++q) {                             // cell of level l whose first body is i
@@ -841,7 +1191,7 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
       }
       upper = x;
     }
-    T.meta[m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first[upper];
+    T.meta[m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first_of(upper);
   }
   const int level = (lp > ln ? lp : ln) + 1;                   // the leaf: one level below the deepest cell the body shares
   const unsigned int body = T.sidx[i];
@@ -870,7 +1220,7 @@ __global__ void bh_finish_kernel(SmallTree T, int n, int keep_root) {
   T.hdr[1] = T.hdr[0] - n; T.hdr[2] = deep + 1; T.hdr[4] = T.hdr[4] + 1;
 }
 
-// deepest level with a cell of >= 2 bodies: the maximum over the header's kDeepSlots words (bh_lcp_kernel); every thread of
+// deepest level with a cell of >= 2 bodies: the maximum over the header's kDeepSlots words (bh_lcp_scan_kernel); every thread of
 // the workgroup gets it (s_tmp: one int of LDS)
 __device__ __forceinline__ int deepest_level(const SmallTree &T, int *s_tmp) {
   if (threadIdx.x < 64) {
@@ -1044,12 +1394,17 @@ struct BhState {
   bool small = false;          // n <= kSmBodies: one workgroup builds the tree in LDS (bh_small_build_kernel)
   SmallTree st{};              // the compact tree (either path)
   int frames_seen = 0;         // st.hdr[4] at the last bh_small_collect
-  // path keys: khi / klo in body order, khi2 / klo2 and idx2 the sorts' other buffers (larger systems)
+  // path keys (larger systems): klo = the second key words in body order, klo2 the same in key order (SmallTree::klo); khi / idx
+  // end up holding the sorted first key words and bodies (SmallTree::khi, ::sidx), khi2 / idx2 are the sorts' other buffers
   unsigned long long *khi = nullptr, *klo = nullptr, *khi2 = nullptr, *klo2 = nullptr;
   unsigned int *idx = nullptr, *idx2 = nullptr;
-  void *sort_tmp = nullptr, *scan_tmp = nullptr;
-  size_t sort_tmp_bytes = 0, scan_tmp_bytes = 0;
-  int *first = nullptr, *cnt = nullptr;    // larger systems: [n + 1] first node of every body's group / its size
+  // radix sort (n > kMergeMaxN): the key kernel's partial digit histograms, where each digit value's keys start, the passes'
+  // look-back words and tile tickets (cleared by one memset per frame)
+  unsigned int *part_hist = nullptr, *bin_base = nullptr, *rx_desc = nullptr;
+  size_t rx_desc_bytes = 0;
+  int *first = nullptr, *first_local = nullptr, *block_sum = nullptr;   // [n + 1] first node of every body's group (absolute / within its scan block), the blocks' totals
+  bool radix = false;                      // sorts by radix passes (n > bh_merge_max_n()) rather than tiles + merge
+  int scan_bpt = 4, scan_shift = 10;       // bodies per thread of bh_lcp_scan_kernel, log2 of its block (kB * bpt bodies)
   signed char *lcpS = nullptr;             // [n + 1] shared digits of neighbours
   int *straddle = nullptr;                 // [kMaxLevels + 1][chunks of kB bodies] cells that reach beyond their chunk (bh_sweep_chunks_kernel)
   int *kids = nullptr;                     // ... and the (up to eight) children of each, [kMaxLevels + 1][chunks][8]
@@ -1064,6 +1419,12 @@ struct BhState {
 };
 
 #define BH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+// bodies up to which the larger systems sort by tiles + merge (radix above); NBODY_BH_MERGE_MAX_N: tests and A/B measurements
+int bh_merge_max_n() {
+  const char *e = getenv("NBODY_BH_MERGE_MAX_N");               // read at every bh_create: a context keeps what it was created with
+  return e && *e ? atoi(e) : kMergeMaxN;
+}
 
 hipError_t bh_create(BhState **out, int n) {
   BhState *b = new BhState();
@@ -1096,30 +1457,32 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->khi2, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->klo2, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
-  t.klo = b->klo2;             // the sorted second key words (khi and idx end up sorted in place: bh_forces)
-  size_t bytes = 0;
-  BH_TRY(rocprim::radix_sort_pairs(nullptr, bytes, b->klo, b->klo2, b->idx, b->idx2, (unsigned int)n));
-  b->sort_tmp_bytes = bytes;
-  BH_TRY(hipMalloc(&b->sort_tmp, bytes));
+  t.klo = b->klo2;             // the sorted second key words (khi and idx end up sorted: bh_forces)
+  b->radix = n > bh_merge_max_n();
+  if (b->radix) {
+    const size_t tiles = (size_t)((n + kRxTile - 1) / kRxTile);
+    BH_TRY(hipMalloc(&b->part_hist, sizeof(unsigned int) * tiles * kRxPasses * kRxBins));
+    BH_TRY(hipMalloc(&b->bin_base, sizeof(unsigned int) * kRxPasses * kRxBins));
+    b->rx_desc_bytes = sizeof(unsigned int) * (tiles * kRxPasses * kRxBins + 64);   // + the passes' tile tickets
+    BH_TRY(hipMalloc(&b->rx_desc, b->rx_desc_bytes));
+  }
   BH_TRY(hipMalloc(&b->first, sizeof(int) * ((size_t)n + 1)));
-  BH_TRY(hipMalloc(&b->cnt, sizeof(int) * ((size_t)n + 1)));
+  BH_TRY(hipMalloc(&b->first_local, sizeof(int) * ((size_t)n + 1)));
+  BH_TRY(hipMalloc(&b->block_sum, sizeof(int) * (kScanBlocks + 1)));
   BH_TRY(hipMalloc(&b->lcpS, (size_t)n + 1));
+  while ((long long)kB * b->scan_bpt * kScanBlocks < (long long)n) { b->scan_bpt *= 2; b->scan_shift += 1; }   // at most kScanBlocks block totals
   if (n <= kChunkSweepMaxN) {
     const size_t nchunks = (size_t)((n + kB * sweep_bpt(n) - 1) / (kB * sweep_bpt(n)));
     BH_TRY(hipMalloc(&b->straddle, sizeof(int) * (size_t)(kMaxLevels + 1) * nchunks));
     BH_TRY(hipMalloc(&b->kids, sizeof(int) * 8 * (size_t)(kMaxLevels + 1) * nchunks));
   }
-  bytes = 0;
-  BH_TRY(rocprim::exclusive_scan(nullptr, bytes, b->cnt, b->first, 0, (size_t)n + 1, rocprim::plus<int>()));
-  b->scan_tmp_bytes = bytes;
-  BH_TRY(hipMalloc(&b->scan_tmp, bytes ? bytes : 16));
   BH_TRY(hipEventCreateWithFlags(&b->ev, hipEventDisableTiming));
   return hipSuccess;
 }
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->sort_tmp, b->scan_tmp, b->first, b->cnt, b->lcpS, b->straddle, b->kids,
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->part_hist, b->bin_base, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
@@ -1181,35 +1544,41 @@ hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned
   const int n = b->n;
   const dim3 blk(kB), grd((n + kB - 1) / kB);
   *status = 0;
-  hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, b->st, posm, n, size_bits, theta, b->khi, b->klo, b->idx);
-  // The order of the 126-bit keys.  Almost always the first word (21 levels) decides it: ONE radix sort, and the pass that
-  // looks at the neighbours' shared digits says whether two of them agree in that whole word (bodies closer than
-  // Size / 2^21) — only then is the frame redone with the stable two-pass sort, low word first.
-  for (int full = 0; full < 2; ++full) {
-    size_t tb = b->sort_tmp_bytes;
-    SmallTree &T = b->st;
-    if (!full) {
-      BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->khi, b->khi2, b->idx, b->idx2, (unsigned int)n, 0u, 63u, s));
-      T.khi = b->khi2; T.sidx = b->idx2;
-    } else {
-      BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->klo, b->klo2, b->idx, b->idx2, (unsigned int)n, 0u, 63u, s));
-      hipLaunchKernelGGL((bh_gather_kernel<unsigned long long>), grd, blk, 0, s, b->khi, b->idx2, b->khi2, n);
-      tb = b->sort_tmp_bytes;
-      BH_TRY(rocprim::radix_sort_pairs(b->sort_tmp, tb, b->khi2, b->khi, b->idx2, b->idx, (unsigned int)n, 0u, 63u, s));
-      T.khi = b->khi; T.sidx = b->idx;
-      BH_TRY(hipMemsetAsync(b->counters + kHdrDeep, 0xFF, sizeof(int) * kDeepSlots, s));      // deepest level: -1 again
-      BH_TRY(hipMemsetAsync(b->counters + 6, 0, sizeof(int), s));
+  // The order of the 126-bit keys (see "the larger systems' own sort" above).  Either way the sorted first key words end up in
+  // b->khi, the bodies in b->idx, and the second key words, still in body order, in b->klo.
+  SmallTree &T = b->st;
+  T.khi = b->khi; T.sidx = b->idx;
+  if (!b->radix) {
+    const int tiles = (n + kTs - 1) / kTs;
+    hipLaunchKernelGGL(bh_tile_sort_kernel, dim3(tiles), dim3(kTsT), 0, s, T, posm, n, size_bits, theta, b->klo, b->khi2, b->idx2);
+    hipLaunchKernelGGL(bh_tile_merge_kernel, grd, blk, 0, s, n, b->khi2, b->idx2, b->klo, b->khi, b->idx);
+  } else {
+    const int tiles = (n + kRxTile - 1) / kRxTile;
+    BH_TRY(hipMemsetAsync(b->rx_desc, 0, b->rx_desc_bytes, s));
+    hipLaunchKernelGGL(bh_keys_hist_kernel, dim3(tiles), dim3(kRxT), 0, s, T, posm, n, size_bits, theta, b->khi, b->klo, b->idx, b->part_hist);
+    hipLaunchKernelGGL(bh_hist_reduce_kernel, dim3(kRxPasses), dim3(kRxBins), 0, s, b->part_hist, tiles, b->bin_base);
+    unsigned int *tickets = b->rx_desc + (size_t)tiles * kRxPasses * kRxBins;
+    for (int d = 0; d < kRxPasses; ++d) {                        // eight passes: the keys are back in b->khi / b->idx at the end
+      RadixPass P;
+      P.kin = (d & 1) ? b->khi2 : b->khi; P.vin = (d & 1) ? b->idx2 : b->idx;
+      P.kout = (d & 1) ? b->khi : b->khi2; P.vout = (d & 1) ? b->idx : b->idx2;
+      P.bin_base = b->bin_base + d * kRxBins;
+      P.desc = b->rx_desc + (size_t)d * tiles * kRxBins;
+      P.ticket = tickets + d;
+      P.shift = 8 * d; P.n = n;
+      hipLaunchKernelGGL(bh_radix_pass_kernel, dim3(tiles), dim3(kRxT), 0, s, P);
     }
-    // (the second key words follow in the same order inside bh_lcp_kernel: b->klo is still in body order)
-    hipLaunchKernelGGL(bh_lcp_kernel, grd, blk, 0, s, T, n, b->klo, b->lcpS, b->cnt);
+    hipLaunchKernelGGL(bh_ties_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->klo);
+  }
+  {
+    // (the second key words follow in the same order inside bh_lcp_scan_kernel: b->klo is still in body order)
+    const int block = kB * b->scan_bpt;
+    hipLaunchKernelGGL(bh_lcp_scan_kernel, dim3((n + block - 1) / block), blk, 0, s, T, n, b->scan_bpt, b->klo, b->lcpS, b->first_local, b->block_sum);
     BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * kHdrWords, hipMemcpyDeviceToHost, s));
     BH_TRY(hipEventRecord(b->ev, s));
-    // the node numbers and the node words need nothing from the host: they run while it waits for the verdict
-    tb = b->scan_tmp_bytes;
-    BH_TRY(rocprim::exclusive_scan(b->scan_tmp, tb, b->cnt, b->first, 0, (size_t)n + 1, rocprim::plus<int>(), s));
-    hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, 0, s, T, posm, n, b->first, b->lcpS);
+    // the node words need nothing from the host: they are written while it waits for the verdict
+    hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, 0, s, T, posm, n, b->first_local, b->block_sum, b->scan_shift, b->first, b->lcpS);
     BH_TRY(hipEventSynchronize(b->ev));
-    if (full || b->h_counters[6] == 0) break;
   }
   if (b->h_counters[3] != 0) {
     *status = b->h_counters[3];

@@ -305,7 +305,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   int *flag_own = detect ? flag_all + 2 : nullptr;                // the own slice's verdict (phase 1): words 2, 3 behind the table
   int *flag = L.phase == 1 ? flag_own : flag_all;                 // what this call's force kernels look at
   const int b0 = L.phase == 0 ? 0 : L.own_begin, b1 = L.phase == 0 ? L.n_pad : L.own_begin + L.own_count;
-  const int inside = L.phase == 2 ? 0 : 1, check_mass = L.phase == 2 ? 0 : 1;
+  const int inside = L.phase == 2 ? 0 : 1, check_mass = L.phase == 0 ? 1 : 2, mass_ref = L.phase == 0 ? 0 : L.own_begin;
   // positions -> (x, y, z, G m) with far-away zero-mass padding; the coincident-body detector rides along
   // equal masses (L.general: the device's finding, raised by the preparation kernel; L.uni_host: what the host knows —
   // 1 equal and nobody else can write the buffer, 0 not equal / not applicable, -1 ask the device)
@@ -318,11 +318,11 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   } else if (detect) {      // the table and its flag words are zero: cleared at creation and by every pass's fold
     hipLaunchKernelGGL(sym_prep_kernel<true>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
                        L.n_pad, (float)L.G, (unsigned long long *)L.dup_table, (unsigned int)(L.dup_slots - 1), flag_all, general,
-                       b0, b1, inside, check_mass, L.phase == 1 ? flag_own : (int *)nullptr);
+                       b0, b1, inside, check_mass, L.phase == 1 ? flag_own : (int *)nullptr, mass_ref);
   } else {
     hipLaunchKernelGGL(sym_prep_kernel<false>, pgrid, block, 0, s, (const float4 *)L.posm, (float4 *)L.posg, L.n_total,
                        L.n_pad, (float)L.G, (unsigned long long *)nullptr, 0u, (int *)nullptr, general, b0, b1, inside,
-                       check_mass, (int *)nullptr);
+                       check_mass, (int *)nullptr, mass_ref);
   }
   if (grid.x == 0) {                                              // nothing to launch in this go (phase 2 of a plan without remote strips)
   } else {

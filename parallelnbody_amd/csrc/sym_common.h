@@ -116,21 +116,29 @@ __global__ __launch_bounds__(kBlock) void mass_check_kernel(const typename SymVe
 // to scale (see forces_sym_pk_kernel, UNI).
 // A sharded context may prepare in two goes (SymLaunch::phase): the bodies of [b0, b1) — its own slice, whose positions its
 // own update has just written — with inside = 1, and the others, once the all-gather has delivered them, with inside = 0.
-// The first go also looks at every mass (masses do not travel: they are what the last upload left) and leaves its
-// coincident-body verdict in flag2 as well: the verdict on the own slice, which is all the strips inside that slice need.
+// Each go looks at the masses of the bodies it prepares and at nothing else — the first go runs while the all-gather may still
+// be writing the other slices' records, and a record in flight is not read, not even for a component the gather never changes
+// (check_mass = 2; a pass in one go, check_mass = 1, looks at every body).  The reference mass is body `ref`'s: body 0 for a
+// pass in one go, the own slice's first body otherwise — its record is the rank's own.  The verdict word is sticky between
+// uploads and starts from the host's scan of the WHOLE uploaded state, so the first go's strips see every difference the
+// upload held; a mass changed later through another rank's bound buffer raises the word in that step's second go, i.e. it
+// takes effect one pass later: masses are immutable between uploads for sharded contexts (include/nbody.h).
+// The first go leaves its coincident-body verdict in flag2 as well: the verdict on the own slice, which is all the strips
+// inside that slice need.
 template <bool DETECT>
 __global__ __launch_bounds__(kBlock) void sym_prep_kernel(const float4 *__restrict__ posm, float4 *__restrict__ posg,
                                                           int n_total, int n_pad, float gscale,
                                                           unsigned long long *__restrict__ table, unsigned int mask,
                                                           int *__restrict__ flag, int *__restrict__ general,
-                                                          int b0, int b1, int inside, int check_mass, int *__restrict__ flag2) {
+                                                          int b0, int b1, int inside, int check_mass, int *__restrict__ flag2,
+                                                          int ref) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_pad) return;
   const bool mine = (i >= b0 && i < b1) == (inside != 0);
   if (i >= n_total) { if (mine) posg[i] = make_float4(kPadFar, kPadFar, kPadFar, 0.f); return; }
-  if (!mine && !(check_mass && general != nullptr)) return;
+  if (!mine && !(check_mass == 1 && general != nullptr)) return;
   float4 p = posm[i];
-  if (check_mass && general != nullptr && !(p.w == posm[0].w)) *general = 1;     // every writer writes the same value
+  if (check_mass && general != nullptr && !(p.w == posm[ref].w)) *general = 1;   // every writer writes the same value
   if (!mine) return;
   if (DETECT) dup_detect<float>(p, table, mask, flag, flag2);
   p.w *= gscale;

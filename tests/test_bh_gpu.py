@@ -372,3 +372,40 @@ def test_bh_frames_of_larger_systems_equal_the_oracle_in_every_bit(nb, oracle, n
             assert size_dev == size, frame
             np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
             assert out.tobytes() == q.tobytes(), frame
+
+
+@pytest.mark.parametrize("n,force_radix", [(5000, False), (5000, True), (8192, False), (12289, True), (40000, False), (40000, True),
+                                           (131072, False), (131073, False), (150001, False), (300000, False)])
+def test_both_sorts_of_the_larger_systems_order_the_bodies_as_the_reference_tree_does(nb, oracle, monkeypatch, n, force_radix):
+    # The larger systems' own sorts of the path keys (no library on the path): tiles sorted in LDS + one merge by rank up to
+    # 131072 bodies, eight one-launch radix passes above (NBODY_BH_MERGE_MAX_N moves the switch: the radix form at small sizes
+    # too), ragged last tiles, and bodies that agree in the whole first key word — inside one tile, across tiles, three in a
+    # row — which the merge orders by the second word on the spot and the radix form in bh_ties_kernel.  Draw order
+    # (= key order), leaf boxes, node count, root CoM and every acceleration equal the oracle's tree in every bit.
+    if force_radix:
+        monkeypatch.setenv("NBODY_BH_MERGE_MAX_N", "4096")
+    rng = np.random.default_rng(n + int(force_radix))
+    posm = _fuzz_scene(rng, n)
+    while len(np.unique(posm[:, :3], axis=0)) != n:            # (the narrowest clumps can put two bodies on one fp32 point:
+        posm = _fuzz_scene(rng, n)                              #  the reference's Add never returns from that — another scene)
+    size = np.abs(posm[:, :3]).max()
+    tiny = np.float32(size * 2.0 ** -24)
+    far = n - 50
+    posm[far, :3] = posm[100, :3] + tiny * np.array([1, 0, 0], np.float32)           # a pair across tiles
+    posm[201, :3] = posm[200, :3] + tiny * np.array([0, 1, 0], np.float32)           # three in a row
+    posm[n // 2, :3] = posm[200, :3] + tiny * np.array([0, 0, 1], np.float32)
+    assert len({tuple(posm[i, :3]) for i in (100, far, 200, 201, n // 2)}) == 5
+    vel = np.zeros((n, 4), np.float32)
+    pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+    ref, com, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+    boxes, order = oracle.octree_leaves_f32(pos, m)
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+        st = e.bh_stats()
+        np.testing.assert_array_equal(e.bh_leaf_order(), order)
+        np.testing.assert_array_equal(e.bh_leaf_boxes()[order], boxes)
+    np.testing.assert_array_equal(a, ref)
+    np.testing.assert_array_equal(st["root_com"], com)
+    assert st["nodes"] == nodes and st["levels"] >= 22
