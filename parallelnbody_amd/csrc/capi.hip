@@ -478,13 +478,13 @@ int bh_status_error(nbody_ctx *c, int status) {
   return NBODY_OK;
 }
 
-// Small systems at theta > 0: queue `nsteps` whole frames (tree, walk, update — two launches each), nothing waits.
-int bh_small_enqueue(nbody_ctx *c, float dt, int nsteps, float *stage = nullptr) {
+// theta > 0: queue `nsteps` whole frames (tree, walk, update), nothing waits.
+int bh_enqueue(nbody_ctx *c, float dt, int nsteps, float *stage = nullptr) {
   const bool timed = c->p.time_kernels != 0;
   for (int s = 0; s < nsteps; ++s) {
     EventPair ev;
     if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
-    HIP_TRY(c, nbody::bh_small_frame(c->bh, c->posm, c->vel, c->acc, c->theta, c->p.G, dt, 0, s == nsteps - 1 ? stage : nullptr, c->stream));
+    HIP_TRY(c, nbody::bh_frame(c->bh, c->posm, c->vel, c->acc, c->theta, c->p.G, dt, 0, s == nsteps - 1 ? stage : nullptr, c->stream));
     if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
     if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) { int rc = timer_drain(c, NBODY_KERNEL_FORCES); if (rc) return rc; }
   }
@@ -494,38 +494,26 @@ int bh_small_enqueue(nbody_ctx *c, float dt, int nsteps, float *stage = nullptr)
 
 // ... and the one wait: the frames that were built count as steps; a refused frame (and all queued behind it) left the
 // state where it was.
-int bh_small_finish(nbody_ctx *c) {
+int bh_finish(nbody_ctx *c) {
   int status = 0, frames = 0;
-  HIP_TRY(c, nbody::bh_small_collect(c->bh, c->stream, &status, &frames));
+  HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &status, &frames));
   c->steps_done += frames;
   return bh_status_error(c, status);
 }
 
-// Barnes-Hut force pass: ComputeCubeSize -> CreateOctree, all on the device.  diagnostic: the pass belongs to no frame
-// (nbody_compute_forces) and leaves the next tree's root centre alone.
+// Barnes-Hut force pass alone: ComputeCubeSize -> CreateOctree -> the walk, accelerations into bh_acc (run_update adds them up
+// and, for nbody_step_end, moves the bodies).  diagnostic: the pass belongs to no frame (nbody_compute_forces) and leaves the
+// next tree's root centre alone.
 int run_forces_bh(nbody_ctx *c, bool diagnostic) {
   { int rc = ensure_bh(c); if (rc) return rc; }
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
   int status = 0;
-  if (nbody::bh_is_small(c->bh)) {
-    HIP_TRY(c, nbody::bh_small_frame(c->bh, c->posm, nullptr, c->bh_acc, c->theta, c->p.G, 0.0f, diagnostic ? 1 : 0, nullptr, c->stream));
-    if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
-    HIP_TRY(c, nbody::bh_small_collect(c->bh, c->stream, &status, nullptr));
-    return bh_status_error(c, status);
-  }
-  // ComputeCubeSize into one of two words that take turns (scratch + 40, + 44; zero since creation): the launch clears the
-  // other one for the next frame — no memset launch
-  unsigned int *words = (unsigned int *)c->scratch + 10;
-  unsigned int *cur = words + c->bh_word, *nxt = words + (c->bh_word ^ 1);
-  c->bh_word ^= 1;
-  HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, 0, c->p.n_total, cur, c->stream, nxt));
-  HIP_TRY(c, nbody::bh_forces(c->bh, c->posm, c->bh_acc, cur, c->theta, c->p.G, diagnostic ? 1 : 0, c->stream, &status));
-  if (status != 0 && timed) c->timers[NBODY_KERNEL_FORCES].pool.push_back(ev);   // the pair goes back unused
-  if (status != 0) return bh_status_error(c, status);
+  HIP_TRY(c, nbody::bh_frame(c->bh, c->posm, nullptr, c->bh_acc, c->theta, c->p.G, 0.0f, diagnostic ? 1 : 0, nullptr, c->stream));
   if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
-  return NBODY_OK;
+  HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &status, nullptr));
+  return bh_status_error(c, status);
 }
 
 // phase (SymLaunch::phase): 0 the whole pass; 1 / 2 the two goes of a sharded fp32 symmetric context (sym_two_goes)
@@ -1253,10 +1241,8 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
   HIP_TRY(c, hipSetDevice(c->p.device));
   if (c->theta > 0.0f) {
     if ((rc = ensure_bh(c))) return rc;
-    if (nbody::bh_is_small(c->bh)) {                             // two launches per frame, one wait per call
-      if ((rc = bh_small_enqueue(c, dt, nsteps))) return rc;
-      return bh_small_finish(c);
-    }
+    if ((rc = bh_enqueue(c, dt, nsteps))) return rc;             // every frame queued, one wait per call
+    return bh_finish(c);
   }
   const bool one_launch = one_launch_ok(c);
   for (int s = 0; s < nsteps; ++s) {
@@ -1389,7 +1375,7 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
   bool bh_frame = false;
   if (live && c->theta > 0.0f) {
     if ((rc = ensure_bh(c))) return rc;
-    bh_frame = nbody::bh_is_small(c->bh);
+    bh_frame = true;
   }
   const size_t ic = (size_t)c->p.i_count, bytes = ic * sizeof(nbody_particle);
   // systems on the one-launch step (theta == 0, up to 16384 bodies): the same launch leaves Size (of the positions before
@@ -1424,7 +1410,7 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
       bh_direct = stride == sizeof(nbody_particle) && in_pinned(c, aos, bytes);
       HIP_TRY(c, hipHostGetDevicePointer(&stage, bh_direct ? aos : c->h_stage, 0));
     }
-    if ((rc = bh_small_enqueue(c, dt, 1, (float *)stage))) return rc;
+    if ((rc = bh_enqueue(c, dt, 1, (float *)stage))) return rc;
   } else if (live && size) {                                     // .cpp:26, 47-56: bounds of the positions BEFORE the step
     HIP_TRY(c, hipMemsetAsync(c->scratch, 0, 4, c->stream));
     HIP_TRY(c, nbody::launch_bounds(c->p.precision, c->posm, c->p.i_begin, c->p.i_count, (unsigned int *)c->scratch, c->stream));
@@ -1441,7 +1427,7 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
     if (!bh_frame) HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
   }
   int frame_rc = NBODY_OK;
-  if (bh_frame) frame_rc = bh_small_finish(c);                   // the frame's one wait
+  if (bh_frame) frame_rc = bh_finish(c);                         // the frame's one wait
   else HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (bh_frame && frame_rc != NBODY_OK && aos) {                 // a refused frame wrote no records: deliver the untouched state
     HIP_TRY(c, nbody::launch_pack_particles(c->p.precision, c->posm, c->vel, c->acc, (float *)c->d_stage, c->p.i_begin,
@@ -1449,7 +1435,7 @@ int nbody_tick(nbody_ctx *c, float dt, float *size, void *aos, size_t stride) {
     HIP_TRY(c, hipMemcpyAsync(direct ? aos : c->h_stage, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  if (bh_frame) { if (size) *size = nbody::bh_small_last_size(c->bh); }
+  if (bh_frame) { if (size) *size = nbody::bh_last_size(c->bh); }
   else if (live && size) memcpy(size, c->h_scratch, 4);
   if (aos && !direct) unstage_particles(c, aos, stride, ic);
   return frame_rc;

@@ -132,20 +132,18 @@ struct BhState;
 hipError_t bh_create(BhState **out, int n);                   // *out is set even on failure: bh_destroy it
 void bh_destroy(BhState *b);
 hipError_t bh_reset_root(BhState *b, hipStream_t s);          // previous CoM := 0 (a new scene, OctreeSearch.cpp:77)
-// Large systems: acc[body] = Octree::ComputeForces(body, theta) on the tree rooted at (previous CoM, *size_bits as float).
-// *status: 0 ok, 1 tree deeper than 42 levels, 2 node pool exhausted.  Synchronises the stream once per tree level.
-// keep_root != 0: the next tree's root centre stays what it was (a diagnostic pass).
-hipError_t bh_forces(BhState *b, const void *posm, void *acc, const unsigned int *size_bits, float theta, double G,
-                     int keep_root, hipStream_t s, int *status);
-// Small systems (bh_is_small): one frame = two launches, queued without waiting for the host — ComputeCubeSize + tree +
-// upsweep by one workgroup, then the walk, which with dt > 0 also applies the Tick's update to (posm, vel) in place.
-// bh_small_collect waits for the stream and reports the frames queued since the last collect.
+// One frame = CreateOctree (OctreeSearch.cpp:74-89: ComputeCubeSize, the tree rooted at the previous CoM, ComputeMass), the walk
+// Octree::ComputeForces(body, theta) of every body and — with dt > 0 — the Tick's update of (posm, vel) in place, QUEUED on the
+// stream: nothing waits for the host (small systems, bh_is_small: two launches; larger ones up to 2^20 bodies: nine; beyond, one
+// wait inside for the deepest level).  bh_collect waits for the stream and reports the frames queued since the last collect:
+// *status 0 ok, 1 tree deeper than 42 levels, 2 node pool exhausted; a refused frame and everything queued behind it leave the
+// state untouched.  keep_root != 0: the next tree's root centre stays what it was (a diagnostic pass).
+// stage (optional): the walk also writes every body's FParticle record (10 floats, body order) there — the frame's mirror.
 bool bh_is_small(const BhState *b);
-// stage (optional): the walk also writes every body's FParticle record (10 floats, body order) there — the frame's mirror
-hipError_t bh_small_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root,
-                          float *stage, hipStream_t s);
-float bh_small_last_size(const BhState *b);                   // Size of the last frame bh_small_collect has seen
-hipError_t bh_small_collect(BhState *b, hipStream_t s, int *status, int *frames);
+hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root, float *stage,
+                    hipStream_t s);
+float bh_last_size(const BhState *b);                         // Size of the last frame bh_collect has seen
+hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames);
 hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t s);   // tuning builds only (tools/bh_phases.py)
 const float *bh_root_device(const BhState *b);                // device (ox, oy, oz, Size) of the last tree (small systems)
 hipError_t bh_get_tree_com(BhState *b, float out[3], hipStream_t s);   // root CoM of the last tree built

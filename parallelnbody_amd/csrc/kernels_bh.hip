@@ -604,6 +604,53 @@ __device__ __forceinline__ void walk_windows(const SmallTree &T, const float4 *s
   ax = sum;
 }
 
+// What follows a body's walk: the acceleration, and with dt > 0 the Tick's update of the body (.cpp:28-31: v += dt*a; x += dt*v,
+// multiply and add kept apart) — nobody else reads that body's position: the tree's leaves carry copies.  A walk kernel returns at
+// once on a refused frame (hdr[3]), so the state of a refused frame — and of everything queued behind it — stays what it was.
+// stage (optional): the frame's FParticle record (.h:8-18), for the renderer hand-off; it may be page-locked HOST memory
+// (nbody_tick hands the caller's pinned mirror over).
+// Sixteen lanes per body: the row's first lane lays the ten floats out in the row's LDS slice `rec` and ten lanes store them with
+// ONE instruction — 40 contiguous bytes per body — instead of ten scattered 4-byte stores.
+__device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int body, const float4 &p, float ax, float ay, float az,
+                                              float4 *__restrict__ posm, float4 *__restrict__ vel, float4 *__restrict__ acc, float dt,
+                                              float *__restrict__ stage, float *rec) {
+  if (!valid || (g != 0 && stage == nullptr)) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
+  if (g == 0) {
+    acc[body] = make_float4(ax, ay, az, 0.f);
+    if (dt > 0.f || stage != nullptr) v = vel != nullptr ? vel[body] : v;
+    if (dt > 0.f) {                                            // v += dt*a; x += dt*v, separate multiply and add
+      v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
+      x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
+      vel[body] = v;
+      posm[body] = x;
+    }
+  }
+  if (stage != nullptr) {
+    if (g == 0) { rec[0] = x.w; rec[1] = x.x; rec[2] = x.y; rec[3] = x.z; rec[4] = v.x; rec[5] = v.y; rec[6] = v.z; rec[7] = ax; rec[8] = ay; rec[9] = az; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (g < 10) stage[(size_t)body * 10 + g] = rec[g];
+  }
+}
+// ... and the same for a walk with one lane per body
+__device__ __forceinline__ void walk_lane_tail(unsigned int body, const float4 &p, float ax, float ay, float az, float4 *__restrict__ posm,
+                                               float4 *__restrict__ vel, float4 *__restrict__ acc, float dt, float *__restrict__ stage) {
+  acc[body] = make_float4(ax, ay, az, 0.f);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
+  if ((dt > 0.f || stage != nullptr) && vel != nullptr) v = vel[body];
+  if (dt > 0.f) {
+    v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
+    x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
+    vel[body] = v;
+    posm[body] = x;
+  }
+  if (stage != nullptr) {
+    float *o = stage + (size_t)body * 10;
+    o[0] = x.w; o[1] = x.x; o[2] = x.y; o[3] = x.z; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = ax; o[8] = ay; o[9] = az;
+  }
+}
+
 __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                                  float4 *__restrict__ acc, int n, float theta, double G, float dt,
                                                                  float *__restrict__ stage) {
@@ -656,39 +703,18 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
     T.clocks[15] = wall_clock64() - c0;
   }
 #endif
-  if (!valid || (g != 0 && stage == nullptr)) return;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
-  if (g == 0) {
-    acc[body] = make_float4(ax, ay, az, 0.f);
-    if (dt > 0.f || stage != nullptr) v = vel[body];
-    if (dt > 0.f) {                                            // v += dt*a; x += dt*v, separate multiply and add
-      v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
-      x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
-      vel[body] = v;
-      posm[body] = x;
-    }
-  }
-  if (stage != nullptr) {
-    // The frame's FParticle record (.h:8-18), for the renderer hand-off.  `stage` may be page-locked HOST memory (nbody_tick
-    // hands the caller's pinned mirror over): the row's first lane lays the ten floats out in the row's LDS slice and ten lanes
-    // store them with ONE instruction — 40 contiguous bytes per body — instead of ten scattered 4-byte stores.
-    float *rec = (float *)s_term[group];
-    if (g == 0) { rec[0] = x.w; rec[1] = x.x; rec[2] = x.y; rec[3] = x.z; rec[4] = v.x; rec[5] = v.y; rec[6] = v.z; rec[7] = ax; rec[8] = ay; rec[9] = az; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (g < 10) stage[(size_t)body * 10 + g] = rec[g];
-  }
+  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group]);
 }
 
 // The same walk for systems whose tree does not go into LDS but that have too few bodies to keep the chip busy with one lane
 // each (bh_walk_lane_kernel): rows of sixteen lanes on the global arrays, no tree copy.
-__global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, const float4 *__restrict__ posm, int n, double G,
-                                                              float4 *__restrict__ acc) {
+__global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
+                                                              float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage) {
   constexpr int kGroups = kWalkT / kWalkG;
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kGroups][kWalkK];
   __shared__ float4 s_term[kGroups][kWalkK];
-  if (T.hdr[3] != 0) return;
+  if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   const int t = threadIdx.x;
   if (t <= kMaxLevels) s_thr[t] = T.thr[t];
   __syncthreads();
@@ -701,7 +727,7 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, const
   float ax = 0.f, ay = 0.f, az = 0.f;
   walk_windows<false>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[group],
                       s_term[group], nodes, valid, p, G, g, (t & 63) - g, ax, ay, az);
-  if (g == 0 && valid) acc[body] = make_float4(ax, ay, az, 0.f);
+  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group]);
 }
 
 // What DrawOctreeBoxes hands to DrawDebugBox (.cpp:39-40) from the compact tree: the leaf's box follows from the body's
@@ -758,6 +784,7 @@ __device__ __forceinline__ void bh_frame_setup(const SmallTree &T, const float o
   if (t == 0) {
     T.root[0] = o[0]; T.root[1] = o[1]; T.root[2] = o[2]; T.root[3] = sz;
     T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
+    T.hdr[7] = (int)__float_as_uint(sz);                      // Size travels with the verdict (nbody_tick)
   }
   for (int q = t; q < kDeepSlots; q += nthreads) T.hdr[kHdrDeep + q] = -1;   // deepest level with a cell of >= 2 bodies (bh_lcp_scan_kernel)
   if (t <= kMaxLevels) {
@@ -767,42 +794,49 @@ __device__ __forceinline__ void bh_frame_setup(const SmallTree &T, const float o
   }
 }
 
-// Keys of kTs bodies, sorted in LDS by (first word, second word on a tie, position): tile_hi / tile_idx hold the tiles one after
-// the other; klo_body the second key words by body.
-__global__ __launch_bounds__(kTsT) void bh_tile_sort_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
-                                                            const unsigned int *__restrict__ size_bits, float theta,
-                                                            unsigned long long *__restrict__ klo_body,
-                                                            unsigned long long *__restrict__ tile_hi,
-                                                            unsigned int *__restrict__ tile_idx) {
-  constexpr int kBuf = kTs * (8 + 2);                          // one sort buffer: hi[kTs], idx[kTs] (local index)
-  __shared__ __attribute__((aligned(16))) unsigned char raw[2 * kBuf + kTs * 8];
+// Path keys of all bodies, one lane each (both words, body order); the first workgroup also sets the frame up.
+__global__ __launch_bounds__(kB) void bh_keys_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+                                                     const unsigned int *__restrict__ size_bits, float theta,
+                                                     unsigned long long *__restrict__ key_hi, unsigned long long *__restrict__ key_lo) {
+  const float sz = __uint_as_float(*size_bits);
+  float o[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
+  if (blockIdx.x == 0) bh_frame_setup(T, o, sz, theta, kB);
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = posm[i];
+  float size = sz;
+  unsigned long long hi = 0, lo = 0;
+  for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
+  for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
+  key_hi[i] = hi; key_lo[i] = lo;
+}
+
+// The keys of TS consecutive bodies, sorted in LDS by (first word, second word on a tie, position): tile_hi / tile_idx hold the
+// tiles one after the other.  TS follows the size of the system (tile_size): small tiles mean more workgroups at work here and
+// more tiles for the merge to look through.
+template <int TS>
+__global__ __launch_bounds__(kTsT) void bh_tile_sort_kernel(int n, const unsigned long long *__restrict__ key_hi,
+                                                            const unsigned long long *__restrict__ key_lo,
+                                                            unsigned long long *__restrict__ tile_hi, unsigned int *__restrict__ tile_idx) {
+  constexpr int kBuf = TS * (8 + 2);                           // one sort buffer: hi[TS], idx[TS] (local index)
+  constexpr int kPer = TS / kTsT > 0 ? TS / kTsT : 1;
+  __shared__ __attribute__((aligned(16))) unsigned char raw[2 * kBuf + TS * 8];
   unsigned long long *lo_l = (unsigned long long *)(raw + 2 * kBuf);   // second key word by local index
   const int t = threadIdx.x;
-  const float sz = __uint_as_float(*size_bits);
-  const float o0[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
-  if (blockIdx.x == 0) bh_frame_setup(T, o0, sz, theta, kTsT);
-  const int base = blockIdx.x * kTs, cnt = min(kTs, n - base);
+  const int base = blockIdx.x * TS, cnt = min(TS, n - base);
   int P = 64;
   while (P < cnt) P <<= 1;
   {
     unsigned long long *hi0 = (unsigned long long *)raw;
-    unsigned short *idx0 = (unsigned short *)(raw + kTs * 8);
+    unsigned short *idx0 = (unsigned short *)(raw + TS * 8);
 #pragma unroll
-    for (int r = 0; r < kTs / kTsT; ++r) {
+    for (int r = 0; r < kPer; ++r) {
       const int i = t + r * kTsT;
-      if (i >= P) break;
-      unsigned long long h = ~0ull, l = ~0ull;
-      if (i < cnt) {
-        const float4 p = posm[base + i];
-        float o[3] = {o0[0], o0[1], o0[2]};
-        float size = sz;
-        h = 0; l = 0;
-        for (int lev = 0; lev < kLevelsPerKey; ++lev) h = (h << 3) | (unsigned long long)descend_level(p, o, size);
-        for (int lev = 0; lev < kLevelsPerKey; ++lev) l = (l << 3) | (unsigned long long)descend_level(p, o, size);
-        klo_body[base + i] = l;
+      if (i < P) {
+        const bool in = i < cnt;
+        lo_l[i] = in ? key_lo[base + i] : ~0ull;
+        hi0[i] = in ? key_hi[base + i] : ~0ull; idx0[i] = (unsigned short)i;
       }
-      lo_l[i] = l;
-      hi0[i] = h; idx0[i] = (unsigned short)i;
     }
   }
   __syncthreads();
@@ -811,9 +845,9 @@ __global__ __launch_bounds__(kTsT) void bh_tile_sort_kernel(SmallTree T, const f
   int cur = 0;
   for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
     const unsigned long long *shi = (const unsigned long long *)(raw + cur * kBuf);
-    const unsigned short *sidx = (const unsigned short *)(raw + cur * kBuf + kTs * 8);
+    const unsigned short *sidx = (const unsigned short *)(raw + cur * kBuf + TS * 8);
     unsigned long long *dhi = (unsigned long long *)(raw + (cur ^ 1) * kBuf);
-    unsigned short *didx = (unsigned short *)(raw + (cur ^ 1) * kBuf + kTs * 8);
+    unsigned short *didx = (unsigned short *)(raw + (cur ^ 1) * kBuf + TS * 8);
     for (int e = t; e < P; e += kTsT) {
       const int run = e >> lg, pos = e & (L - 1);
       const bool left = (run & 1) == 0;
@@ -835,48 +869,106 @@ __global__ __launch_bounds__(kTsT) void bh_tile_sort_kernel(SmallTree T, const f
     else __syncthreads();
   }
   const unsigned long long *hi = (const unsigned long long *)(raw + cur * kBuf);
-  const unsigned short *idx = (const unsigned short *)(raw + cur * kBuf + kTs * 8);
+  const unsigned short *idx = (const unsigned short *)(raw + cur * kBuf + TS * 8);
   for (int e = t; e < cnt; e += kTsT) { tile_hi[base + e] = hi[e]; tile_idx[base + e] = (unsigned int)(base + idx[e]); }
 }
 
+// A sorted array's every `stride`-th key in LDS: a lower-bound search does its first steps there and only the last log2(stride)
+// on the array itself — each of those is a dependent load from L2.
+// s_smp[q] = keys[q * stride] for q < ceil(count / stride); returns #keys in [0, count) that are < h.
+__device__ __forceinline__ int lower_bound_sampled(const unsigned long long *__restrict__ keys, int count, const unsigned long long *s_smp,
+                                                   int stride_shift, unsigned long long h) {
+  const int nsmp = (count + (1 << stride_shift) - 1) >> stride_shift;
+  int x = 0, y = nsmp;
+  while (x < y) { const int mid = (x + y) >> 1; if (s_smp[mid] < h) x = mid + 1; else y = mid; }
+  if (x == 0) return 0;                                        // keys[0] >= h
+  // keys[(x - 1) << shift] < h <= keys[x << shift] (or the end): the answer lies in ((x - 1) << shift, x << shift]
+  int lo = ((x - 1) << stride_shift) + 1, hi = min(x << stride_shift, count);
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < h) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
 // Every element's place among all tiles: its place in its own tile + for every other tile the number of that tile's elements
-// that sort before it (an earlier tile's equal keys come first: the order is (key, tile, place) — stable).  kMergeW searches run
-// side by side: each is a chain of dependent loads from L2.
+// that sort before it (an earlier tile's equal keys come first: the order is (key, tile, place) — stable).  The tiles' sampled keys
+// sit in LDS (lower_bound_sampled); kMergeW tiles are searched side by side.  Elements that agree with mine in the whole first
+// key word (bodies closer than Size / 2^21: rare) are counted by their second words, looked up only then.
 constexpr int kMergeW = 8;
-__global__ __launch_bounds__(kB) void bh_tile_merge_kernel(int n, const unsigned long long *__restrict__ tile_hi,
+constexpr int kMergeSmp = 8192;            // sampled keys in LDS (64 KB)
+__global__ __launch_bounds__(kB) void bh_tile_merge_kernel(int n, int ts, int stride_shift, const unsigned long long *__restrict__ tile_hi,
                                                            const unsigned int *__restrict__ tile_idx,
                                                            const unsigned long long *__restrict__ klo_body,
                                                            unsigned long long *__restrict__ out_hi, unsigned int *__restrict__ out_idx) {
+  __shared__ unsigned long long s_smp[kMergeSmp];
+  const int ntiles = (n + ts - 1) / ts, per_tile = ts >> stride_shift;   // samples per tile (the tiles' sample ranges do not mix)
+  for (int q0 = threadIdx.x; q0 < ntiles * per_tile; q0 += 8 * kB) {      // eight loads in flight per thread
+    unsigned long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u * kB, e = q << stride_shift;        // (per_tile * 2^stride_shift = ts: sample q is element q << stride_shift)
+      v[u] = (q < ntiles * per_tile && e < n) ? tile_hi[e] : ~0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int q = q0 + u * kB; if (q < ntiles * per_tile) s_smp[q] = v[u]; }
+  }
+  __syncthreads();
   const int e = blockIdx.x * kB + threadIdx.x;
   if (e >= n) return;
-  const int a = e / kTs, ntiles = (n + kTs - 1) / kTs;
+  const int a = e / ts;
+  int coarse_steps = 1;                                        // halvings that close a range of per_tile samples
+  while ((1 << (coarse_steps - 1)) < per_tile) ++coarse_steps;
   const unsigned long long h = tile_hi[e];
   const unsigned int b = tile_idx[e];
-  int rank = e - a * kTs;
+  int rank = e - a * ts;
   for (int tb = 0; tb < ntiles; tb += kMergeW) {
-    int x[kMergeW], y[kMergeW];
+    int lo[kMergeW], hi[kMergeW], cnt[kMergeW];
+    // first steps on the samples in LDS: tile's keys below mine lie in (lo, hi]
 #pragma unroll
     for (int q = 0; q < kMergeW; ++q) {
       const int tile = tb + q;
-      x[q] = 0;
-      y[q] = (tile < ntiles && tile != a) ? min(kTs, n - tile * kTs) : 0;
+      cnt[q] = (tile < ntiles && tile != a) ? min(ts, n - tile * ts) : 0;
+      lo[q] = 0; hi[q] = (cnt[q] + (1 << stride_shift) - 1) >> stride_shift;   // for now: the range of samples
     }
-    for (int step = 0; step < 13; ++step) {                    // a range of 4096 closes in 13 halvings
+    for (int step = 0; step < coarse_steps; ++step) {            // a fixed number of halvings, the tiles side by side (LDS round trips)
+#pragma unroll
+      for (int q = 0; q < kMergeW; ++q) {
+        const int mid = (lo[q] + hi[q]) >> 1;
+        const bool open = lo[q] < hi[q];
+        const unsigned long long sv = s_smp[open ? (tb + q) * per_tile + mid : 0];
+        if (open) { if (sv < h) lo[q] = mid + 1; else hi[q] = mid; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kMergeW; ++q) {
+      const int x = lo[q];
+      lo[q] = x == 0 ? 0 : ((x - 1) << stride_shift) + 1;
+      hi[q] = x == 0 ? 0 : min(x << stride_shift, cnt[q]);
+    }
+    // the last log2(stride) steps on the tiles themselves, the tiles side by side (each step is a dependent load from L2)
+    for (int step = 0; step < stride_shift; ++step) {
 #pragma unroll
       for (int q = 0; q < kMergeW; ++q)
-        if (x[q] < y[q]) {
-          const int tile = tb + q, mid = (x[q] + y[q]) >> 1;
-          const unsigned long long hp = tile_hi[(size_t)tile * kTs + mid];
-          bool before = hp < h;
-          if (hp == h) {                                         // the whole first key word agrees (bodies closer than Size / 2^21)
-            const unsigned long long lp = klo_body[tile_idx[(size_t)tile * kTs + mid]], lm = klo_body[b];
-            before = tile < a ? lp <= lm : lp < lm;
-          }
-          if (before) x[q] = mid + 1; else y[q] = mid;
+        if (lo[q] < hi[q]) {
+          const int mid = (lo[q] + hi[q]) >> 1;
+          if (tile_hi[(size_t)(tb + q) * ts + mid] < h) lo[q] = mid + 1; else hi[q] = mid;
         }
     }
+    unsigned long long at[kMergeW];
 #pragma unroll
-    for (int q = 0; q < kMergeW; ++q) rank += x[q];
+    for (int q = 0; q < kMergeW; ++q) at[q] = lo[q] < cnt[q] ? tile_hi[(size_t)(tb + q) * ts + lo[q]] : 0ull;
+#pragma unroll
+    for (int q = 0; q < kMergeW; ++q) {
+      int x = lo[q];
+      if (x < cnt[q] && at[q] == h) {                           // the whole first key word agrees: the second words decide
+        const int tile = tb + q;
+        const unsigned long long lm = klo_body[b];
+        while (x < cnt[q] && tile_hi[(size_t)tile * ts + x] == h) {
+          const unsigned long long lp = klo_body[tile_idx[(size_t)tile * ts + x]];
+          if (!(tile < a ? lp <= lm : lp < lm)) break;          // (equal first words stand in the order of their second words)
+          ++x;
+        }
+      }
+      rank += x;
+    }
   }
   out_hi[rank] = h; out_idx[rank] = b;
 }
@@ -890,61 +982,58 @@ constexpr int kRxPasses = 8;               // 63 key bits
 constexpr unsigned int kRxAgg = 1u << 30, kRxIncl = 2u << 30, kRxVal = (1u << 30) - 1u;
 
 // Path keys of all bodies (both words, body order) and, per workgroup of kRxTile bodies, how many of its keys carry each value
-// of each of the first word's eight digits: part_hist[workgroup][digit][value].
-__global__ __launch_bounds__(kRxT) void bh_keys_hist_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+// of each of the first word's eight digits: part_hist[workgroup][digit][value].  (No global atomics: contended device-scope
+// atomics cost ~0.8 us each on this part.)
+constexpr int kKhT = 1024;                 // threads: four bodies each
+__global__ __launch_bounds__(kKhT) void bh_keys_hist_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                             const unsigned int *__restrict__ size_bits, float theta,
                                                             unsigned long long *__restrict__ key_hi,
-                                                            unsigned long long *__restrict__ key_lo, unsigned int *__restrict__ idx,
+                                                            unsigned long long *__restrict__ key_lo,
                                                             unsigned int *__restrict__ part_hist) {
   __shared__ unsigned int s_h[kRxPasses][kRxBins];
   const int t = threadIdx.x;
   const float sz = __uint_as_float(*size_bits);
   const float o0[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
-  if (blockIdx.x == 0) bh_frame_setup(T, o0, sz, theta, kRxT);
-  for (int q = t; q < kRxPasses * kRxBins; q += kRxT) (&s_h[0][0])[q] = 0u;
+  if (blockIdx.x == 0) bh_frame_setup(T, o0, sz, theta, kKhT);
+  for (int q = t; q < kRxPasses * kRxBins; q += kKhT) (&s_h[0][0])[q] = 0u;
   __syncthreads();
-  for (int r = 0; r < kRxKpt; ++r) {
-    const int i = blockIdx.x * kRxTile + r * kRxT + t;
-    if (i >= n) break;
-    const float4 p = posm[i];
-    float o[3] = {o0[0], o0[1], o0[2]};
-    float size = sz;
-    unsigned long long hi = 0, lo = 0;
-    for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
-    for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
-    key_hi[i] = hi; key_lo[i] = lo; idx[i] = (unsigned int)i;
 #pragma unroll
-    for (int d = 0; d < kRxPasses; ++d) atomicAdd(&s_h[d][(hi >> (8 * d)) & 0xFFull], 1u);
+  for (int r = 0; r < kRxTile / kKhT; ++r) {
+    const int i = blockIdx.x * kRxTile + r * kKhT + t;
+    if (i < n) {
+      const float4 p = posm[i];
+      float o[3] = {o0[0], o0[1], o0[2]};
+      float size = sz;
+      unsigned long long hi = 0, lo = 0;
+      for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
+      for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
+      key_hi[i] = hi; key_lo[i] = lo;
+#pragma unroll
+      for (int d = 0; d < kRxPasses; ++d) atomicAdd(&s_h[d][(hi >> (8 * d)) & 0xFFull], 1u);
+    }
   }
   __syncthreads();
   unsigned int *out = part_hist + (size_t)blockIdx.x * (kRxPasses * kRxBins);
-  for (int q = t; q < kRxPasses * kRxBins; q += kRxT) out[q] = (&s_h[0][0])[q];
+  for (int q = t; q < kRxPasses * kRxBins; q += kKhT) out[q] = (&s_h[0][0])[q];
 }
 
-// bin_base[digit][value] = number of keys whose digit is smaller: the sum of the workgroups' counts, scanned.  One workgroup
-// per digit, thread v owns value v.
+// The workgroups' counts added up in kRxSlices slices: slice_hist[slice][digit][value] = the counts of the workgroups slice,
+// slice + kRxSlices, ...  (a pass adds the slices of its digit and scans them itself: bh_radix_pass_kernel).
+constexpr int kRxSlices = 16;
 __global__ __launch_bounds__(kRxBins) void bh_hist_reduce_kernel(const unsigned int *__restrict__ part_hist, int nparts,
-                                                                  unsigned int *__restrict__ bin_base) {
-  __shared__ unsigned int s_w[kRxBins / 64];
-  const int d = blockIdx.x, v = threadIdx.x, lane = v & 63, wave = v >> 6;
+                                                                  unsigned int *__restrict__ slice_hist) {
+  const int d = blockIdx.x, sl = blockIdx.y, v = threadIdx.x;
   unsigned int c = 0;
-  for (int w = 0; w < nparts; ++w) c += part_hist[((size_t)w * kRxPasses + d) * kRxBins + v];
-  unsigned int incl = c;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) { const unsigned int u = __shfl_up(incl, off, 64); if (lane >= off) incl += u; }
-  if (lane == 63) s_w[wave] = incl;
-  __syncthreads();
-  unsigned int base = 0;
-  for (int w = 0; w < wave; ++w) base += s_w[w];
-  bin_base[d * kRxBins + v] = base + incl - c;
+  for (int w = sl; w < nparts; w += kRxSlices) c += part_hist[((size_t)w * kRxPasses + d) * kRxBins + v];
+  slice_hist[((size_t)sl * kRxPasses + d) * kRxBins + v] = c;
 }
 
 struct RadixPass {
   const unsigned long long *kin; const unsigned int *vin;
   unsigned long long *kout; unsigned int *vout;
-  const unsigned int *bin_base;            // [256] of this pass's digit
+  const unsigned int *slice_hist;          // [kRxSlices][8][256]: how many keys carry each value of each digit (bh_hist_reduce_kernel)
+  int digit;
   unsigned int *desc;                      // [tiles][256] look-back words of this pass, zero before the launch
-  unsigned int *ticket;                    // zero before the launch
   int shift, n;
 };
 
@@ -955,12 +1044,14 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
   __shared__ unsigned int s_scan[kRxT / 64];
   __shared__ unsigned long long s_k[kRxTile];
   __shared__ unsigned int s_v[kRxTile];
-  __shared__ int s_tile;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) s_tile = (int)atomicAdd(P.ticket, 1u);          // tiles in the order the workgroups START: a tile's predecessors are running or done
+  // Workgroup g takes the tiles g, g + gridDim.x, ... in this order.  The host launches no more workgroups than the device can
+  // hold at once, so every tile a look-back waits for belongs to a workgroup that is running (or will be as soon as another
+  // process's kernel leaves) and that never waits for a later tile: the wait always ends.  (A ticket counter would do the same
+  // for any grid — and serialise the workgroups' starts on one device-scope atomic: 256 of them cost the pass 20 us.)
+  for (int tile = blockIdx.x; tile * kRxTile < P.n; tile += gridDim.x) {
   for (int q = t; q < (kRxT / 64) * kRxBins; q += kRxT) (&s_cnt[0][0])[q] = 0u;
   __syncthreads();
-  const int tile = s_tile;
   const int tbase = tile * kRxTile, tcount = min(kRxTile, P.n - tbase);
   // wave w owns the tile's keys [1024 w, 1024 (w + 1)), sixty-four consecutive ones a round: a key's place among the keys of its
   // digit value is (keys of the value in earlier waves) + (in earlier rounds of this wave) + (in lower lanes of this round)
@@ -972,7 +1063,7 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
     const int e = wave * (64 * kRxKpt) + r * 64 + lane;
     const bool valid = e < tcount;
     k[r] = valid ? P.kin[tbase + e] : ~0ull;
-    v[r] = valid ? P.vin[tbase + e] : 0u;
+    v[r] = valid ? (P.vin ? P.vin[tbase + e] : (unsigned int)(tbase + e)) : 0u;   // the first pass's bodies are the positions themselves
   }
 #pragma unroll
   for (int r = 0; r < kRxKpt; ++r) {
@@ -1003,15 +1094,22 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
   // where the tile's keys of value t go: decoupled look-back over the earlier tiles' counts of the value
   unsigned int *mine = P.desc + (size_t)tile * kRxBins + t;
   __hip_atomic_store(mine, (tile == 0 ? kRxIncl : kRxAgg) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (eight earlier tiles' words in flight at a time: with every tile of a pass resident at once the wait is a ripple through
+  // the tiles, and its length goes with the latency of one look)
   unsigned int earlier = 0;
-  for (int p = tile - 1; p >= 0; --p) {
-    unsigned int w;
-    do {
-      w = __hip_atomic_load(P.desc + (size_t)p * kRxBins + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((w >> 30) == 0u) __builtin_amdgcn_s_sleep(1);
-    } while ((w >> 30) == 0u);
-    earlier += w & kRxVal;
-    if ((w >> 30) == 2u) break;
+  for (int p = tile - 1; p >= 0;) {
+    unsigned int w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      w[j] = p - j >= 0 ? __hip_atomic_load(P.desc + (size_t)(p - j) * kRxBins + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kRxIncl;
+    int used = 0;
+    bool done = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!done && used == j && (w[j] >> 30) != 0u) { earlier += w[j] & kRxVal; used = j + 1; done = (w[j] >> 30) == 2u; }
+    if (done) break;
+    p -= used;
+    if (used == 0) __builtin_amdgcn_s_sleep(1);
   }
   if (tile > 0) __hip_atomic_store(mine, kRxIncl | (earlier + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // exclusive scan of the tile's counts over the values: where a value's keys start in the tile's sorted order
@@ -1024,7 +1122,19 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
   for (int w = 0; w < wave; ++w) sbase += s_scan[w];
   const unsigned int start = sbase + incl - total;
   s_start[t] = start;
-  s_goes[t] = P.bin_base[t] + earlier - start;                 // output index = s_goes[value] + place in the tile's sorted order
+  // where the keys of value t start in the whole output: the slices' counts of this digit added up, scanned over the values
+  unsigned int all = 0;
+#pragma unroll
+  for (int sl = 0; sl < kRxSlices; ++sl) all += P.slice_hist[((size_t)sl * kRxPasses + P.digit) * kRxBins + t];
+  unsigned int gincl = all;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned int u = __shfl_up(gincl, off, 64); if (lane >= off) gincl += u; }
+  __syncthreads();                                              // s_scan has been read by everybody
+  if (lane == 63) s_scan[wave] = gincl;
+  __syncthreads();
+  unsigned int gbase = 0;
+  for (int w = 0; w < wave; ++w) gbase += s_scan[w];
+  s_goes[t] = (gbase + gincl - all) + earlier - start;         // output index = s_goes[value] + place in the tile's sorted order
   __syncthreads();
   // the keys into LDS in sorted order, then out: consecutive threads write consecutive addresses within a value's run
 #pragma unroll
@@ -1042,6 +1152,8 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
     const unsigned int d = (unsigned int)(key >> P.shift) & 0xFFu;
     const unsigned int dst = s_goes[d] + (unsigned int)pos;
     P.kout[dst] = key; P.vout[dst] = s_v[pos];
+  }
+  __syncthreads();                                              // the LDS arrays are the next tile's
   }
 }
 
@@ -1079,6 +1191,7 @@ __device__ __forceinline__ int shared_digits(unsigned long long ha, unsigned lon
 // (first_local[i] = nodes of the block's earlier bodies) and leaves the block's total in block_sum; the few block totals
 // (at most kScanBlocks) are scanned again by every workgroup of the next kernel as it starts (bh_nodes_kernel).
 // The second key words arrive in body order (klo_body: only the first words went through the sort) and leave in key order (T.klo).
+constexpr int kNodeSmp = 8192;             // sampled sorted keys bh_nodes_kernel keeps in LDS (64 KB; fewer for systems of many workgroups)
 constexpr int kScanBlocks = 1024;          // block totals the consumers scan in LDS; a block is kB * bpt bodies (bpt: a power of two)
 __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int bpt, const unsigned long long *__restrict__ klo_body,
                                                          signed char *__restrict__ lcpS, int *__restrict__ first_local,
@@ -1161,10 +1274,22 @@ __device__ __forceinline__ void scan_block_sums(const int *__restrict__ block_su
 // body i (key order): the words of the cells it opens, its leaf's word, CoM and level
 __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                       const int *__restrict__ first_local, const int *__restrict__ block_sum,
-                                                      int block_shift, int *__restrict__ first, const signed char *__restrict__ lcpS) {
+                                                      int block_shift, int *__restrict__ first, const signed char *__restrict__ lcpS,
+                                                      int smp_shift) {
   __shared__ int s_base[kScanBlocks + 1];
   __shared__ int s_tmp[kB / 64];
+  extern __shared__ unsigned long long s_smp[];                // every 2^smp_shift-th sorted first key word (lower_bound_sampled): dynamic LDS
   const int nblocks = (n + (1 << block_shift) - 1) >> block_shift;
+  {
+    const int nsmp = (n + (1 << smp_shift) - 1) >> smp_shift;   // eight loads in flight per thread: the fill is a chain of L2 round trips otherwise
+    for (int q0 = threadIdx.x; q0 < nsmp; q0 += 8 * kB) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int q = q0 + u * kB; v[u] = q < nsmp ? T.khi[(size_t)q << smp_shift] : 0ull; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int q = q0 + u * kB; if (q < nsmp) s_smp[q] = v[u]; }
+    }
+  }
   scan_block_sums<kB>(block_sum, nblocks, s_base, s_tmp);
   const int total = s_base[nblocks];
   auto first_of = [&](int j) { return j < n ? s_base[j >> block_shift] + first_local[j] : total; };   // first node of body j's group
@@ -1182,12 +1307,17 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
   const unsigned long long h0 = T.khi[i], l0 = T.klo[i];
   for (int q = 0; q < open; ++q) {                             // cell of level l whose first body is i
     const int l = lp + 1 + q;
-    int upper = n;
-    if (l > 0) {
-      int x = i + 1, y = n;                                    // first body behind the cell
+    int upper = n;                                             // first body behind the cell
+    if (l > 0 && l <= kLevelsPerKey) {
+      // the first key whose first l digits exceed mine = the first key >= (my first l digits + 1, then zeros): a lower bound on
+      // the sorted first key words, its first steps on the samples in LDS
+      const int sh = 3 * (kLevelsPerKey - l);
+      upper = lower_bound_sampled(T.khi, n, s_smp, smp_shift, ((h0 >> sh) + 1ull) << sh);
+    } else if (l > kLevelsPerKey) {                             // the cell lies below the first key word's 21 levels (rare): both words
+      int x = i + 1, y = n;
       while (x < y) {
         const int mid = (x + y) >> 1;
-        if (same_prefix(T.khi[mid], l > kLevelsPerKey ? T.klo[mid] : 0ull, h0, l > kLevelsPerKey ? l0 : 0ull, l)) x = mid + 1; else y = mid;
+        if (same_prefix(T.khi[mid], T.klo[mid], h0, l0, l)) x = mid + 1; else y = mid;
       }
       upper = x;
     }
@@ -1354,10 +1484,11 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
 // Octree::ComputeForces (.h:99-108) on the compact tree, one lane per body in key order, node by node: a 16-byte and a
 // 4-byte load, the squared distance and a compare per node (accept_threshold); root, double-precision factor and the three
 // multiply-adds only where a term is added.
-__global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, const float4 *__restrict__ posm, int n, double G,
-                                                          float4 *__restrict__ acc) {
+__global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
+                                                          float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage) {
 #pragma clang fp contract(off)
   __shared__ float s_thr[kMaxLevels + 2];
+  if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   if (threadIdx.x <= kMaxLevels) s_thr[threadIdx.x] = T.thr[threadIdx.x];
   __syncthreads();
   const int k = blockIdx.x * kB + threadIdx.x;
@@ -1383,7 +1514,7 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, const flo
     }
     node = (take || d2 == 0.f) ? past : node + 1;              // ... and ends the subtree; children 0..7 otherwise
   }
-  acc[body] = make_float4(ax, ay, az, 0.f);
+  walk_lane_tail(body, p, ax, ay, az, posm, vel, acc, dt, stage);
 }
 
 
@@ -1393,16 +1524,21 @@ struct BhState {
   int n = 0, node_cap = 0;
   bool small = false;          // n <= kSmBodies: one workgroup builds the tree in LDS (bh_small_build_kernel)
   SmallTree st{};              // the compact tree (either path)
-  int frames_seen = 0;         // st.hdr[4] at the last bh_small_collect
+  int frames_seen = 0;         // st.hdr[4] at the last bh_collect
+  unsigned int *size_words = nullptr;   // larger systems: two device words for ComputeCubeSize that take turns (zero since creation)
+  int size_word = 0;
   // path keys (larger systems): klo = the second key words in body order, klo2 the same in key order (SmallTree::klo); khi / idx
   // end up holding the sorted first key words and bodies (SmallTree::khi, ::sidx), khi2 / idx2 are the sorts' other buffers
   unsigned long long *khi = nullptr, *klo = nullptr, *khi2 = nullptr, *klo2 = nullptr;
   unsigned int *idx = nullptr, *idx2 = nullptr;
   // radix sort (n > kMergeMaxN): the key kernel's partial digit histograms, where each digit value's keys start, the passes'
   // look-back words and tile tickets (cleared by one memset per frame)
-  unsigned int *part_hist = nullptr, *bin_base = nullptr, *rx_desc = nullptr;
+  unsigned int *part_hist = nullptr, *slice_hist = nullptr, *rx_desc = nullptr;
   size_t rx_desc_bytes = 0;
+  int rx_resident = 1;                     // workgroups of bh_radix_pass_kernel the device holds at once
   int *first = nullptr, *first_local = nullptr, *block_sum = nullptr;   // [n + 1] first node of every body's group (absolute / within its scan block), the blocks' totals
+  int tile_size = kTs;                     // bodies per tile of the tiles + merge sort (1024, 2048 or 4096: tile_size)
+  int smp_shift = 0;                       // bh_nodes_kernel keeps every 2^smp_shift-th sorted key in LDS
   bool radix = false;                      // sorts by radix passes (n > bh_merge_max_n()) rather than tiles + merge
   int scan_bpt = 4, scan_shift = 10;       // bodies per thread of bh_lcp_scan_kernel, log2 of its block (kB * bpt bodies)
   signed char *lcpS = nullptr;             // [n + 1] shared digits of neighbours
@@ -1414,7 +1550,6 @@ struct BhState {
   float *root = nullptr;       // ox, oy, oz, size
   float *prev_com = nullptr;   // the previous tree's root CoM (zero before the first frame)
   int last_nodes = 0, last_levels = 0;
-  bool stats_pending = false;  // larger systems: a frame was built since bh_stats last fetched the header
   int div_mode = 0;            // reading of `/=` in ComputeMass (sweep_compact_cell)
 };
 
@@ -1424,6 +1559,14 @@ struct BhState {
 int bh_merge_max_n() {
   const char *e = getenv("NBODY_BH_MERGE_MAX_N");               // read at every bh_create: a context keeps what it was created with
   return e && *e ? atoi(e) : kMergeMaxN;
+}
+
+// bodies per tile of the tiles + merge sort: small tiles put more workgroups to work on the sort, but the merge looks through
+// every tile for every element.  NBODY_BH_TILE: tests and tuning.
+int bh_tile_size(int n) {
+  const char *e = getenv("NBODY_BH_TILE");
+  if (e && *e) { const int v = atoi(e); if (v == 1024 || v == 2048 || v == 4096) return v; }
+  return n <= 16384 ? 1024 : (n <= 98304 ? 2048 : 4096);      // frames, tile 1024 / 2048 / 4096: N = 16384 179 / 181 / 203 us, 32768 230 / 226 / 241, 65536 282 / 261 / 265, 131072 404 / 347 / 336 (profiles/r04_bh_tile_size_sweep.txt)
 }
 
 hipError_t bh_create(BhState **out, int n) {
@@ -1454,17 +1597,27 @@ hipError_t bh_create(BhState **out, int n) {
   t.khi = b->khi; t.klo = b->klo; t.sidx = b->idx; t.hdr = b->counters; t.root = b->root; t.prev_com = b->prev_com;
   t.cap = b->node_cap;
   if (b->small) return hipSuccess;
+  BH_TRY(hipMalloc(&b->size_words, 2 * sizeof(unsigned int)));
+  BH_TRY(hipMemset(b->size_words, 0, 2 * sizeof(unsigned int)));
   BH_TRY(hipMalloc(&b->khi2, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->klo2, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
   t.klo = b->klo2;             // the sorted second key words (khi and idx end up sorted: bh_forces)
   b->radix = n > bh_merge_max_n();
+  b->tile_size = bh_tile_size(n);
+  { const int budget = n <= 131072 ? kNodeSmp : 2048;          // many workgroups: a smaller table each (its fill is traffic)
+    while ((((n - 1) >> b->smp_shift) + 1) > budget) ++b->smp_shift; }
   if (b->radix) {
     const size_t tiles = (size_t)((n + kRxTile - 1) / kRxTile);
     BH_TRY(hipMalloc(&b->part_hist, sizeof(unsigned int) * tiles * kRxPasses * kRxBins));
-    BH_TRY(hipMalloc(&b->bin_base, sizeof(unsigned int) * kRxPasses * kRxBins));
-    b->rx_desc_bytes = sizeof(unsigned int) * (tiles * kRxPasses * kRxBins + 64);   // + the passes' tile tickets
+    BH_TRY(hipMalloc(&b->slice_hist, sizeof(unsigned int) * kRxSlices * kRxPasses * kRxBins));
+    b->rx_desc_bytes = sizeof(unsigned int) * tiles * kRxPasses * kRxBins;
     BH_TRY(hipMalloc(&b->rx_desc, b->rx_desc_bytes));
+    int per_cu = 0, dev = 0, cus = 0;
+    BH_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bh_radix_pass_kernel, kRxT, 0));
+    BH_TRY(hipGetDevice(&dev));
+    BH_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    b->rx_resident = std::max(1, per_cu * cus);
   }
   BH_TRY(hipMalloc(&b->first, sizeof(int) * ((size_t)n + 1)));
   BH_TRY(hipMalloc(&b->first_local, sizeof(int) * ((size_t)n + 1)));
@@ -1482,7 +1635,7 @@ hipError_t bh_create(BhState **out, int n) {
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->part_hist, b->bin_base, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
@@ -1500,10 +1653,95 @@ hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t 
 }
 const float *bh_root_device(const BhState *b) { return b->root; }
 
-// Small systems: queue one frame — tree, walk and (dt > 0) the update — on the stream; nothing waits for the host.
+// One CreateOctree (.cpp:74-89) + walk (+ update) of a larger system, queued on the stream.  Up to kChunkSweepMaxN bodies nothing
+// waits for the host; above, the level-by-level ComputeMass needs the deepest level there (one wait inside).
+static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_v, float theta, double G, float dt, int keep_root,
+                                 float *stage, hipStream_t s) {
+  float4 *posm = (float4 *)posm_v;
+  const int n = b->n;
+  const dim3 blk(kB), grd((n + kB - 1) / kB);
+  // ComputeCubeSize (.cpp:47-56) into one of two words that take turns: the launch clears the other one for the next frame
+  unsigned int *cur = b->size_words + b->size_word, *nxt = b->size_words + (b->size_word ^ 1);
+  b->size_word ^= 1;
+  BH_TRY(launch_bounds(0 /* NBODY_PREC_F32 */, posm, 0, n, cur, s, nxt));
+  const unsigned int *size_bits = cur;
+  // The order of the 126-bit keys (see "the larger systems' own sort" above).  Either way the sorted first key words end up in
+  // b->khi, the bodies in b->idx, and the second key words, still in body order, in b->klo.
+  SmallTree &T = b->st;
+  T.khi = b->khi; T.sidx = b->idx;
+  if (!b->radix) {
+    hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, T, posm, n, size_bits, theta, b->khi, b->klo);
+    const int ts = b->tile_size, tiles = (n + ts - 1) / ts;
+    if (ts == 1024) hipLaunchKernelGGL(bh_tile_sort_kernel<1024>, dim3(tiles), dim3(kTsT), 0, s, n, b->khi, b->klo, b->khi2, b->idx2);
+    else if (ts == 2048) hipLaunchKernelGGL(bh_tile_sort_kernel<2048>, dim3(tiles), dim3(kTsT), 0, s, n, b->khi, b->klo, b->khi2, b->idx2);
+    else hipLaunchKernelGGL(bh_tile_sort_kernel<4096>, dim3(tiles), dim3(kTsT), 0, s, n, b->khi, b->klo, b->khi2, b->idx2);
+    int shift = 0;                                               // the tiles' samples must fit the merge's LDS table
+    while (((tiles * ts) >> shift) > kMergeSmp) ++shift;
+    hipLaunchKernelGGL(bh_tile_merge_kernel, grd, blk, 0, s, n, ts, shift, b->khi2, b->idx2, b->klo, b->khi, b->idx);
+  } else {
+    const int tiles = (n + kRxTile - 1) / kRxTile;
+    BH_TRY(hipMemsetAsync(b->rx_desc, 0, b->rx_desc_bytes, s));
+    hipLaunchKernelGGL(bh_keys_hist_kernel, dim3(tiles), dim3(kKhT), 0, s, T, posm, n, size_bits, theta, b->khi, b->klo, b->part_hist);
+    hipLaunchKernelGGL(bh_hist_reduce_kernel, dim3(kRxPasses, kRxSlices), dim3(kRxBins), 0, s, b->part_hist, tiles, b->slice_hist);
+    const int pass_grid = std::min(tiles, b->rx_resident);        // all workgroups of a pass resident at once (bh_radix_pass_kernel)
+    for (int d = 0; d < kRxPasses; ++d) {                        // eight passes: the keys are back in b->khi / b->idx at the end
+      RadixPass P;
+      P.kin = (d & 1) ? b->khi2 : b->khi; P.vin = d == 0 ? nullptr : ((d & 1) ? b->idx2 : b->idx);
+      P.kout = (d & 1) ? b->khi : b->khi2; P.vout = (d & 1) ? b->idx : b->idx2;
+      P.slice_hist = b->slice_hist; P.digit = d;
+      P.desc = b->rx_desc + (size_t)d * tiles * kRxBins;
+      P.shift = 8 * d; P.n = n;
+      hipLaunchKernelGGL(bh_radix_pass_kernel, dim3(pass_grid), dim3(kRxT), 0, s, P);
+    }
+    hipLaunchKernelGGL(bh_ties_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->klo);
+  }
+  // (the second key words follow in the same order inside bh_lcp_scan_kernel: b->klo is still in body order)
+  const int block = kB * b->scan_bpt;
+  hipLaunchKernelGGL(bh_lcp_scan_kernel, dim3((n + block - 1) / block), blk, 0, s, T, n, b->scan_bpt, b->klo, b->lcpS, b->first_local, b->block_sum);
+  hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, sizeof(unsigned long long) * (size_t)(((n - 1) >> b->smp_shift) + 1), s, T, posm, n,
+                     b->first_local, b->block_sum, b->scan_shift, b->first, b->lcpS, b->smp_shift);
+  // ComputeMass, children before parents.  Up to kChunkSweepMaxN bodies in two launches (the cells that end inside their
+  // chunk of kB bodies, then the few that do not, by one workgroup); above it a launch per level over all bodies — there the
+  // one workgroup of the second launch would have more than a chunk per thread to look at per level (chunks are 256 bodies up to
+  // N = 262144, 1024 bodies above) — and for that the host must know the deepest level: the frame's one wait.
+  // NBODY_BH_LEVEL_SWEEPS=1: a launch per level at any size (A/B).
+  static const bool level_sweeps = [] { const char *e = getenv("NBODY_BH_LEVEL_SWEEPS"); return e && e[0] == '1'; }();
+  if (level_sweeps || n > kChunkSweepMaxN) {
+    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * kHdrWords, hipMemcpyDeviceToHost, s));
+    BH_TRY(hipStreamSynchronize(s));
+    int maxl = -1;
+    for (int q = 0; q < kDeepSlots; ++q) maxl = std::max(maxl, b->h_counters[kHdrDeep + q]);
+    for (int l = maxl; l >= 0; --l)                              // (a refused frame: every kernel from here on returns at once)
+      hipLaunchKernelGGL(bh_sweep_level_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, l, b->div_mode);
+    hipLaunchKernelGGL(bh_finish_kernel, dim3(1), dim3(1), 0, s, b->st, n, keep_root);
+  } else {
+    const int bpt = sweep_bpt(n), nchunks = (n + kB * bpt - 1) / (kB * bpt);
+    if (bpt == 1)
+      hipLaunchKernelGGL(bh_sweep_chunks_kernel<1>, dim3(nchunks), blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
+    else
+      hipLaunchKernelGGL(bh_sweep_chunks_kernel<4>, dim3(nchunks), blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
+    hipLaunchKernelGGL(bh_sweep_top_kernel, dim3(1), dim3(std::min(kTopT, (nchunks + 63) / 64 * 64)), 0, s, b->st, posm, n, b->straddle, b->kids,
+                       nchunks, b->div_mode, keep_root);   // a thread per chunk: few waves, cheap barriers
+  }
+  // the walk, with the Tick's update of every body behind it (dt > 0).  One lane per body needs enough bodies to hide its loads;
+  // below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning)
+  static const int rows_max_n = [] { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); return e && *e ? atoi(e) : kRowsMaxN; }();
+  if (n <= rows_max_n)
+    hipLaunchKernelGGL(bh_walk_rows_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, posm, (float4 *)vel,
+                       (float4 *)acc_v, n, G, dt, stage);
+  else
+    hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, n, G, dt, stage);
+  return hipGetLastError();
+}
+
+// Queue one frame — CreateOctree (.cpp:74-89), the walk and (dt > 0) the Tick's update (.cpp:28-31) — on the stream; nothing waits
+// for the host (systems of more than 2^20 bodies: one wait inside).  Small systems: two launches (bh_small_build_kernel,
+// bh_walk_compact_kernel); larger ones: bh_large_frame.
 // keep_root: the tree is a diagnostic's (nbody_compute_forces), the next frame's root centre stays what it was.
-hipError_t bh_small_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root,
-                          float *stage, hipStream_t s) {
+// stage (optional): the walk also writes every body's FParticle record (10 floats, body order) there — the frame's mirror.
+hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root, float *stage,
+                    hipStream_t s) {
+  if (!b->small) return bh_large_frame(b, posm, vel, acc, theta, G, dt, keep_root, stage, s);
   const int n = b->n;
   int P = 1;
   while (P < n) P <<= 1;
@@ -1513,13 +1751,13 @@ hipError_t bh_small_frame(BhState *b, void *posm, void *vel, void *acc, float th
   return hipGetLastError();
 }
 
-// Size (ComputeCubeSize) of the last small-system frame collected by bh_small_collect
-float bh_small_last_size(const BhState *b) { float f; unsigned int u = (unsigned int)b->h_counters[7]; memcpy(&f, &u, 4); return f; }
+// Size (ComputeCubeSize) of the last frame bh_collect has seen
+float bh_last_size(const BhState *b) { float f; unsigned int u = (unsigned int)b->h_counters[7]; memcpy(&f, &u, 4); return f; }
 
 // Wait for the stream and read the verdict of the frames queued since the last call: *status 0 ok, 1 depth limit, 2 node
 // pool; *frames = how many of them were built (a refused frame and everything queued behind it leave the state untouched).
 // A refusal is cleared here, so that the next call starts afresh.
-hipError_t bh_small_collect(BhState *b, hipStream_t s, int *status, int *frames) {
+hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
   BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
   BH_TRY(hipStreamSynchronize(s));
   *status = b->h_counters[3];
@@ -1535,92 +1773,9 @@ hipError_t bh_small_collect(BhState *b, hipStream_t s, int *status, int *frames)
 
 hipError_t bh_reset_root(BhState *b, hipStream_t s) { return hipMemsetAsync(b->prev_com, 0, sizeof(float) * 3, s); }
 
-// One CreateOctree (.cpp:74-89) of a larger system on the device.  size_bits: device word holding Size as left by the
-// bounds kernel.  *status: 0 ok, 1 depth limit (bodies closer than Size/2^42 — the reference would keep recursing), 2 node pool.
-hipError_t bh_forces(BhState *b, const void *posm_v, void *acc_v, const unsigned int *size_bits, float theta, double G,
-                     int keep_root, hipStream_t s, int *status) {
-  if (b->small) return hipErrorInvalidValue;                  // bh_small_frame is the small systems' pass
-  const float4 *posm = (const float4 *)posm_v;
-  const int n = b->n;
-  const dim3 blk(kB), grd((n + kB - 1) / kB);
-  *status = 0;
-  // The order of the 126-bit keys (see "the larger systems' own sort" above).  Either way the sorted first key words end up in
-  // b->khi, the bodies in b->idx, and the second key words, still in body order, in b->klo.
-  SmallTree &T = b->st;
-  T.khi = b->khi; T.sidx = b->idx;
-  if (!b->radix) {
-    const int tiles = (n + kTs - 1) / kTs;
-    hipLaunchKernelGGL(bh_tile_sort_kernel, dim3(tiles), dim3(kTsT), 0, s, T, posm, n, size_bits, theta, b->klo, b->khi2, b->idx2);
-    hipLaunchKernelGGL(bh_tile_merge_kernel, grd, blk, 0, s, n, b->khi2, b->idx2, b->klo, b->khi, b->idx);
-  } else {
-    const int tiles = (n + kRxTile - 1) / kRxTile;
-    BH_TRY(hipMemsetAsync(b->rx_desc, 0, b->rx_desc_bytes, s));
-    hipLaunchKernelGGL(bh_keys_hist_kernel, dim3(tiles), dim3(kRxT), 0, s, T, posm, n, size_bits, theta, b->khi, b->klo, b->idx, b->part_hist);
-    hipLaunchKernelGGL(bh_hist_reduce_kernel, dim3(kRxPasses), dim3(kRxBins), 0, s, b->part_hist, tiles, b->bin_base);
-    unsigned int *tickets = b->rx_desc + (size_t)tiles * kRxPasses * kRxBins;
-    for (int d = 0; d < kRxPasses; ++d) {                        // eight passes: the keys are back in b->khi / b->idx at the end
-      RadixPass P;
-      P.kin = (d & 1) ? b->khi2 : b->khi; P.vin = (d & 1) ? b->idx2 : b->idx;
-      P.kout = (d & 1) ? b->khi : b->khi2; P.vout = (d & 1) ? b->idx : b->idx2;
-      P.bin_base = b->bin_base + d * kRxBins;
-      P.desc = b->rx_desc + (size_t)d * tiles * kRxBins;
-      P.ticket = tickets + d;
-      P.shift = 8 * d; P.n = n;
-      hipLaunchKernelGGL(bh_radix_pass_kernel, dim3(tiles), dim3(kRxT), 0, s, P);
-    }
-    hipLaunchKernelGGL(bh_ties_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->klo);
-  }
-  {
-    // (the second key words follow in the same order inside bh_lcp_scan_kernel: b->klo is still in body order)
-    const int block = kB * b->scan_bpt;
-    hipLaunchKernelGGL(bh_lcp_scan_kernel, dim3((n + block - 1) / block), blk, 0, s, T, n, b->scan_bpt, b->klo, b->lcpS, b->first_local, b->block_sum);
-    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * kHdrWords, hipMemcpyDeviceToHost, s));
-    BH_TRY(hipEventRecord(b->ev, s));
-    // the node words need nothing from the host: they are written while it waits for the verdict
-    hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, 0, s, T, posm, n, b->first_local, b->block_sum, b->scan_shift, b->first, b->lcpS);
-    BH_TRY(hipEventSynchronize(b->ev));
-  }
-  if (b->h_counters[3] != 0) {
-    *status = b->h_counters[3];
-    BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
-    return hipSuccess;
-  }
-  int maxl = -1;
-  for (int q = 0; q < kDeepSlots; ++q) maxl = std::max(maxl, b->h_counters[kHdrDeep + q]);
-  // ComputeMass, children before parents.  Up to kChunkSweepMaxN bodies in two launches (the cells that end inside their
-  // chunk of kB bodies, then the few that do not, by one workgroup); above it a launch per level over all bodies — there the
-  // one workgroup of the second launch would have more than a chunk per thread to look at per level (chunks are 256 bodies up to
-  // N = 262144, 1024 bodies above).
-  // NBODY_BH_LEVEL_SWEEPS=1: a launch per level at any size (A/B).
-  static const bool level_sweeps = [] { const char *e = getenv("NBODY_BH_LEVEL_SWEEPS"); return e && e[0] == '1'; }();
-  if (level_sweeps || n > kChunkSweepMaxN) {
-    for (int l = maxl; l >= 0; --l)
-      hipLaunchKernelGGL(bh_sweep_level_kernel, grd, blk, 0, s, b->st, posm, n, b->first, b->lcpS, l, b->div_mode);
-    hipLaunchKernelGGL(bh_finish_kernel, dim3(1), dim3(1), 0, s, b->st, n, keep_root);
-  } else {
-    const int bpt = sweep_bpt(n), nchunks = (n + kB * bpt - 1) / (kB * bpt);
-    if (bpt == 1)
-      hipLaunchKernelGGL(bh_sweep_chunks_kernel<1>, dim3(nchunks), blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
-    else
-      hipLaunchKernelGGL(bh_sweep_chunks_kernel<4>, dim3(nchunks), blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
-    hipLaunchKernelGGL(bh_sweep_top_kernel, dim3(1), dim3(std::min(kTopT, (nchunks + 63) / 64 * 64)), 0, s, b->st, posm, n, b->straddle, b->kids,
-                       nchunks, b->div_mode, keep_root);   // a thread per chunk: few waves, cheap barriers
-  }
-  // one lane per body needs enough bodies to hide its loads; below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning)
-  static const int rows_max_n = [] { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); return e && *e ? atoi(e) : kRowsMaxN; }();
-  if (n <= rows_max_n)
-    hipLaunchKernelGGL(bh_walk_rows_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, posm, n, G,
-                       (float4 *)acc_v);
-  else
-    hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, n, G, (float4 *)acc_v);
-  b->stats_pending = true;                                     // bh_stats fetches the header when somebody asks
-  b->last_levels = maxl + 1;
-  return hipGetLastError();
-}
-
 // What DrawOctreeBoxes hands to DrawDebugBox: (Origin, Size) of the leaf holding each body, written at the body's index
 hipError_t bh_leaf_boxes(BhState *b, void *out, hipStream_t s) {
-  if (b->last_levels <= 0 && b->last_nodes <= 0 && !b->stats_pending) return hipErrorInvalidValue;
+  if (b->last_levels <= 0 && b->last_nodes <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(bh_small_leaf_boxes_kernel, dim3((b->n + kB - 1) / kB), dim3(kB), 0, s, b->st, b->n, (float4 *)out);
   return hipGetLastError();
 }
@@ -1630,20 +1785,14 @@ void bh_set_div_mode(BhState *b, int div_mode) { b->div_mode = div_mode ? 1 : 0;
 // The bodies in the order DrawOctreeBoxes meets their leaves (OctreeSearch.cpp:36-45: depth first, children 0..7): the
 // path keys are the octant digits root to leaf, so key order IS that order.
 hipError_t bh_leaf_order(BhState *b, int *out_host, hipStream_t s) {
-  if (b->last_levels <= 0 && b->last_nodes <= 0 && !b->stats_pending) return hipErrorInvalidValue;
+  if (b->last_levels <= 0 && b->last_nodes <= 0) return hipErrorInvalidValue;
   BH_TRY(hipStreamSynchronize(s));
   return hipMemcpy(out_host, b->st.sidx, sizeof(unsigned int) * (size_t)b->n, hipMemcpyDeviceToHost);
 }
 
 // nodes: the reference's count (every cell of >= 2 bodies has eight children, empty ones included); levels with such cells
 hipError_t bh_stats(BhState *b, hipStream_t s, int *nodes, int *levels) {
-  if (b->stats_pending) {
-    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
-    BH_TRY(hipStreamSynchronize(s));
-    b->last_nodes = 1 + 8 * b->h_counters[1];
-    b->last_levels = b->h_counters[2];
-    b->stats_pending = false;
-  }
+  (void)s;                                                     // the counts are those of the last frame bh_collect has seen
   if (nodes) *nodes = b->last_nodes;
   if (levels) *levels = b->last_levels;
   return hipSuccess;
@@ -1651,7 +1800,7 @@ hipError_t bh_stats(BhState *b, hipStream_t s, int *nodes, int *levels) {
 
 // centre of mass of the root of the last tree built
 hipError_t bh_get_tree_com(BhState *b, float out[3], hipStream_t s) {
-  if (b->last_nodes <= 0 && !b->stats_pending) return hipErrorInvalidValue;
+  if (b->last_nodes <= 0) return hipErrorInvalidValue;
   BH_TRY(hipStreamSynchronize(s));
   return hipMemcpy(out, b->st.com, sizeof(float) * 3, hipMemcpyDeviceToHost);
 }
