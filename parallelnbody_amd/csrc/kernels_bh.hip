@@ -76,6 +76,7 @@ constexpr unsigned int kLinkMask = (1u << kLevelShift) - 1u;
 constexpr int kWalkT = 256;                // threads per workgroup of the compact walk
 constexpr int kWalkG = 16;                 // lanes per body there
 constexpr int kWalkK = 48;                 // taken nodes a body lists before their terms are worked out and added
+constexpr int kWaveMaxN = 12288;           // ... and up to here with a whole wave per body (frames: N = 8192 157 us against 168, 16384 192 / 186: profiles/r04_bh_walk_ab.txt)
 constexpr int kRowsMaxN = 20480;           // larger systems up to here walk with sixteen lanes per body on the global tree
                                            // (frames: N = 8192 208 us against 275 with a lane per body, 16384 231 / 270, 32768 321 / 272)
 
@@ -704,6 +705,164 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
   }
 #endif
   walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same walk with a whole WAVE per body (round 4): the window is sixty-four consecutive nodes.  A body's walk is a chain of
+// dependent round trips — to LDS on the small systems' tree, to L2 on the larger ones' — one per window; sixteen-node windows made
+// it ~27 links long for a typical body of the shipped scene, sixty-four-node windows make it ~10, every branch is wave-uniform
+// (w0 and the list count are the same in all lanes), and the listed terms are worked out sixty-four at a time.
+// Which nodes of a window the reference's recursion visits: node j is skipped iff some earlier node i of the window ended the
+// recursion (taken, or d == 0) and covers it, i.e. past_i > j — subtrees nest, so that is "the largest past among the ended
+// nodes before j exceeds j": ONE exclusive max-scan over the wave (six DPP steps) instead of an OR of cover masks per row.
+template <int CTRL, int RM> __device__ __forceinline__ int dpp_max0(int v) {     // max(v, v as seen through the control; 0 where nothing arrives)
+  return max(v, __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xf, false));
+}
+__device__ __forceinline__ int wave_incl_max(int v) {             // inclusive maximum over lanes 0 .. own (values >= 0)
+  v = dpp_max0<0x111, 0xf>(v); v = dpp_max0<0x112, 0xf>(v); v = dpp_max0<0x114, 0xf>(v); v = dpp_max0<0x118, 0xf>(v);   // row_shr:1,2,4,8
+  v = dpp_max0<0x142, 0xa>(v);                                   // row_bcast:15 into rows 1, 3
+  v = dpp_max0<0x143, 0xc>(v);                                   // row_bcast:31 into rows 2, 3
+  return v;
+}
+
+// K: nodes a body lists before their terms (.h:104) are worked out and added — in the walk's order, the reference's own order of
+// additions — by lanes 0, 1, 2 (x, y, z).  list / term: the wave's own LDS slices (term: 3 K floats).
+template <bool LDS_TREE, int K, typename LIST_T>
+__device__ __forceinline__ void walk_wave(const SmallTree &T, const float4 *s_a, const float *s_m, const unsigned short *s_past,
+                                          const float *s_thr, LIST_T *list, float *term, int nodes, bool valid, const float4 &p,
+                                          double G, int lane, float &ax, float &ay, float &az) {
+#pragma clang fp contract(off)
+  float sum = 0.f;                                             // lanes 0, 1, 2: the x, y, z sums (ZeroVector, .cpp:84)
+  int w0 = valid ? 0 : nodes;                                  // first node of the window: the same in every lane
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (;;) {
+    int cnt = 0;
+    while (w0 < nodes && cnt + 64 <= K) {
+      const int my = w0 + lane;
+      const bool in = my < nodes;
+      float4 a;
+      int past;
+      if (LDS_TREE) {
+        a = s_a[in ? my : 0];
+        past = s_past[in ? my : 0];
+      } else {
+        const float4 c = T.com[in ? my : 0];
+        const unsigned int w = T.meta[in ? my : 0];
+        const bool leaf = (w & kLeafBit) != 0u;
+        a = make_float4(c.x, c.y, c.z, leaf ? 0.0f : s_thr[(w >> kLevelShift) & 63u]);
+        past = leaf ? my + 1 : (int)(w & kLinkMask);
+      }
+      const float ex = p.x - a.x, ey = p.y - a.y, ez = p.z - a.z;
+      float d2 = ex * ex + ey * ey;
+      d2 = d2 + ez * ez;
+      const bool take = in && d2 >= a.w;                       // .h:103: Size / d < Theta, or an occupied leaf
+      const bool zero = in && d2 == 0.f;                       // .h:102: d == 0 adds nothing and ends the subtree
+      const int reach = (take || zero) ? past : 0;             // the recursion does not go below this node: nothing before `past`
+      const int incl = wave_incl_max(reach);
+      const int excl = __builtin_amdgcn_update_dpp(0, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1 — the ended nodes BEFORE mine
+      const bool adds = take && !zero && excl <= my;           // visited (no earlier ended node covers it), taken, d != 0
+      const unsigned long long am = __ballot(adds);
+      if (adds) list[cnt + __popcll(am & below)] = (LIST_T)my; // lane order = the walk's order
+      cnt += (int)__popcll(am);
+      w0 = max(min(w0 + 64, nodes), __builtin_amdgcn_readlane(incl, 63));   // behind whatever the window's ended nodes cover
+    }
+    if (cnt == 0) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < cnt; e += 64) {                      // the listed nodes' terms (.h:104), sixty-four at a time
+      const int nd = (int)list[e];
+      float tx, ty, tz;
+      if (LDS_TREE) { const float4 a = s_a[nd]; force_term(a.x, a.y, a.z, s_m[nd], p, G, tx, ty, tz); }
+      else { const float4 c = T.com[nd]; force_term(c.x, c.y, c.z, c.w, p, G, tx, ty, tz); }
+      term[3 * e] = tx; term[3 * e + 1] = ty; term[3 * e + 2] = tz;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 3) {                                            // added in the walk's order, one lane per component, eight loads in flight
+      const float *col = term + lane;
+      for (int e = 0; e < cnt; e += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = col[3 * min(e + q, K - 1)];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum = (e + q < cnt) ? sum + v[q] : sum;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sum), 0));
+  ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sum), 1));
+  az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sum), 2));
+}
+
+constexpr int kWvT = 512;                  // small systems: eight waves = eight bodies per workgroup next to the LDS tree
+constexpr int kWvK = 128;
+__global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
+                                                                    float4 *__restrict__ acc, int n, double G, float dt,
+                                                                    float *__restrict__ stage) {
+  constexpr int kWaves = kWvT / 64;
+  __shared__ float4 s_a[kSmNodesLds];
+  __shared__ float s_m[kSmNodesLds];
+  __shared__ unsigned short s_past[kSmNodesLds];
+  __shared__ float s_thr[kMaxLevels + 2];
+  __shared__ unsigned short s_list[kWaves][kWvK];
+  __shared__ float s_term[kWaves][3 * kWvK];
+  if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
+  const int t = threadIdx.x;
+  const int nodes = T.hdr[0];
+  const bool in_lds = nodes <= kSmNodesLds;
+  if (t <= kMaxLevels) s_thr[t] = T.thr[t];
+  __syncthreads();
+  if (in_lds) {
+#pragma unroll 4
+    for (int m = t; m < nodes; m += kWvT) {
+      const float4 c = T.com[m];
+      const unsigned int w = T.meta[m];
+      const bool leaf = (w & kLeafBit) != 0u;
+      s_a[m] = make_float4(c.x, c.y, c.z, leaf ? 0.0f : s_thr[(w >> kLevelShift) & 63u]);
+      s_m[m] = c.w;
+      s_past[m] = (unsigned short)(leaf ? m + 1 : (int)(w & kLinkMask));
+    }
+    __syncthreads();
+  }
+  const int wave = t >> 6, lane = t & 63;
+  const int k = blockIdx.x * kWaves + wave;
+  const bool valid = k < n;
+  const unsigned int body = valid ? T.sidx[k] : 0u;
+  const float4 p = posm[body];
+  float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
+  if (in_lds)
+    walk_wave<true, kWvK>(T, s_a, s_m, s_past, s_thr, s_list[wave], s_term[wave], nodes, valid, p, G, lane, ax, ay, az);
+  else   // a tree too large for LDS (deep chains of single-child cells): the same windows on the global arrays
+    walk_wave<false, kWvK>(T, s_a, s_m, s_past, s_thr, s_list[wave], s_term[wave], nodes, valid, p, G, lane, ax, ay, az);
+  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave]);
+}
+
+// ... and on the larger systems' tree in its global arrays: a window is sixty-four consecutive nodes — one coalesced 1 KB load
+constexpr int kWvGT = 256;                 // four bodies per workgroup
+constexpr int kWvGK = 192;
+__global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
+                                                                  float4 *__restrict__ acc, int n, double G, float dt,
+                                                                  float *__restrict__ stage) {
+  constexpr int kWaves = kWvGT / 64;
+  __shared__ float s_thr[kMaxLevels + 2];
+  __shared__ unsigned int s_list[kWaves][kWvGK];
+  __shared__ float s_term[kWaves][3 * kWvGK];
+  if (T.hdr[3] != 0) return;
+  const int t = threadIdx.x;
+  if (t <= kMaxLevels) s_thr[t] = T.thr[t];
+  __syncthreads();
+  const int nodes = T.hdr[0];
+  const int wave = t >> 6, lane = t & 63;
+  const int k = blockIdx.x * kWaves + wave;
+  const bool valid = k < n;
+  const unsigned int body = valid ? T.sidx[k] : 0u;
+  const float4 p = posm[body];
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  walk_wave<false, kWvGK>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[wave],
+                          s_term[wave], nodes, valid, p, G, lane, ax, ay, az);
+  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave]);
 }
 
 // The same walk for systems whose tree does not go into LDS but that have too few bodies to keep the chip busy with one lane
@@ -1653,6 +1812,12 @@ hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t 
 }
 const float *bh_root_device(const BhState *b) { return b->root; }
 
+// NBODY_BH_WALK=rows: the walks with sixteen lanes per body (round 3) instead of a wave per body — A/B measurements
+static bool bh_wave_walk() {
+  static const bool v = [] { const char *e = getenv("NBODY_BH_WALK"); return !(e && e[0] == 'r'); }();
+  return v;
+}
+
 // One CreateOctree (.cpp:74-89) + walk (+ update) of a larger system, queued on the stream.  Up to kChunkSweepMaxN bodies nothing
 // waits for the host; above, the level-by-level ComputeMass needs the deepest level there (one wait inside).
 static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_v, float theta, double G, float dt, int keep_root,
@@ -1726,7 +1891,11 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   // the walk, with the Tick's update of every body behind it (dt > 0).  One lane per body needs enough bodies to hide its loads;
   // below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning)
   static const int rows_max_n = [] { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); return e && *e ? atoi(e) : kRowsMaxN; }();
-  if (n <= rows_max_n)
+  static const int wave_max_n = [] { const char *e = getenv("NBODY_BH_WAVE_MAX_N"); return e && *e ? atoi(e) : kWaveMaxN; }();
+  if (n <= wave_max_n && n <= rows_max_n && bh_wave_walk())
+    hipLaunchKernelGGL(bh_walk_wave_rows_kernel, dim3((n + kWvGT / 64 - 1) / (kWvGT / 64)), dim3(kWvGT), 0, s, b->st, posm, (float4 *)vel,
+                       (float4 *)acc_v, n, G, dt, stage);
+  else if (n <= rows_max_n)
     hipLaunchKernelGGL(bh_walk_rows_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, posm, (float4 *)vel,
                        (float4 *)acc_v, n, G, dt, stage);
   else
@@ -1746,8 +1915,12 @@ hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, d
   int P = 1;
   while (P < n) P <<= 1;
   hipLaunchKernelGGL(bh_small_build_kernel, dim3(1), dim3(kSmT), 0, s, b->st, (const float4 *)posm, n, P, b->div_mode, keep_root, theta);
-  hipLaunchKernelGGL(bh_walk_compact_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, (float4 *)posm,
-                     (float4 *)vel, (float4 *)acc, n, theta, G, dt, stage);
+  if (bh_wave_walk())
+    hipLaunchKernelGGL(bh_walk_wave_compact_kernel, dim3((n + kWvT / 64 - 1) / (kWvT / 64)), dim3(kWvT), 0, s, b->st, (float4 *)posm,
+                       (float4 *)vel, (float4 *)acc, n, G, dt, stage);
+  else
+    hipLaunchKernelGGL(bh_walk_compact_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, (float4 *)posm,
+                       (float4 *)vel, (float4 *)acc, n, theta, G, dt, stage);
   return hipGetLastError();
 }
 
