@@ -726,7 +726,7 @@ __device__ __forceinline__ int wave_incl_max(int v) {             // inclusive m
 }
 
 // K: nodes a body lists before their terms (.h:104) are worked out and added — in the walk's order, the reference's own order of
-// additions — by lanes 0, 1, 2 (x, y, z).  list / term: the wave's own LDS slices (term: 3 K floats).
+// additions — by lanes 0, 1, 2 (x, y, z).  list / term: the wave's own LDS slices (term: 3 K floats, 16-byte aligned; K a multiple of 8).
 template <bool LDS_TREE, int K, typename LIST_T>
 __device__ __forceinline__ void walk_wave(const SmallTree &T, const float4 *s_a, const float *s_m, const unsigned short *s_past,
                                           const float *s_thr, LIST_T *list, float *term, int nodes, bool valid, const float4 &p,
@@ -769,23 +769,27 @@ __device__ __forceinline__ void walk_wave(const SmallTree &T, const float4 *s_a,
     if (cnt == 0) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < cnt; e += 64) {                      // the listed nodes' terms (.h:104), sixty-four at a time
-      const int nd = (int)list[e];
-      float tx, ty, tz;
-      if (LDS_TREE) { const float4 a = s_a[nd]; force_term(a.x, a.y, a.z, s_m[nd], p, G, tx, ty, tz); }
-      else { const float4 c = T.com[nd]; force_term(c.x, c.y, c.z, c.w, p, G, tx, ty, tz); }
-      term[3 * e] = tx; term[3 * e + 1] = ty; term[3 * e + 2] = tz;
+    // the listed nodes' terms (.h:104), sixty-four at a time, into three columns (x, y, z); the list's last eight-term group is
+    // filled up with +0: a sum that started at +0 never is -0, so adding +0 leaves every bit of it alone — and the adding loop
+    // below needs no bounds
+    const int cnt8 = (cnt + 7) & ~7;
+    for (int e = lane; e < cnt8; e += 64) {
+      float tx = 0.f, ty = 0.f, tz = 0.f;
+      if (e < cnt) {
+        const int nd = (int)list[e];
+        if (LDS_TREE) { const float4 a = s_a[nd]; force_term(a.x, a.y, a.z, s_m[nd], p, G, tx, ty, tz); }
+        else { const float4 c = T.com[nd]; force_term(c.x, c.y, c.z, c.w, p, G, tx, ty, tz); }
+      }
+      term[e] = tx; term[K + e] = ty; term[2 * K + e] = tz;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane < 3) {                                            // added in the walk's order, one lane per component, eight loads in flight
-      const float *col = term + lane;
-      for (int e = 0; e < cnt; e += 8) {
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = col[3 * min(e + q, K - 1)];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sum = (e + q < cnt) ? sum + v[q] : sum;
+    if (lane < 3) {                                            // added in the walk's order, one lane per component, eight terms a go
+      const float4 *col = (const float4 *)(term + lane * K);
+      for (int e = 0; e < cnt8; e += 8) {
+        const float4 u = col[e >> 2], v = col[(e >> 2) + 1];
+        sum = sum + u.x; sum = sum + u.y; sum = sum + u.z; sum = sum + u.w;
+        sum = sum + v.x; sum = sum + v.y; sum = sum + v.z; sum = sum + v.w;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T,
   __shared__ unsigned short s_past[kSmNodesLds];
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned short s_list[kWaves][kWvK];
-  __shared__ float s_term[kWaves][3 * kWvK];
+  __shared__ __attribute__((aligned(16))) float s_term[kWaves][3 * kWvK];
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   const int t = threadIdx.x;
   const int nodes = T.hdr[0];
@@ -815,14 +819,21 @@ __global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T,
   if (t <= kMaxLevels) s_thr[t] = T.thr[t];
   __syncthreads();
   if (in_lds) {
-#pragma unroll 4
-    for (int m = t; m < nodes; m += kWvT) {
-      const float4 c = T.com[m];
-      const unsigned int w = T.meta[m];
-      const bool leaf = (w & kLeafBit) != 0u;
-      s_a[m] = make_float4(c.x, c.y, c.z, leaf ? 0.0f : s_thr[(w >> kLevelShift) & 63u]);
-      s_m[m] = c.w;
-      s_past[m] = (unsigned short)(leaf ? m + 1 : (int)(w & kLinkMask));
+    for (int m0 = t; m0 < nodes; m0 += 4 * kWvT) {               // four nodes' loads in flight per thread: the fill is round trips to L2
+      float4 c[4];
+      unsigned int w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int m = min(m0 + u * kWvT, nodes - 1); c[u] = T.com[m]; w[u] = T.meta[m]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = m0 + u * kWvT;
+        if (m < nodes) {
+          const bool leaf = (w[u] & kLeafBit) != 0u;
+          s_a[m] = make_float4(c[u].x, c[u].y, c[u].z, leaf ? 0.0f : s_thr[(w[u] >> kLevelShift) & 63u]);
+          s_m[m] = c[u].w;
+          s_past[m] = (unsigned short)(leaf ? m + 1 : (int)(w[u] & kLinkMask));
+        }
+      }
     }
     __syncthreads();
   }
@@ -848,7 +859,7 @@ __global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, f
   constexpr int kWaves = kWvGT / 64;
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kWaves][kWvGK];
-  __shared__ float s_term[kWaves][3 * kWvGK];
+  __shared__ __attribute__((aligned(16))) float s_term[kWaves][3 * kWvGK];
   if (T.hdr[3] != 0) return;
   const int t = threadIdx.x;
   if (t <= kMaxLevels) s_thr[t] = T.thr[t];
@@ -1453,34 +1464,60 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
   const int total = s_base[nblocks];
   auto first_of = [&](int j) { return j < n ? s_base[j >> block_shift] + first_local[j] : total; };   // first node of body j's group
   const int i = blockIdx.x * kB + threadIdx.x;
-  if (i >= n) return;
+  const bool valid = i < n;
   if (total > T.cap) {                                         // (a pool sized for 42 cells per body cannot run out below 2^25 nodes)
     if (i == 0) { T.hdr[0] = 0; T.hdr[3] = 2; }
     return;
   }
   if (i == 0) T.hdr[0] = total;
-  const int lp = lcpS[i], ln = lcpS[i + 1], m0 = first_of(i);
-  first[i] = m0;                                               // absolute node numbers for the kernels that follow
+  const int lp = valid ? (int)lcpS[i] : 0, ln = valid ? (int)lcpS[i + 1] : 0, m0 = valid ? first_of(i) : 0;
+  if (valid) first[i] = m0;                                    // absolute node numbers for the kernels that follow
   if (i == n - 1) first[n] = total;
   const int open = ln > lp ? ln - lp : 0;
-  const unsigned long long h0 = T.khi[i], l0 = T.klo[i];
-  for (int q = 0; q < open; ++q) {                             // cell of level l whose first body is i
-    const int l = lp + 1 + q;
-    int upper = n;                                             // first body behind the cell
-    if (l > 0 && l <= kLevelsPerKey) {
-      // the first key whose first l digits exceed mine = the first key >= (my first l digits + 1, then zeros): a lower bound on
-      // the sorted first key words, its first steps on the samples in LDS
-      const int sh = 3 * (kLevelsPerKey - l);
-      upper = lower_bound_sampled(T.khi, n, s_smp, smp_shift, ((h0 >> sh) + 1ull) << sh);
-    } else if (l > kLevelsPerKey) {                             // the cell lies below the first key word's 21 levels (rare): both words
+  const unsigned long long h0 = valid ? T.khi[i] : 0ull;
+  // The cells a body opens, levels lp + 1 .. ln: where each ends is a search, and a wave's bodies open anything from none to a
+  // ladder of twenty — so the WAVE shares them out: the cells of its 64 bodies are numbered through (a scan of the counts), lane k
+  // takes cells k, k + 64, ... and fetches what it needs of the owning lane by shuffles.  (Cells below the first key word's 21
+  // levels need both words — rare — and stay with their own lane.)
+  const int lane = threadIdx.x & 63;
+  const int open_a = max(0, min(ln, kLevelsPerKey) - lp);       // this body's cells of level <= 21
+  int incl = open_a;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off, 64); if (lane >= off) incl += u; }
+  const int cells = __shfl(incl, 63, 64), excl = incl - open_a;
+  for (int k0 = 0; k0 < cells; k0 += 64) {
+    const int k = k0 + lane;
+    int src = 0;                                               // the lane whose cells hold number k: the first lane with incl > k
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) { const int v = __shfl(incl, src + step - 1, 64); if (v <= k) src += step; }
+    src = min(src, 63);
+    const int s_lp = __shfl(lp, src, 64), s_m0 = __shfl(m0, src, 64), s_excl = __shfl(excl, src, 64);
+    const unsigned int hl = __shfl((unsigned int)h0, src, 64), hh = __shfl((unsigned int)(h0 >> 32), src, 64);
+    if (k < cells) {
+      const int q = k - s_excl, l = s_lp + 1 + q;              // cell of level l whose first body is lane src's
+      int upper = n;                                           // first body behind the cell
+      if (l > 0) {
+        // the first key whose first l digits exceed the cell's = the first key >= (those digits + 1, then zeros): a lower bound
+        // on the sorted first key words, its first steps on the samples in LDS
+        const unsigned long long hs = ((unsigned long long)hh << 32) | hl;
+        const int sh = 3 * (kLevelsPerKey - l);
+        upper = lower_bound_sampled(T.khi, n, s_smp, smp_shift, ((hs >> sh) + 1ull) << sh);
+      }
+      T.meta[s_m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first_of(upper);
+    }
+  }
+  if (!valid) return;
+  if (ln > kLevelsPerKey) {                                    // cells below the first key word's 21 levels (rare): both words
+    const unsigned long long l0 = T.klo[i];
+    for (int q = open_a; q < open; ++q) {
+      const int l = lp + 1 + q;
       int x = i + 1, y = n;
       while (x < y) {
         const int mid = (x + y) >> 1;
         if (same_prefix(T.khi[mid], T.klo[mid], h0, l0, l)) x = mid + 1; else y = mid;
       }
-      upper = x;
+      T.meta[m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first_of(x);
     }
-    T.meta[m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first_of(upper);
   }
   const int level = (lp > ln ? lp : ln) + 1;                   // the leaf: one level below the deepest cell the body shares
   const unsigned int body = T.sidx[i];
