@@ -83,7 +83,11 @@ constexpr int kRowsMaxN = 20480;           // larger systems up to here walk wit
 struct SmallTree {
   float4 *com;                  // [cap] preorder nodes: centre of mass, total mass
   unsigned int *meta;           // [cap] leaf bit | level << 25 | (internal: the node after the subtree; leaf: the body)
-  unsigned long long *khi, *klo;   // [n] sorted path keys (what the leaf boxes are rebuilt from)
+  unsigned long long *khi, *klo;   // [n] sorted path keys (what the leaf boxes are rebuilt from).  klo: the second key words — in key
+                                   // order when klo_by_body == 0 (small systems), in BODY order otherwise (larger systems: only the
+                                   // first words go through the sort, and the second ones are looked at only where two first
+                                   // words agree or a cell lies below level 21: second_word())
+  int klo_by_body;
   unsigned int *sidx;           // [n] body at each sorted position = DrawOctreeBoxes' order
   unsigned char *leaf_level;    // [n] level of the leaf of the body at each sorted position
   int *hdr;                     // [0] compact nodes, [1] cells with >= 2 bodies, [2] levels, [3] status (sticky), [4] frames built
@@ -93,6 +97,11 @@ struct SmallTree {
   long long *clocks;            // build with -DNBODY_BH_PHASE_CLOCKS: wall_clock64 at the kernels' phase boundaries
   int cap;
 };
+
+// second key word of the body at sorted position i
+__device__ __forceinline__ unsigned long long second_word(const SmallTree &T, int i) {
+  return T.klo_by_body ? T.klo[T.sidx[i]] : T.klo[i];
+}
 
 constexpr int kHdrDeep = 8, kDeepSlots = 1024;   // header words [8, 1032): the deepest level, one word per slot (larger systems):
                                                  // same-address atomics queue up (N = 2^20, 4096 workgroups: the lcp kernel: 71 us with 64 slots)
@@ -905,8 +914,9 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float
 __global__ __launch_bounds__(kB) void bh_small_leaf_boxes_kernel(SmallTree T, int n, float4 *__restrict__ out) {
   const int i = blockIdx.x * kB + threadIdx.x;
   if (i >= n) return;
-  const unsigned long long h = T.khi[i], l = T.klo[i];
+  const unsigned long long h = T.khi[i];
   const int level = T.leaf_level[i];
+  const unsigned long long l = level > kLevelsPerKey ? second_word(T, i) : 0ull;
   float o[3] = {T.root[0], T.root[1], T.root[2]};
   float size = T.root[3];
   for (int lev = 0; lev < level; ++lev) {
@@ -1265,7 +1275,8 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
   unsigned int *mine = P.desc + (size_t)tile * kRxBins + t;
   __hip_atomic_store(mine, (tile == 0 ? kRxIncl : kRxAgg) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // (eight earlier tiles' words in flight at a time: with every tile of a pass resident at once the wait is a ripple through
-  // the tiles, and its length goes with the latency of one look)
+  // the tiles, and its length goes with the latency of one look — ~9 us of a 20 us pass at 256 tiles; without it the pass takes
+  // 11.3 us.  Adding up ALL earlier tiles' counts instead, sixteen coherent loads in flight, was tried: 28.7 us a pass.)
   unsigned int earlier = 0;
   for (int p = tile - 1; p >= 0;) {
     unsigned int w[8];
@@ -1360,28 +1371,31 @@ __device__ __forceinline__ int shared_digits(unsigned long long ha, unsigned lon
 // launch — no scan library, no second pass over the data: a workgroup scans its block of kB * bpt consecutive bodies
 // (first_local[i] = nodes of the block's earlier bodies) and leaves the block's total in block_sum; the few block totals
 // (at most kScanBlocks) are scanned again by every workgroup of the next kernel as it starts (bh_nodes_kernel).
-// The second key words arrive in body order (klo_body: only the first words went through the sort) and leave in key order (T.klo).
+// The second key words stay in body order (T.klo, klo_by_body): they are looked up only where two neighbours agree in the whole
+// first word (bodies closer than Size / 2^21).
 constexpr int kNodeSmp = 8192;             // sampled sorted keys bh_nodes_kernel keeps in LDS (64 KB; fewer for systems of many workgroups)
 constexpr int kScanBlocks = 1024;          // block totals the consumers scan in LDS; a block is kB * bpt bodies (bpt: a power of two)
-__global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int bpt, const unsigned long long *__restrict__ klo_body,
-                                                         signed char *__restrict__ lcpS, int *__restrict__ first_local,
-                                                         int *__restrict__ block_sum) {
+__global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int bpt, signed char *__restrict__ lcpS,
+                                                         int *__restrict__ first_local, int *__restrict__ block_sum) {
   __shared__ int s_w[kB / 64];
   __shared__ int s_m[kB / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i0 = (blockIdx.x * kB + t) * bpt;                  // this thread's bodies: i0 .. i0 + bpt - 1, in key order
   int sum = 0, deep = -1;
+  auto shared_at = [&](unsigned long long ha, int ia, unsigned long long hb, int ib) {   // digits the bodies at sorted positions ia, ib share
+    const unsigned long long x = ha ^ hb;
+    if (x != 0ull) return (__clzll((long long)x) - 1) / 3;
+    return shared_digits(ha, second_word(T, ia), hb, second_word(T, ib));
+  };
   if (i0 < n) {
-    unsigned long long hp = 0, lp_w = 0, h = T.khi[i0], l = klo_body[T.sidx[i0]];
-    int lp = -1;
-    if (i0 > 0) { hp = T.khi[i0 - 1]; lp_w = klo_body[T.sidx[i0 - 1]]; lp = shared_digits(hp, lp_w, h, l); }
+    unsigned long long h = T.khi[i0];
+    int lp = i0 > 0 ? shared_at(T.khi[i0 - 1], i0 - 1, h, i0) : -1;
     for (int q = 0; q < bpt; ++q) {
       const int i = i0 + q;
       if (i >= n) break;
-      T.klo[i] = l;
       int ln = -1;
-      unsigned long long hn = 0, l_n = 0;
-      if (i + 1 < n) { hn = T.khi[i + 1]; l_n = klo_body[T.sidx[i + 1]]; ln = shared_digits(h, l, hn, l_n); }
+      unsigned long long hn = 0;
+      if (i + 1 < n) { hn = T.khi[i + 1]; ln = shared_at(h, i, hn, i + 1); }
       lcpS[i] = (signed char)lp;
       const int c = (ln > lp ? ln - lp : 0) + 1;
       first_local[i] = c;                                      // the count for now; the scan below turns it into the prefix
@@ -1390,7 +1404,7 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
       if (ln == kMaxLevels) T.hdr[3] = 1;                      // the reference would recurse on: the frame is refused
       if (ln >= kLevelsPerKey) T.hdr[6] = 1;                   // neighbours that agree in the whole first key word
       deep = max(deep, ln);
-      lp = ln; h = hn; l = l_n;
+      lp = ln; h = hn;
     }
   }
   // exclusive scan of the threads' sums over the block
@@ -1508,13 +1522,13 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
   }
   if (!valid) return;
   if (ln > kLevelsPerKey) {                                    // cells below the first key word's 21 levels (rare): both words
-    const unsigned long long l0 = T.klo[i];
+    const unsigned long long l0 = second_word(T, i);
     for (int q = open_a; q < open; ++q) {
       const int l = lp + 1 + q;
       int x = i + 1, y = n;
       while (x < y) {
         const int mid = (x + y) >> 1;
-        if (same_prefix(T.khi[mid], T.klo[mid], h0, l0, l)) x = mid + 1; else y = mid;
+        if (same_prefix(T.khi[mid], second_word(T, mid), h0, l0, l)) x = mid + 1; else y = mid;
       }
       T.meta[m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first_of(x);
     }
@@ -1723,9 +1737,9 @@ struct BhState {
   int frames_seen = 0;         // st.hdr[4] at the last bh_collect
   unsigned int *size_words = nullptr;   // larger systems: two device words for ComputeCubeSize that take turns (zero since creation)
   int size_word = 0;
-  // path keys (larger systems): klo = the second key words in body order, klo2 the same in key order (SmallTree::klo); khi / idx
+  // path keys (larger systems): klo = the second key words in body order (SmallTree::klo, klo_by_body); khi / idx
   // end up holding the sorted first key words and bodies (SmallTree::khi, ::sidx), khi2 / idx2 are the sorts' other buffers
-  unsigned long long *khi = nullptr, *klo = nullptr, *khi2 = nullptr, *klo2 = nullptr;
+  unsigned long long *khi = nullptr, *klo = nullptr, *khi2 = nullptr;
   unsigned int *idx = nullptr, *idx2 = nullptr;
   // radix sort (n > kMergeMaxN): the key kernel's partial digit histograms, where each digit value's keys start, the passes'
   // look-back words and tile tickets (cleared by one memset per frame)
@@ -1796,9 +1810,8 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->size_words, 2 * sizeof(unsigned int)));
   BH_TRY(hipMemset(b->size_words, 0, 2 * sizeof(unsigned int)));
   BH_TRY(hipMalloc(&b->khi2, sizeof(unsigned long long) * n));
-  BH_TRY(hipMalloc(&b->klo2, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
-  t.klo = b->klo2;             // the sorted second key words (khi and idx end up sorted: bh_forces)
+  t.klo_by_body = 1;           // the second key words stay where the key kernel put them (second_word())
   b->radix = n > bh_merge_max_n();
   b->tile_size = bh_tile_size(n);
   { const int budget = n <= 131072 ? kNodeSmp : 2048;          // many workgroups: a smaller table each (its fill is traffic)
@@ -1831,7 +1844,7 @@ hipError_t bh_create(BhState **out, int n) {
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->klo2, b->idx, b->idx2, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
@@ -1899,7 +1912,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   }
   // (the second key words follow in the same order inside bh_lcp_scan_kernel: b->klo is still in body order)
   const int block = kB * b->scan_bpt;
-  hipLaunchKernelGGL(bh_lcp_scan_kernel, dim3((n + block - 1) / block), blk, 0, s, T, n, b->scan_bpt, b->klo, b->lcpS, b->first_local, b->block_sum);
+  hipLaunchKernelGGL(bh_lcp_scan_kernel, dim3((n + block - 1) / block), blk, 0, s, T, n, b->scan_bpt, b->lcpS, b->first_local, b->block_sum);
   hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, sizeof(unsigned long long) * (size_t)(((n - 1) >> b->smp_shift) + 1), s, T, posm, n,
                      b->first_local, b->block_sum, b->scan_shift, b->first, b->lcpS, b->smp_shift);
   // ComputeMass, children before parents.  Up to kChunkSweepMaxN bodies in two launches (the cells that end inside their
