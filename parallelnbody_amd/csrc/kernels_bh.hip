@@ -111,8 +111,15 @@ constexpr int kDbgClocks = 16 + 3 * 512;   // tuning builds: 16 phase stamps + (
 #define BH_CLOCK(k) do { if (threadIdx.x == 0) T.clocks[k] = wall_clock64(); } while (0)
 #define BH_WALK_CLOCK(k) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) T.clocks[k] = wall_clock64(); } while (0)
 #define BH_WALK_COUNT(k, v) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) T.clocks[k] = (v); } while (0)
-#define BH_WG_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512) T.clocks[16 + 3 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+#ifdef NBODY_BH_LEVEL_CLOCKS
+#define BH_WG_STAMP(slot) do { } while (0)
+#define BH_LEVEL_CLOCK(l) do { if (threadIdx.x == 0) T.clocks[16 + (l)] = wall_clock64(); } while (0)
 #else
+#define BH_WG_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512) T.clocks[16 + 3 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+#define BH_LEVEL_CLOCK(l) do { } while (0)
+#endif
+#else
+#define BH_LEVEL_CLOCK(l) do { } while (0)
 #define BH_CLOCK(k) do { } while (0)
 #define BH_WALK_CLOCK(k) do { } while (0)
 #define BH_WALK_COUNT(k, v) do { } while (0)
@@ -220,95 +227,117 @@ __device__ __forceinline__ float4 sweep_compact_cell(const float4 *com, const un
 
 // What the structure phases of bh_small_build_kernel leave in LDS for the node phases: sorted first key words and bodies,
 // the second key words by body, the first node of every body's group, the shared digits of neighbours (lcpS[i] = lcp(i-1),
-// -1 at both ends) and, when the tree fits in LDS, the body whose group each node belongs to.
+// -1 at both ends) and — when the tree fits in LDS — the body that opens each cell (cells numbered in preorder: a cell's
+// number is its node number less the bodies before it).
 struct SmallScratch {
   const unsigned long long *hi; const unsigned short *idx; const unsigned long long *lo_by_body;
-  const int *first; const signed char *lcpS; const unsigned short *owner;
+  const int *first; const signed char *lcpS; const unsigned short *cowner;
   const float *root; int *maxl; int *lvl;
 };
 
-// One word per node, the leaves' (CoM, M), ComputeMass level by level, and the hand-over to the walk.  IN_LDS: com / meta /
-// cells are LDS arrays (the compiler sees the address space: ds_read, not flat loads); otherwise the tree is too large for
-// LDS and lives in its global arrays from the start (deep chains of single-child cells: slow, correct).
-template <bool IN_LDS>
-__device__ __forceinline__ void small_tree_nodes(const SmallTree &T, float4 *com, unsigned int *meta, unsigned short *cells,
-                                                 const SmallScratch &sc, const float4 *__restrict__ posm, int n, int nodes,
-                                                 int div_mode, int keep_root) {
+// The first body behind the cell of level l (> 0) that holds body i (key order).  Most cells hold a handful of bodies: steps of
+// 1, 2, 4, ... from body i until one lands outside, then the halving between the last two — about 2 log2(bodies of the cell)
+// looks at the keys instead of log2(n).
+__device__ __forceinline__ int cell_end(const SmallScratch &sc, int i, int l, int n) {
+  const unsigned long long h0 = sc.hi[i], l0 = l > kLevelsPerKey ? sc.lo_by_body[sc.idx[i]] : 0ull;
+  auto inside = [&](int j) {
+    const unsigned long long hm = sc.hi[j], lm = l > kLevelsPerKey ? sc.lo_by_body[sc.idx[j]] : 0ull;
+    return same_prefix(hm, lm, h0, l0, l);
+  };
+  int x = i, step = 1;                                         // x: a body of the cell
+  while (x + step < n && inside(x + step)) { x += step; step <<= 1; }
+  int y = min(x + step, n);                                    // the first body behind the cell lies in (x, y]
+  while (y - x > 1) { const int mid = (x + y) >> 1; if (inside(mid)) x = mid; else y = mid; }
+  return y;
+}
+
+// The tree in LDS (nodes <= kSmNodesLds): the cells' words, ComputeMass level by level, and the hand-over to the walk.  The
+// leaves' words are written already, and lvl[l] says where level l's list of cells starts (bh_small_build_kernel's scan pass);
+// mine: this thread's own bodies t, t + 1024, ...; leaf_of[body]: its leaf — what goes there (CenterOfMass = Position, TotalMass = Mass,
+// .h:85-88) is written once the structure data, whose place the CoMs take, is dead.  kids (or null): room for eight 16-bit node
+// numbers per cell — every cell's children are then listed once, by walking the top level of its subtree (a chain of dependent
+// reads that needs none of the sums: all cells at once), and a level's step is eight loads side by side instead of that chain.
+// A cell of fewer than eight children lists node `nodes` for the rest: a node of mass +0 at (+0, +0, +0), whose terms are +0 —
+// and adding +0 to a sum that started at +0 (never -0) leaves every bit of it alone: the step needs no conditions.  One wave
+// runs a level's step for up to 64 cells and the levels follow one another: what counts is the number of instructions on that path.
+__device__ __forceinline__ void small_tree_in_lds(const SmallTree &T, float4 *com, unsigned int *meta, unsigned short *cells,
+                                                  unsigned short *kids, const SmallScratch &sc, const float4 mine[4], const unsigned short *leaf_of,
+                                                  const float4 *__restrict__ posm, int n, int nodes, int div_mode, int keep_root) {
+#pragma clang fp contract(off)
   const int t = threadIdx.x;
-  // ---- one word per node: body i's cells (levels lcp(i-1)+1 .. lcp(i)) in preorder, then its leaf
-  for (int m = t; m < nodes; m += kSmT) {
-    int i;
-    if (IN_LDS) {
-      i = sc.owner[m];
-    } else {                                                   // the body whose group holds node m
-      int a = 0, b = n - 1;
-      while (a < b) { const int mid = (a + b + 1) >> 1; if (sc.first[mid] <= m) a = mid; else b = mid - 1; }
-      i = a;
-    }
-    const int q = m - sc.first[i], lp = sc.lcpS[i], ln = sc.lcpS[i + 1];
-    const int open = ln > lp ? ln - lp : 0;
-    if (q == open) {                                           // the leaf: one level below the deepest cell the body shares
-      const int level = (lp > ln ? lp : ln) + 1;
-      meta[m] = kLeafBit | ((unsigned int)level << kLevelShift) | (unsigned int)sc.idx[i];
-      T.leaf_level[i] = (unsigned char)level;
-    } else {                                                   // cell of level l whose first body is i
-      const int l = lp + 1 + q;
-      int upper = n;
-      if (l > 0) {
-        const unsigned long long h0 = sc.hi[i], l0 = l > kLevelsPerKey ? sc.lo_by_body[sc.idx[i]] : 0ull;
-        int x = i + 1, y = n;                                  // first body behind the cell
-        while (x < y) {
-          const int mid = (x + y) >> 1;
-          const unsigned long long hm = sc.hi[mid], lm = l > kLevelsPerKey ? sc.lo_by_body[sc.idx[mid]] : 0ull;
-          if (same_prefix(hm, lm, h0, l0, l)) x = mid + 1; else y = mid;
-        }
-        upper = x;
-      }
-      meta[m] = ((unsigned int)l << kLevelShift) | (unsigned int)sc.first[upper];
-      atomicAdd(&sc.lvl[l], 1);
-      atomicMax(sc.maxl, l);
-    }
+  const int ncells = nodes - n;
+  // ---- one word per cell, by cell: body i's cells are those of levels lcp(i-1)+1 .. lcp(i), consecutive nodes from first[i] on
+  for (int ci = t; ci < ncells; ci += kSmT) {
+    const int i = sc.cowner[ci], m0 = sc.first[i];
+    const int q = ci - (m0 - i), l = (int)sc.lcpS[i] + 1 + q;
+    const int upper = l > 0 ? cell_end(sc, i, l, n) : n;        // first body behind the cell
+    meta[m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)sc.first[upper];
+    cells[atomicAdd(&sc.lvl[l], 1)] = (unsigned short)(m0 + q);   // into its level's list (afterwards lvl[l] is the list's END)
   }
-  __syncthreads();                                             // the structure data is dead from here (LDS: the CoMs take it)
+  __syncthreads();                                             // the structure data is dead from here: the CoMs take its place
   BH_CLOCK(5);
   const int maxl = *sc.maxl;
-  if (IN_LDS) {                                                // the cells level by level: lvl[l] := where level l's list starts
-    if (t == 0) { int run = 0; for (int l = 0; l <= maxl; ++l) { const int c = sc.lvl[l]; sc.lvl[l] = run; run += c; } }
-    __syncthreads();
-  }
-  // ---- leaves: CenterOfMass = Position, TotalMass = Mass (.h:85-88); cells into their level's list
-  for (int m = t; m < nodes; m += kSmT) {
-    const unsigned int w = meta[m];
-    if (w & kLeafBit) com[m] = posm[w & kLinkMask];
-    else if (IN_LDS) cells[atomicAdd(&sc.lvl[(w >> kLevelShift) & 63u], 1)] = (unsigned short)m;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int i = t + r * kSmT; if (i < n) com[leaf_of[i]] = mine[r]; }
+  if (kids != nullptr) {                                       // the children of every cell, listed (node `nodes`: no more)
+    if (t == 0) com[nodes] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = t; k < ncells; k += kSmT) {
+      const int m = cells[k], end = (int)(meta[m] & kLinkMask);
+      unsigned short *kd = kids + 8 * k;
+      int c = 0;
+      for (int ch = m + 1; ch != end;) {
+        const unsigned int cw = meta[ch];
+        kd[c++] = (unsigned short)ch;
+        ch = (cw & kLeafBit) ? ch + 1 : (int)(cw & kLinkMask);
+      }
+      for (; c < 8; ++c) kd[c] = (unsigned short)nodes;
+    }
   }
   __syncthreads();
   BH_CLOCK(6);
-  // ---- ComputeMass (.h:89-95), deepest cells first; a cell's children are met by walking its subtree's top level
-  if (IN_LDS) {                                                // after the scatter lvl[l] is the END of level l's list
-    for (int l = maxl; l >= 0; --l) {
-      const int lo_ = l > 0 ? sc.lvl[l - 1] : 0, hi_ = sc.lvl[l];
-      for (int k = lo_ + t; k < hi_; k += kSmT) {
-        const int m = cells[k];
-        com[m] = sweep_compact_cell(com, meta, m, meta[m], l, div_mode, posm, sc.root);
-      }
-      __syncthreads();
+  // ---- ComputeMass (.h:89-95), deepest cells first.  Which cells a level has and which nodes their children are needs none of
+  // the sums: a thread fetches its cell of the NEXT level and that cell's children's numbers before this level's barrier, so that
+  // a level's step is the eight loads of the sums, the additions and the store.  (Where each level's list ends: lane l of every
+  // wave keeps lvl[l] and hands it out by readlane.)
+  const int my_end = sc.lvl[t & 63];
+  auto list_end = [&](int l) { return l >= 0 ? __builtin_amdgcn_readlane(my_end, l) : 0; };
+  auto cell_sums = [&](int m, int k, int l, const uint4 &pk) {
+    if (kids != nullptr) {                                     // the children in octant order = preorder, the eight loads side by side
+      const unsigned int kd[8] = {pk.x & 0xFFFFu, pk.x >> 16, pk.y & 0xFFFFu, pk.y >> 16, pk.z & 0xFFFFu, pk.z >> 16, pk.w & 0xFFFFu, pk.w >> 16};
+      float4 ch[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ch[c] = com[kd[c]];
+      float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { M = M + ch[c].w; cx = cx + ch[c].w * ch[c].x; cy = cy + ch[c].w * ch[c].y; cz = cz + ch[c].w * ch[c].z; }
+      com[m] = cell_com_from_sums(M, cx, cy, cz, meta, m, l, div_mode, posm, sc.root);
+    } else {
+      (void)k;
+      com[m] = sweep_compact_cell(com, meta, m, meta[m], l, div_mode, posm, sc.root);
     }
-  } else {
-    for (int l = maxl; l >= 0; --l) {
-      for (int m = t; m < nodes; m += kSmT) {
-        const unsigned int w = meta[m];
-        if ((w & kLeafBit) || (int)((w >> kLevelShift) & 63u) != l) continue;
-        com[m] = sweep_compact_cell(com, meta, m, w, l, div_mode, posm, sc.root);
-      }
-      __threadfence();
-      __syncthreads();
-    }
+  };
+  int m_nx = -1;
+  uint4 pk_nx = make_uint4(0u, 0u, 0u, 0u);
+  auto fetch = [&](int l) {                                    // this thread's (first) cell of level l
+    m_nx = -1;
+    if (l < 0) return;
+    const int k = list_end(l - 1) + t;
+    if (k < list_end(l)) { m_nx = cells[k]; if (kids != nullptr) pk_nx = ((const uint4 *)kids)[k]; }
+  };
+  fetch(maxl);
+  for (int l = maxl; l >= 0; --l) {
+    const int m = m_nx, lo_ = list_end(l - 1), hi_ = list_end(l);
+    const uint4 pk = pk_nx;
+    BH_LEVEL_CLOCK(l);
+    fetch(l - 1);
+    if (m >= 0) cell_sums(m, lo_ + t, l, pk);
+    for (int k = lo_ + t + kSmT; k < hi_; k += kSmT)            // (a level of more than 1024 cells)
+      cell_sums(cells[k], k, l, kids != nullptr ? ((const uint4 *)kids)[k] : make_uint4(0u, 0u, 0u, 0u));
+    __syncthreads();
   }
   BH_CLOCK(7);
   // ---- hand the tree to the walk
-  if (IN_LDS)
-    for (int m = t; m < nodes; m += kSmT) { T.com[m] = com[m]; T.meta[m] = meta[m]; }
+  for (int m = t; m < nodes; m += kSmT) { T.com[m] = com[m]; T.meta[m] = meta[m]; }
   if (t == 0) {
     if (!keep_root) { const float4 c = com[0]; T.prev_com[0] = c.x; T.prev_com[1] = c.y; T.prev_com[2] = c.z; }   // .cpp:78
     T.hdr[0] = nodes; T.hdr[1] = nodes - n; T.hdr[2] = n >= 2 ? maxl + 1 : 0; T.hdr[4] = T.hdr[4] + 1;
@@ -316,19 +345,102 @@ __device__ __forceinline__ void small_tree_nodes(const SmallTree &T, float4 *com
   BH_CLOCK(8);
 }
 
+// The same for a tree too large for LDS (deep chains of single-child cells — more than kSmNodesLds nodes from at most 4096
+// bodies): it lives in its global arrays from the start, a thread per node, a pass over all nodes per level.  Slow, correct.
+__device__ __forceinline__ void small_tree_in_global(const SmallTree &T, const SmallScratch &sc, const float4 *__restrict__ posm, int n,
+                                                     int nodes, int div_mode, int keep_root) {
+  const int t = threadIdx.x;
+  for (int m = t; m < nodes; m += kSmT) {
+    int a = 0, b = n - 1;                                      // the body whose group holds node m
+    while (a < b) { const int mid = (a + b + 1) >> 1; if (sc.first[mid] <= m) a = mid; else b = mid - 1; }
+    const int i = a, q = m - sc.first[i], lp = sc.lcpS[i], ln = sc.lcpS[i + 1];
+    const int open = ln > lp ? ln - lp : 0;
+    if (q == open) {                                           // the leaf (its level was noted by the scan pass)
+      const unsigned int body = sc.idx[i];
+      T.meta[m] = kLeafBit | ((unsigned int)((lp > ln ? lp : ln) + 1) << kLevelShift) | body;
+      T.com[m] = posm[body];
+    } else {
+      const int l = lp + 1 + q;
+      const int upper = l > 0 ? cell_end(sc, i, l, n) : n;
+      T.meta[m] = ((unsigned int)l << kLevelShift) | (unsigned int)sc.first[upper];
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  const int maxl = *sc.maxl;
+  for (int l = maxl; l >= 0; --l) {
+    for (int m = t; m < nodes; m += kSmT) {
+      const unsigned int w = T.meta[m];
+      if ((w & kLeafBit) || (int)((w >> kLevelShift) & 63u) != l) continue;
+      T.com[m] = sweep_compact_cell(T.com, T.meta, m, w, l, div_mode, posm, sc.root);
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (!keep_root) { const float4 c = T.com[0]; T.prev_com[0] = c.x; T.prev_com[1] = c.y; T.prev_com[2] = c.z; }   // .cpp:78
+    T.hdr[0] = nodes; T.hdr[1] = nodes - n; T.hdr[2] = n >= 2 ? maxl + 1 : 0; T.hdr[4] = T.hdr[4] + 1;
+  }
+}
+
+// The first (or the next) 21 levels of Octree::Add's descent (.h:50-56, 68-75) of one body: the octant digits, three bits a
+// level, and where the descent stands.  plain: every size on the way is 2^-100 or more (a root of 2^-58 and more) — the child
+// centre is then the plain fp32 o +- 0.5f * Size (descend_level).  There `p >= o` is read off the sign of the fp32 difference
+// p - o (a difference of two floats has the sign of the exact one, and +0 where they are equal — with p's own -0 turned into +0
+// first); the child centre is o + copysign(h, p - o), and the inverted signs are gathered ten levels to a 32-bit word: four
+// instructions per axis and level.
+__device__ __forceinline__ unsigned long long descend_word(const float4 &p, float o[3], float &size, bool plain) {
+#pragma clang fp contract(off)
+  if (!plain) {
+    unsigned long long h = 0;
+    for (int lev = 0; lev < kLevelsPerKey; ++lev) h = (h << 3) | (unsigned long long)descend_level(p, o, size);
+    return h;
+  }
+  const float px = p.x + 0.0f, py = p.y + 0.0f, pz = p.z + 0.0f;
+  float o0 = o[0], o1 = o[1], o2 = o[2], sz = size;
+  auto level = [&](unsigned int acc) {
+    const float h = 0.5f * sz;
+    const unsigned int dx = __float_as_uint(px - o0), dy = __float_as_uint(py - o1), dz = __float_as_uint(pz - o2);
+    o0 = o0 + __uint_as_float((__float_as_uint(h) & 0x7FFFFFFFu) | (dx & 0x80000000u));
+    o1 = o1 + __uint_as_float((__float_as_uint(h) & 0x7FFFFFFFu) | (dy & 0x80000000u));
+    o2 = o2 + __uint_as_float((__float_as_uint(h) & 0x7FFFFFFFu) | (dz & 0x80000000u));
+    sz = h;
+    acc = __builtin_amdgcn_alignbit(acc, dx, 31);              // (acc << 1) | sign: 1 where p < o
+    acc = __builtin_amdgcn_alignbit(acc, dy, 31);
+    return __builtin_amdgcn_alignbit(acc, dz, 31);
+  };
+  unsigned int a = 0, b = 0, c = 0;
+#pragma unroll
+  for (int lev = 0; lev < 10; ++lev) a = level(a);
+#pragma unroll
+  for (int lev = 0; lev < 10; ++lev) b = level(b);
+  c = level(c);
+  o[0] = o0; o[1] = o1; o[2] = o2; size = sz;
+  a = ~a & 0x3FFFFFFFu; b = ~b & 0x3FFFFFFFu; c = ~c & 7u;
+  return ((unsigned long long)a << 33) | ((unsigned long long)b << 3) | (unsigned long long)c;
+}
+
+constexpr int kSmSamples = 256;            // the sample sort's splitters: 128 up to 2048 bodies, 256 above
+constexpr int kSmBucketMax = 512;          // more bodies than this in one bucket (that many on one 21-level path): merge sort
+
 __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const float4 *__restrict__ posm, int n, int P,
                                                               int div_mode, int keep_root, float theta) {
   __shared__ __attribute__((aligned(16))) unsigned char raw[kSmLds];
   __shared__ int s_scan[kSmT / 64];
   __shared__ float s_red[kSmT / 64];
   __shared__ float s_root[4];
-  __shared__ int s_lvl[kMaxLevels + 2];                        // cells per level, then where each level's list ends
-  __shared__ int s_maxl, s_err, s_total, s_tie;
+  __shared__ int s_lvl[64];                                    // cells per level, then where each level's list starts, then where it ends
+  __shared__ int s_maxl, s_err, s_tie, s_bmax;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (T.hdr[3] != 0) return;                                   // an earlier frame of this call was refused: stay there
   BH_CLOCK(0);
   unsigned long long *lo_by_body = (unsigned long long *)(raw + 2 * kSmBuf);   // [n] second key word of body i
-  unsigned short *owner = (unsigned short *)(raw + kSmRegionA + kSmNodesLds * 4);   // [nodes] (the cells' lists later)
+  unsigned short *cells = (unsigned short *)(raw + kSmRegionA + kSmNodesLds * 4);   // [cells] the cells by level
+  // the sample sort's tables stand where the node words go later
+  unsigned long long *smp = (unsigned long long *)(raw + kSmRegionA);          // [samples] sampled first key words
+  unsigned long long *spl = smp + kSmSamples;                                  // [samples] ... sorted: the splitters
+  int *bcnt = (int *)(spl + kSmSamples);                                       // [samples + 2] bodies per bucket, then where each bucket starts
+  static_assert(2 * kSmSamples * 8 + (kSmSamples + 2) * 4 <= kSmNodesLds * 4, "the sample sort's tables fit");
 
   // ---- ComputeCubeSize (.cpp:47-56) and the root (.cpp:77-79)
   float mx = 0.0f;
@@ -339,11 +451,17 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
     mine[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) { mine[r] = posm[i]; mx = fmaxf(mx, fmaxf(fmaxf(fabsf(mine[r].x), fabsf(mine[r].y)), fabsf(mine[r].z))); }
   }
+  // the sample: every (n / samples)-th body of the PREVIOUS frame's key order — bodies move little in a frame, so these stand close
+  // to the quantiles of this frame's order too and the buckets come out even (any bodies would do: the first frame takes
+  // every (n / samples)-th body as numbered)
+  const int smp_cap = n > 2048 ? kSmSamples : kSmSamples / 2, nsmp = min(smp_cap, n);
+  int sample_body = 0;
+  if (t < nsmp) { sample_body = (int)(((long long)t * n + n / 2) / nsmp); sample_body = min(sample_body, n - 1);
+                  if (T.hdr[4] > 0) sample_body = min((int)T.sidx[sample_body], n - 1); }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   if (lane == 0) s_red[wave] = mx;
   if (t == 0) { s_maxl = -1; s_err = 0; }
-  if (t <= kMaxLevels) s_lvl[t] = 0;
   __syncthreads();
   if (t == 0) {
     float m = s_red[0];
@@ -363,71 +481,187 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
   // ---- path keys, sort, shared digits.  Almost always the first key word (21 levels) decides the order and nobody needs
   // the second: the first go computes 21 levels per body and sorts on them alone; only when two neighbours turn out to agree in
   // the whole word (bodies closer than Size / 2^21) is it all done again with both words.
+  // The sort is a sample sort: 128 bodies' first key words, put in order (every sample counts the samples before it), split the
+  // key space where the bodies are — however clustered; a body finds its bucket by seven halvings among the splitters,
+  // the buckets are counted (LDS atomics, whose answers also number a bucket's bodies), a scan says where each bucket starts,
+  // and every body finds its place among its bucket's bodies by comparing with each of them — in which order the atomics
+  // answered does not matter.  Only a bucket of more than kSmBucketMax bodies sends the system to the merge sort (below).
   const unsigned long long *hi = nullptr;
   const unsigned short *idx = nullptr;
   int *first = nullptr;
   signed char *lcpS = nullptr;
-  static_assert(4 * (kSmBodies + 4) + kSmBodies + 16 <= kSmBuf, "scan and lcp fit in a sort buffer");
+  static_assert(4 * (kSmBodies + 4) + (kSmBodies + 16) + 2 * kSmNodesLds <= kSmBuf, "scan, lcp and the cells' owners fit in a sort buffer");
+  const bool plain = s_root[3] >= 0x1p-58f;
+  unsigned long long *hiA = (unsigned long long *)raw, *hiB = (unsigned long long *)(raw + kSmBuf);
+  unsigned short *idxA = (unsigned short *)(raw + kSmBodies * 8), *idxB = (unsigned short *)(raw + kSmBuf + kSmBodies * 8);
   for (int both = 0; both < 2; ++both) {
-    {
-      unsigned long long *hi0 = (unsigned long long *)raw;
-      unsigned short *idx0 = (unsigned short *)(raw + kSmBodies * 8);
+    unsigned long long kh[kSmBodies / kSmT], kl[kSmBodies / kSmT];
+#pragma unroll
+    for (int r = 0; r < kSmBodies / kSmT; ++r) {
+      const int i = t + r * kSmT;
+      kh[r] = ~0ull; kl[r] = 0ull;
+      if (i < n) {
+        float o[3] = {s_root[0], s_root[1], s_root[2]};
+        float size = s_root[3];
+        kh[r] = descend_word(mine[r], o, size, plain);
+        if (both) kl[r] = descend_word(mine[r], o, size, plain);
+        lo_by_body[i] = kl[r];
+        hiB[i] = kh[r];                                        // by body, for the sample (the sorted keys go here in the end)
+      }
+    }
+    if (t <= kSmSamples + 1) bcnt[t] = 0;
+    if (t == 0) { s_tie = 0; s_bmax = 0; }
+    __syncthreads();
+    if (!both) BH_CLOCK(2);
+    if (t < nsmp) smp[t] = hiB[sample_body];
+    __syncthreads();
+    {                                                          // a sample's place: the samples before it (equal ones in their own order).
+      // 1024 / samples neighbouring lanes share a sample, each looks at its part of the samples, a few DPP adds put it together
+      const int parts = kSmT / smp_cap, per = smp_cap / parts;
+      const int j = t / parts, part = t % parts;
+      const unsigned long long mykey = smp[min(j, nsmp - 1)];
+      int before = 0;
+      for (int u = 0; u < per; ++u) {
+        const int k = part * per + u;
+        const unsigned long long sk = smp[min(k, nsmp - 1)];
+        before += (k < nsmp && (sk < mykey || (sk == mykey && k < j))) ? 1 : 0;
+      }
+      before += __shfl_xor(before, 1, 64);
+      before += __shfl_xor(before, 2, 64);
+      if (parts == 8) before += __shfl_xor(before, 4, 64);
+      if (part == 0 && j < nsmp) spl[before] = mykey;
+    }
+    __syncthreads();
+    if (!both) BH_CLOCK(9);
+    unsigned int slot[kSmBodies / kSmT], bucket[kSmBodies / kSmT];
+#pragma unroll
+    for (int r = 0; r < kSmBodies / kSmT; ++r) {                // bucket = splitters below the key (equal first words share a bucket)
+      const int i = t + r * kSmT;
+      slot[r] = 0u; bucket[r] = 0u;
+      if (i < n) {
+        int x = 0, y = nsmp;
+        while (x < y) { const int mid = (x + y) >> 1; if (spl[mid] < kh[r]) x = mid + 1; else y = mid; }
+        bucket[r] = (unsigned int)x;
+        slot[r] = (unsigned int)atomicAdd(&bcnt[x], 1);
+      }
+    }
+    __syncthreads();
+    if (wave < 5) {                                            // where each bucket starts: exclusive scan of the counts (samples + 1 of them)
+      const int c = t <= kSmSamples ? bcnt[t] : 0;
+      int incl = c, big = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) big = max(big, __shfl_xor(big, off, 64));
+      if (lane == 63) s_scan[wave] = incl;
+      if (lane == 0) atomicMax(&s_bmax, big);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_s_barrier();                            // (all sixteen waves meet here: see the else branch)
+      int run = incl - c;
+      for (int w = 0; w < wave; ++w) run += s_scan[w];
+      if (t <= kSmSamples + 1) bcnt[t] = run;                   // (from bcnt[samples + 1] on: n)
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_s_barrier();
+    }
+    __syncthreads();
+    if (!both) BH_CLOCK(10);
+    if (s_bmax <= kSmBucketMax) {
+      // the bodies by bucket (in the order the atomics answered), then every body's place among its bucket's bodies: those
+      // with a smaller (first word, second word, body)
 #pragma unroll
       for (int r = 0; r < kSmBodies / kSmT; ++r) {
         const int i = t + r * kSmT;
-        if (i >= P) break;
-        unsigned long long h = ~0ull, l = 0ull;
+        if (i < n) { const int pos = bcnt[bucket[r]] + (int)slot[r]; hiA[pos] = kh[r]; idxA[pos] = (unsigned short)i; }
+      }
+      __syncthreads();
+      if (!both) BH_CLOCK(11);
+      int place[kSmBodies / kSmT];
+#pragma unroll
+      for (int r = 0; r < kSmBodies / kSmT; ++r) {
+        const int i = t + r * kSmT;
+        place[r] = 0;
         if (i < n) {
-          float o[3] = {s_root[0], s_root[1], s_root[2]};
-          float size = s_root[3];
-          h = 0;
-          for (int lev = 0; lev < kLevelsPerKey; ++lev) h = (h << 3) | (unsigned long long)descend_level(mine[r], o, size);
-          if (both) for (int lev = 0; lev < kLevelsPerKey; ++lev) l = (l << 3) | (unsigned long long)descend_level(mine[r], o, size);
-          lo_by_body[i] = l;
-        }
-        hi0[i] = h; idx0[i] = (unsigned short)(i < n ? i : 0xFFFF);
-      }
-    }
-    if (t == 0) s_tie = 0;
-    __syncthreads();
-    if (!both) BH_CLOCK(2);
-    // ---- merge sort by rank: runs of L become runs of 2L; every element finds its place by a binary search in the partner
-    // run (left run: partner elements strictly before it; right run: partner elements not after it — a stable merge).
-    // log2(P) rounds, buffers ping-pong; the rounds whose pairs of runs lie inside a wave's own 64 elements need only that
-    // wave's order, the others a barrier.  Ties in the first key word look the second one up by body (second go only).
-    int cur = 0;
-    for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
-      const unsigned long long *shi = (const unsigned long long *)(raw + cur * kSmBuf);
-      const unsigned short *sidx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
-      unsigned long long *dhi = (unsigned long long *)(raw + (cur ^ 1) * kSmBuf);
-      unsigned short *didx = (unsigned short *)(raw + (cur ^ 1) * kSmBuf + kSmBodies * 8);
-      for (int e = t; e < P; e += kSmT) {
-        const int run = e >> lg, pos = e & (L - 1);
-        const bool left = (run & 1) == 0;
-        const int pbase = (run ^ 1) * L;
-        const unsigned long long h = shi[e];
-        const unsigned short b = sidx[e];
-        int x = 0, y = L;
-        while (x < y) {
-          const int mid = (x + y) >> 1;
-          const unsigned long long hp = shi[pbase + mid];
-          bool before = hp < h;                                // partner element sorts before mine?
-          if (hp == h) {
-            const unsigned short bp = sidx[pbase + mid];
-            const unsigned long long lp = bp == 0xFFFF ? ~0ull : lo_by_body[bp], lm = b == 0xFFFF ? ~0ull : lo_by_body[b];
-            before = left ? lp < lm : lp <= lm;
+          const int a = bcnt[bucket[r]], b = bcnt[bucket[r] + 1];
+          // the bodies of its bucket that are not above it: one of them is the body itself, so that many less one stand before
+          // it — unless two bodies agree in the whole first word (rare): they get the same place, and the check below sees it
+          int notabove = 0;
+          if (!both) {
+            for (int k = a; k < b; k += 8) {                     // eight loads in flight: the loop is a chain of LDS round trips otherwise
+              unsigned long long hk[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) hk[u] = hiA[min(k + u, b - 1)];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) notabove += (k + u < b && hk[u] <= kh[r]) ? 1 : 0;
+            }
+            notabove -= 1;
+          } else {                                             // second word, then body, where the first words agree
+            for (int k = a; k < b; ++k) {
+              const unsigned long long hk = hiA[k];
+              bool less = hk < kh[r];
+              if (hk == kh[r]) {
+                const int ik = idxA[k];
+                if (ik != i) { const unsigned long long lk = lo_by_body[ik]; less = lk < kl[r] || (lk == kl[r] && ik < i); }
+              }
+              notabove += less ? 1 : 0;
+            }
           }
-          if (before) x = mid + 1; else y = mid;
+          place[r] = a + notabove;
+          hiB[place[r]] = kh[r]; idxB[place[r]] = (unsigned short)i;
         }
-        const int dest = (run & ~1) * L + pos + x;
-        dhi[dest] = h; didx[dest] = b;
       }
-      if (2 * L <= 64 && 4 * L <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
-      else __syncthreads();
+      __syncthreads();
+      if (!both) {                                             // two bodies with one place: the second go will tell them apart
+#pragma unroll
+        for (int r = 0; r < kSmBodies / kSmT; ++r) { const int i = t + r * kSmT; if (i < n && idxB[place[r]] != (unsigned short)i) s_tie = 1; }
+      }
+      hi = hiB; idx = idxB;
+      first = (int *)raw;                                        // [n + 1], in the buffer the sort left behind
+    } else {
+      // ---- merge sort by rank: runs of L become runs of 2L; every element finds its place by a binary search in the partner
+      // run (left run: partner elements strictly before it; right run: partner elements not after it — a stable merge).
+      // log2(P) rounds, buffers ping-pong; the rounds whose pairs of runs lie inside a wave's own 64 elements need only that
+      // wave's order, the others a barrier.  Ties in the first key word look the second one up by body (second go only).
+#pragma unroll
+      for (int r = 0; r < kSmBodies / kSmT; ++r) {
+        const int i = t + r * kSmT;
+        if (i < P) { hiA[i] = kh[r]; idxA[i] = (unsigned short)(i < n ? i : 0xFFFF); }
+      }
+      __syncthreads();
+      int cur = 0;
+      for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
+        const unsigned long long *shi = (const unsigned long long *)(raw + cur * kSmBuf);
+        const unsigned short *sidx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
+        unsigned long long *dhi = (unsigned long long *)(raw + (cur ^ 1) * kSmBuf);
+        unsigned short *didx = (unsigned short *)(raw + (cur ^ 1) * kSmBuf + kSmBodies * 8);
+        for (int e = t; e < P; e += kSmT) {
+          const int run = e >> lg, pos = e & (L - 1);
+          const bool left = (run & 1) == 0;
+          const int pbase = (run ^ 1) * L;
+          const unsigned long long h = shi[e];
+          const unsigned short b = sidx[e];
+          int x = 0, y = L;
+          while (x < y) {
+            const int mid = (x + y) >> 1;
+            const unsigned long long hp = shi[pbase + mid];
+            bool before = hp < h;                                // partner element sorts before mine?
+            if (hp == h) {
+              const unsigned short bp = sidx[pbase + mid];
+              const unsigned long long lp = bp == 0xFFFF ? ~0ull : lo_by_body[bp], lm = b == 0xFFFF ? ~0ull : lo_by_body[b];
+              before = left ? lp < lm : lp <= lm;
+            }
+            if (before) x = mid + 1; else y = mid;
+          }
+          const int dest = (run & ~1) * L + pos + x;
+          dhi[dest] = h; didx[dest] = b;
+        }
+        if (2 * L <= 64 && 4 * L <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+      }
+      hi = (const unsigned long long *)(raw + cur * kSmBuf);
+      idx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
+      first = (int *)(raw + (cur ^ 1) * kSmBuf);                 // [n + 1], in the buffer the sort left behind
     }
-    hi = (const unsigned long long *)(raw + cur * kSmBuf);
-    idx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
-    first = (int *)(raw + (cur ^ 1) * kSmBuf);                 // [n + 1], in the buffer the sort left behind
     lcpS = (signed char *)(first + kSmBodies + 4);             // [n + 1]
     if (!both) BH_CLOCK(3);
     // ---- shared digits of neighbours, the keys and the draw order for later (leaf boxes, DrawOctreeBoxes' order)
@@ -448,51 +682,86 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
       lcpS[i] = (signed char)v;
       if (i < n) { T.khi[i] = hi[i]; T.klo[i] = li; T.sidx[i] = idx[i]; }
     }
+    if (t < 64) s_lvl[t] = 0;
     __syncthreads();
     if (both || s_tie == 0) break;
     __syncthreads();                                           // everybody has seen the tie flag before the next go clears it
   }
   __syncthreads();
+#ifdef NBODY_BH_PHASE_CLOCKS
+  if (t == 0) T.clocks[14] = s_bmax;                           // the fullest bucket of the sample sort
+#endif
   if (s_err != 0) { if (t == 0) T.hdr[3] = 1; return; }
-  // ---- number the nodes: exclusive scan of (cells opened at body i) + 1, four bodies per thread
+  // ---- number the nodes: exclusive scan of (cells opened at body i) + 1, four bodies per thread.  The same pass writes the
+  // leaves' words, counts the cells by level and notes which body opens each cell (numbered node - bodies before it).
+  unsigned short *cowner = (unsigned short *)(lcpS + kSmBodies + 16);   // [cells]
+  unsigned int *meta = (unsigned int *)(raw + kSmRegionA);
+  unsigned short *leaf_of = cells + (kSmNodesLds - n);        // [n] every body's leaf (at most kSmNodesLds - n cells are listed in front)
+  int nodes;
   {
-    int c[4], sum = 0;
+    int c[4], lp[4], ln[4], sum = 0, deep = -1;
+    unsigned int body[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = 4 * t + q;
-      c[q] = 0;
-      if (i < n) { const int d = (int)lcpS[i + 1] - (int)lcpS[i]; c[q] = (d > 0 ? d : 0) + 1; }
+      c[q] = 0; lp[q] = 0; ln[q] = -1; body[q] = 0u;
+      if (i < n) {
+        lp[q] = (int)lcpS[i]; ln[q] = (int)lcpS[i + 1]; body[q] = idx[i];
+        const int d = ln[q] - lp[q];
+        c[q] = (d > 0 ? d : 0) + 1;
+        deep = max(deep, ln[q]);
+      }
       sum += c[q];
     }
     int incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) deep = max(deep, __shfl_xor(deep, off, 64));
     if (lane == 63) s_scan[wave] = incl;
+    if (lane == 0 && deep >= 0) atomicMax(&s_maxl, deep);
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += s_scan[w];
-    int run = base + incl - sum;
-    const int total = [&] { int v = 0; for (int w = 0; w < kSmT / 64; ++w) v += s_scan[w]; return v; }();
+    int run = incl - sum, total = 0;
+    for (int w = 0; w < kSmT / 64; ++w) { const int v = s_scan[w]; if (w < wave) run += v; total += v; }
+    nodes = total;
+    if (nodes > T.cap) { if (t == 0) T.hdr[3] = 2; return; }
+    const bool in_lds = nodes <= kSmNodesLds;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = 4 * t + q;
       if (i < n) {
         first[i] = run;
-        if (total <= kSmNodesLds) for (int k = 0; k < c[q]; ++k) owner[run + k] = (unsigned short)i;
+        const int open = c[q] - 1;
+        const int level = (lp[q] > ln[q] ? lp[q] : ln[q]) + 1;  // the leaf: one level below the deepest cell the body shares
+        T.leaf_level[i] = (unsigned char)level;
+        if (in_lds) {
+          for (int k = 0; k < open; ++k) { cowner[run - i + k] = (unsigned short)i; atomicAdd(&s_lvl[lp[q] + 1 + k], 1); }
+          leaf_of[body[q]] = (unsigned short)(run + open);
+          meta[run + open] = kLeafBit | ((unsigned int)level << kLevelShift) | body[q];
+        }
       }
       run += c[q];
     }
-    if (t == kSmT - 1) { s_total = run; first[n] = run; }
+    if (t == kSmT - 1) first[n] = run;
+    __syncthreads();
+    if (t < 64) {                                              // where each level's list of cells starts
+      const int cnt = s_lvl[t];
+      int inc = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+      s_lvl[t] = inc - cnt;
+    }
     __syncthreads();
   }
-  const int nodes = s_total;
-  if (nodes > T.cap) { if (t == 0) T.hdr[3] = 2; return; }
   BH_CLOCK(4);
-  const SmallScratch sc = {hi, idx, lo_by_body, first, lcpS, owner, s_root, &s_maxl, s_lvl};
-  if (nodes <= kSmNodesLds)   // the tree in LDS: CoMs over the sort's space once the structure is known, words and cell lists behind
-    small_tree_nodes<true>(T, (float4 *)raw, (unsigned int *)(raw + kSmRegionA), owner, sc, posm, n, nodes, div_mode, keep_root);
-  else
-    small_tree_nodes<false>(T, T.com, T.meta, nullptr, sc, posm, n, nodes, div_mode, keep_root);
+  const SmallScratch sc = {hi, idx, lo_by_body, first, lcpS, cowner, s_root, &s_maxl, s_lvl};
+  if (nodes <= kSmNodesLds) {   // the tree in LDS: CoMs over the sort's space once the structure is known, words and cell lists behind,
+    const int ncells = nodes - n;                                // the children's lists behind the CoMs where there is room
+    unsigned short *kids = (nodes + 1 + ncells) * 16 <= kSmRegionA ? (unsigned short *)(raw + (nodes + 1) * 16) : nullptr;
+    small_tree_in_lds(T, (float4 *)raw, meta, cells, kids, sc, mine, leaf_of, posm, n, nodes, div_mode, keep_root);
+  } else {
+    small_tree_in_global(T, sc, posm, n, nodes, div_mode, keep_root);
+  }
 }
 
 template <typename T> __device__ __forceinline__ T mul_add_sep(T a, T b, T c) {
@@ -672,6 +941,7 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kGroups][kWalkK];
   __shared__ float4 s_term[kGroups][kWalkK];
+  (void)theta;
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   BH_WALK_CLOCK(9);
   BH_WG_STAMP(0);
@@ -822,6 +1092,7 @@ __global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T,
   __shared__ unsigned short s_list[kWaves][kWvK];
   __shared__ __attribute__((aligned(16))) float s_term[kWaves][3 * kWvK];
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
+  BH_WG_STAMP(0);
   const int t = threadIdx.x;
   const int nodes = T.hdr[0];
   const bool in_lds = nodes <= kSmNodesLds;
@@ -852,10 +1123,19 @@ __global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T,
   const unsigned int body = valid ? T.sidx[k] : 0u;
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
+  BH_WG_STAMP(1);
   if (in_lds)
     walk_wave<true, kWvK>(T, s_a, s_m, s_past, s_thr, s_list[wave], s_term[wave], nodes, valid, p, G, lane, ax, ay, az);
   else   // a tree too large for LDS (deep chains of single-child cells): the same windows on the global arrays
     walk_wave<false, kWvK>(T, s_a, s_m, s_past, s_thr, s_list[wave], s_term[wave], nodes, valid, p, G, lane, ax, ay, az);
+  BH_WG_STAMP(2);
+#ifdef NBODY_BH_PHASE_CLOCKS
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {       // the shader clock under this load: s_sleep 127 = 127 * 64 cycles
+    const long long c0 = wall_clock64();
+    for (int q = 0; q < 16; ++q) __builtin_amdgcn_s_sleep(127);
+    T.clocks[15] = wall_clock64() - c0;
+  }
+#endif
   walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave]);
 }
 

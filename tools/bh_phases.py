@@ -24,8 +24,11 @@ with nb.NBodyEngine(n, theta=1.0) as e:
     print(f"N={n}: build kernel phases, us (mean of {reps}):")
     for nm, v in zip(names, acc / reps):
         print(f"  {nm:24s} {v:8.2f}")
-    print(f"  {'total':24s} {acc.sum() / reps:8.2f}   {e.bh_stats()}")
-    wg = np.array(out[16:], np.float64).reshape(512, 3)[:(n + 15) // 16]      # the last frame's workgroups: start, fill end, end
+    if out[9] and out[10] and out[11]:
+        print(f"  (inside the sort, last frame: samples ranked {(out[9] - out[2]) / 100:.2f}, buckets found and scanned {(out[10] - out[9]) / 100:.2f}, scattered {(out[11] - out[10]) / 100:.2f}, ranked {(out[3] - out[11]) / 100:.2f})")
+    print(f"  {'total':24s} {acc.sum() / reps:8.2f}   {e.bh_stats()}   fullest bucket of the sample sort {out[14]} (more than 256: merge sort)")
+    wg = np.array(out[16:], np.float64).reshape(512, 3)
+    wg = wg[wg[:, 0] > 0][:512]      # the last frame's workgroups: start, fill end, end
     t0 = wg[:, 0].min()
     print(f"  walk kernel, all {len(wg)} workgroups of the last frame (us from the first start): starts up to {(wg[:, 0].max() - t0) / 100:.2f}, "
           f"fill {((wg[:, 1] - wg[:, 0]) / 100).mean():.2f} mean / {((wg[:, 1] - wg[:, 0]) / 100).max():.2f} max, "
