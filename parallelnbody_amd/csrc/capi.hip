@@ -1653,6 +1653,14 @@ __attribute__((visibility("default"))) int nbody_debug_bh_clocks(nbody_ctx *c, l
   return NBODY_OK;
 }
 
+// Not in include/nbody.h either: how many frames of the larger systems were sorted starting from the previous frame's order, and how
+// often a frame given up by that sort (a bucket ran over) was queued again with the cold sorts (tests/test_bh_gpu.py).
+__attribute__((visibility("default"))) int nbody_debug_bh_sort_counts(nbody_ctx *c, long long *warm_frames, long long *retries) {
+  if (!c || c->multi || !c->bh || !warm_frames || !retries) return NBODY_ERR_INVALID;
+  nbody::bh_debug_sort_counts(c->bh, warm_frames, retries);
+  return NBODY_OK;
+}
+
 int nbody_steps_done(nbody_ctx *c, int64_t *steps) {
   if (!c || !steps) return NBODY_ERR_INVALID;
   *steps = c->steps_done;

@@ -1637,6 +1637,156 @@ __global__ __launch_bounds__(kB) void bh_ties_kernel(int n, const unsigned long 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The sort of a frame that FOLLOWS a frame (round 4): bodies move little in a frame, so the previous frame's key order is
+// almost this frame's.  Two launches:
+//   bh_keys_bucket_kernel   visits the bodies in the previous order, 256 to a workgroup; a body's new first key word is compared
+//                           with the previous frame's sorted keys at every 256th place — the boundaries of n / 256 buckets of 256
+//                           consecutive places each — and the body goes into the bucket whose range holds it.  A workgroup's
+//                           bodies lie next to each other in space, so they fall into a handful of neighbouring buckets: the
+//                           boundaries it needs are a window of 64 around its own place (LDS), its bodies are counted per
+//                           bucket in LDS and ONE global atomic per touched bucket reserves their slots (a body outside the
+//                           window — it crossed a coarse cell boundary, or the root box moved — searches the boundaries in global
+//                           memory and takes a slot by itself).  A bucket has room for 384 bodies; one more and the frame is
+//                           given up (header word 3 := 3): every later kernel of it, and of the frames queued behind it, returns
+//                           at once, the state stays what it was, and bh_collect queues those frames again, the first of them
+//                           with the sorts below.
+//   bh_bucket_sort_kernel   a workgroup per bucket: where the bucket starts in the order is the sum of the counts before it; its
+//                           bodies are sorted in LDS (the merge by rank of bh_tile_sort_kernel; bodies that agree in the whole
+//                           first key word look the second one up) and written to their final places.
+// The counts live in two arrays that take turns: a frame's second kernel clears the array the next frame counts in.
+constexpr int kWarmMu = 256;               // places of the previous order per bucket (= bodies per workgroup of the first kernel)
+constexpr int kWarmCap = 384;              // slots per bucket
+constexpr int kWarmWin = 64;               // boundaries a workgroup keeps in LDS
+constexpr int kStatusRetry = 3;            // header word 3: the frame was given up by the warm sort; queue it again with the cold one
+
+__global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+                                                            const unsigned int *__restrict__ size_bits, float theta,
+                                                            const unsigned long long *__restrict__ prev_hi,
+                                                            const unsigned int *__restrict__ prev_idx,
+                                                            unsigned long long *__restrict__ key_lo, unsigned long long *__restrict__ slot_hi,
+                                                            unsigned int *__restrict__ slot_idx, unsigned int *__restrict__ gcount, int nb) {
+  static_assert(kWarmMu == kB, "a workgroup visits one bucket's worth of places");
+  __shared__ unsigned long long s_b[kWarmWin];                 // boundaries jlo .. jhi: the previous order's keys at places 256 j
+  __shared__ unsigned int s_cnt[kWarmWin + 1], s_base[kWarmWin + 1];
+  __shared__ int s_stop;
+  const int t = threadIdx.x, w = blockIdx.x;
+  if (t == 0) s_stop = T.hdr[3];                               // (one thread asks: other workgroups of this launch may be giving the frame up)
+  __syncthreads();
+  if (s_stop != 0) return;                                     // a frame before this one was refused: nothing of this one happens
+  const float sz = __uint_as_float(*size_bits);
+  float o[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
+  if (w == 0) bh_frame_setup(T, o, sz, theta, kB);
+  // bucket(h) = the largest j in 1 .. nb - 1 with boundary j <= h, or 0; the window: boundaries jlo .. jhi around this workgroup's own
+  const int jlo = max(1, w - (kWarmWin / 2 - 1)), jhi = min(nb - 1, w + kWarmWin / 2);
+  const int nwin = jhi - jlo + 1;
+  if (t < nwin) s_b[t] = prev_hi[(size_t)(jlo + t) * kWarmMu];
+  if (t <= kWarmWin) s_cnt[t] = 0u;
+  __syncthreads();
+  const int i = w * kB + t;
+  const bool valid = i < n;
+  unsigned int body = 0u, local = 0u;
+  unsigned long long hi = 0ull;
+  int bucket = 0, q = -1;
+  if (valid) {
+    body = prev_idx[i];
+    const float4 p = posm[body];
+    float size = sz;
+    unsigned long long lo = 0ull;
+    for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
+    for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
+    key_lo[body] = lo;
+    int x = 0, y = nwin;                                       // boundaries of the window that are <= hi
+    while (x < y) { const int mid = (x + y) >> 1; if (s_b[mid] <= hi) x = mid + 1; else y = mid; }
+    if (x == 0 && jlo > 1) {                                   // below the window: the boundaries 1 .. jlo - 1, in global memory
+      int a = 1, b = jlo;                                      // first boundary in [1, jlo) that is > hi
+      while (a < b) { const int mid = (a + b) >> 1; if (prev_hi[(size_t)mid * kWarmMu] <= hi) a = mid + 1; else b = mid; }
+      bucket = a - 1;
+    } else if (x == nwin && jhi < nb - 1) {                    // above it
+      int a = jhi + 1, b = nb;
+      while (a < b) { const int mid = (a + b) >> 1; if (prev_hi[(size_t)mid * kWarmMu] <= hi) a = mid + 1; else b = mid; }
+      bucket = a - 1;
+    } else {
+      bucket = jlo - 1 + x;
+    }
+    q = bucket - (jlo - 1);
+    if (q >= 0 && q <= kWarmWin) local = atomicAdd(&s_cnt[q], 1u); else q = -1;
+  }
+  __syncthreads();
+  if (t <= kWarmWin && s_cnt[t] != 0u) s_base[t] = atomicAdd(&gcount[jlo - 1 + t], s_cnt[t]);
+  __syncthreads();
+  if (!valid) return;
+  const unsigned int pos = q >= 0 ? s_base[q] + local : atomicAdd(&gcount[bucket], 1u);
+  if (pos >= (unsigned int)kWarmCap) { T.hdr[3] = kStatusRetry; return; }
+  slot_hi[(size_t)bucket * kWarmCap + pos] = hi;
+  slot_idx[(size_t)bucket * kWarmCap + pos] = body;
+}
+
+constexpr int kBsT = 512;                  // threads of a bucket's workgroup: one per element of the padded bucket
+__global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int nb, const unsigned int *__restrict__ gcount,
+                                                              unsigned int *__restrict__ gcount_next,
+                                                              const unsigned long long *__restrict__ slot_hi,
+                                                              const unsigned int *__restrict__ slot_idx,
+                                                              const unsigned long long *__restrict__ klo_body,
+                                                              unsigned long long *__restrict__ out_hi, unsigned int *__restrict__ out_idx) {
+  static_assert(kWarmCap <= kBsT, "one thread per element");
+  __shared__ unsigned long long s_hi[2][kBsT];
+  __shared__ unsigned short s_ix[2][kBsT];
+  __shared__ unsigned int s_body[kBsT];
+  __shared__ unsigned int s_part[kBsT / 64];
+  if (T.hdr[3] != 0) return;                                   // the frame was given up (or an earlier one refused)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+  (void)nb;
+  // where the bucket starts: the counts of the buckets before it
+  unsigned int sum = 0u;
+  for (int j = t; j < b; j += kBsT) sum += gcount[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) s_part[wave] = sum;
+  const int cnt = (int)gcount[b];
+  if (t == 0) gcount_next[b] = 0u;                             // the next frame counts there
+  int P = 64;
+  while (P < cnt) P <<= 1;
+  if (t < P) {
+    const bool in = t < cnt;
+    s_hi[0][t] = in ? slot_hi[(size_t)b * kWarmCap + t] : ~0ull;
+    s_ix[0][t] = (unsigned short)t;
+    s_body[t] = in ? slot_idx[(size_t)b * kWarmCap + t] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  unsigned int start = 0u;
+  for (int wv = 0; wv < kBsT / 64; ++wv) start += s_part[wv];
+  // merge sort by rank (bh_tile_sort_kernel): runs of L become runs of 2L, every element finds its place by a binary search in
+  // the partner run — left run: partner elements strictly before it; right run: partner elements not after it (stable)
+  int cur = 0;
+  for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
+    if (t < P) {
+      const int run = t >> lg, pos = t & (L - 1);
+      const bool left = (run & 1) == 0;
+      const int pbase = (run ^ 1) * L;
+      const unsigned long long h = s_hi[cur][t];
+      const unsigned short ix = s_ix[cur][t];
+      int x = 0, y = L;
+      while (x < y) {
+        const int mid = (x + y) >> 1;
+        const unsigned long long hp = s_hi[cur][pbase + mid];
+        bool before = hp < h;
+        if (hp == h) {                                         // the whole first key word agrees (rare): the second words decide
+          const unsigned int bp = s_body[s_ix[cur][pbase + mid]], bm = s_body[ix];
+          const unsigned long long lp = bp == 0xFFFFFFFFu ? ~0ull : klo_body[bp], lm = bm == 0xFFFFFFFFu ? ~0ull : klo_body[bm];
+          before = left ? lp < lm : lp <= lm;
+        }
+        if (before) x = mid + 1; else y = mid;
+      }
+      const int dest = (run & ~1) * L + pos + x;
+      s_hi[cur ^ 1][dest] = h; s_ix[cur ^ 1][dest] = ix;
+    }
+    if (2 * L <= 64 && 4 * L <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+  }
+  if (t < cnt) { out_hi[start + t] = s_hi[cur][t]; out_idx[start + t] = s_body[s_ix[cur][t]]; }
+}
+
 // digits two path keys share (0 .. 42; 42: the same path all the way down)
 __device__ __forceinline__ int shared_digits(unsigned long long ha, unsigned long long la, unsigned long long hb, unsigned long long lb) {
   const unsigned long long x = ha ^ hb;
@@ -2026,6 +2176,14 @@ struct BhState {
   unsigned int *part_hist = nullptr, *slice_hist = nullptr, *rx_desc = nullptr;
   size_t rx_desc_bytes = 0;
   int rx_resident = 1;                     // workgroups of bh_radix_pass_kernel the device holds at once
+  // the sort of a frame that follows a frame (bh_keys_bucket_kernel): slots of kWarmCap bodies per bucket, the buckets' counts (two
+  // arrays that take turns), whether b->khi / b->idx hold a previous frame's order, and what bh_collect needs to queue frames again
+  unsigned long long *slot_hi = nullptr;
+  unsigned int *slot_idx = nullptr, *gcount = nullptr;
+  int nb = 0, gturn = 0;
+  bool warm = false;
+  long long warm_frames = 0, retries = 0;  // frames queued with the warm sort; times bh_collect queued frames again (tests, tuning)
+  struct { void *posm, *vel, *acc; float theta; double G; float dt; int keep_root; float *stage; int queued; } last{};
   int *first = nullptr, *first_local = nullptr, *block_sum = nullptr;   // [n + 1] first node of every body's group (absolute / within its scan block), the blocks' totals
   int tile_size = kTs;                     // bodies per tile of the tiles + merge sort (1024, 2048 or 4096: tile_size)
   int smp_shift = 0;                       // bh_nodes_kernel keeps every 2^smp_shift-th sorted key in LDS
@@ -2108,6 +2266,11 @@ hipError_t bh_create(BhState **out, int n) {
     BH_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     b->rx_resident = std::max(1, per_cu * cus);
   }
+  b->nb = (n + kWarmMu - 1) / kWarmMu;
+  BH_TRY(hipMalloc(&b->slot_hi, sizeof(unsigned long long) * (size_t)b->nb * kWarmCap));
+  BH_TRY(hipMalloc(&b->slot_idx, sizeof(unsigned int) * (size_t)b->nb * kWarmCap));
+  BH_TRY(hipMalloc(&b->gcount, sizeof(unsigned int) * 2 * (size_t)b->nb));
+  BH_TRY(hipMemset(b->gcount, 0, sizeof(unsigned int) * 2 * (size_t)b->nb));
   BH_TRY(hipMalloc(&b->first, sizeof(int) * ((size_t)n + 1)));
   BH_TRY(hipMalloc(&b->first_local, sizeof(int) * ((size_t)n + 1)));
   BH_TRY(hipMalloc(&b->block_sum, sizeof(int) * (kScanBlocks + 1)));
@@ -2124,7 +2287,7 @@ hipError_t bh_create(BhState **out, int n) {
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->slot_hi, b->slot_idx, b->gcount, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
@@ -2141,6 +2304,7 @@ hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t 
   return hipMemcpy(out, b->st.clocks, sizeof(long long) * kDbgClocks, hipMemcpyDeviceToHost);
 }
 const float *bh_root_device(const BhState *b) { return b->root; }
+void bh_debug_sort_counts(const BhState *b, long long *warm_frames, long long *retries) { *warm_frames = b->warm_frames; *retries = b->retries; }
 
 // NBODY_BH_WALK=rows: the walks with sixteen lanes per body (round 3) instead of a wave per body — A/B measurements
 static bool bh_wave_walk() {
@@ -2164,7 +2328,16 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   // b->khi, the bodies in b->idx, and the second key words, still in body order, in b->klo.
   SmallTree &T = b->st;
   T.khi = b->khi; T.sidx = b->idx;
-  if (!b->radix) {
+  static const bool warm_off = [] { const char *e = getenv("NBODY_BH_WARM_SORT"); return e && e[0] == '0'; }();   // A/B, tests
+  if (b->warm && !warm_off) {
+    // a frame that follows a frame: the previous order is almost this frame's (bh_keys_bucket_kernel)
+    unsigned int *gc = b->gcount + (size_t)b->gturn * b->nb, *gc_next = b->gcount + (size_t)(b->gturn ^ 1) * b->nb;
+    b->gturn ^= 1;
+    b->warm_frames += 1;
+    hipLaunchKernelGGL(bh_keys_bucket_kernel, dim3(b->nb), blk, 0, s, T, posm, n, size_bits, theta, b->khi, b->idx, b->klo, b->slot_hi,
+                       b->slot_idx, gc, b->nb);
+    hipLaunchKernelGGL(bh_bucket_sort_kernel, dim3(b->nb), dim3(kBsT), 0, s, T, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->klo, b->khi, b->idx);
+  } else if (!b->radix) {
     hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, T, posm, n, size_bits, theta, b->khi, b->klo);
     const int ts = b->tile_size, tiles = (n + ts - 1) / ts;
     if (ts == 1024) hipLaunchKernelGGL(bh_tile_sort_kernel<1024>, dim3(tiles), dim3(kTsT), 0, s, n, b->khi, b->klo, b->khi2, b->idx2);
@@ -2230,6 +2403,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
                        (float4 *)acc_v, n, G, dt, stage);
   else
     hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, n, G, dt, stage);
+  b->warm = true;                                               // b->khi / b->idx hold an order the next frame can start from
   return hipGetLastError();
 }
 
@@ -2240,7 +2414,10 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
 // stage (optional): the walk also writes every body's FParticle record (10 floats, body order) there — the frame's mirror.
 hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root, float *stage,
                     hipStream_t s) {
-  if (!b->small) return bh_large_frame(b, posm, vel, acc, theta, G, dt, keep_root, stage, s);
+  if (!b->small) {
+    b->last = {posm, vel, acc, theta, G, dt, keep_root, stage, b->last.queued + 1};
+    return bh_large_frame(b, posm, vel, acc, theta, G, dt, keep_root, stage, s);
+  }
   const int n = b->n;
   int P = 1;
   while (P < n) P <<= 1;
@@ -2261,11 +2438,29 @@ float bh_last_size(const BhState *b) { float f; unsigned int u = (unsigned int)b
 // pool; *frames = how many of them were built (a refused frame and everything queued behind it leave the state untouched).
 // A refusal is cleared here, so that the next call starts afresh.
 hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
-  BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
-  BH_TRY(hipStreamSynchronize(s));
+  int built = 0;
+  for (;;) {
+    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+    BH_TRY(hipStreamSynchronize(s));
+    const int now = b->h_counters[4] - b->frames_seen;
+    built += now;
+    b->frames_seen = b->h_counters[4];
+    if (b->small || b->h_counters[3] != kStatusRetry) break;
+    // The warm sort gave a frame up (a bucket ran over): that frame and the ones queued behind it did nothing.  Queue them again,
+    // the first with the cold sorts; the counts start from zero.
+    const int left = b->last.queued - now;
+    b->last.queued = 0;
+    b->retries += 1;
+    BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
+    BH_TRY(hipMemsetAsync(b->gcount, 0, sizeof(unsigned int) * 2 * (size_t)b->nb, s));
+    b->warm = false;
+    const auto a = b->last;
+    for (int k = 0; k < left; ++k)
+      BH_TRY(bh_frame(b, a.posm, a.vel, a.acc, a.theta, a.G, a.dt, a.keep_root, k == left - 1 ? a.stage : nullptr, s));
+  }
+  b->last.queued = 0;
   *status = b->h_counters[3];
-  if (frames) *frames = b->h_counters[4] - b->frames_seen;
-  b->frames_seen = b->h_counters[4];
+  if (frames) *frames = built;
   if (b->h_counters[4] > 0) {
     b->last_nodes = b->n >= 2 ? 1 + 8 * b->h_counters[1] : 1;   // the reference's count: every split makes eight children
     b->last_levels = b->h_counters[2];
@@ -2274,7 +2469,10 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
   return hipSuccess;
 }
 
-hipError_t bh_reset_root(BhState *b, hipStream_t s) { return hipMemsetAsync(b->prev_com, 0, sizeof(float) * 3, s); }
+hipError_t bh_reset_root(BhState *b, hipStream_t s) {
+  b->warm = false;                                              // a new scene: the previous order says nothing about it
+  return hipMemsetAsync(b->prev_com, 0, sizeof(float) * 3, s);
+}
 
 // What DrawOctreeBoxes hands to DrawDebugBox: (Origin, Size) of the leaf holding each body, written at the body's index
 hipError_t bh_leaf_boxes(BhState *b, void *out, hipStream_t s) {

@@ -409,3 +409,94 @@ def test_both_sorts_of_the_larger_systems_order_the_bodies_as_the_reference_tree
     np.testing.assert_array_equal(a, ref)
     np.testing.assert_array_equal(st["root_com"], com)
     assert st["nodes"] == nodes and st["levels"] >= 22
+
+
+def _sort_counts(e):
+    import ctypes
+    warm, retries = ctypes.c_longlong(), ctypes.c_longlong()
+    assert e._L.nbody_debug_bh_sort_counts(e._h, ctypes.byref(warm), ctypes.byref(retries)) == 0
+    return warm.value, retries.value
+
+
+@pytest.mark.parametrize("n", [8192, 40000])
+def test_the_sort_that_starts_from_the_previous_frames_order(nb, oracle, n):
+    # A frame that follows a frame visits the bodies in the previous key order and drops them into buckets bounded by the
+    # previous sorted keys (bh_keys_bucket_kernel / bh_bucket_sort_kernel).  The same scene twice: the second pass is such a
+    # frame, with bodies that agree in the whole first key word inside it.  Then the host replaces the records of the RUNNING
+    # simulation by a scene that has nothing to do with the order on the device — nearly all bodies in one small clump: its
+    # buckets run over, the frame is given up on the device and queued again with the cold sorts.  Every acceleration, the draw
+    # order, the leaf boxes and the root CoM equal the oracle's tree in every bit each time.
+    rng = np.random.default_rng(n)
+    posm = _fuzz_scene(rng, n)
+    while len(np.unique(posm[:, :3], axis=0)) != n:
+        posm = _fuzz_scene(rng, n)
+    tiny = np.float32(np.abs(posm[:, :3]).max() * 2.0 ** -24)
+    posm[n - 50, :3] = posm[100, :3] + tiny * np.array([1, 0, 0], np.float32)
+    posm[201, :3] = posm[200, :3] + tiny * np.array([0, 1, 0], np.float32)
+    vel = np.zeros((n, 4), np.float32)
+
+    def check(e, posm):
+        pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+        ref, com, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+        boxes, order = oracle.octree_leaves_f32(pos, m)
+        e.compute_forces()
+        np.testing.assert_array_equal(e.accelerations(), ref)
+        st = e.bh_stats()
+        np.testing.assert_array_equal(e.bh_leaf_order(), order)
+        np.testing.assert_array_equal(e.bh_leaf_boxes()[order], boxes)
+        np.testing.assert_array_equal(st["root_com"], com)
+        assert st["nodes"] == nodes
+
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        check(e, posm)
+        assert _sort_counts(e) == (0, 0)
+        check(e, posm)                                          # from the first pass's order
+        assert _sort_counts(e) == (1, 0)
+        clump = posm.copy()
+        clump[1:, :3] = (posm[1:, :3] * np.float32(2.0 ** -9) + np.float32(0.7) * np.abs(posm[:, :3]).max()).astype(np.float32)
+        while len(np.unique(clump[:, :3], axis=0)) != n:
+            clump[1:, :3] += rng.normal(0, tiny * 64, (n - 1, 3)).astype(np.float32)
+        e.push_particles(particles_from(nb, clump, vel))
+        check(e, clump)
+        warm, retries = _sort_counts(e)
+        assert retries == 1 and warm == 2, (warm, retries)
+        check(e, clump)                                         # and on from the retried frame's order
+        assert _sort_counts(e) == (3, 1)
+
+
+def test_frames_queued_behind_a_frame_the_warm_sort_gives_up(nb, oracle):
+    # nbody_step queues its frames without waiting.  When the warm sort gives one of them up, that frame and every frame
+    # queued behind it leave the state alone; bh_collect queues them again.  Seven Ticks in three calls, the records replaced
+    # by the clump in between: every byte of the records equals the oracle's after each call.
+    n = 8192
+    rng = np.random.default_rng(77)
+    posm = _fuzz_scene(rng, n)
+    vel = np.concatenate([rng.uniform(-20, 20, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    q = particles_from(nb, posm, vel)
+    com, size = None, 0.0
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        e.step(0.01, 2)
+        for _ in range(2):
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+        assert e.particles().tobytes() == q.tobytes()
+        assert _sort_counts(e) == (1, 0)
+        far = np.float32(0.7) * np.abs(q["Position"]).max()
+        clump = (rng.uniform(-30, 30, (n - 1, 3)) + far).astype(np.float32)
+        while len(np.unique(clump, axis=0)) != n - 1:
+            clump = (rng.uniform(-30, 30, (n - 1, 3)) + far).astype(np.float32)
+        q["Position"][1:] = clump
+        q["Mass"] *= np.float32(1e-4)                           # (so that the clump does not blow the scene apart within five frames)
+        e.push_particles(q)
+        e.step(0.01, 3)                                         # the first of the three is given up, all three are queued again
+        for _ in range(3):
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+        assert e.particles().tobytes() == q.tobytes()
+        warm, retries = _sort_counts(e)
+        assert retries >= 1 and warm >= 1 + 3, (warm, retries)     # (the clump flies apart: a later frame may be given up as well)
+        e.step(0.01, 2)
+        for _ in range(2):
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+        assert e.particles().tobytes() == q.tobytes()
+        np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
