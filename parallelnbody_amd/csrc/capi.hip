@@ -469,6 +469,7 @@ int ensure_bh(nbody_ctx *c) {
     return fail(c, NBODY_ERR_HIP, "bh_create: %s", hipGetErrorString(e));
   }
   nbody::bh_set_div_mode(c->bh, c->p.bh_div_mode);
+  if (c->posm_escaped) nbody::bh_positions_external(c->bh);
   return NBODY_OK;
 }
 
@@ -576,6 +577,7 @@ int run_update(nbody_ctx *c, float dt) {
     // bodies moved without the fused update's preparation of the next all-pairs pass: posg and the detector table are
     // those of older positions (the next theta == 0 pass runs the preparation kernel again)
     if (dt > 0.0f) c->sym_posg_valid = false;
+    if (dt > 0.0f && c->bh) nbody::bh_positions_changed(c->bh);   // ... and the next Barnes-Hut frame looks at the positions for its Size
   } else if (c->sym) {
     const nbody::SymLaunch L = make_sym_launch(c);
     HIP_TRY(c, nbody::launch_update_sym(L, c->posm, c->vel, c->acc, c->p.i_begin, c->p.i_count, dt, c->stream));
@@ -646,6 +648,7 @@ int upload_soa(nbody_ctx *c, const T *posm4, const T *vel4, bool keep_history = 
   c->have_state = true;
   c->floor_eps2 = -1.0;
   c->sym_posg_valid = false;
+  if (c->bh) nbody::bh_positions_changed(c->bh);                   // the next Barnes-Hut frame looks at the positions for its Size
   if (keep_history) return NBODY_OK;
   c->steps_done = 0;
   if (c->bh) HIP_TRY(c, nbody::bh_reset_root(c->bh, c->stream));   // a new scene: root centre starts at zero again
@@ -712,6 +715,7 @@ int posm_escapes(nbody_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->sym_dup_table, 0, (size_t)c->sym_dup_slots * 8 + 64, c->stream));
   c->posm_escaped = true;
   c->sym_posg_valid = false;
+  if (c->bh) nbody::bh_positions_external(c->bh);
   return NBODY_OK;
 }
 
@@ -1241,8 +1245,14 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
   HIP_TRY(c, hipSetDevice(c->p.device));
   if (c->theta > 0.0f) {
     if ((rc = ensure_bh(c))) return rc;
-    if ((rc = bh_enqueue(c, dt, nsteps))) return rc;             // every frame queued, one wait per call
-    return bh_finish(c);
+    // every frame queued, one wait per call — the larger systems' in batches of 64: a frame their warm sort gives up takes the
+    // frames queued behind it along (bh_collect queues them again), and that should not be hundreds
+    const int batch = nbody::bh_is_small(c->bh) ? nsteps : 64;
+    for (int done = 0; done < nsteps; done += batch) {
+      if ((rc = bh_enqueue(c, dt, std::min(batch, nsteps - done)))) return rc;
+      if ((rc = bh_finish(c))) return rc;
+    }
+    return NBODY_OK;
   }
   const bool one_launch = one_launch_ok(c);
   for (int s = 0; s < nsteps; ++s) {
@@ -1574,6 +1584,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) t
   HIP_TRY(c, hipMemcpy(c->acc, acc.data(), acc.size(), hipMemcpyHostToDevice));
   { const int rc2 = f64 ? note_masses(c, (const double *)posm.data()) : note_masses(c, (const float *)posm.data()); if (rc2) return rc2; }
   c->have_state = true; c->floor_eps2 = -1.0; c->step_open = false; c->step_local = false; c->sym_posg_valid = false;
+  if (c->bh) nbody::bh_positions_changed(c->bh);
   c->steps_done = h.steps_done;
   // Barnes-Hut: the opening angle and the root of the next tree (the previous tree's CoM, OctreeSearch.cpp:77-79) are
   // part of the trajectory.  Only contexts that can run the walk take them over.
@@ -1599,6 +1610,7 @@ int nbody_set_theta(nbody_ctx *c, float theta) {
   if (theta > 0.0f && (c->p.precision != NBODY_PREC_F32 || c->p.i_count != c->p.n_total))
     return fail(c, NBODY_ERR_UNSUPPORTED, "nbody_set_theta: Barnes-Hut needs an fp32 context that owns all bodies");
   if (theta != c->theta) c->sym_posg_valid = false;   // the other force pass moves bodies without preparing the next all-pairs pass
+  if (theta != c->theta && c->bh) nbody::bh_positions_changed(c->bh);   // ... nor leaving the next Barnes-Hut frame's Size
   c->theta = theta;
   return NBODY_OK;
 }

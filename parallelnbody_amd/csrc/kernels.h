@@ -131,6 +131,8 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
 struct BhState;
 hipError_t bh_create(BhState **out, int n);                   // *out is set even on failure: bh_destroy it
 void bh_destroy(BhState *b);
+void bh_positions_changed(BhState *b);                         // a body was moved by something other than a frame's walk
+void bh_positions_external(BhState *b);                        // the caller holds the position buffer from now on
 hipError_t bh_reset_root(BhState *b, hipStream_t s);          // previous CoM := 0 (a new scene, OctreeSearch.cpp:77)
 // One frame = CreateOctree (OctreeSearch.cpp:74-89: ComputeCubeSize, the tree rooted at the previous CoM, ComputeMass), the walk
 // Octree::ComputeForces(body, theta) of every body and — with dt > 0 — the Tick's update of (posm, vel) in place, QUEUED on the

@@ -45,6 +45,29 @@ __device__ __forceinline__ void child_box(const float o[3], float size, int c, f
   *csize = (float)(0.5 * (double)size);
 }
 
+// ComputeCubeSize (.cpp:47-56) of a frame of the larger systems stands in kSizeSlots words (bit patterns of non-negative floats,
+// which order as unsigned integers): the bounds kernel leaves it in the first of them; a walk that moves the bodies (dt > 0) leaves
+// the NEXT frame's there, every wave that finishes raising its workgroup's slot where its body reaches further out — the frame
+// that follows then needs no pass over the positions of its own.
+constexpr int kSizeSlots = 64;
+__device__ __forceinline__ float frame_size(const unsigned int *__restrict__ size_bits) {
+  unsigned int v = size_bits[threadIdx.x & (kSizeSlots - 1)];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned int)__shfl_xor((int)v, off, 64));
+  return __uint_as_float(v);
+}
+// x: the position a lane's body has moved to (mine: the lane has one); the wave's largest |coordinate| goes to the workgroup's slot
+__device__ __forceinline__ void note_next_size(unsigned int *__restrict__ next_size, bool mine, const float4 &x) {
+  if (next_size == nullptr) return;                            // (uniform)
+  float m = mine ? fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fabsf(x.z)) : 0.0f;   // GetAbsMax (bounds_kernel)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) {
+    // (an atomic whose answer nobody waits for: asking the slot first would put an L2 round trip at the end of every wave)
+    if (m > 0.0f) atomicMax(next_size + (blockIdx.x & (kSizeSlots - 1)), __float_as_uint(m));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Small systems (the reference ships N = 2000; up to kSmBodies): the whole CreateOctree head — ComputeCubeSize, the root
 // rule, Add, ComputeMass (.cpp:47-56, 77-81; .h:60-97) — by ONE workgroup in ONE launch, and a COMPACT tree for the walk.
@@ -892,9 +915,18 @@ __device__ __forceinline__ void walk_windows(const SmallTree &T, const float4 *s
 // ONE instruction — 40 contiguous bytes per body — instead of ten scattered 4-byte stores.
 __device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int body, const float4 &p, float ax, float ay, float az,
                                               float4 *__restrict__ posm, float4 *__restrict__ vel, float4 *__restrict__ acc, float dt,
-                                              float *__restrict__ stage, float *rec) {
-  if (!valid || (g != 0 && stage == nullptr)) return;
+                                              float *__restrict__ stage, float *rec, unsigned int *__restrict__ next_size = nullptr) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
+  if (next_size != nullptr) {                                  // (larger systems, dt > 0: every lane of the wave comes by here)
+    if (valid && g == 0) {
+      v = vel[body];
+      v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
+      x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
+    }
+    note_next_size(next_size, valid && g == 0, x);
+    v = make_float4(0.f, 0.f, 0.f, 0.f); x = p;
+  }
+  if (!valid || (g != 0 && stage == nullptr)) return;
   if (g == 0) {
     acc[body] = make_float4(ax, ay, az, 0.f);
     if (dt > 0.f || stage != nullptr) v = vel != nullptr ? vel[body] : v;
@@ -913,17 +945,22 @@ __device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int bo
   }
 }
 // ... and the same for a walk with one lane per body
-__device__ __forceinline__ void walk_lane_tail(unsigned int body, const float4 &p, float ax, float ay, float az, float4 *__restrict__ posm,
-                                               float4 *__restrict__ vel, float4 *__restrict__ acc, float dt, float *__restrict__ stage) {
-  acc[body] = make_float4(ax, ay, az, 0.f);
+__device__ __forceinline__ void walk_lane_tail(bool valid, unsigned int body, const float4 &p, float ax, float ay, float az,
+                                               float4 *__restrict__ posm, float4 *__restrict__ vel, float4 *__restrict__ acc, float dt,
+                                               float *__restrict__ stage, unsigned int *__restrict__ next_size) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
-  if ((dt > 0.f || stage != nullptr) && vel != nullptr) v = vel[body];
-  if (dt > 0.f) {
-    v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
-    x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
-    vel[body] = v;
-    posm[body] = x;
+  if (valid) {
+    acc[body] = make_float4(ax, ay, az, 0.f);
+    if ((dt > 0.f || stage != nullptr) && vel != nullptr) v = vel[body];
+    if (dt > 0.f) {
+      v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
+      x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
+      vel[body] = v;
+      posm[body] = x;
+    }
   }
+  note_next_size(next_size, valid, x);                         // (every lane of the wave comes by here)
+  if (!valid) return;
   if (stage != nullptr) {
     float *o = stage + (size_t)body * 10;
     o[0] = x.w; o[1] = x.x; o[2] = x.y; o[3] = x.z; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = ax; o[8] = ay; o[9] = az;
@@ -1144,7 +1181,7 @@ constexpr int kWvGT = 256;                 // four bodies per workgroup
 constexpr int kWvGK = 192;
 __global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                                   float4 *__restrict__ acc, int n, double G, float dt,
-                                                                  float *__restrict__ stage) {
+                                                                  float *__restrict__ stage, unsigned int *__restrict__ next_size) {
   constexpr int kWaves = kWvGT / 64;
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kWaves][kWvGK];
@@ -1162,13 +1199,14 @@ __global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, f
   float ax = 0.f, ay = 0.f, az = 0.f;
   walk_wave<false, kWvGK>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[wave],
                           s_term[wave], nodes, valid, p, G, lane, ax, ay, az);
-  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave]);
+  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave], next_size);
 }
 
 // The same walk for systems whose tree does not go into LDS but that have too few bodies to keep the chip busy with one lane
 // each (bh_walk_lane_kernel): rows of sixteen lanes on the global arrays, no tree copy.
 __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
-                                                              float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage) {
+                                                              float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage,
+                                                              unsigned int *__restrict__ next_size) {
   constexpr int kGroups = kWalkT / kWalkG;
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kGroups][kWalkK];
@@ -1186,7 +1224,7 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float
   float ax = 0.f, ay = 0.f, az = 0.f;
   walk_windows<false>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[group],
                       s_term[group], nodes, valid, p, G, g, (t & 63) - g, ax, ay, az);
-  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group]);
+  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group], next_size);
 }
 
 // What DrawOctreeBoxes hands to DrawDebugBox (.cpp:39-40) from the compact tree: the leaf's box follows from the body's
@@ -1239,8 +1277,10 @@ constexpr int kMergeMaxN = 131072;         // tiles + merge up to here (32 tiles
 
 // What the first workgroup of a frame's first kernel sets up: the root (centre = the previous tree's CoM, half-width = Size as
 // the bounds kernel left it: ComputeCubeSize), the header words this frame counts in, the 43 acceptance thresholds of the walk.
-__device__ __forceinline__ void bh_frame_setup(const SmallTree &T, const float o[3], float sz, float theta, int nthreads) {
+__device__ __forceinline__ void bh_frame_setup(const SmallTree &T, const float o[3], float sz, float theta, int nthreads,
+                                               unsigned int *__restrict__ next_size) {
   const int t = threadIdx.x;
+  if (t < kSizeSlots) next_size[t] = 0u;                      // where this frame's walk leaves the next frame's Size
   if (t == 0) {
     T.root[0] = o[0]; T.root[1] = o[1]; T.root[2] = o[2]; T.root[3] = sz;
     T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
@@ -1256,11 +1296,12 @@ __device__ __forceinline__ void bh_frame_setup(const SmallTree &T, const float o
 
 // Path keys of all bodies, one lane each (both words, body order); the first workgroup also sets the frame up.
 __global__ __launch_bounds__(kB) void bh_keys_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
-                                                     const unsigned int *__restrict__ size_bits, float theta,
-                                                     unsigned long long *__restrict__ key_hi, unsigned long long *__restrict__ key_lo) {
-  const float sz = __uint_as_float(*size_bits);
+                                                     const unsigned int *__restrict__ size_bits, unsigned int *__restrict__ next_size,
+                                                     float theta, unsigned long long *__restrict__ key_hi,
+                                                     unsigned long long *__restrict__ key_lo) {
+  const float sz = frame_size(size_bits);
   float o[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
-  if (blockIdx.x == 0) bh_frame_setup(T, o, sz, theta, kB);
+  if (blockIdx.x == 0) bh_frame_setup(T, o, sz, theta, kB, next_size);
   const int i = blockIdx.x * kB + threadIdx.x;
   if (i >= n) return;
   const float4 p = posm[i];
@@ -1446,15 +1487,16 @@ constexpr unsigned int kRxAgg = 1u << 30, kRxIncl = 2u << 30, kRxVal = (1u << 30
 // atomics cost ~0.8 us each on this part.)
 constexpr int kKhT = 1024;                 // threads: four bodies each
 __global__ __launch_bounds__(kKhT) void bh_keys_hist_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
-                                                            const unsigned int *__restrict__ size_bits, float theta,
+                                                            const unsigned int *__restrict__ size_bits,
+                                                            unsigned int *__restrict__ next_size, float theta,
                                                             unsigned long long *__restrict__ key_hi,
                                                             unsigned long long *__restrict__ key_lo,
                                                             unsigned int *__restrict__ part_hist) {
   __shared__ unsigned int s_h[kRxPasses][kRxBins];
   const int t = threadIdx.x;
-  const float sz = __uint_as_float(*size_bits);
+  const float sz = frame_size(size_bits);
   const float o0[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
-  if (blockIdx.x == 0) bh_frame_setup(T, o0, sz, theta, kKhT);
+  if (blockIdx.x == 0) bh_frame_setup(T, o0, sz, theta, kKhT, next_size);
   for (int q = t; q < kRxPasses * kRxBins; q += kKhT) (&s_h[0][0])[q] = 0u;
   __syncthreads();
 #pragma unroll
@@ -1661,7 +1703,8 @@ constexpr int kWarmWin = 64;               // boundaries a workgroup keeps in LD
 constexpr int kStatusRetry = 3;            // header word 3: the frame was given up by the warm sort; queue it again with the cold one
 
 __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
-                                                            const unsigned int *__restrict__ size_bits, float theta,
+                                                            const unsigned int *__restrict__ size_bits,
+                                                            unsigned int *__restrict__ next_size, float theta,
                                                             const unsigned long long *__restrict__ prev_hi,
                                                             const unsigned int *__restrict__ prev_idx,
                                                             unsigned long long *__restrict__ key_lo, unsigned long long *__restrict__ slot_hi,
@@ -1674,9 +1717,9 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   if (t == 0) s_stop = T.hdr[3];                               // (one thread asks: other workgroups of this launch may be giving the frame up)
   __syncthreads();
   if (s_stop != 0) return;                                     // a frame before this one was refused: nothing of this one happens
-  const float sz = __uint_as_float(*size_bits);
+  const float sz = frame_size(size_bits);
   float o[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
-  if (w == 0) bh_frame_setup(T, o, sz, theta, kB);
+  if (w == 0) bh_frame_setup(T, o, sz, theta, kB, next_size);
   // bucket(h) = the largest j in 1 .. nb - 1 with boundary j <= h, or 0; the window: boundaries jlo .. jhi around this workgroup's own
   const int jlo = max(1, w - (kWarmWin / 2 - 1)), jhi = min(nb - 1, w + kWarmWin / 2);
   const int nwin = jhi - jlo + 1;
@@ -2125,16 +2168,17 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
 // 4-byte load, the squared distance and a compare per node (accept_threshold); root, double-precision factor and the three
 // multiply-adds only where a term is added.
 __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
-                                                          float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage) {
+                                                          float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage,
+                                                          unsigned int *__restrict__ next_size) {
 #pragma clang fp contract(off)
   __shared__ float s_thr[kMaxLevels + 2];
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   if (threadIdx.x <= kMaxLevels) s_thr[threadIdx.x] = T.thr[threadIdx.x];
   __syncthreads();
   const int k = blockIdx.x * kB + threadIdx.x;
-  if (k >= n) return;
-  const int nodes = T.hdr[0];
-  const unsigned int body = T.sidx[k];
+  const bool valid = k < n;
+  const int nodes = valid ? T.hdr[0] : 0;
+  const unsigned int body = valid ? T.sidx[k] : 0u;
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   int node = 0;
@@ -2154,7 +2198,7 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
     }
     node = (take || d2 == 0.f) ? past : node + 1;              // ... and ends the subtree; children 0..7 otherwise
   }
-  walk_lane_tail(body, p, ax, ay, az, posm, vel, acc, dt, stage);
+  walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, next_size);
 }
 
 
@@ -2165,8 +2209,10 @@ struct BhState {
   bool small = false;          // n <= kSmBodies: one workgroup builds the tree in LDS (bh_small_build_kernel)
   SmallTree st{};              // the compact tree (either path)
   int frames_seen = 0;         // st.hdr[4] at the last bh_collect
-  unsigned int *size_words = nullptr;   // larger systems: two device words for ComputeCubeSize that take turns (zero since creation)
+  unsigned int *size_words = nullptr;   // larger systems: two sets of kSizeSlots device words for ComputeCubeSize that take turns (frame_size)
   int size_word = 0;
+  bool size_ready = false;              // the previous frame's walk left this frame's Size there, and nothing has moved a body since
+  bool external = false;                // the caller holds the position buffer: bodies may move behind the library's back
   // path keys (larger systems): klo = the second key words in body order (SmallTree::klo, klo_by_body); khi / idx
   // end up holding the sorted first key words and bodies (SmallTree::khi, ::sidx), khi2 / idx2 are the sorts' other buffers
   unsigned long long *khi = nullptr, *klo = nullptr, *khi2 = nullptr;
@@ -2245,8 +2291,8 @@ hipError_t bh_create(BhState **out, int n) {
   t.khi = b->khi; t.klo = b->klo; t.sidx = b->idx; t.hdr = b->counters; t.root = b->root; t.prev_com = b->prev_com;
   t.cap = b->node_cap;
   if (b->small) return hipSuccess;
-  BH_TRY(hipMalloc(&b->size_words, 2 * sizeof(unsigned int)));
-  BH_TRY(hipMemset(b->size_words, 0, 2 * sizeof(unsigned int)));
+  BH_TRY(hipMalloc(&b->size_words, 2 * kSizeSlots * sizeof(unsigned int)));
+  BH_TRY(hipMemset(b->size_words, 0, 2 * kSizeSlots * sizeof(unsigned int)));
   BH_TRY(hipMalloc(&b->khi2, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
   t.klo_by_body = 1;           // the second key words stay where the key kernel put them (second_word())
@@ -2319,10 +2365,18 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   float4 *posm = (float4 *)posm_v;
   const int n = b->n;
   const dim3 blk(kB), grd((n + kB - 1) / kB);
-  // ComputeCubeSize (.cpp:47-56) into one of two words that take turns: the launch clears the other one for the next frame
-  unsigned int *cur = b->size_words + b->size_word, *nxt = b->size_words + (b->size_word ^ 1);
+  // ComputeCubeSize (.cpp:47-56): the previous frame's walk has left it in this frame's slot words when that frame moved the
+  // bodies and nothing else has since (size_ready); otherwise a pass over the positions.  The frame's first kernel clears the
+  // other set of words, where this frame's walk (dt > 0) leaves the next frame's.
+  unsigned int *cur = b->size_words + (size_t)b->size_word * kSizeSlots, *nxt = b->size_words + (size_t)(b->size_word ^ 1) * kSizeSlots;
   b->size_word ^= 1;
-  BH_TRY(launch_bounds(0 /* NBODY_PREC_F32 */, posm, 0, n, cur, s, nxt));
+  static const bool size_off = [] { const char *e = getenv("NBODY_BH_SIZE_FROM_WALK"); return e && e[0] == '0'; }();   // A/B, tests
+  if (!(b->size_ready && !b->external && !size_off)) {
+    BH_TRY(hipMemsetAsync(cur, 0, kSizeSlots * sizeof(unsigned int), s));
+    BH_TRY(launch_bounds(0 /* NBODY_PREC_F32 */, posm, 0, n, cur, s, nullptr));
+  }
+  unsigned int *next_size = dt > 0.0f ? nxt : nullptr;         // (a pass that moves nothing leaves nothing)
+  b->size_ready = dt > 0.0f;
   const unsigned int *size_bits = cur;
   // The order of the 126-bit keys (see "the larger systems' own sort" above).  Either way the sorted first key words end up in
   // b->khi, the bodies in b->idx, and the second key words, still in body order, in b->klo.
@@ -2334,11 +2388,11 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
     unsigned int *gc = b->gcount + (size_t)b->gturn * b->nb, *gc_next = b->gcount + (size_t)(b->gturn ^ 1) * b->nb;
     b->gturn ^= 1;
     b->warm_frames += 1;
-    hipLaunchKernelGGL(bh_keys_bucket_kernel, dim3(b->nb), blk, 0, s, T, posm, n, size_bits, theta, b->khi, b->idx, b->klo, b->slot_hi,
+    hipLaunchKernelGGL(bh_keys_bucket_kernel, dim3(b->nb), blk, 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->idx, b->klo, b->slot_hi,
                        b->slot_idx, gc, b->nb);
     hipLaunchKernelGGL(bh_bucket_sort_kernel, dim3(b->nb), dim3(kBsT), 0, s, T, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->klo, b->khi, b->idx);
   } else if (!b->radix) {
-    hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, T, posm, n, size_bits, theta, b->khi, b->klo);
+    hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->klo);
     const int ts = b->tile_size, tiles = (n + ts - 1) / ts;
     if (ts == 1024) hipLaunchKernelGGL(bh_tile_sort_kernel<1024>, dim3(tiles), dim3(kTsT), 0, s, n, b->khi, b->klo, b->khi2, b->idx2);
     else if (ts == 2048) hipLaunchKernelGGL(bh_tile_sort_kernel<2048>, dim3(tiles), dim3(kTsT), 0, s, n, b->khi, b->klo, b->khi2, b->idx2);
@@ -2349,7 +2403,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   } else {
     const int tiles = (n + kRxTile - 1) / kRxTile;
     BH_TRY(hipMemsetAsync(b->rx_desc, 0, b->rx_desc_bytes, s));
-    hipLaunchKernelGGL(bh_keys_hist_kernel, dim3(tiles), dim3(kKhT), 0, s, T, posm, n, size_bits, theta, b->khi, b->klo, b->part_hist);
+    hipLaunchKernelGGL(bh_keys_hist_kernel, dim3(tiles), dim3(kKhT), 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->klo, b->part_hist);
     hipLaunchKernelGGL(bh_hist_reduce_kernel, dim3(kRxPasses, kRxSlices), dim3(kRxBins), 0, s, b->part_hist, tiles, b->slice_hist);
     const int pass_grid = std::min(tiles, b->rx_resident);        // all workgroups of a pass resident at once (bh_radix_pass_kernel)
     for (int d = 0; d < kRxPasses; ++d) {                        // eight passes: the keys are back in b->khi / b->idx at the end
@@ -2397,12 +2451,12 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   static const int wave_max_n = [] { const char *e = getenv("NBODY_BH_WAVE_MAX_N"); return e && *e ? atoi(e) : kWaveMaxN; }();
   if (n <= wave_max_n && n <= rows_max_n && bh_wave_walk())
     hipLaunchKernelGGL(bh_walk_wave_rows_kernel, dim3((n + kWvGT / 64 - 1) / (kWvGT / 64)), dim3(kWvGT), 0, s, b->st, posm, (float4 *)vel,
-                       (float4 *)acc_v, n, G, dt, stage);
+                       (float4 *)acc_v, n, G, dt, stage, next_size);
   else if (n <= rows_max_n)
     hipLaunchKernelGGL(bh_walk_rows_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, posm, (float4 *)vel,
-                       (float4 *)acc_v, n, G, dt, stage);
+                       (float4 *)acc_v, n, G, dt, stage, next_size);
   else
-    hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, n, G, dt, stage);
+    hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, n, G, dt, stage, next_size);
   b->warm = true;                                               // b->khi / b->idx hold an order the next frame can start from
   return hipGetLastError();
 }
@@ -2451,6 +2505,7 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
     const int left = b->last.queued - now;
     b->last.queued = 0;
     b->retries += 1;
+    b->size_ready = false;                                       // (the given-up frame's walk left nothing)
     BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
     BH_TRY(hipMemsetAsync(b->gcount, 0, sizeof(unsigned int) * 2 * (size_t)b->nb, s));
     b->warm = false;
@@ -2459,6 +2514,7 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
       BH_TRY(bh_frame(b, a.posm, a.vel, a.acc, a.theta, a.G, a.dt, a.keep_root, k == left - 1 ? a.stage : nullptr, s));
   }
   b->last.queued = 0;
+  if (b->h_counters[3] != 0) b->size_ready = false;            // a refused frame's walk left nothing either
   *status = b->h_counters[3];
   if (frames) *frames = built;
   if (b->h_counters[4] > 0) {
@@ -2469,8 +2525,14 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
   return hipSuccess;
 }
 
+// a body has been moved by something other than a frame's walk (an upload, the two-kernel update): the next frame looks at the positions itself
+void bh_positions_changed(BhState *b) { b->size_ready = false; }
+// the caller holds the position buffer from now on (nbody_device_buffer): every frame looks at the positions itself
+void bh_positions_external(BhState *b) { b->external = true; }
+
 hipError_t bh_reset_root(BhState *b, hipStream_t s) {
-  b->warm = false;                                              // a new scene: the previous order says nothing about it
+  b->warm = false;
+  b->size_ready = false;                                              // a new scene: the previous order says nothing about it
   return hipMemsetAsync(b->prev_com, 0, sizeof(float) * 3, s);
 }
 

@@ -29,4 +29,10 @@ with nb.NBodyEngine(n, theta=theta) as e:
         e.synchronize()
         best = min(best, (time.perf_counter() - t0) / k)
     st = e.bh_stats() if theta > 0 else {'nodes': 0, 'levels': 0}
-print(f"N={n} theta={theta} mode={mode}: {best * 1e6:.1f} us per frame (best of 3 runs of {k}); nodes {st['nodes']} levels {st['levels']}", flush=True)
+    import ctypes
+    warm, retries = ctypes.c_longlong(), ctypes.c_longlong()
+    counts = ""
+    if theta > 0 and n > 4096 and e._L.nbody_debug_bh_sort_counts(e._h, ctypes.byref(warm), ctypes.byref(retries)) == 0:
+        counts = f"; {warm.value} frames sorted from the previous order, {retries.value} times frames were queued again"
+    size = e.bounds()
+print(f"N={n} theta={theta} mode={mode}: {best * 1e6:.1f} us per frame (best of 3 runs of {k}); nodes {st['nodes']} levels {st['levels']}{counts}; Size at the end {size:.6g}", flush=True)
