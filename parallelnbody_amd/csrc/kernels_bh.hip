@@ -37,6 +37,11 @@ constexpr int kB = 256;
 constexpr int kLevelsPerKey = 21;
 constexpr int kMaxLevels = 2 * kLevelsPerKey;   // 42
 
+// A workgroup barrier for data handed over in LDS: it waits for this wave's LDS traffic only.  (__syncthreads() also waits for every
+// global store and load the wave has in flight — a round trip to L2, ~1 us, at each barrier behind a store; the stores of these
+// kernels are read by later launches, and loads fetched ahead are meant to stay in flight.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // child centre and size exactly as Octree::Add computes them (.h:71-74)
 __device__ __forceinline__ void child_box(const float o[3], float size, int c, float out[3], float *csize) {
   out[0] = (float)((double)o[0] + (double)size * ((c & 4) ? 0.5 : -0.5));
@@ -214,16 +219,17 @@ __device__ __forceinline__ bool same_prefix(unsigned long long ha, unsigned long
 
 // The end of Octree::ComputeMass for one cell (.h:94-95): CenterOfMass /= TotalMass, or the cell's own box origin when it
 // holds no mass.  (M, cx, cy, cz): the children's masses and mass-weighted centres, summed in octant order.
+// (meta / com may be arrays that hold the nodes from number `off` on: a chunk's nodes in LDS)
 __device__ __forceinline__ float4 cell_com_from_sums(float M, float cx, float cy, float cz, const unsigned int *meta, int m, int l,
-                                                     int div_mode, const float4 *__restrict__ posm, const float *root) {
+                                                     int div_mode, const float4 *__restrict__ posm, const float *root, int off = 0) {
 #pragma clang fp contract(off)
   if (M != 0.f) {
     if (div_mode == 0) { const float rv = 1.0f / M; cx = cx * rv; cy = cy * rv; cz = cz * rv; }
     else { cx = cx / M; cy = cy / M; cz = cz / M; }
   } else {                                                     // CenterOfMass = Origin (.h:95 else branch): the cell's own box
     int c = m + 1;
-    while (!(meta[c] & kLeafBit)) ++c;                          // any body of the cell: its path leads through the cell
-    const float4 p = posm[meta[c] & kLinkMask];
+    while (!(meta[c - off] & kLeafBit)) ++c;                    // any body of the cell: its path leads through the cell
+    const float4 p = posm[meta[c - off] & kLinkMask];
     float o[3] = {root[0], root[1], root[2]};
     float size = root[3];
     for (int lev = 0; lev < l; ++lev) (void)descend_level(p, o, size);
@@ -234,18 +240,18 @@ __device__ __forceinline__ float4 cell_com_from_sums(float M, float cx, float cy
 
 // Octree::ComputeMass of one cell of the compact tree whose children are done (.h:89-95): node m, its word w, level l.
 __device__ __forceinline__ float4 sweep_compact_cell(const float4 *com, const unsigned int *meta, int m, unsigned int w, int l,
-                                                     int div_mode, const float4 *__restrict__ posm, const float *root) {
+                                                     int div_mode, const float4 *__restrict__ posm, const float *root, int off = 0) {
 #pragma clang fp contract(off)
   const int end = (int)(w & kLinkMask);
   float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
   for (int c = m + 1; c != end;) {
-    const float4 ch = com[c];
-    const unsigned int cw = meta[c];
+    const float4 ch = com[c - off];
+    const unsigned int cw = meta[c - off];
     M = M + ch.w;
     cx = cx + ch.w * ch.x; cy = cy + ch.w * ch.y; cz = cz + ch.w * ch.z;
     c = (cw & kLeafBit) ? c + 1 : (int)(cw & kLinkMask);
   }
-  return cell_com_from_sums(M, cx, cy, cz, meta, m, l, div_mode, posm, root);
+  return cell_com_from_sums(M, cx, cy, cz, meta, m, l, div_mode, posm, root, off);
 }
 
 // What the structure phases of bh_small_build_kernel leave in LDS for the node phases: sorted first key words and bodies,
@@ -297,7 +303,7 @@ __device__ __forceinline__ void small_tree_in_lds(const SmallTree &T, float4 *co
     meta[m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)sc.first[upper];
     cells[atomicAdd(&sc.lvl[l], 1)] = (unsigned short)(m0 + q);   // into its level's list (afterwards lvl[l] is the list's END)
   }
-  __syncthreads();                                             // the structure data is dead from here: the CoMs take its place
+  lds_barrier();                                             // the structure data is dead from here: the CoMs take its place
   BH_CLOCK(5);
   const int maxl = *sc.maxl;
 #pragma unroll
@@ -316,7 +322,7 @@ __device__ __forceinline__ void small_tree_in_lds(const SmallTree &T, float4 *co
       for (; c < 8; ++c) kd[c] = (unsigned short)nodes;
     }
   }
-  __syncthreads();
+  lds_barrier();
   BH_CLOCK(6);
   // ---- ComputeMass (.h:89-95), deepest cells first.  Which cells a level has and which nodes their children are needs none of
   // the sums: a thread fetches its cell of the NEXT level and that cell's children's numbers before this level's barrier, so that
@@ -356,7 +362,7 @@ __device__ __forceinline__ void small_tree_in_lds(const SmallTree &T, float4 *co
     if (m >= 0) cell_sums(m, lo_ + t, l, pk);
     for (int k = lo_ + t + kSmT; k < hi_; k += kSmT)            // (a level of more than 1024 cells)
       cell_sums(cells[k], k, l, kids != nullptr ? ((const uint4 *)kids)[k] : make_uint4(0u, 0u, 0u, 0u));
-    __syncthreads();
+    lds_barrier();
   }
   BH_CLOCK(7);
   // ---- hand the tree to the walk
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   if (lane == 0) s_red[wave] = mx;
   if (t == 0) { s_maxl = -1; s_err = 0; }
-  __syncthreads();
+  lds_barrier();
   if (t == 0) {
     float m = s_red[0];
     for (int w = 1; w < kSmT / 64; ++w) m = fmaxf(m, s_red[w]);
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
     T.root[0] = s_root[0]; T.root[1] = s_root[1]; T.root[2] = s_root[2]; T.root[3] = m;
     T.hdr[7] = (int)__float_as_uint(m);                        // Size travels with the verdict (nbody_tick)
   }
-  __syncthreads();
+  lds_barrier();
   if (t >= kSmT - 64 && t - (kSmT - 64) <= kMaxLevels) {        // the opening rule per level, as a threshold on d2 (the
     const int l = t - (kSmT - 64);                             // last wave: it owns the fewest bodies)
     float sz = s_root[3];
@@ -534,10 +540,10 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
     }
     if (t <= kSmSamples + 1) bcnt[t] = 0;
     if (t == 0) { s_tie = 0; s_bmax = 0; }
-    __syncthreads();
+    lds_barrier();
     if (!both) BH_CLOCK(2);
     if (t < nsmp) smp[t] = hiB[sample_body];
-    __syncthreads();
+    lds_barrier();
     {                                                          // a sample's place: the samples before it (equal ones in their own order).
       // 1024 / samples neighbouring lanes share a sample, each looks at its part of the samples, a few DPP adds put it together
       const int parts = kSmT / smp_cap, per = smp_cap / parts;
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
       if (parts == 8) before += __shfl_xor(before, 4, 64);
       if (part == 0 && j < nsmp) spl[before] = mykey;
     }
-    __syncthreads();
+    lds_barrier();
     if (!both) BH_CLOCK(9);
     unsigned int slot[kSmBodies / kSmT], bucket[kSmBodies / kSmT];
 #pragma unroll
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
         slot[r] = (unsigned int)atomicAdd(&bcnt[x], 1);
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (wave < 5) {                                            // where each bucket starts: exclusive scan of the counts (samples + 1 of them)
       const int c = t <= kSmSamples ? bcnt[t] : 0;
       int incl = c, big = c;
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_s_barrier();
     }
-    __syncthreads();
+    lds_barrier();
     if (!both) BH_CLOCK(10);
     if (s_bmax <= kSmBucketMax) {
       // the bodies by bucket (in the order the atomics answered), then every body's place among its bucket's bodies: those
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
         const int i = t + r * kSmT;
         if (i < n) { const int pos = bcnt[bucket[r]] + (int)slot[r]; hiA[pos] = kh[r]; idxA[pos] = (unsigned short)i; }
       }
-      __syncthreads();
+      lds_barrier();
       if (!both) BH_CLOCK(11);
       int place[kSmBodies / kSmT];
 #pragma unroll
@@ -633,7 +639,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
           hiB[place[r]] = kh[r]; idxB[place[r]] = (unsigned short)i;
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (!both) {                                             // two bodies with one place: the second go will tell them apart
 #pragma unroll
         for (int r = 0; r < kSmBodies / kSmT; ++r) { const int i = t + r * kSmT; if (i < n && idxB[place[r]] != (unsigned short)i) s_tie = 1; }
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
         const int i = t + r * kSmT;
         if (i < P) { hiA[i] = kh[r]; idxA[i] = (unsigned short)(i < n ? i : 0xFFFF); }
       }
-      __syncthreads();
+      lds_barrier();
       int cur = 0;
       for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
         const unsigned long long *shi = (const unsigned long long *)(raw + cur * kSmBuf);
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
           dhi[dest] = h; didx[dest] = b;
         }
         if (2 * L <= 64 && 4 * L <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
-        else __syncthreads();
+        else lds_barrier();
       }
       hi = (const unsigned long long *)(raw + cur * kSmBuf);
       idx = (const unsigned short *)(raw + cur * kSmBuf + kSmBodies * 8);
@@ -706,11 +712,11 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
       if (i < n) { T.khi[i] = hi[i]; T.klo[i] = li; T.sidx[i] = idx[i]; }
     }
     if (t < 64) s_lvl[t] = 0;
-    __syncthreads();
+    lds_barrier();
     if (both || s_tie == 0) break;
-    __syncthreads();                                           // everybody has seen the tie flag before the next go clears it
+    lds_barrier();                                           // everybody has seen the tie flag before the next go clears it
   }
-  __syncthreads();
+  lds_barrier();
 #ifdef NBODY_BH_PHASE_CLOCKS
   if (t == 0) T.clocks[14] = s_bmax;                           // the fullest bucket of the sample sort
 #endif
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
     for (int off = 32; off > 0; off >>= 1) deep = max(deep, __shfl_xor(deep, off, 64));
     if (lane == 63) s_scan[wave] = incl;
     if (lane == 0 && deep >= 0) atomicMax(&s_maxl, deep);
-    __syncthreads();
+    lds_barrier();
     int run = incl - sum, total = 0;
     for (int w = 0; w < kSmT / 64; ++w) { const int v = s_scan[w]; if (w < wave) run += v; total += v; }
     nodes = total;
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
       run += c[q];
     }
     if (t == kSmT - 1) first[n] = run;
-    __syncthreads();
+    lds_barrier();
     if (t < 64) {                                              // where each level's list of cells starts
       const int cnt = s_lvl[t];
       int inc = cnt;
@@ -774,7 +780,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
       for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
       s_lvl[t] = inc - cnt;
     }
-    __syncthreads();
+    lds_barrier();
   }
   BH_CLOCK(4);
   const SmallScratch sc = {hi, idx, lo_by_body, first, lcpS, cowner, s_root, &s_maxl, s_lvl};
@@ -1306,9 +1312,8 @@ __global__ __launch_bounds__(kB) void bh_keys_kernel(SmallTree T, const float4 *
   if (i >= n) return;
   const float4 p = posm[i];
   float size = sz;
-  unsigned long long hi = 0, lo = 0;
-  for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
-  for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
+  const bool plain = sz >= 0x1p-58f;
+  const unsigned long long hi = descend_word(p, o, size, plain), lo = descend_word(p, o, size, plain);
   key_hi[i] = hi; key_lo[i] = lo;
 }
 
@@ -1506,9 +1511,8 @@ __global__ __launch_bounds__(kKhT) void bh_keys_hist_kernel(SmallTree T, const f
       const float4 p = posm[i];
       float o[3] = {o0[0], o0[1], o0[2]};
       float size = sz;
-      unsigned long long hi = 0, lo = 0;
-      for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
-      for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
+      const bool plain = sz >= 0x1p-58f;
+      const unsigned long long hi = descend_word(p, o, size, plain), lo = descend_word(p, o, size, plain);
       key_hi[i] = hi; key_lo[i] = lo;
 #pragma unroll
       for (int d = 0; d < kRxPasses; ++d) atomicAdd(&s_h[d][(hi >> (8 * d)) & 0xFFull], 1u);
@@ -1707,7 +1711,7 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
                                                             unsigned int *__restrict__ next_size, float theta,
                                                             const unsigned long long *__restrict__ prev_hi,
                                                             const unsigned int *__restrict__ prev_idx,
-                                                            unsigned long long *__restrict__ key_lo, unsigned long long *__restrict__ slot_hi,
+                                                            unsigned long long *__restrict__ slot_lo, unsigned long long *__restrict__ slot_hi,
                                                             unsigned int *__restrict__ slot_idx, unsigned int *__restrict__ gcount, int nb) {
   static_assert(kWarmMu == kB, "a workgroup visits one bucket's worth of places");
   __shared__ unsigned long long s_b[kWarmWin];                 // boundaries jlo .. jhi: the previous order's keys at places 256 j
@@ -1729,16 +1733,15 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   const int i = w * kB + t;
   const bool valid = i < n;
   unsigned int body = 0u, local = 0u;
-  unsigned long long hi = 0ull;
+  unsigned long long hi = 0ull, lo = 0ull;
   int bucket = 0, q = -1;
   if (valid) {
     body = prev_idx[i];
     const float4 p = posm[body];
     float size = sz;
-    unsigned long long lo = 0ull;
-    for (int l = 0; l < kLevelsPerKey; ++l) hi = (hi << 3) | (unsigned long long)descend_level(p, o, size);
-    for (int l = 0; l < kLevelsPerKey; ++l) lo = (lo << 3) | (unsigned long long)descend_level(p, o, size);
-    key_lo[body] = lo;
+    const bool plain = sz >= 0x1p-58f;
+    hi = descend_word(p, o, size, plain);
+    lo = descend_word(p, o, size, plain);                       // (goes with the body into its slot: no scattered store by body)
     int x = 0, y = nwin;                                       // boundaries of the window that are <= hi
     while (x < y) { const int mid = (x + y) >> 1; if (s_b[mid] <= hi) x = mid + 1; else y = mid; }
     if (x == 0 && jlo > 1) {                                   // below the window: the boundaries 1 .. jlo - 1, in global memory
@@ -1762,20 +1765,25 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   const unsigned int pos = q >= 0 ? s_base[q] + local : atomicAdd(&gcount[bucket], 1u);
   if (pos >= (unsigned int)kWarmCap) { T.hdr[3] = kStatusRetry; return; }
   slot_hi[(size_t)bucket * kWarmCap + pos] = hi;
+  slot_lo[(size_t)bucket * kWarmCap + pos] = lo;
   slot_idx[(size_t)bucket * kWarmCap + pos] = body;
 }
 
-constexpr int kBsT = 512;                  // threads of a bucket's workgroup: one per element of the padded bucket
+constexpr int kBsP = 512;                  // the padded bucket at most
+// kBsT threads: 512 — an element each — where the buckets are few and what counts is one bucket's way through the rounds
+// (N = 65536: 14.2 us against 19.0 with 256); 256 — two elements each — where there are thousands of them (2^20: 47.5 against 53.1)
+template <int kBsT>
 __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int nb, const unsigned int *__restrict__ gcount,
                                                               unsigned int *__restrict__ gcount_next,
                                                               const unsigned long long *__restrict__ slot_hi,
                                                               const unsigned int *__restrict__ slot_idx,
-                                                              const unsigned long long *__restrict__ klo_body,
-                                                              unsigned long long *__restrict__ out_hi, unsigned int *__restrict__ out_idx) {
-  static_assert(kWarmCap <= kBsT, "one thread per element");
-  __shared__ unsigned long long s_hi[2][kBsT];
-  __shared__ unsigned short s_ix[2][kBsT];
-  __shared__ unsigned int s_body[kBsT];
+                                                              const unsigned long long *__restrict__ slot_lo,
+                                                              unsigned long long *__restrict__ out_hi, unsigned int *__restrict__ out_idx,
+                                                              unsigned long long *__restrict__ out_lo) {
+  static_assert(kWarmCap <= kBsP && kBsP % kBsT == 0, "whole rounds of the workgroup");
+  __shared__ unsigned long long s_hi[2][kBsP];
+  __shared__ unsigned short s_ix[2][kBsP];
+  __shared__ unsigned int s_body[kBsP];
   __shared__ unsigned int s_part[kBsT / 64];
   if (T.hdr[3] != 0) return;                                   // the frame was given up (or an earlier one refused)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
@@ -1790,11 +1798,11 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
   if (t == 0) gcount_next[b] = 0u;                             // the next frame counts there
   int P = 64;
   while (P < cnt) P <<= 1;
-  if (t < P) {
-    const bool in = t < cnt;
-    s_hi[0][t] = in ? slot_hi[(size_t)b * kWarmCap + t] : ~0ull;
-    s_ix[0][t] = (unsigned short)t;
-    s_body[t] = in ? slot_idx[(size_t)b * kWarmCap + t] : 0xFFFFFFFFu;
+  for (int e = t; e < P; e += kBsT) {
+    const bool in = e < cnt;
+    s_hi[0][e] = in ? slot_hi[(size_t)b * kWarmCap + e] : ~0ull;
+    s_ix[0][e] = (unsigned short)e;
+    s_body[e] = in ? slot_idx[(size_t)b * kWarmCap + e] : 0xFFFFFFFFu;
   }
   __syncthreads();
   unsigned int start = 0u;
@@ -1803,20 +1811,20 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
   // the partner run — left run: partner elements strictly before it; right run: partner elements not after it (stable)
   int cur = 0;
   for (int L = 1, lg = 0; L < P; L <<= 1, ++lg, cur ^= 1) {
-    if (t < P) {
-      const int run = t >> lg, pos = t & (L - 1);
+    for (int e = t; e < P; e += kBsT) {
+      const int run = e >> lg, pos = e & (L - 1);
       const bool left = (run & 1) == 0;
       const int pbase = (run ^ 1) * L;
-      const unsigned long long h = s_hi[cur][t];
-      const unsigned short ix = s_ix[cur][t];
+      const unsigned long long h = s_hi[cur][e];
+      const unsigned short ix = s_ix[cur][e];
       int x = 0, y = L;
       while (x < y) {
         const int mid = (x + y) >> 1;
         const unsigned long long hp = s_hi[cur][pbase + mid];
         bool before = hp < h;
         if (hp == h) {                                         // the whole first key word agrees (rare): the second words decide
-          const unsigned int bp = s_body[s_ix[cur][pbase + mid]], bm = s_body[ix];
-          const unsigned long long lp = bp == 0xFFFFFFFFu ? ~0ull : klo_body[bp], lm = bm == 0xFFFFFFFFu ? ~0ull : klo_body[bm];
+          const int ip = s_ix[cur][pbase + mid];
+          const unsigned long long lp = ip >= cnt ? ~0ull : slot_lo[(size_t)b * kWarmCap + ip], lm = ix >= cnt ? ~0ull : slot_lo[(size_t)b * kWarmCap + ix];
           before = left ? lp < lm : lp <= lm;
         }
         if (before) x = mid + 1; else y = mid;
@@ -1824,10 +1832,13 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
       const int dest = (run & ~1) * L + pos + x;
       s_hi[cur ^ 1][dest] = h; s_ix[cur ^ 1][dest] = ix;
     }
-    if (2 * L <= 64 && 4 * L <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    if (2 * L <= 64 && 4 * L <= 64 && P <= kBsT) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
     else __syncthreads();
   }
-  if (t < cnt) { out_hi[start + t] = s_hi[cur][t]; out_idx[start + t] = s_body[s_ix[cur][t]]; }
+  for (int e = t; e < cnt; e += kBsT) {                        // (the second key words follow into key order: SmallTree::klo_by_body == 0)
+    const int ix = s_ix[cur][e];
+    out_hi[start + e] = s_hi[cur][e]; out_idx[start + e] = s_body[ix]; out_lo[start + e] = slot_lo[(size_t)b * kWarmCap + ix];
+  }
 }
 
 // digits two path keys share (0 .. 42; 42: the same path all the way down)
@@ -1852,7 +1863,13 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
                                                          int *__restrict__ first_local, int *__restrict__ block_sum) {
   __shared__ int s_w[kB / 64];
   __shared__ int s_m[kB / 64];
+  __shared__ int s_stop;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // a frame the warm sort gave up (or one queued behind a refused frame) has no order to look at — and must keep its verdict: one
+  // thread asks (other workgroups of this launch may be refusing the frame right now)
+  if (t == 0) s_stop = T.hdr[3];
+  __syncthreads();
+  if (s_stop != 0) return;
   const int i0 = (blockIdx.x * kB + t) * bpt;                  // this thread's bodies: i0 .. i0 + bpt - 1, in key order
   int sum = 0, deep = -1;
   auto shared_at = [&](unsigned long long ha, int ia, unsigned long long hb, int ib) {   // digits the bodies at sorted positions ia, ib share
@@ -2053,25 +2070,43 @@ __device__ __forceinline__ int deepest_level(const SmallTree &T, int *s_tmp) {
 // chunk — the cell's first body is in the chunk anyway.  What is left are the cells that reach beyond their chunk's end:
 // at most one per level and chunk (cells of one level are disjoint, and each of these holds body b), noted in
 // straddle[level][chunk] ...
+// Chunks of 256 bodies stage their nodes — the bodies' groups are consecutive in preorder — in LDS (up to kChunkNodes<1> of them; a
+// chunk of deep chains stays in global memory): a cell's children are met by following the skip links, a chain of dependent
+// loads per cell and level — from LDS (N = 65536: 16.1 -> 13.8 us).  Chunks of 1024 bodies do not: 80 KB of LDS leave one workgroup
+// of four waves per CU (N = 2^20: 52 -> 96 us).  And only the levels on which the chunk has a cell at all are visited (a mask of
+// its bodies' ladders): about half of the tree's levels for a typical chunk.
+template <int BPT> constexpr int kChunkNodes = BPT == 1 ? 1536 : 1;
 template <int BPT>      // bodies per thread: a chunk is kB * BPT consecutive bodies (thread t owns bodies t, t + kB, ... of it)
 __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                              const int *__restrict__ first, const signed char *__restrict__ lcpS,
                                                              int *__restrict__ straddle, int *__restrict__ kids, int nchunks,
                                                              int div_mode) {
-  __shared__ int s_deep;
+  __shared__ float4 s_com[kChunkNodes<BPT>];
+  __shared__ unsigned int s_meta[kChunkNodes<BPT>];
+  __shared__ unsigned int s_mask[2];
   __shared__ int s_strad[kMaxLevels + 1];
-  const int chunk = blockIdx.x, base = chunk * (kB * BPT);
+  const int chunk = blockIdx.x, base = chunk * (kB * BPT), t = threadIdx.x;
   if (T.hdr[3] != 0) return;                                    // a refused frame (uniform)
-  const int deep = deepest_level(T, &s_deep);
-  if (threadIdx.x <= kMaxLevels) s_strad[threadIdx.x] = -1;
+  if (t <= kMaxLevels) s_strad[t] = -1;
+  if (t < 2) s_mask[t] = 0u;
   int lp[BPT], ln[BPT], m0[BPT];
+  unsigned long long mask = 0ull;                              // the levels this thread's bodies open cells on
 #pragma unroll
   for (int q = 0; q < BPT; ++q) {
-    const int i = base + q * kB + threadIdx.x;
+    const int i = base + q * kB + t;
     lp[q] = i < n ? (int)lcpS[i] : 0; ln[q] = i < n ? (int)lcpS[i + 1] : -1; m0[q] = i < n ? first[i] : 0;
+    if (ln[q] > lp[q]) mask |= ((2ull << ln[q]) - 1ull) & ~((2ull << lp[q]) - 1ull);   // levels lp + 1 .. ln (lp >= -1)
   }
-  const int chunk_end = first[min(base + kB * BPT, n)];        // the first node behind the chunk's bodies
+  const int chunk_start = first[base], chunk_end = first[min(base + kB * BPT, n)];   // the chunk's nodes: [chunk_start, chunk_end)
+  const int nr = chunk_end - chunk_start;
+  const bool in_lds = BPT == 1 && nr <= kChunkNodes<BPT>;
+  if (in_lds)
+    for (int k = t; k < nr; k += kB) { s_com[k] = T.com[chunk_start + k]; s_meta[k] = T.meta[chunk_start + k]; }
+  unsigned int mlo = (unsigned int)mask, mhi = (unsigned int)(mask >> 32);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { mlo |= (unsigned int)__shfl_xor((int)mlo, off, 64); mhi |= (unsigned int)__shfl_xor((int)mhi, off, 64); }
   __syncthreads();
+  if ((t & 63) == 0) { if (mlo) atomicOr(&s_mask[0], mlo); if (mhi) atomicOr(&s_mask[1], mhi); }
   // The cells this chunk's bodies open that reach beyond the chunk — at most one per level — are noted for the second launch
   // together with their children.  A cell's children are met by following the skip links from node m + 1: a chain of
   // dependent loads that needs none of the sums.  So the chains are walked HERE, by all chunks at once and one lane per
@@ -2082,34 +2117,47 @@ __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const 
   for (int q = 0; q < BPT; ++q)
     for (int l = lp[q] + 1; l <= ln[q]; ++l) {
       const int m = m0[q] + (l - lp[q] - 1);
-      if ((int)(T.meta[m] & kLinkMask) > chunk_end) s_strad[l] = m;
+      const unsigned int w = in_lds ? s_meta[m - chunk_start] : T.meta[m];
+      if ((int)(w & kLinkMask) > chunk_end) s_strad[l] = m;
     }
   __syncthreads();
-  if (threadIdx.x <= kMaxLevels) {
-    const int l = threadIdx.x, m = s_strad[l];
+  if (t <= kMaxLevels) {
+    const int l = t, m = s_strad[l];
     straddle[l * nchunks + chunk] = m;
     if (m >= 0) {
       const int end = (int)(T.meta[m] & kLinkMask);
       int *k8 = kids + ((size_t)l * nchunks + chunk) * 8;
       int k = 0;
       for (int c = m + 1; c != end;) {
-        const unsigned int cw = T.meta[c];
+        const unsigned int cw = (in_lds && c < chunk_end) ? s_meta[c - chunk_start] : T.meta[c];
         k8[k++] = c;
         c = (cw & kLeafBit) ? c + 1 : (int)(cw & kLinkMask);
       }
       for (; k < 8; ++k) k8[k] = -1;
     }
   }
-  for (int l = deep; l >= 0; --l) {
+  unsigned long long levels = ((unsigned long long)s_mask[1] << 32) | s_mask[0];
+  while (levels != 0ull) {                                     // deepest level first
+    const int l = 63 - __clzll((long long)levels);
+    levels &= ~(1ull << l);
 #pragma unroll
     for (int q = 0; q < BPT; ++q)
       if (lp[q] < l && l <= ln[q]) {
         const int m = m0[q] + (l - lp[q] - 1);
-        const unsigned int w = T.meta[m];
-        if ((int)(w & kLinkMask) <= chunk_end) T.com[m] = sweep_compact_cell(T.com, T.meta, m, w, l, div_mode, posm, T.root);
+        if (in_lds) {
+          const unsigned int w = s_meta[m - chunk_start];
+          if ((int)(w & kLinkMask) <= chunk_end) {
+            const float4 r = sweep_compact_cell(s_com, s_meta, m, w, l, div_mode, posm, T.root, chunk_start);
+            s_com[m - chunk_start] = r;
+            T.com[m] = r;
+          }
+        } else {
+          const unsigned int w = T.meta[m];
+          if ((int)(w & kLinkMask) <= chunk_end) T.com[m] = sweep_compact_cell(T.com, T.meta, m, w, l, div_mode, posm, T.root);
+        }
       }
-    __threadfence_block();
-    __syncthreads();
+    if (in_lds) lds_barrier();                                   // (the cells' sums go on to global memory without being waited for)
+    else { __threadfence_block(); __syncthreads(); }
   }
 }
 
@@ -2120,6 +2168,11 @@ constexpr int kChunkSweepMaxN = 1 << 20;      // larger systems sweep with a lau
 // bodies per thread of the first launch: as few as keep the chunks within one per thread of the second launch's workgroup
 constexpr int sweep_bpt(int n) { return n <= kTopT * kB ? 1 : 4; }
 static_assert((kChunkSweepMaxN + 4 * kB - 1) / (4 * kB) <= kTopT, "bh_sweep_top_kernel: one chunk per thread");
+// (Round 4 tried to take the levels' hand-over off the way through L2 — the cells computed here entered into an LDS table keyed by
+// (level, node), the final children's sums fetched one and two levels ahead; then a thread per cell instead of per chunk with every
+// cell's children fetched before the level loop: 33 - 37 us at N = 65536 against 24.8 for this form, 78 - 93 against 56 at 2^20.
+// What the loads of this form wait for is memory other XCDs wrote (~1.5 us away), once per level; the table's looks and the
+// cells' numbering cost more than they saved.)
 __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                              const int *__restrict__ straddle, const int *__restrict__ kids,
                                                              int nchunks, int div_mode, int keep_root) {
@@ -2167,6 +2220,9 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
 // Octree::ComputeForces (.h:99-108) on the compact tree, one lane per body in key order, node by node: a 16-byte and a
 // 4-byte load, the squared distance and a compare per node (accept_threshold); root, double-precision factor and the three
 // multiply-adds only where a term is added.
+// (Fetching the NEXT node of the preorder while a node is looked at — the walk goes there whenever it descends or the node is a
+// leaf, two steps in three — was tried in round 4: slower at every size, N = 32768 200 us a frame against 185, 65536 213 / 197,
+// 2^18 316 / 284, 2^20 843 / 710.)
 __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                           float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage,
                                                           unsigned int *__restrict__ next_size) {
@@ -2224,7 +2280,7 @@ struct BhState {
   int rx_resident = 1;                     // workgroups of bh_radix_pass_kernel the device holds at once
   // the sort of a frame that follows a frame (bh_keys_bucket_kernel): slots of kWarmCap bodies per bucket, the buckets' counts (two
   // arrays that take turns), whether b->khi / b->idx hold a previous frame's order, and what bh_collect needs to queue frames again
-  unsigned long long *slot_hi = nullptr;
+  unsigned long long *slot_hi = nullptr, *slot_lo = nullptr, *klo_sorted = nullptr;   // (klo_sorted: a warm frame's second key words, in key order)
   unsigned int *slot_idx = nullptr, *gcount = nullptr;
   int nb = 0, gturn = 0;
   bool warm = false;
@@ -2314,6 +2370,8 @@ hipError_t bh_create(BhState **out, int n) {
   }
   b->nb = (n + kWarmMu - 1) / kWarmMu;
   BH_TRY(hipMalloc(&b->slot_hi, sizeof(unsigned long long) * (size_t)b->nb * kWarmCap));
+  BH_TRY(hipMalloc(&b->slot_lo, sizeof(unsigned long long) * (size_t)b->nb * kWarmCap));
+  BH_TRY(hipMalloc(&b->klo_sorted, sizeof(unsigned long long) * (size_t)n));
   BH_TRY(hipMalloc(&b->slot_idx, sizeof(unsigned int) * (size_t)b->nb * kWarmCap));
   BH_TRY(hipMalloc(&b->gcount, sizeof(unsigned int) * 2 * (size_t)b->nb));
   BH_TRY(hipMemset(b->gcount, 0, sizeof(unsigned int) * 2 * (size_t)b->nb));
@@ -2333,7 +2391,7 @@ hipError_t bh_create(BhState **out, int n) {
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->slot_hi, b->slot_idx, b->gcount, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->slot_hi, b->slot_lo, b->klo_sorted, b->slot_idx, b->gcount, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
@@ -2381,16 +2439,22 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   // The order of the 126-bit keys (see "the larger systems' own sort" above).  Either way the sorted first key words end up in
   // b->khi, the bodies in b->idx, and the second key words, still in body order, in b->klo.
   SmallTree &T = b->st;
-  T.khi = b->khi; T.sidx = b->idx;
+  T.khi = b->khi; T.sidx = b->idx; T.klo = b->klo; T.klo_by_body = 1;
   static const bool warm_off = [] { const char *e = getenv("NBODY_BH_WARM_SORT"); return e && e[0] == '0'; }();   // A/B, tests
   if (b->warm && !warm_off) {
     // a frame that follows a frame: the previous order is almost this frame's (bh_keys_bucket_kernel)
     unsigned int *gc = b->gcount + (size_t)b->gturn * b->nb, *gc_next = b->gcount + (size_t)(b->gturn ^ 1) * b->nb;
     b->gturn ^= 1;
     b->warm_frames += 1;
-    hipLaunchKernelGGL(bh_keys_bucket_kernel, dim3(b->nb), blk, 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->idx, b->klo, b->slot_hi,
+    hipLaunchKernelGGL(bh_keys_bucket_kernel, dim3(b->nb), blk, 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->idx, b->slot_lo, b->slot_hi,
                        b->slot_idx, gc, b->nb);
-    hipLaunchKernelGGL(bh_bucket_sort_kernel, dim3(b->nb), dim3(kBsT), 0, s, T, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->klo, b->khi, b->idx);
+    if (b->nb <= 1024)
+      hipLaunchKernelGGL(bh_bucket_sort_kernel<512>, dim3(b->nb), dim3(512), 0, s, T, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->slot_lo, b->khi, b->idx,
+                         b->klo_sorted);
+    else
+      hipLaunchKernelGGL(bh_bucket_sort_kernel<256>, dim3(b->nb), dim3(256), 0, s, T, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->slot_lo, b->khi, b->idx,
+                         b->klo_sorted);
+    T.klo = b->klo_sorted; T.klo_by_body = 0;                    // (this frame's second key words stand in key order)
   } else if (!b->radix) {
     hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->klo);
     const int ts = b->tile_size, tiles = (n + ts - 1) / ts;
