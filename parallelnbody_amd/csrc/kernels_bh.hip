@@ -2001,11 +2001,27 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
       const int q = k - s_excl, l = s_lp + 1 + q;              // cell of level l whose first body is lane src's
       int upper = n;                                           // first body behind the cell
       if (l > 0) {
-        // the first key whose first l digits exceed the cell's = the first key >= (those digits + 1, then zeros): a lower bound
-        // on the sorted first key words, its first steps on the samples in LDS
+        // Most cells hold a handful of bodies: steps of 1, 2, 4, ... 64 from the cell's first body until one lands outside, then
+        // the halving between the last two — neighbouring keys, a cache line or two (the small systems' cell_end).  A cell of
+        // more than 127 bodies: the first key whose first l digits exceed the cell's = the first key >= (those digits + 1, then
+        // zeros), a lower bound on the sorted first key words, its first steps on the samples in LDS.
         const unsigned long long hs = ((unsigned long long)hh << 32) | hl;
         const int sh = 3 * (kLevelsPerKey - l);
-        upper = lower_bound_sampled(T.khi, n, s_smp, smp_shift, ((hs >> sh) + 1ull) << sh);
+        const unsigned long long pre = hs >> sh;
+        int x = blockIdx.x * kB + (threadIdx.x & ~63) + src, step = 1;   // x: a body of the cell
+        bool found = false;
+        while (step <= 64) {
+          const int j = x + step;
+          if (j >= n || (T.khi[j] >> sh) != pre) { found = true; break; }
+          x = j; step <<= 1;
+        }
+        if (found) {
+          int y = min(x + step, n);                                // the first body behind the cell lies in (x, y]
+          while (y - x > 1) { const int mid = (x + y) >> 1; if ((T.khi[mid] >> sh) == pre) x = mid; else y = mid; }
+          upper = y;
+        } else {
+          upper = lower_bound_sampled(T.khi, n, s_smp, smp_shift, (pre + 1ull) << sh);
+        }
       }
       T.meta[s_m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first_of(upper);
     }
@@ -2354,7 +2370,7 @@ hipError_t bh_create(BhState **out, int n) {
   t.klo_by_body = 1;           // the second key words stay where the key kernel put them (second_word())
   b->radix = n > bh_merge_max_n();
   b->tile_size = bh_tile_size(n);
-  { const int budget = n <= 131072 ? kNodeSmp : 2048;          // many workgroups: a smaller table each (its fill is traffic)
+  { const int budget = n <= 131072 ? kNodeSmp / 4 : 512;       // many workgroups: a smaller table each (its fill is traffic; only cells of more than 127 bodies look at it)
     while ((((n - 1) >> b->smp_shift) + 1) > budget) ++b->smp_shift; }
   if (b->radix) {
     const size_t tiles = (size_t)((n + kRxTile - 1) / kRxTile);

@@ -1,5 +1,6 @@
 """Where one workgroup's tree build spends its time (bh_small_build_kernel, N <= 4096): wall_clock64 stamps at the phase
-boundaries.  Needs a tuning build:   make -C parallelnbody_amd/csrc EXTRA=-DNBODY_BH_PHASE_CLOCKS   (touch kernels_bh.hip first)
+boundaries.  Needs a tuning build next to the shipped library:   make -C parallelnbody_amd/csrc variant NAME=phase_clocks EXTRA=-DNBODY_BH_PHASE_CLOCKS
+    NBODY_AMD_LIB=parallelnbody_amd/libnbody_amd.phase_clocks.so
     python3 tools/bh_phases.py [N]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

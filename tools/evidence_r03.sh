@@ -31,10 +31,10 @@ bash tools/step_by_n.sh "$OUT/whole_step_by_n.txt"
   echo "# the same bodies with distinct masses (general form of the kernels)"
   for n in 8192 16384 32768 65536; do python3 tools/steps_plain.py $n 1000 distinct; done; } > "$OUT/whole_step_no_events.txt" 2>&1
 echo "steps done"
-# last: where the small systems' build kernel spends its time (a tuning build with wall_clock64 stamps; it replaces the library in
-# this scratch copy, so nothing runs after it)
-touch parallelnbody_amd/csrc/kernels_bh.hip parallelnbody_amd/csrc/capi.hip
-make -C parallelnbody_amd/csrc EXTRA=-DNBODY_BH_PHASE_CLOCKS > "$OUT/phase_build.log" 2>&1
-{ python3 tools/bh_phases.py 2000; python3 tools/bh_phases.py 4096; } > "$OUT/bh_build_phases.txt" 2>&1
+# last: where the small systems' build kernel spends its time — a tuning build with wall_clock64 stamps, built NEXT TO the shipped
+# library (make variant: its own objects, its own .so), so that whatever runs from this checkout afterwards still tests the product
+make -C parallelnbody_amd/csrc variant NAME=phase_clocks EXTRA=-DNBODY_BH_PHASE_CLOCKS > "$OUT/phase_build.log" 2>&1 || { echo "phase-clock build failed"; exit 1; }
+{ NBODY_AMD_LIB=$ROOT/parallelnbody_amd/libnbody_amd.phase_clocks.so python3 tools/bh_phases.py 2000
+  NBODY_AMD_LIB=$ROOT/parallelnbody_amd/libnbody_amd.phase_clocks.so python3 tools/bh_phases.py 4096; } > "$OUT/bh_build_phases.txt" 2>&1
 echo "phases done"
 ls "$OUT"
