@@ -61,10 +61,10 @@ __device__ __forceinline__ float frame_size(const unsigned int *__restrict__ siz
   for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned int)__shfl_xor((int)v, off, 64));
   return __uint_as_float(v);
 }
-// x: the position a lane's body has moved to (mine: the lane has one); the wave's largest |coordinate| goes to the workgroup's slot
-__device__ __forceinline__ void note_next_size(unsigned int *__restrict__ next_size, bool mine, const float4 &x) {
+// (x, y, z): the position a lane's body has moved to (mine: the lane has one); the wave's largest |coordinate| goes to the workgroup's slot
+__device__ __forceinline__ void note_next_size(unsigned int *__restrict__ next_size, bool mine, float x, float y, float z) {
   if (next_size == nullptr) return;                            // (uniform)
-  float m = mine ? fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fabsf(x.z)) : 0.0f;   // GetAbsMax (bounds_kernel)
+  float m = mine ? fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) : 0.0f;   // GetAbsMax (bounds_kernel)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) {
@@ -922,20 +922,20 @@ __device__ __forceinline__ void walk_windows(const SmallTree &T, const float4 *s
 __device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int body, const float4 &p, float ax, float ay, float az,
                                               float4 *__restrict__ posm, float4 *__restrict__ vel, float4 *__restrict__ acc, float dt,
                                               float *__restrict__ stage, float *rec, unsigned int *__restrict__ next_size = nullptr) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
   if (next_size != nullptr) {                                  // (larger systems, dt > 0: every lane of the wave comes by here)
+    float nx = 0.f, ny = 0.f, nz = 0.f;                         // where the body is about to go (the same arithmetic as below)
     if (valid && g == 0) {
-      v = vel[body];
-      v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
-      x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
+      const float4 u = vel[body];
+      nx = mul_add_sep(dt, mul_add_sep(dt, ax, u.x), p.x); ny = mul_add_sep(dt, mul_add_sep(dt, ay, u.y), p.y);
+      nz = mul_add_sep(dt, mul_add_sep(dt, az, u.z), p.z);
     }
-    note_next_size(next_size, valid && g == 0, x);
-    v = make_float4(0.f, 0.f, 0.f, 0.f); x = p;
+    note_next_size(next_size, valid && g == 0, nx, ny, nz);
   }
   if (!valid || (g != 0 && stage == nullptr)) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
   if (g == 0) {
     acc[body] = make_float4(ax, ay, az, 0.f);
-    if (dt > 0.f || stage != nullptr) v = vel != nullptr ? vel[body] : v;
+    if ((dt > 0.f || stage != nullptr) && vel != nullptr) v = vel[body];   // (not `vel ? vel[body] : v`: a select of addresses parks v in scratch)
     if (dt > 0.f) {                                            // v += dt*a; x += dt*v, separate multiply and add
       v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
       x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
@@ -965,7 +965,7 @@ __device__ __forceinline__ void walk_lane_tail(bool valid, unsigned int body, co
       posm[body] = x;
     }
   }
-  note_next_size(next_size, valid, x);                         // (every lane of the wave comes by here)
+  note_next_size(next_size, valid, x.x, x.y, x.z);             // (every lane of the wave comes by here)
   if (!valid) return;
   if (stage != nullptr) {
     float *o = stage + (size_t)body * 10;
@@ -2182,6 +2182,8 @@ __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const 
 constexpr int kTopT = 1024;
 constexpr int kChunkSweepMaxN = 1 << 20;      // larger systems sweep with a launch per level (bh_forces)
 // bodies per thread of the first launch: as few as keep the chunks within one per thread of the second launch's workgroup
+// (chunks of 1024 bodies already from N = 65537 — fewer cells left for the second launch — were measured in round 4: frames of
+// N = 98304 233 us against 211, 131072 235 / 217, 262144 282 / 282)
 constexpr int sweep_bpt(int n) { return n <= kTopT * kB ? 1 : 4; }
 static_assert((kChunkSweepMaxN + 4 * kB - 1) / (4 * kB) <= kTopT, "bh_sweep_top_kernel: one chunk per thread");
 // (Round 4 tried to take the levels' hand-over off the way through L2 — the cells computed here entered into an LDS table keyed by
