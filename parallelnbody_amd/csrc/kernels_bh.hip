@@ -1255,14 +1255,14 @@ __global__ __launch_bounds__(kB) void bh_small_leaf_boxes_kernel(SmallTree T, in
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Larger systems (n > kSmBodies): the same compact preorder tree, built by the whole chip — path keys, ONE rocPRIM radix
-// sort on the first key word (two, over the whole 126-bit key, only when neighbours tie in that word), the neighbours' shared
-// digits, an exclusive scan that numbers the nodes, one pass that writes the node words and the leaves, ComputeMass (two
+// Larger systems (n > kSmBodies): the same compact preorder tree, built by the whole chip — path keys and their order (a frame
+// that follows a frame: bh_keys_bucket_kernel + bh_bucket_sort_kernel, from the previous frame's order; a first frame: the cold
+// sorts below; bodies that agree in the whole first key word are ordered by the second), the neighbours' shared digits and
+// the exclusive scan that numbers the nodes (one launch), one pass that writes the node words and the leaves, ComputeMass (two
 // launches up to kChunkSweepMaxN bodies, a launch per level above: body i opens the cell of level l iff
-// lcp(i-1) < l <= lcp(i)), and a walk — sixteen lanes per body on the global arrays up to kRowsMaxN bodies, one lane per
-// body above (enough bodies to hide the loads: the windows buy latency, not throughput).  The host waits ONCE per frame —
-// for the verdict (and the deepest level, which only the launch-per-level form needs on the host), while the scan and the
-// node pass are already running.
+// lcp(i-1) < l <= lcp(i)), and a walk — a wave per body on the global arrays up to kWaveMaxN bodies, sixteen lanes per body up
+// to kRowsMaxN, one lane per body above (enough bodies to hide the loads: the windows buy latency, not throughput) — with the
+// Tick's update and the next frame's Size in it.  Up to kChunkSweepMaxN bodies nothing waits for the host: seven launches a frame.
 //
 // ---------------------------------------------------------------------------------------------------------------------
 // The larger systems' own sort of the path keys (Octree::Add's order, OctreeSearch.h:60-81): 8-byte first key word + 4-byte
