@@ -134,6 +134,9 @@ def lib():
     sig("nbody_save_checkpoint", c_int, vp, ctypes.c_char_p)
     sig("nbody_load_checkpoint", c_int, vp, ctypes.c_char_p, ctypes.POINTER(c_i64))
     sig("nbody_steps_done", c_int, vp, ctypes.POINTER(c_i64))
+    # exported for tests and tuning, not in include/nbody.h
+    sig("nbody_debug_bh_sort_counts", c_int, vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong))
+    sig("nbody_debug_bh_clocks", c_int, vp, ctypes.POINTER(ctypes.c_longlong))
     sig("nbody_ic_reference_box", c_int, c_i32, c_f, fp, ctypes.c_uint64, fp, fp)
     sig("nbody_ic_plummer", c_int, c_i32, c_d, c_d, c_d, ctypes.c_uint64, fp, fp)
     sig("nbody_block_pairs_describe", c_i32, c_i32, c_i32)

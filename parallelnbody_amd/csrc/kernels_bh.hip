@@ -1953,6 +1953,7 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
   __shared__ int s_base[kScanBlocks + 1];
   __shared__ int s_tmp[kB / 64];
   extern __shared__ unsigned long long s_smp[];                // every 2^smp_shift-th sorted first key word (lower_bound_sampled): dynamic LDS
+  if (T.hdr[3] != 0) return;                                   // a frame given up or refused: there is no order to number (uniform: set before this launch)
   const int nblocks = (n + (1 << block_shift) - 1) >> block_shift;
   {
     const int nsmp = (n + (1 << smp_shift) - 1) >> smp_shift;   // eight loads in flight per thread: the fill is a chain of L2 round trips otherwise
