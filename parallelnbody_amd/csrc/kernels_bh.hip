@@ -2213,6 +2213,11 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
     }
   };
   fetch(deep);
+  // A chunk's cells form a ladder of consecutive levels, each the child of the next one up: that child's sum is this thread's own
+  // result of the step before and comes out of a register — a ladder of single-child cells (the levels above a system that fills a
+  // corner of its root box: a runaway body sets Size) then loads nothing at all.
+  int m_own = -1;
+  float4 r_own = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int l = deep; l >= 0; --l) {
     const int m = m_nx;
     const int kid[8] = {ka_nx.x, ka_nx.y, ka_nx.z, ka_nx.w, kb_nx.x, kb_nx.y, kb_nx.z, kb_nx.w};
@@ -2220,12 +2225,17 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
     if (m >= 0) {
       float4 ch[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) ch[k] = T.com[kid[k] >= 0 ? kid[k] : m];   // eight loads in flight (absent children: any address)
+      for (int k = 0; k < 8; ++k) {                              // up to eight loads in flight
+        ch[k] = r_own;
+        if (kid[k] >= 0 && kid[k] != m_own) ch[k] = T.com[kid[k]];
+      }
       float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k)                                // the children in octant order, as sweep_compact_cell adds them
         if (kid[k] >= 0) { M = M + ch[k].w; cx = cx + ch[k].w * ch[k].x; cy = cy + ch[k].w * ch[k].y; cz = cz + ch[k].w * ch[k].z; }
-      T.com[m] = cell_com_from_sums(M, cx, cy, cz, T.meta, m, l, div_mode, posm, T.root);
+      r_own = cell_com_from_sums(M, cx, cy, cz, T.meta, m, l, div_mode, posm, T.root);
+      m_own = m;
+      T.com[m] = r_own;
     }
     __threadfence_block();
     __syncthreads();
