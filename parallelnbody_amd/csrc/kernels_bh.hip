@@ -139,15 +139,8 @@ constexpr int kDbgClocks = 16 + 3 * 512;   // tuning builds: 16 phase stamps + (
 #define BH_CLOCK(k) do { if (threadIdx.x == 0) T.clocks[k] = wall_clock64(); } while (0)
 #define BH_WALK_CLOCK(k) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) T.clocks[k] = wall_clock64(); } while (0)
 #define BH_WALK_COUNT(k, v) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) T.clocks[k] = (v); } while (0)
-#ifdef NBODY_BH_LEVEL_CLOCKS
-#define BH_WG_STAMP(slot) do { } while (0)
-#define BH_LEVEL_CLOCK(l) do { if (threadIdx.x == 0) T.clocks[16 + (l)] = wall_clock64(); } while (0)
-#else
 #define BH_WG_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512) T.clocks[16 + 3 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
-#define BH_LEVEL_CLOCK(l) do { } while (0)
-#endif
 #else
-#define BH_LEVEL_CLOCK(l) do { } while (0)
 #define BH_CLOCK(k) do { } while (0)
 #define BH_WALK_CLOCK(k) do { } while (0)
 #define BH_WALK_COUNT(k, v) do { } while (0)
@@ -357,7 +350,6 @@ __device__ __forceinline__ void small_tree_in_lds(const SmallTree &T, float4 *co
   for (int l = maxl; l >= 0; --l) {
     const int m = m_nx, lo_ = list_end(l - 1), hi_ = list_end(l);
     const uint4 pk = pk_nx;
-    BH_LEVEL_CLOCK(l);
     fetch(l - 1);
     if (m >= 0) cell_sums(m, lo_ + t, l, pk);
     for (int k = lo_ + t + kSmT; k < hi_; k += kSmT)            // (a level of more than 1024 cells)
@@ -800,16 +792,43 @@ template <typename T> __device__ __forceinline__ T mul_add_sep(T a, T b, T c) {
 }
 
 // One accepted node's term of Octree::ComputeForces (.h:104): float(G * M / pow(d, 3)) * (CoM - Pos), d = Dist.
+// The walks are bound by the instructions of this term (N = 2^20: 16 000 per wave), so:
+//  * (CoM - Pos) is taken as -(Pos - CoM), the difference the squared distance was made of: a - b and -(b - a) agree in every bit
+//    except that equal operands give +0 and -0 — and such a term goes into a sum that started at +0 and therefore never is -0, so
+//    adding either zero leaves every bit of it alone;
+//  * the correctly rounded square root is v_sqrt_f32 (one ulp) put right by the two fused residuals the compiler's own sqrtf uses,
+//    without its scaling for arguments below 2^-96 and its special cases, and the double-precision division likewise without its
+//    scaling and special cases: a wave with an argument below 2^-96, an infinite / NaN one or a mass that is not finite in any of
+//    its lanes takes sqrtf and the division themselves.
 __device__ __forceinline__ void force_term(float cx, float cy, float cz, float M, const float4 &p, double G, float &tx, float &ty,
                                            float &tz) {
 #pragma clang fp contract(off)
   const float ex = p.x - cx, ey = p.y - cy, ez = p.z - cz;
   float d2 = ex * ex + ey * ey;
   d2 = d2 + ez * ez;
-  const float d = sqrtf(d2);                                   // FVector::Dist, .h:101 (correctly rounded)
-  const double dd = (double)d;
-  const float s = (float)(G * (double)M / ((dd * dd) * dd));   // (d*d)*d in double = the correctly rounded cube
-  tx = s * (cx - p.x); ty = s * (cy - p.y); tz = s * (cz - p.z);
+  float d, s;                                                  // FVector::Dist, .h:101 (correctly rounded); the scale factor
+  if (__any(!(d2 >= 0x1p-96f) || d2 == __builtin_inff() || !(fabsf(M) <= 0x1.fffffep127f))) {
+    d = sqrtf(d2);
+    const double dd = (double)d;
+    s = (float)(G * (double)M / ((dd * dd) * dd));             // (d*d)*d in double = the correctly rounded cube
+  } else {
+    const float r = __builtin_amdgcn_sqrtf(d2);
+    const float below = __uint_as_float(__float_as_uint(r) - 1u), above = __uint_as_float(__float_as_uint(r) + 1u);
+    const float eb = __builtin_fmaf(-below, r, d2), ea = __builtin_fmaf(-above, r, d2);
+    d = eb <= 0.0f ? below : r;
+    d = ea > 0.0f ? above : d;
+    // ... and the correctly rounded double quotient is the compiler's own sequence — reciprocal, two Newton steps, quotient, one
+    // residual step — without the operand scaling and the special cases that cannot occur here: d in [2^-48, 2^64), so d^3 in
+    // [2^-144, 2^192), G M finite: every value on the way is a normal double (a mass of +-0 gives +0 where the division gives the
+    // mass's sign: a term of +-0 either way, which changes no sum).
+    const double dd = (double)d, den = (dd * dd) * dd, num = G * (double)M;
+    double rc = __builtin_amdgcn_rcp(den);
+    rc = __builtin_fma(rc, __builtin_fma(-den, rc, 1.0), rc);
+    rc = __builtin_fma(rc, __builtin_fma(-den, rc, 1.0), rc);
+    const double q0 = num * rc;
+    s = (float)__builtin_fma(__builtin_fma(-den, q0, num), rc, q0);
+  }
+  tx = s * -ex; ty = s * -ey; tz = s * -ez;
 }
 
 // value of lane (l - N) mod 16 of the same 16-lane row (v_mov_b32_dpp row_ror:N: the row rotates right)
@@ -2275,7 +2294,8 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
     const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
     float d2 = ex * ex + ey * ey;
     d2 = d2 + ez * ez;
-    const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];   // .h:103
+    const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];   // .h:103 (reading the threshold for leaves as well, without
+                                                                       // the branch around it, costs more than the branch: 2^20 737 us a frame against 662)
     if (take && d2 != 0.f) {                                   // .h:102: d == 0 adds nothing ...
       float tx, ty, tz;
       force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
