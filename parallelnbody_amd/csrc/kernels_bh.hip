@@ -2295,7 +2295,8 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
     float d2 = ex * ex + ey * ey;
     d2 = d2 + ez * ez;
     const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];   // .h:103 (reading the threshold for leaves as well, without
-                                                                       // the branch around it, costs more than the branch: 2^20 737 us a frame against 662)
+                                                                       // the branch around it, costs more than the branch: 2^20 737 us a frame against 662;
+                                                                       // x and y as v_pk_*_f32 pairs: 648 against 638)
     if (take && d2 != 0.f) {                                   // .h:102: d == 0 adds nothing ...
       float tx, ty, tz;
       force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
