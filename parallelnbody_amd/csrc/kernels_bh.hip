@@ -118,6 +118,7 @@ struct SmallTree {
   int klo_by_body;
   unsigned int *sidx;           // [n] body at each sorted position = DrawOctreeBoxes' order
   unsigned char *leaf_level;    // [n] level of the leaf of the body at each sorted position
+  int *verdict;                 // page-locked HOST memory: the frame's last kernel copies header words 0 .. 7 there (bh_collect reads them after its wait)
   int *hdr;                     // [0] compact nodes, [1] cells with >= 2 bodies, [2] levels, [3] status (sticky), [4] frames built
   float *root;                  // ox, oy, oz, Size of the current tree
   float *prev_com;              // the previous tree's root CoM = the next tree's root centre (.cpp:77-79)
@@ -129,6 +130,13 @@ struct SmallTree {
 // second key word of the body at sorted position i
 __device__ __forceinline__ unsigned long long second_word(const SmallTree &T, int i) {
   return T.klo_by_body ? T.klo[T.sidx[i]] : T.klo[i];
+}
+
+// The frame's verdict for the host: every walk kernel — a frame's last launch, refused or not — has its first workgroup copy the
+// header's first eight words (node count, cells, levels, status, frames built, ..., Size) into page-locked host memory, so that
+// bh_collect's one wait needs no copy queued behind the frame (~4 us of an actor-style frame).
+__device__ __forceinline__ void hand_verdict(const SmallTree &T) {
+  if (blockIdx.x == 0 && threadIdx.x < 8) T.verdict[threadIdx.x] = T.hdr[threadIdx.x];
 }
 
 constexpr int kHdrDeep = 8, kDeepSlots = 1024;   // header words [8, 1032): the deepest level, one word per slot (larger systems):
@@ -1004,6 +1012,7 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
   __shared__ unsigned int s_list[kGroups][kWalkK];
   __shared__ float4 s_term[kGroups][kWalkK];
   (void)theta;
+  hand_verdict(T);
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   BH_WALK_CLOCK(9);
   BH_WG_STAMP(0);
@@ -1153,6 +1162,7 @@ __global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T,
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned short s_list[kWaves][kWvK];
   __shared__ __attribute__((aligned(16))) float s_term[kWaves][3 * kWvK];
+  hand_verdict(T);
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   BH_WG_STAMP(0);
   const int t = threadIdx.x;
@@ -1211,6 +1221,7 @@ __global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, f
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kWaves][kWvGK];
   __shared__ __attribute__((aligned(16))) float s_term[kWaves][3 * kWvGK];
+  hand_verdict(T);
   if (T.hdr[3] != 0) return;
   const int t = threadIdx.x;
   if (t <= kMaxLevels) s_thr[t] = T.thr[t];
@@ -1236,6 +1247,7 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kGroups][kWalkK];
   __shared__ float4 s_term[kGroups][kWalkK];
+  hand_verdict(T);
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   const int t = threadIdx.x;
   if (t <= kMaxLevels) s_thr[t] = T.thr[t];
@@ -2276,6 +2288,7 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
                                                           unsigned int *__restrict__ next_size) {
 #pragma clang fp contract(off)
   __shared__ float s_thr[kMaxLevels + 2];
+  hand_verdict(T);
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   if (threadIdx.x <= kMaxLevels) s_thr[threadIdx.x] = T.thr[threadIdx.x];
   __syncthreads();
@@ -2347,6 +2360,7 @@ struct BhState {
   hipEvent_t ev = nullptr;                 // larger systems: "the verdict and the deepest level are on the host"
   int *counters = nullptr;     // device: the tree's header (SmallTree::hdr; [5]: deepest level, larger systems)
   int *h_counters = nullptr;   // pinned
+  int *h_verdict = nullptr;    // pinned and mapped: header words 0 .. 7 as the last frame's walk left them (SmallTree::verdict)
   float *root = nullptr;       // ox, oy, oz, size
   float *prev_com = nullptr;   // the previous tree's root CoM (zero before the first frame)
   int last_nodes = 0, last_levels = 0;
@@ -2381,6 +2395,8 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->counters, sizeof(int) * kHdrWords));
   BH_TRY(hipMemset(b->counters, 0, sizeof(int) * kHdrWords));
   BH_TRY(hipHostMalloc(&b->h_counters, sizeof(int) * kHdrWords, hipHostMallocDefault));
+  BH_TRY(hipHostMalloc(&b->h_verdict, sizeof(int) * 8, hipHostMallocMapped));
+  memset(b->h_verdict, 0, sizeof(int) * 8);
   BH_TRY(hipMalloc(&b->root, sizeof(float) * 4));
   BH_TRY(hipMemset(b->root, 0, sizeof(float) * 4));
   BH_TRY(hipMalloc(&b->prev_com, sizeof(float) * 3));
@@ -2395,6 +2411,7 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&t.clocks, sizeof(long long) * kDbgClocks));
   BH_TRY(hipMemset(t.clocks, 0, sizeof(long long) * kDbgClocks));
   t.khi = b->khi; t.klo = b->klo; t.sidx = b->idx; t.hdr = b->counters; t.root = b->root; t.prev_com = b->prev_com;
+  BH_TRY(hipHostGetDevicePointer((void **)&t.verdict, b->h_verdict, 0));
   t.cap = b->node_cap;
   if (b->small) return hipSuccess;
   BH_TRY(hipMalloc(&b->size_words, 2 * kSizeSlots * sizeof(unsigned int)));
@@ -2445,6 +2462,7 @@ void bh_destroy(BhState *b) {
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
+  if (b->h_verdict) (void)hipHostFree(b->h_verdict);
   if (b->ev) (void)hipEventDestroy(b->ev);
   delete b;
 }
@@ -2608,8 +2626,8 @@ float bh_last_size(const BhState *b) { float f; unsigned int u = (unsigned int)b
 hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
   int built = 0;
   for (;;) {
-    BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
-    BH_TRY(hipStreamSynchronize(s));
+    BH_TRY(hipStreamSynchronize(s));                            // (the frames' walks have left the verdict in page-locked memory: hand_verdict)
+    memcpy(b->h_counters, b->h_verdict, sizeof(int) * 8);
     const int now = b->h_counters[4] - b->frames_seen;
     built += now;
     b->frames_seen = b->h_counters[4];
