@@ -500,3 +500,41 @@ def test_frames_queued_behind_a_frame_the_warm_sort_gives_up(nb, oracle):
             com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
         assert e.particles().tobytes() == q.tobytes()
         np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
+
+
+def test_size_of_the_next_frame_comes_out_of_the_walk_only_while_nothing_else_moves_a_body(nb, oracle):
+    # A larger system's walk leaves the NEXT frame's Size (ComputeCubeSize of the positions it has just written) in slot words, so
+    # that the next frame needs no pass over the positions.  Whatever else moves a body in between — the two-call step (force pass,
+    # then the update kernel), records pushed by the host, a position pointer handed out — must send the next frame back to looking
+    # at the positions.  Ten Ticks driven five different ways, with a runaway body that owns Size in some of them: every byte of
+    # the records, Size and the root centre equal the oracle's after each.
+    n = 6000
+    rng = np.random.default_rng(11)
+    posm = _fuzz_scene(rng, n)
+    vel = np.concatenate([rng.uniform(-20, 20, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    vel[7, :3] = (4.0e5, -1.0e5, 2.0e5)                        # body 7 leaves: it is Size from the second frame on
+    q = particles_from(nb, posm, vel)
+    com, size = None, 0.0
+
+    def ref_tick():
+        nonlocal com, size
+        com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        e.step(0.01, 2); ref_tick(); ref_tick()                 # a pass over the positions, then Size out of the first frame's walk
+        assert e.particles().tobytes() == q.tobytes()
+        e.step_begin(); e.step_end(0.01); ref_tick()            # the two-call step: its update kernel moves the bodies
+        assert e.particles().tobytes() == q.tobytes()
+        size_dev, out = e.tick(0.01); ref_tick()                # ... so this frame must look at the positions again
+        assert size_dev == size and out.tobytes() == q.tobytes()
+        q["Position"][7] *= np.float32(0.25); q["Velocity"][7] = 0   # the host pulls the runaway back in: Size shrinks
+        e.push_particles(q)
+        size_dev, out = e.tick(0.01); ref_tick()
+        assert size_dev == size and out.tobytes() == q.tobytes()
+        e.step(0.01, 2); ref_tick(); ref_tick()
+        assert e.particles().tobytes() == q.tobytes()
+        e.device_ptr(nb.BUF_POSM)                              # the caller holds the positions from now on: every frame looks
+        e.step(0.01, 3); ref_tick(); ref_tick(); ref_tick()
+        assert e.particles().tobytes() == q.tobytes()
+        np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
