@@ -948,7 +948,8 @@ __device__ __forceinline__ void walk_windows(const SmallTree &T, const float4 *s
 // ONE instruction — 40 contiguous bytes per body — instead of ten scattered 4-byte stores.
 __device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int body, const float4 &p, float ax, float ay, float az,
                                               float4 *__restrict__ posm, float4 *__restrict__ vel, float4 *__restrict__ acc, float dt,
-                                              float *__restrict__ stage, float *rec, unsigned int *__restrict__ next_size = nullptr) {
+                                              float *__restrict__ stage, float *rec, unsigned int *__restrict__ next_size = nullptr,
+                                              float4 *__restrict__ pos_sorted = nullptr, int k = 0) {
   if (next_size != nullptr) {                                  // (larger systems, dt > 0: every lane of the wave comes by here)
     float nx = 0.f, ny = 0.f, nz = 0.f;                         // where the body is about to go (the same arithmetic as below)
     if (valid && g == 0) {
@@ -969,6 +970,7 @@ __device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int bo
       vel[body] = v;
       posm[body] = x;
     }
+    if (pos_sorted != nullptr) pos_sorted[k] = x;              // the positions in key order, for the next frame's key kernel (larger systems)
   }
   if (stage != nullptr) {
     if (g == 0) { rec[0] = x.w; rec[1] = x.x; rec[2] = x.y; rec[3] = x.z; rec[4] = v.x; rec[5] = v.y; rec[6] = v.z; rec[7] = ax; rec[8] = ay; rec[9] = az; }
@@ -980,7 +982,8 @@ __device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int bo
 // ... and the same for a walk with one lane per body
 __device__ __forceinline__ void walk_lane_tail(bool valid, unsigned int body, const float4 &p, float ax, float ay, float az,
                                                float4 *__restrict__ posm, float4 *__restrict__ vel, float4 *__restrict__ acc, float dt,
-                                               float *__restrict__ stage, unsigned int *__restrict__ next_size) {
+                                               float *__restrict__ stage, unsigned int *__restrict__ next_size,
+                                               float4 *__restrict__ pos_sorted, int k) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
   if (valid) {
     acc[body] = make_float4(ax, ay, az, 0.f);
@@ -991,6 +994,7 @@ __device__ __forceinline__ void walk_lane_tail(bool valid, unsigned int body, co
       vel[body] = v;
       posm[body] = x;
     }
+    pos_sorted[k] = x;                                         // the positions in key order, for the next frame's key kernel: one coalesced store
   }
   note_next_size(next_size, valid, x.x, x.y, x.z);             // (every lane of the wave comes by here)
   if (!valid) return;
@@ -1216,7 +1220,8 @@ constexpr int kWvGT = 256;                 // four bodies per workgroup
 constexpr int kWvGK = 192;
 __global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                                   float4 *__restrict__ acc, int n, double G, float dt,
-                                                                  float *__restrict__ stage, unsigned int *__restrict__ next_size) {
+                                                                  float *__restrict__ stage, unsigned int *__restrict__ next_size,
+                                                                  float4 *__restrict__ pos_sorted) {
   constexpr int kWaves = kWvGT / 64;
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kWaves][kWvGK];
@@ -1235,14 +1240,14 @@ __global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, f
   float ax = 0.f, ay = 0.f, az = 0.f;
   walk_wave<false, kWvGK>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[wave],
                           s_term[wave], nodes, valid, p, G, lane, ax, ay, az);
-  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave], next_size);
+  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave], next_size, pos_sorted, k);
 }
 
 // The same walk for systems whose tree does not go into LDS but that have too few bodies to keep the chip busy with one lane
 // each (bh_walk_lane_kernel): rows of sixteen lanes on the global arrays, no tree copy.
 __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                               float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage,
-                                                              unsigned int *__restrict__ next_size) {
+                                                              unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted) {
   constexpr int kGroups = kWalkT / kWalkG;
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kGroups][kWalkK];
@@ -1261,7 +1266,7 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float
   float ax = 0.f, ay = 0.f, az = 0.f;
   walk_windows<false>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[group],
                       s_term[group], nodes, valid, p, G, g, (t & 63) - g, ax, ay, az);
-  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group], next_size);
+  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group], next_size, pos_sorted, k);
 }
 
 // What DrawOctreeBoxes hands to DrawDebugBox (.cpp:39-40) from the compact tree: the leaf's box follows from the body's
@@ -1740,8 +1745,9 @@ constexpr int kStatusRetry = 3;            // header word 3: the frame was given
 __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                             const unsigned int *__restrict__ size_bits,
                                                             unsigned int *__restrict__ next_size, float theta,
-                                                            const unsigned long long *__restrict__ prev_hi,
+                                                            const unsigned long long *__restrict__ bound,
                                                             const unsigned int *__restrict__ prev_idx,
+                                                            const float4 *__restrict__ prev_pos,
                                                             unsigned long long *__restrict__ slot_lo, unsigned long long *__restrict__ slot_hi,
                                                             unsigned int *__restrict__ slot_idx, unsigned int *__restrict__ gcount, int nb) {
   static_assert(kWarmMu == kB, "a workgroup visits one bucket's worth of places");
@@ -1758,7 +1764,7 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   // bucket(h) = the largest j in 1 .. nb - 1 with boundary j <= h, or 0; the window: boundaries jlo .. jhi around this workgroup's own
   const int jlo = max(1, w - (kWarmWin / 2 - 1)), jhi = min(nb - 1, w + kWarmWin / 2);
   const int nwin = jhi - jlo + 1;
-  if (t < nwin) s_b[t] = prev_hi[(size_t)(jlo + t) * kWarmMu];
+  if (t < nwin) s_b[t] = bound[jlo + t];                       // (the previous order's keys at places 256 j, gathered by its sort: bh_bucket_sort_kernel)
   if (t <= kWarmWin) s_cnt[t] = 0u;
   __syncthreads();
   const int i = w * kB + t;
@@ -1768,7 +1774,9 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   int bucket = 0, q = -1;
   if (valid) {
     body = prev_idx[i];
-    const float4 p = posm[body];
+    // (the previous frame's walk left the positions in its key order — this kernel's order — where nothing else has moved a body
+    // since: a coalesced read instead of a 16-byte record out of every 64-byte sector)
+    const float4 p = prev_pos != nullptr ? prev_pos[i] : posm[body];
     float size = sz;
     const bool plain = sz >= 0x1p-58f;
     hi = descend_word(p, o, size, plain);
@@ -1777,11 +1785,11 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
     while (x < y) { const int mid = (x + y) >> 1; if (s_b[mid] <= hi) x = mid + 1; else y = mid; }
     if (x == 0 && jlo > 1) {                                   // below the window: the boundaries 1 .. jlo - 1, in global memory
       int a = 1, b = jlo;                                      // first boundary in [1, jlo) that is > hi
-      while (a < b) { const int mid = (a + b) >> 1; if (prev_hi[(size_t)mid * kWarmMu] <= hi) a = mid + 1; else b = mid; }
+      while (a < b) { const int mid = (a + b) >> 1; if (bound[mid] <= hi) a = mid + 1; else b = mid; }
       bucket = a - 1;
     } else if (x == nwin && jhi < nb - 1) {                    // above it
       int a = jhi + 1, b = nb;
-      while (a < b) { const int mid = (a + b) >> 1; if (prev_hi[(size_t)mid * kWarmMu] <= hi) a = mid + 1; else b = mid; }
+      while (a < b) { const int mid = (a + b) >> 1; if (bound[mid] <= hi) a = mid + 1; else b = mid; }
       bucket = a - 1;
     } else {
       bucket = jlo - 1 + x;
@@ -1803,6 +1811,13 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
 constexpr int kBsP = 512;                  // the padded bucket at most
 // kBsT threads: 512 — an element each — where the buckets are few and what counts is one bucket's way through the rounds
 // (N = 65536: 14.2 us against 19.0 with 256); 256 — two elements each — where there are thousands of them (2^20: 47.5 against 53.1)
+// After a cold sort: the sorted keys at every 256th place, side by side, for the frame that follows (bh_keys_bucket_kernel's boundaries;
+// a warm frame's bucket sort gathers them itself)
+__global__ __launch_bounds__(kB) void bh_bound_kernel(const unsigned long long *__restrict__ khi, int nb, unsigned long long *__restrict__ bound) {
+  const int j = blockIdx.x * kB + threadIdx.x;
+  if (j < nb) bound[j] = khi[(size_t)j * kWarmMu];
+}
+
 template <int kBsT>
 __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int nb, const unsigned int *__restrict__ gcount,
                                                               unsigned int *__restrict__ gcount_next,
@@ -1810,7 +1825,7 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
                                                               const unsigned int *__restrict__ slot_idx,
                                                               const unsigned long long *__restrict__ slot_lo,
                                                               unsigned long long *__restrict__ out_hi, unsigned int *__restrict__ out_idx,
-                                                              unsigned long long *__restrict__ out_lo) {
+                                                              unsigned long long *__restrict__ out_lo, unsigned long long *__restrict__ bound) {
   static_assert(kWarmCap <= kBsP && kBsP % kBsT == 0, "whole rounds of the workgroup");
   __shared__ unsigned long long s_hi[2][kBsP];
   __shared__ unsigned short s_ix[2][kBsP];
@@ -1869,6 +1884,7 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
   for (int e = t; e < cnt; e += kBsT) {                        // (the second key words follow into key order: SmallTree::klo_by_body == 0)
     const int ix = s_ix[cur][e];
     out_hi[start + e] = s_hi[cur][e]; out_idx[start + e] = s_body[ix]; out_lo[start + e] = slot_lo[(size_t)b * kWarmCap + ix];
+    if (((start + e) & (kWarmMu - 1)) == 0u) bound[(start + e) / kWarmMu] = s_hi[cur][e];   // the next frame's bucket boundaries, side by side
   }
 }
 
@@ -2285,7 +2301,7 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
 // 2^18 316 / 284, 2^20 843 / 710.)
 __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                           float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage,
-                                                          unsigned int *__restrict__ next_size) {
+                                                          unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted) {
 #pragma clang fp contract(off)
   __shared__ float s_thr[kMaxLevels + 2];
   hand_verdict(T);
@@ -2317,7 +2333,7 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
     }
     node = (take || d2 == 0.f) ? past : node + 1;              // ... and ends the subtree; children 0..7 otherwise
   }
-  walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, next_size);
+  walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, next_size, pos_sorted, k);
 }
 
 
@@ -2331,6 +2347,8 @@ struct BhState {
   unsigned int *size_words = nullptr;   // larger systems: two sets of kSizeSlots device words for ComputeCubeSize that take turns (frame_size)
   int size_word = 0;
   bool size_ready = false;              // the previous frame's walk left this frame's Size there, and nothing has moved a body since
+  float4 *pos_sorted = nullptr;         // the positions in the last frame's key order, written by its walk
+  bool pos_ready = false;               // ... and they are what posm[b->idx[i]] holds (nothing else has moved a body or sorted since)
   bool external = false;                // the caller holds the position buffer: bodies may move behind the library's back
   // path keys (larger systems): klo = the second key words in body order (SmallTree::klo, klo_by_body); khi / idx
   // end up holding the sorted first key words and bodies (SmallTree::khi, ::sidx), khi2 / idx2 are the sorts' other buffers
@@ -2343,6 +2361,7 @@ struct BhState {
   int rx_resident = 1;                     // workgroups of bh_radix_pass_kernel the device holds at once
   // the sort of a frame that follows a frame (bh_keys_bucket_kernel): slots of kWarmCap bodies per bucket, the buckets' counts (two
   // arrays that take turns), whether b->khi / b->idx hold a previous frame's order, and what bh_collect needs to queue frames again
+  unsigned long long *bound = nullptr;     // [nb] the sorted keys at places 256 j: the next frame's bucket boundaries
   unsigned long long *slot_hi = nullptr, *slot_lo = nullptr, *klo_sorted = nullptr;   // (klo_sorted: a warm frame's second key words, in key order)
   unsigned int *slot_idx = nullptr, *gcount = nullptr;
   int nb = 0, gturn = 0;
@@ -2437,6 +2456,8 @@ hipError_t bh_create(BhState **out, int n) {
   }
   b->nb = (n + kWarmMu - 1) / kWarmMu;
   BH_TRY(hipMalloc(&b->slot_hi, sizeof(unsigned long long) * (size_t)b->nb * kWarmCap));
+  BH_TRY(hipMalloc(&b->bound, sizeof(unsigned long long) * (size_t)b->nb));
+  BH_TRY(hipMalloc(&b->pos_sorted, sizeof(float4) * (size_t)n));
   BH_TRY(hipMalloc(&b->slot_lo, sizeof(unsigned long long) * (size_t)b->nb * kWarmCap));
   BH_TRY(hipMalloc(&b->klo_sorted, sizeof(unsigned long long) * (size_t)n));
   BH_TRY(hipMalloc(&b->slot_idx, sizeof(unsigned int) * (size_t)b->nb * kWarmCap));
@@ -2458,7 +2479,7 @@ hipError_t bh_create(BhState **out, int n) {
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->slot_hi, b->slot_lo, b->klo_sorted, b->slot_idx, b->gcount, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->bound, b->pos_sorted, b->slot_hi, b->slot_lo, b->klo_sorted, b->slot_idx, b->gcount, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
@@ -2514,14 +2535,15 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
     unsigned int *gc = b->gcount + (size_t)b->gturn * b->nb, *gc_next = b->gcount + (size_t)(b->gturn ^ 1) * b->nb;
     b->gturn ^= 1;
     b->warm_frames += 1;
-    hipLaunchKernelGGL(bh_keys_bucket_kernel, dim3(b->nb), blk, 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->idx, b->slot_lo, b->slot_hi,
+    hipLaunchKernelGGL(bh_keys_bucket_kernel, dim3(b->nb), blk, 0, s, T, posm, n, size_bits, nxt, theta, b->bound, b->idx,
+                       (b->pos_ready && !b->external && !size_off) ? b->pos_sorted : nullptr, b->slot_lo, b->slot_hi,
                        b->slot_idx, gc, b->nb);
     if (b->nb <= 1024)
       hipLaunchKernelGGL(bh_bucket_sort_kernel<512>, dim3(b->nb), dim3(512), 0, s, T, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->slot_lo, b->khi, b->idx,
-                         b->klo_sorted);
+                         b->klo_sorted, b->bound);
     else
       hipLaunchKernelGGL(bh_bucket_sort_kernel<256>, dim3(b->nb), dim3(256), 0, s, T, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->slot_lo, b->khi, b->idx,
-                         b->klo_sorted);
+                         b->klo_sorted, b->bound);
     T.klo = b->klo_sorted; T.klo_by_body = 0;                    // (this frame's second key words stand in key order)
   } else if (!b->radix) {
     hipLaunchKernelGGL(bh_keys_kernel, grd, blk, 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->klo);
@@ -2549,7 +2571,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
     }
     hipLaunchKernelGGL(bh_ties_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->klo);
   }
-  // (the second key words follow in the same order inside bh_lcp_scan_kernel: b->klo is still in body order)
+  if (T.klo_by_body) hipLaunchKernelGGL(bh_bound_kernel, dim3((b->nb + kB - 1) / kB), blk, 0, s, b->khi, b->nb, b->bound);   // (a cold frame)
   const int block = kB * b->scan_bpt;
   hipLaunchKernelGGL(bh_lcp_scan_kernel, dim3((n + block - 1) / block), blk, 0, s, T, n, b->scan_bpt, b->lcpS, b->first_local, b->block_sum);
   hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, sizeof(unsigned long long) * (size_t)(((n - 1) >> b->smp_shift) + 1), s, T, posm, n,
@@ -2583,12 +2605,13 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   static const int wave_max_n = [] { const char *e = getenv("NBODY_BH_WAVE_MAX_N"); return e && *e ? atoi(e) : kWaveMaxN; }();
   if (n <= wave_max_n && n <= rows_max_n && bh_wave_walk())
     hipLaunchKernelGGL(bh_walk_wave_rows_kernel, dim3((n + kWvGT / 64 - 1) / (kWvGT / 64)), dim3(kWvGT), 0, s, b->st, posm, (float4 *)vel,
-                       (float4 *)acc_v, n, G, dt, stage, next_size);
+                       (float4 *)acc_v, n, G, dt, stage, next_size, b->pos_sorted);
   else if (n <= rows_max_n)
     hipLaunchKernelGGL(bh_walk_rows_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, posm, (float4 *)vel,
-                       (float4 *)acc_v, n, G, dt, stage, next_size);
+                       (float4 *)acc_v, n, G, dt, stage, next_size, b->pos_sorted);
   else
-    hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, n, G, dt, stage, next_size);
+    hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, n, G, dt, stage, next_size, b->pos_sorted);
+  b->pos_ready = true;                                          // (every walk writes them, moving or not)
   b->warm = true;                                               // b->khi / b->idx hold an order the next frame can start from
   return hipGetLastError();
 }
@@ -2637,7 +2660,7 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
     const int left = b->last.queued - now;
     b->last.queued = 0;
     b->retries += 1;
-    b->size_ready = false;                                       // (the given-up frame's walk left nothing)
+    b->size_ready = false; b->pos_ready = false;                 // (the given-up frame's walk left nothing)
     BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
     BH_TRY(hipMemsetAsync(b->gcount, 0, sizeof(unsigned int) * 2 * (size_t)b->nb, s));
     b->warm = false;
@@ -2646,7 +2669,7 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
       BH_TRY(bh_frame(b, a.posm, a.vel, a.acc, a.theta, a.G, a.dt, a.keep_root, k == left - 1 ? a.stage : nullptr, s));
   }
   b->last.queued = 0;
-  if (b->h_counters[3] != 0) b->size_ready = false;            // a refused frame's walk left nothing either
+  if (b->h_counters[3] != 0) { b->size_ready = false; b->pos_ready = false; }   // a refused frame's walk left nothing either
   *status = b->h_counters[3];
   if (frames) *frames = built;
   if (b->h_counters[4] > 0) {
@@ -2658,13 +2681,13 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
 }
 
 // a body has been moved by something other than a frame's walk (an upload, the two-kernel update): the next frame looks at the positions itself
-void bh_positions_changed(BhState *b) { b->size_ready = false; }
+void bh_positions_changed(BhState *b) { b->size_ready = false; b->pos_ready = false; }
 // the caller holds the position buffer from now on (nbody_device_buffer): every frame looks at the positions itself
 void bh_positions_external(BhState *b) { b->external = true; }
 
 hipError_t bh_reset_root(BhState *b, hipStream_t s) {
   b->warm = false;
-  b->size_ready = false;                                              // a new scene: the previous order says nothing about it
+  b->size_ready = false; b->pos_ready = false;                                              // a new scene: the previous order says nothing about it
   return hipMemsetAsync(b->prev_com, 0, sizeof(float) * 3, s);
 }
 
