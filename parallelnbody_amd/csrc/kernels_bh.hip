@@ -2134,22 +2134,23 @@ __device__ __forceinline__ int deepest_level(const SmallTree &T, int *s_tmp) {
 // chunk — the cell's first body is in the chunk anyway.  What is left are the cells that reach beyond their chunk's end:
 // at most one per level and chunk (cells of one level are disjoint, and each of these holds body b), noted in
 // straddle[level][chunk] ...
-// Chunks of 256 bodies stage their nodes — the bodies' groups are consecutive in preorder — in LDS (up to kChunkNodes<1> of them; a
-// chunk of deep chains stays in global memory): a cell's children are met by following the skip links, a chain of dependent
-// loads per cell and level — from LDS (N = 65536: 16.1 -> 13.8 us).  Chunks of 1024 bodies do not: 80 KB of LDS leave one workgroup
-// of four waves per CU (N = 2^20: 52 -> 96 us).  And only the levels on which the chunk has a cell at all are visited (a mask of
-// its bodies' ladders): about half of the tree's levels for a typical chunk.
-template <int BPT> constexpr int kChunkNodes = BPT == 1 ? 1536 : 1;
-template <int BPT>      // bodies per thread: a chunk is kB * BPT consecutive bodies (thread t owns bodies t, t + kB, ... of it)
-__global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
+// A chunk stages its nodes — the bodies' groups are consecutive in preorder — in LDS (up to kChunkNodes<NT> of them; a chunk of
+// deep chains stays in global memory): a cell's children are met by following the skip links, a chain of dependent loads per
+// cell and level — from LDS (N = 65536: 16.1 -> 13.8 us).  A thread owns ONE body: chunks of 1024 bodies are workgroups of 1024
+// threads (four bodies to each of 256 threads with 80 KB of LDS left one workgroup of four waves per CU: N = 2^20 52 -> 96 us).  And
+// only the levels on which the chunk has a cell at all are visited (a mask of its bodies' ladders).
+template <int NT> constexpr int kChunkNodes = NT == 256 ? 1536 : 3584;
+template <int NT>       // threads = bodies of a chunk
+__global__ __launch_bounds__(NT) void bh_sweep_chunks_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                              const int *__restrict__ first, const signed char *__restrict__ lcpS,
                                                              int *__restrict__ straddle, int *__restrict__ kids, int nchunks,
                                                              int div_mode) {
-  __shared__ float4 s_com[kChunkNodes<BPT>];
-  __shared__ unsigned int s_meta[kChunkNodes<BPT>];
+  constexpr int BPT = 1;
+  __shared__ float4 s_com[kChunkNodes<NT>];
+  __shared__ unsigned int s_meta[kChunkNodes<NT>];
   __shared__ unsigned int s_mask[2];
   __shared__ int s_strad[kMaxLevels + 1];
-  const int chunk = blockIdx.x, base = chunk * (kB * BPT), t = threadIdx.x;
+  const int chunk = blockIdx.x, base = chunk * NT, t = threadIdx.x;
   if (T.hdr[3] != 0) return;                                    // a refused frame (uniform)
   if (t <= kMaxLevels) s_strad[t] = -1;
   if (t < 2) s_mask[t] = 0u;
@@ -2157,15 +2158,15 @@ __global__ __launch_bounds__(kB) void bh_sweep_chunks_kernel(SmallTree T, const 
   unsigned long long mask = 0ull;                              // the levels this thread's bodies open cells on
 #pragma unroll
   for (int q = 0; q < BPT; ++q) {
-    const int i = base + q * kB + t;
+    const int i = base + q * NT + t;
     lp[q] = i < n ? (int)lcpS[i] : 0; ln[q] = i < n ? (int)lcpS[i + 1] : -1; m0[q] = i < n ? first[i] : 0;
     if (ln[q] > lp[q]) mask |= ((2ull << ln[q]) - 1ull) & ~((2ull << lp[q]) - 1ull);   // levels lp + 1 .. ln (lp >= -1)
   }
-  const int chunk_start = first[base], chunk_end = first[min(base + kB * BPT, n)];   // the chunk's nodes: [chunk_start, chunk_end)
+  const int chunk_start = first[base], chunk_end = first[min(base + NT, n)];   // the chunk's nodes: [chunk_start, chunk_end)
   const int nr = chunk_end - chunk_start;
-  const bool in_lds = BPT == 1 && nr <= kChunkNodes<BPT>;
+  const bool in_lds = nr <= kChunkNodes<NT>;
   if (in_lds)
-    for (int k = t; k < nr; k += kB) { s_com[k] = T.com[chunk_start + k]; s_meta[k] = T.meta[chunk_start + k]; }
+    for (int k = t; k < nr; k += NT) { s_com[k] = T.com[chunk_start + k]; s_meta[k] = T.meta[chunk_start + k]; }
   unsigned int mlo = (unsigned int)mask, mhi = (unsigned int)(mask >> 32);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { mlo |= (unsigned int)__shfl_xor((int)mlo, off, 64); mhi |= (unsigned int)__shfl_xor((int)mhi, off, 64); }
@@ -2593,9 +2594,9 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   } else {
     const int bpt = sweep_bpt(n), nchunks = (n + kB * bpt - 1) / (kB * bpt);
     if (bpt == 1)
-      hipLaunchKernelGGL(bh_sweep_chunks_kernel<1>, dim3(nchunks), blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
+      hipLaunchKernelGGL(bh_sweep_chunks_kernel<kB>, dim3(nchunks), blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
     else
-      hipLaunchKernelGGL(bh_sweep_chunks_kernel<4>, dim3(nchunks), blk, 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
+      hipLaunchKernelGGL(bh_sweep_chunks_kernel<4 * kB>, dim3(nchunks), dim3(4 * kB), 0, s, b->st, posm, n, b->first, b->lcpS, b->straddle, b->kids, nchunks, b->div_mode);
     hipLaunchKernelGGL(bh_sweep_top_kernel, dim3(1), dim3(std::min(kTopT, (nchunks + 63) / 64 * 64)), 0, s, b->st, posm, n, b->straddle, b->kids,
                        nchunks, b->div_mode, keep_root);   // a thread per chunk: few waves, cheap barriers
   }
