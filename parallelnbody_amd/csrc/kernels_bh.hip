@@ -2231,9 +2231,9 @@ __global__ __launch_bounds__(NT) void bh_sweep_chunks_kernel(SmallTree T, const 
 constexpr int kTopT = 1024;
 constexpr int kChunkSweepMaxN = 1 << 20;      // larger systems sweep with a launch per level (bh_forces)
 // bodies per thread of the first launch: as few as keep the chunks within one per thread of the second launch's workgroup
-// (chunks of 1024 bodies already from N = 65537 — fewer cells left for the second launch — were measured in round 4: frames of
-// N = 98304 233 us against 211, 131072 235 / 217, 262144 282 / 282)
-constexpr int sweep_bpt(int n) { return n <= kTopT * kB ? 1 : 4; }
+// chunks of 256 bodies up to N = 98304, of 1024 above: fewer cells are left for the second launch (frames, 256 / 1024: N = 65536
+// 192.8 / 192.4 us, 131072 213.9 / 209.6, 262144 265.4 / 252.0; beyond kTopT * kB bodies the second launch has no thread per 256-body chunk)
+constexpr int sweep_bpt(int n) { return n <= 98304 ? 1 : 4; }
 static_assert((kChunkSweepMaxN + 4 * kB - 1) / (4 * kB) <= kTopT, "bh_sweep_top_kernel: one chunk per thread");
 // (Round 4 tried to take the levels' hand-over off the way through L2 — the cells computed here entered into an LDS table keyed by
 // (level, node), the final children's sums fetched one and two levels ahead; then a thread per cell instead of per chunk with every
