@@ -1723,7 +1723,7 @@ __global__ __launch_bounds__(kB) void bh_ties_kernel(int n, const unsigned long 
 // The sort of a frame that FOLLOWS a frame (round 4): bodies move little in a frame, so the previous frame's key order is
 // almost this frame's.  Two launches:
 //   bh_keys_bucket_kernel   visits the bodies in the previous order, 256 to a workgroup; a body's new first key word is compared
-//                           with the previous frame's sorted keys at every 256th place — the boundaries of n / 256 buckets of 256
+//                           with the previous frame's sorted keys at every 224th place — the boundaries of n / 224 buckets of 224
 //                           consecutive places each — and the body goes into the bucket whose range holds it.  A workgroup's
 //                           bodies lie next to each other in space, so they fall into a handful of neighbouring buckets: the
 //                           boundaries it needs are a window of 64 around its own place (LDS), its bodies are counted per
@@ -1737,7 +1737,8 @@ __global__ __launch_bounds__(kB) void bh_ties_kernel(int n, const unsigned long 
 //                           bodies are sorted in LDS (the merge by rank of bh_tile_sort_kernel; bodies that agree in the whole
 //                           first key word look the second one up) and written to their final places.
 // The counts live in two arrays that take turns: a frame's second kernel clears the array the next frame counts in.
-constexpr int kWarmMu = 256;               // places of the previous order per bucket (= bodies per workgroup of the first kernel)
+constexpr int kWarmMu = 224;               // places of the previous order per bucket: a little under 256, so that a bucket's bodies — their number
+                                           // wanders by a few dozen — almost always fit a padded bucket of 256 in the second kernel (512 otherwise)
 constexpr int kWarmCap = 384;              // slots per bucket
 constexpr int kWarmWin = 64;               // boundaries a workgroup keeps in LDS
 constexpr int kStatusRetry = 3;            // header word 3: the frame was given up by the warm sort; queue it again with the cold one
@@ -1750,7 +1751,7 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
                                                             const float4 *__restrict__ prev_pos,
                                                             unsigned long long *__restrict__ slot_lo, unsigned long long *__restrict__ slot_hi,
                                                             unsigned int *__restrict__ slot_idx, unsigned int *__restrict__ gcount, int nb) {
-  static_assert(kWarmMu == kB, "a workgroup visits one bucket's worth of places");
+
   __shared__ unsigned long long s_b[kWarmWin];                 // boundaries jlo .. jhi: the previous order's keys at places 256 j
   __shared__ unsigned int s_cnt[kWarmWin + 1], s_base[kWarmWin + 1];
   __shared__ int s_stop;
@@ -1762,9 +1763,10 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   float o[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
   if (w == 0) bh_frame_setup(T, o, sz, theta, kB, next_size);
   // bucket(h) = the largest j in 1 .. nb - 1 with boundary j <= h, or 0; the window: boundaries jlo .. jhi around this workgroup's own
-  const int jlo = max(1, w - (kWarmWin / 2 - 1)), jhi = min(nb - 1, w + kWarmWin / 2);
+  const int mid_j = (int)(((long long)w * kB + kB / 2) / kWarmMu);   // the bucket this workgroup's places lie in
+  const int jlo = max(1, mid_j - (kWarmWin / 2 - 1)), jhi = min(nb - 1, mid_j + kWarmWin / 2);
   const int nwin = jhi - jlo + 1;
-  if (t < nwin) s_b[t] = bound[jlo + t];                       // (the previous order's keys at places 256 j, gathered by its sort: bh_bucket_sort_kernel)
+  if (t < nwin) s_b[t] = bound[jlo + t];                       // (the previous order's keys at places 224 j, gathered by its sort: bh_bucket_sort_kernel)
   if (t <= kWarmWin) s_cnt[t] = 0u;
   __syncthreads();
   const int i = w * kB + t;
@@ -1811,7 +1813,7 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
 constexpr int kBsP = 512;                  // the padded bucket at most
 // kBsT threads: 512 — an element each — where the buckets are few and what counts is one bucket's way through the rounds
 // (N = 65536: 14.2 us against 19.0 with 256); 256 — two elements each — where there are thousands of them (2^20: 47.5 against 53.1)
-// After a cold sort: the sorted keys at every 256th place, side by side, for the frame that follows (bh_keys_bucket_kernel's boundaries;
+// After a cold sort: the sorted keys at every 224th place, side by side, for the frame that follows (bh_keys_bucket_kernel's boundaries;
 // a warm frame's bucket sort gathers them itself)
 __global__ __launch_bounds__(kB) void bh_bound_kernel(const unsigned long long *__restrict__ khi, int nb, unsigned long long *__restrict__ bound) {
   const int j = blockIdx.x * kB + threadIdx.x;
@@ -1884,7 +1886,7 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
   for (int e = t; e < cnt; e += kBsT) {                        // (the second key words follow into key order: SmallTree::klo_by_body == 0)
     const int ix = s_ix[cur][e];
     out_hi[start + e] = s_hi[cur][e]; out_idx[start + e] = s_body[ix]; out_lo[start + e] = slot_lo[(size_t)b * kWarmCap + ix];
-    if (((start + e) & (kWarmMu - 1)) == 0u) bound[(start + e) / kWarmMu] = s_hi[cur][e];   // the next frame's bucket boundaries, side by side
+    if ((start + e) % kWarmMu == 0u) bound[(start + e) / kWarmMu] = s_hi[cur][e];   // the next frame's bucket boundaries, side by side
   }
 }
 
@@ -2536,7 +2538,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
     unsigned int *gc = b->gcount + (size_t)b->gturn * b->nb, *gc_next = b->gcount + (size_t)(b->gturn ^ 1) * b->nb;
     b->gturn ^= 1;
     b->warm_frames += 1;
-    hipLaunchKernelGGL(bh_keys_bucket_kernel, dim3(b->nb), blk, 0, s, T, posm, n, size_bits, nxt, theta, b->bound, b->idx,
+    hipLaunchKernelGGL(bh_keys_bucket_kernel, grd, blk, 0, s, T, posm, n, size_bits, nxt, theta, b->bound, b->idx,
                        (b->pos_ready && !b->external && !size_off) ? b->pos_sorted : nullptr, b->slot_lo, b->slot_hi,
                        b->slot_idx, gc, b->nb);
     if (b->nb <= 1024)
