@@ -101,6 +101,7 @@ constexpr int kSmLds = kSmRegionA + kSmNodesLds * 4 + kSmNodesLds * 2;
 constexpr unsigned int kLeafBit = 0x80000000u;
 constexpr int kLevelShift = 25;
 constexpr unsigned int kLinkMask = (1u << kLevelShift) - 1u;
+constexpr int kSmGlobalWalkN = 2560;       // small systems from here on walk the tree in global memory (bh_frame)
 constexpr int kWalkT = 256;                // threads per workgroup of the compact walk
 constexpr int kWalkG = 16;                 // lanes per body there
 constexpr int kWalkK = 48;                 // taken nodes a body lists before their terms are worked out and added
@@ -2634,7 +2635,13 @@ hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, d
   int P = 1;
   while (P < n) P <<= 1;
   hipLaunchKernelGGL(bh_small_build_kernel, dim3(1), dim3(kSmT), 0, s, b->st, (const float4 *)posm, n, P, b->div_mode, keep_root, theta);
-  if (bh_wave_walk())
+  // from kSmGlobalWalkN bodies on the waves walk the tree in its global arrays (the larger systems' kernel): with a 146 KB copy of the
+  // tree a CU holds one workgroup of eight bodies, and more bodies than that need second rounds (frames, LDS / global: N = 2000
+  // 50.5 / 52.8 us, 3000 75.3 / 70.6, 4096 106.2 / 94.0)
+  if (bh_wave_walk() && n >= kSmGlobalWalkN)
+    hipLaunchKernelGGL(bh_walk_wave_rows_kernel, dim3((n + kWvGT / 64 - 1) / (kWvGT / 64)), dim3(kWvGT), 0, s, b->st, (float4 *)posm, (float4 *)vel,
+                       (float4 *)acc, n, G, dt, stage, (unsigned int *)nullptr, (float4 *)nullptr);
+  else if (bh_wave_walk())
     hipLaunchKernelGGL(bh_walk_wave_compact_kernel, dim3((n + kWvT / 64 - 1) / (kWvT / 64)), dim3(kWvT), 0, s, b->st, (float4 *)posm,
                        (float4 *)vel, (float4 *)acc, n, G, dt, stage);
   else
