@@ -124,6 +124,8 @@ struct SmallTree {
   float *root;                  // ox, oy, oz, Size of the current tree
   float *prev_com;              // the previous tree's root CoM = the next tree's root centre (.cpp:77-79)
   float *thr;                   // [kMaxLevels + 2] a cell of level l is accepted (.h:103) iff the squared distance >= thr[l]
+  int *lvl;                     // larger systems, [2][64]: how many chunks leave a cell of level l to ComputeMass' second launch, and how many of
+                                // them leave one of level l - 1 as well (bh_sweep_chunks_kernel counts, bh_sweep_top_kernel skips barriers by them)
   long long *clocks;            // build with -DNBODY_BH_PHASE_CLOCKS: wall_clock64 at the kernels' phase boundaries
   int cap;
 };
@@ -1329,6 +1331,7 @@ __device__ __forceinline__ void bh_frame_setup(const SmallTree &T, const float o
     T.hdr[6] = 0;                                             // no two neighbours agree in the whole first key word yet
     T.hdr[7] = (int)__float_as_uint(sz);                      // Size travels with the verdict (nbody_tick)
   }
+  if (t < 128) T.lvl[t] = 0;                                  // (bh_sweep_chunks_kernel counts there)
   for (int q = t; q < kDeepSlots; q += nthreads) T.hdr[kHdrDeep + q] = -1;   // deepest level with a cell of >= 2 bodies (bh_lcp_scan_kernel)
   if (t <= kMaxLevels) {
     float s_l = sz;
@@ -2192,6 +2195,10 @@ __global__ __launch_bounds__(NT) void bh_sweep_chunks_kernel(SmallTree T, const 
   if (t <= kMaxLevels) {
     const int l = t, m = s_strad[l];
     straddle[l * nchunks + chunk] = m;
+    if (m >= 0) {                                              // (for the second launch: which levels hand a sum from one chunk's thread to another's)
+      atomicAdd(&T.lvl[l], 1);
+      if (l > 0 && s_strad[l - 1] >= 0) atomicAdd(&T.lvl[64 + l], 1);
+    }
     if (m >= 0) {
       const int end = (int)(T.meta[m] & kLinkMask);
       int *k8 = kids + ((size_t)l * nchunks + chunk) * 8;
@@ -2254,21 +2261,33 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
   // node numbers — which depend on none of the sums — are fetched while this level's sums are formed
   const int c = threadIdx.x;
   const bool mine = c < nchunks;
-  int m_nx = -1;
-  int4 ka_nx = make_int4(-1, -1, -1, -1), kb_nx = ka_nx;
-  auto fetch = [&](int l) {
-    m_nx = (mine && l >= 0) ? straddle[l * nchunks + c] : -1;
-    if (m_nx >= 0) {
-      const int4 *k8 = (const int4 *)(kids + ((size_t)l * nchunks + c) * 8);
-      ka_nx = k8[0]; kb_nx = k8[1];
+  // (they come from memory other XCDs wrote, ~1 us away — a whole level's step: so they are asked for THREE levels ahead, and the
+  // loads do not wait for one another: the children's numbers are read whether or not there is a cell)
+  int m_nx = -1, m_n2 = -1, m_n3 = -1;
+  int4 ka_nx = make_int4(-1, -1, -1, -1), kb_nx = ka_nx, ka_n2 = ka_nx, kb_n2 = ka_nx, ka_n3 = ka_nx, kb_n3 = ka_nx;
+  auto fetch = [&](int l) {                                    // shift the queue by a level and ask for level l - 2's
+    m_nx = m_n2; ka_nx = ka_n2; kb_nx = kb_n2;
+    m_n2 = m_n3; ka_n2 = ka_n3; kb_n2 = kb_n3;
+    const int l3 = l - 2;
+    m_n3 = -1;
+    if (mine && l3 >= 0) {
+      m_n3 = straddle[l3 * nchunks + c];
+      const int4 *k8 = (const int4 *)(kids + ((size_t)l3 * nchunks + c) * 8);
+      ka_n3 = k8[0]; kb_n3 = k8[1];
     }
   };
-  fetch(deep);
+  fetch(deep + 2); fetch(deep + 1); fetch(deep);               // levels deep, deep - 1, deep - 2 on their way; level deep's in hand
   // A chunk's cells form a ladder of consecutive levels, each the child of the next one up: that child's sum is this thread's own
   // result of the step before and comes out of a register — a ladder of single-child cells (the levels above a system that fills a
   // corner of its root box: a runaway body sets Size) then loads nothing at all.
   int m_own = -1;
   float4 r_own = make_float4(0.f, 0.f, 0.f, 0.f);
+  // A level's sums must be out in memory before the next level reads them (the store's way to L2 and back: ~1 us a level) — unless
+  // nobody reads another thread's: level l has no cell here, or level l - 1 has none, or each has one and both are one chunk's (its
+  // own register).  The first launch has counted (T.lvl).
+  __shared__ int s_lvl[128];
+  if (threadIdx.x < 128) s_lvl[threadIdx.x] = T.lvl[threadIdx.x];
+  __syncthreads();
   for (int l = deep; l >= 0; --l) {
     const int m = m_nx;
     const int kid[8] = {ka_nx.x, ka_nx.y, ka_nx.z, ka_nx.w, kb_nx.x, kb_nx.y, kb_nx.z, kb_nx.w};
@@ -2288,8 +2307,11 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
       m_own = m;
       T.com[m] = r_own;
     }
-    __threadfence_block();
-    __syncthreads();
+    const int here = s_lvl[l], above = l > 0 ? s_lvl[l - 1] : 0;
+    if (!(here == 0 || above == 0 || (here == 1 && above == 1 && s_lvl[64 + l] == 1))) {
+      __threadfence_block();
+      __syncthreads();
+    }
   }
   if (threadIdx.x == 0) {
     if (!keep_root) { const float4 c = T.com[0]; T.prev_com[0] = c.x; T.prev_com[1] = c.y; T.prev_com[2] = c.z; }   // .cpp:78
@@ -2431,6 +2453,8 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&t.meta, sizeof(unsigned int) * (size_t)b->node_cap));
   BH_TRY(hipMalloc(&t.leaf_level, (size_t)n));
   BH_TRY(hipMalloc(&t.thr, sizeof(float) * (kMaxLevels + 2)));
+  BH_TRY(hipMalloc(&t.lvl, sizeof(int) * 128));
+  BH_TRY(hipMemset(t.lvl, 0, sizeof(int) * 128));
   BH_TRY(hipMalloc(&t.clocks, sizeof(long long) * kDbgClocks));
   BH_TRY(hipMemset(t.clocks, 0, sizeof(long long) * kDbgClocks));
   t.khi = b->khi; t.klo = b->klo; t.sidx = b->idx; t.hdr = b->counters; t.root = b->root; t.prev_com = b->prev_com;
@@ -2484,7 +2508,7 @@ hipError_t bh_create(BhState **out, int n) {
 void bh_destroy(BhState *b) {
   if (!b) return;
   void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->bound, b->pos_sorted, b->slot_hi, b->slot_lo, b->klo_sorted, b->slot_idx, b->gcount, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
-                  b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.clocks};
+                  b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.lvl, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
   if (b->h_verdict) (void)hipHostFree(b->h_verdict);
