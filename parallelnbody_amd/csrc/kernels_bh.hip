@@ -2340,12 +2340,12 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
   const unsigned int body = valid ? T.sidx[k] : 0u;
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
-  unsigned int node = 0u;                                      // (unsigned: 32-bit offsets from the arrays' bases, no sign extension)
-  const unsigned int unodes = (unsigned int)nodes;
-  while (node < unodes) {
+  int node = 0;
+  while (node < nodes) {
     const float4 cm = T.com[node];
     const unsigned int w = T.meta[node];
     const bool leaf = (w & kLeafBit) != 0u;
+    const int past = leaf ? node + 1 : (int)(w & kLinkMask);
     const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
     float d2 = ex * ex + ey * ey;
     d2 = d2 + ez * ez;
@@ -2357,8 +2357,7 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
       force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
       ax = ax + tx; ay = ay + ty; az = az + tz;
     }
-    // ... and ends the subtree; children 0..7 otherwise (behind a leaf stands the next node either way)
-    node = (!leaf && (take || d2 == 0.f)) ? (w & kLinkMask) : node + 1u;
+    node = (take || d2 == 0.f) ? past : node + 1;              // ... and ends the subtree; children 0..7 otherwise
   }
   walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, next_size, pos_sorted, k);
 }
