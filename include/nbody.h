@@ -237,6 +237,9 @@ NBODY_API int nbody_exchange_write_recv(nbody_ctx *ctx, const void *host);
  * 74-89) on the device — same region octree (root centre = previous tree's CoM, half-width = ComputeCubeSize), same
  * mass upsweep, same depth-first walk with `Size/d < Theta`, same arithmetic — instead of the all-pairs kernels.
  * fp32 contexts that own all bodies only.  nbody_set_particles / nbody_set_state_* reset the "previous CoM" to zero.
+ * Systems of more than 4096 bodies sort a frame's path keys starting from the previous frame's order and take its Size out of the
+ * previous frame's walk: a frame whose sort gives up (the records were replaced, the root box jumped) is queued again
+ * by the library at the call's one wait; nothing of it shows but the time.
  */
 NBODY_API int nbody_set_theta(nbody_ctx *ctx, float theta);
 /* The opening angle in force (nbody_params.theta, nbody_set_theta, or what nbody_load_checkpoint took over from a file). */
@@ -266,7 +269,7 @@ NBODY_API int nbody_get_particles(nbody_ctx *ctx, void *aos, size_t stride);
  * ComputeCubeSize of the current positions (.cpp:26) and one Tick body (.cpp:27-31); then the owned FParticle records
  * as nbody_get_particles delivers them (what .cpp:33,41 draws).  size and aos may each be NULL.  Same results as
  * nbody_get_bounds + nbody_step(dt, 1) + nbody_get_particles; not for sharded symmetric contexts (phased step).
- * Systems whose step is a kernel or two (theta = 0 up to 16384 bodies; theta > 0 up to 4096) write the records from that
+ * Systems whose step is a kernel or two (theta = 0 up to 16384 bodies) and every theta > 0 frame (its walk) write the records from that
  * kernel straight into page-locked host memory — into `aos` itself when it lies in a range pinned with
  * nbody_pin_host_buffer (stride 40), so that the frame queues no copy of the mirror at all. */
 NBODY_API int nbody_tick(nbody_ctx *ctx, float dt, float *size, void *aos, size_t stride);
