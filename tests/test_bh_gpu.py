@@ -538,3 +538,35 @@ def test_size_of_the_next_frame_comes_out_of_the_walk_only_while_nothing_else_mo
         e.step(0.01, 3); ref_tick(); ref_tick(); ref_tick()
         assert e.particles().tobytes() == q.tobytes()
         np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
+
+
+@pytest.mark.parametrize("n", [2559, 2560, 4096, 4097, 12288, 12289, 98304, 98305])
+def test_both_sides_of_the_round_four_switches_cold_and_warm(nb, oracle, n):
+    # Sizes on both sides of the theta > 0 path's switches that round 4 added or moved — small systems walking the tree in LDS / in
+    # global memory (2560), the one-workgroup build / the whole chip (4097), a wave / sixteen lanes per body (12289), ComputeMass over
+    # chunks of 256 / 1024 bodies (98305) — each with a first pass (cold sorts, Size from the bounds kernel) and a second one that
+    # starts from the first one's order: accelerations, draw order, node count and root CoM equal the oracle's tree in every bit.
+    rng = np.random.default_rng(n)
+    posm = _fuzz_scene(rng, n)
+    while len(np.unique(posm[:, :3], axis=0)) != n:
+        posm = _fuzz_scene(rng, n)
+    vel = np.zeros((n, 4), np.float32)
+    pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+    try:
+        ref, com, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+    except Exception:                                          # (a scene deeper than the oracle's own limit)
+        pytest.skip("scene too deep for the oracle")
+    _, order = oracle.octree_leaves_f32(pos, m)
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        for _ in range(2):
+            try:
+                e.compute_forces()
+            except nb.NBodyError as err:                          # deeper than 42 levels: the reference would recurse on
+                assert "42" in str(err) or "deep" in str(err).lower(), err
+                pytest.skip("two bodies closer than Size / 2^42")
+            np.testing.assert_array_equal(e.accelerations(), ref)
+            np.testing.assert_array_equal(e.bh_leaf_order(), order)
+            st = e.bh_stats()
+            np.testing.assert_array_equal(st["root_com"], com)
+            assert st["nodes"] == nodes
