@@ -2249,7 +2249,12 @@ static_assert((kChunkSweepMaxN + 4 * kB - 1) / (4 * kB) <= kTopT, "bh_sweep_top_
 // (level, node), the final children's sums fetched one and two levels ahead; then a thread per cell instead of per chunk with every
 // cell's children fetched before the level loop: 33 - 37 us at N = 65536 against 24.8 for this form, 78 - 93 against 56 at 2^20.
 // What the loads of this form wait for is memory other XCDs wrote (~1.5 us away), once per level; the table's looks and the
-// cells' numbering cost more than they saved.)
+// cells' numbering cost more than they saved.  A last form had the first launch list every level's cells as 80-byte records —
+// children, and for each child whether its sum is final in memory or comes from this launch's own level below (then out of an
+// LDS slot per chunk) — with a thread per cell, four cells' records and final sums fetched side by side before the level loop and
+// nothing but LDS reads, the additions, an LDS write and an LDS barrier per level: bit-exact, the launch itself 11.8 us against
+// 14.8 at N = 8192 and 23.6 / 23.4 at 65536, but the frames no faster on one box — 8192 140.5 us against 137.6, 32768 183.0 /
+// 178.9, 65536 193.3 / 191.1, 2^18 246.2 / 245.3: the first launch pays for the tags and the records what the second saves.)
 __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                              const int *__restrict__ straddle, const int *__restrict__ kids,
                                                              int nchunks, int div_mode, int keep_root) {
