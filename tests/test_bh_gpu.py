@@ -540,6 +540,59 @@ def test_size_of_the_next_frame_comes_out_of_the_walk_only_while_nothing_else_mo
         np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
 
 
+def test_bh_fuzz_every_byte_of_the_frames_on_random_scenes(nb, oracle):
+    """Whole Ticks (.cpp:25-31) on random scenes, driven the ways a host drives them: sizes on both sides of every switch of the
+    theta > 0 path, random opening angles and both readings of the CoM division, velocities from a crawl to speeds that tear the
+    previous frame's order apart (the sort that starts from it must then give frames up and queue them again), frames queued
+    several at a time (`step`) or one by one with the mirror and Size (`tick`).  After every call every byte of the records —
+    Position, Velocity, Acceleration, Mass — equals the oracle's, and so do Size and the root centre at the end.
+    NBODY_FUZZ_SEED / NBODY_FUZZ_TRIALS run it longer."""
+    rng = np.random.default_rng(int(os.environ.get("NBODY_FUZZ_SEED", "404")))
+    trials = int(os.environ.get("NBODY_FUZZ_TRIALS", "30"))
+    ran = warm_total = retries_total = 0
+    for trial in range(trials):
+        u = rng.random()
+        n = (int(rng.integers(2, 4097)) if u < 0.3 else int(rng.integers(4097, 21000)) if u < 0.75 else int(rng.integers(21000, 70000)))
+        theta = float(rng.choice([1.0, 1.0, 0.5, 1.7]))
+        div_mode = int(rng.integers(0, 2))
+        posm = _fuzz_scene(rng, n)
+        posm[:, 3] *= np.float32(10.0 ** rng.uniform(-7, -2))    # (from scenes that barely move under gravity to ones that collapse)
+        speed = 10.0 ** rng.uniform(-1, 4.5)
+        vel = np.concatenate([rng.normal(0, speed, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+        dt = float(rng.choice([0.01, 0.002, 0.05]))
+        q = particles_from(nb, posm, vel)
+        com, size = None, 0.0
+        what = f"trial {trial}: n={n} theta={theta} div_mode={div_mode} speed={speed:.3g} dt={dt}"
+        with nb.NBodyEngine(n, theta=theta, bh_div_mode=div_mode) as e:
+            e.set_state(posm, vel)
+            try:
+                for call in range(int(rng.integers(2, 5))):
+                    if rng.random() < 0.5:
+                        k = int(rng.integers(1, 4))
+                        e.step(dt, k)
+                        out = e.particles()
+                        size_dev = None
+                    else:
+                        k = 1
+                        size_dev, out = e.tick(dt)
+                    for _ in range(k):
+                        com, size = oracle.tick_aos_f32(q, dt, theta=theta, root_com=com, size=size, pow_mode=3, div_mode=div_mode)
+                    assert out.tobytes() == q.tobytes(), (what, call)
+                    if size_dev is not None:
+                        assert size_dev == size, (what, call)
+            except nb.NBodyError as err:                          # deeper than 42 levels: the reference would recurse on
+                assert "42" in str(err) or "deep" in str(err).lower(), (what, err)
+                continue
+            np.testing.assert_array_equal(e.bh_stats()["root_com"], com, err_msg=what)
+            if n > 4096:
+                w, r = _sort_counts(e)
+                warm_total += w; retries_total += r
+        ran += 1
+    assert ran >= trials // 2, ran
+    print(f"frames fuzz: {ran} of {trials} scenes ran to the end; larger systems: {warm_total} frames sorted from the previous order, "
+          f"{retries_total} times frames were queued again")
+
+
 @pytest.mark.parametrize("n", [2559, 2560, 4096, 4097, 12288, 12289, 98304, 98305])
 def test_both_sides_of_the_round_four_switches_cold_and_warm(nb, oracle, n):
     # Sizes on both sides of the theta > 0 path's switches that round 4 added or moved — small systems walking the tree in LDS / in
