@@ -2166,7 +2166,9 @@ __global__ __launch_bounds__(NT) void bh_sweep_chunks_kernel(SmallTree T, const 
   for (int q = 0; q < BPT; ++q) {
     const int i = base + q * NT + t;
     lp[q] = i < n ? (int)lcpS[i] : 0; ln[q] = i < n ? (int)lcpS[i + 1] : -1; m0[q] = i < n ? first[i] : 0;
-    if (ln[q] > lp[q]) mask |= ((2ull << ln[q]) - 1ull) & ~((2ull << lp[q]) - 1ull);   // levels lp + 1 .. ln (lp >= -1)
+    // levels lp + 1 .. ln.  (lp = -1 for the first body of all: the shift counts stay in 0 .. 43 — `2ull << lp` there is a shift by
+    // 63 on this hardware, an empty mask, and the levels only that body opens were left out: round 4's frames fuzz found it)
+    if (ln[q] > lp[q]) mask |= ((2ull << ln[q]) - 1ull) & ~((1ull << (lp[q] + 1)) - 1ull);
   }
   const int chunk_start = first[base], chunk_end = first[min(base + NT, n)];   // the chunk's nodes: [chunk_start, chunk_end)
   const int nr = chunk_end - chunk_start;

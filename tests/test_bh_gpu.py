@@ -540,6 +540,35 @@ def test_size_of_the_next_frame_comes_out_of_the_walk_only_while_nothing_else_mo
         np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
 
 
+@pytest.mark.parametrize("n", [9000, 30000, 120000])
+def test_levels_that_only_the_first_body_in_key_order_opens(nb, oracle, n):
+    # ComputeMass over chunks visits only the levels on which the chunk's bodies open cells.  The first body of the key order has no
+    # predecessor: its ladder starts at the root.  A shallow scene with a pair of near-twins in every corner of the box — whichever
+    # corner comes first in the key order, its pair's common cells go twenty levels deeper than anything else in the first chunk
+    # (found by the frames fuzz: those levels were left out and the pair's cells kept stale sums).
+    rng = np.random.default_rng(n)
+    posm = np.concatenate([rng.uniform(-1000, 1000, (n, 3)), 10.0 ** rng.uniform(0, 3, (n, 1))], 1).astype(np.float32)
+    k = 0
+    for sx in (-1, 1):
+        for sy in (-1, 1):
+            for sz in (-1, 1):
+                corner = np.array([sx, sy, sz], np.float32) * np.float32(999.5)
+                posm[k, :3] = corner
+                posm[k + 1, :3] = corner + np.float32(2.0 ** -11) * np.array([1, -1, 1], np.float32)
+                k += 2
+    assert len(np.unique(posm[:, :3], axis=0)) == n
+    pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+    ref, com, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, np.zeros((n, 4), np.float32))
+        for _ in range(2):                                      # a cold pass and one from its order
+            e.compute_forces()
+            st = e.bh_stats()
+            np.testing.assert_array_equal(st["root_com"], com)
+            np.testing.assert_array_equal(e.accelerations(), ref)
+            assert st["nodes"] == nodes and st["levels"] >= 20
+
+
 def test_bh_fuzz_every_byte_of_the_frames_on_random_scenes(nb, oracle):
     """Whole Ticks (.cpp:25-31) on random scenes, driven the ways a host drives them: sizes on both sides of every switch of the
     theta > 0 path, random opening angles and both readings of the CoM division, velocities from a crawl to speeds that tear the
