@@ -901,6 +901,9 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
     (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, p.device);
   }
   if ((e = hipHostMalloc(&c->h_scratch, 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+  // the hipMemset calls above run on the null stream and return early; the context's own stream is non-blocking and would not
+  // wait for them (kernels_bh.hip, bh_create)
+  if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(e, "hipStreamSynchronize after the creation memsets");
   g_create_error.clear();   // e.g. the reason AUTO passed over the symmetric plan: not an error of this call
   *out = c;
   return NBODY_OK;

@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(kB) void bh_small_leaf_boxes_kernel(SmallTree T, in
 //                   a digit go is found by decoupled look-back over the earlier tiles' counters, and the keys leave through
 //                   LDS in bin order.  The global digit histograms come from the key kernel (partial histograms per
 //                   workgroup, no global atomics: contended device-scope atomics cost ~0.8 us each here), ties in the whole
-//                   first key word are put right afterwards (bh_ties_kernel).
+//                   first key word are put right afterwards (bh_ties_gather_kernel, bh_ties_place_kernel).
 constexpr int kTsT = 1024;                 // threads of a tile-sort workgroup
 constexpr int kTs = 4096;                  // bodies per tile
 constexpr int kMergeMaxN = 131072;         // tiles + merge up to here (32 tiles), radix above
@@ -1704,23 +1704,47 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
   }
 }
 
-// After the radix sort on the first key word: runs of bodies that agree in that whole word (closer than Size / 2^21; almost
-// never any) are put in the order of their second words.  The thread at the start of a run sorts it by insertion.
-__global__ __launch_bounds__(kB) void bh_ties_kernel(int n, const unsigned long long *__restrict__ khi, unsigned int *__restrict__ sidx,
-                                                     const unsigned long long *__restrict__ klo_body) {
+// After the radix sort on the first key word: runs of bodies that agree in that whole word (closer than Size / 2^21) are put in
+// the order of their second words.  Usually there are hardly any — but a runaway body can blow Size up until a whole clump, tens
+// of thousands of bodies, shares one first key word (round 4's frames fuzz: the run's first thread sorting it by insertion took
+// a minute).  So every body of a run finds its own place: the run's ends by two searches in the sorted first words, its rank by
+// counting the run's second words below its own — a wave reads the same word at a time, one broadcast load — ties in both words
+// (the frame is refused anyway: 42 levels) by position.  Two launches: the first lays the run's bodies and second words out in
+// the order the radix passes left (tmp_idx, tmp_lo), the second writes every body of a run to its place.
+__global__ __launch_bounds__(kB) void bh_ties_gather_kernel(int n, const unsigned long long *__restrict__ khi,
+                                                            const unsigned int *__restrict__ sidx,
+                                                            const unsigned long long *__restrict__ klo_body,
+                                                            unsigned int *__restrict__ tmp_idx, unsigned long long *__restrict__ tmp_lo) {
   const int i = blockIdx.x * kB + threadIdx.x;
-  if (i + 1 >= n) return;
+  if (i >= n) return;
   const unsigned long long h = khi[i];
-  if (khi[i + 1] != h || (i > 0 && khi[i - 1] == h)) return;
-  int end = i + 2;
-  while (end < n && khi[end] == h) ++end;
-  for (int a = i + 1; a < end; ++a) {
-    const unsigned int body = sidx[a];
-    const unsigned long long l = klo_body[body];
-    int q = a - 1;
-    while (q >= i && klo_body[sidx[q]] > l) { sidx[q + 1] = sidx[q]; --q; }
-    sidx[q + 1] = body;
+  const bool tie = (i > 0 && khi[i - 1] == h) || (i + 1 < n && khi[i + 1] == h);
+  if (!tie) return;
+  const unsigned int body = sidx[i];
+  tmp_idx[i] = body;
+  tmp_lo[i] = klo_body[body];
+}
+__global__ __launch_bounds__(kB) void bh_ties_place_kernel(int n, const unsigned long long *__restrict__ khi, unsigned int *__restrict__ sidx,
+                                                           const unsigned int *__restrict__ tmp_idx,
+                                                           const unsigned long long *__restrict__ tmp_lo) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long h = khi[i];
+  const bool tie = (i > 0 && khi[i - 1] == h) || (i + 1 < n && khi[i + 1] == h);
+  if (!tie) return;
+  int lo = 0, hi = i;                                           // the run's first place: the first key word >= h
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (khi[mid] < h) lo = mid + 1; else hi = mid; }
+  const int start = lo;
+  lo = i + 1; hi = n;                                           // ... and the first place behind it
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (khi[mid] <= h) lo = mid + 1; else hi = mid; }
+  const int end = lo;
+  const unsigned long long mine = tmp_lo[i];
+  int rank = 0;
+  for (int j = start; j < end; ++j) {
+    const unsigned long long o = tmp_lo[j];
+    rank += (o < mine || (o == mine && j < i)) ? 1 : 0;
   }
+  sidx[start + rank] = tmp_idx[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2509,6 +2533,11 @@ hipError_t bh_create(BhState **out, int n) {
     BH_TRY(hipMalloc(&b->kids, sizeof(int) * 8 * (size_t)(kMaxLevels + 1) * nchunks));
   }
   BH_TRY(hipEventCreateWithFlags(&b->ev, hipEventDisableTiming));
+  // The hipMemset calls above go to the NULL stream and return before they have run; the frames run on the context's stream, which
+  // is non-blocking — it does not wait for the null stream.  This state is created by the first theta > 0 call, right in front of
+  // its first frame: without this wait a memset could land in the middle of that frame (the Size words cleared after part of the
+  // bounds kernel's maxima were in: a first frame with a root box too small — round 4's frames fuzz, one large scene in ten).
+  BH_TRY(hipStreamSynchronize(nullptr));
   return hipSuccess;
 }
 
@@ -2604,7 +2633,9 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
       P.shift = 8 * d; P.n = n;
       hipLaunchKernelGGL(bh_radix_pass_kernel, dim3(pass_grid), dim3(kRxT), 0, s, P);
     }
-    hipLaunchKernelGGL(bh_ties_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->klo);
+    // (b->idx2 and b->klo_sorted are free here: the passes ended in b->idx, and a cold frame's second words stay in body order)
+    hipLaunchKernelGGL(bh_ties_gather_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->klo, b->idx2, b->klo_sorted);
+    hipLaunchKernelGGL(bh_ties_place_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->idx2, b->klo_sorted);
   }
   if (T.klo_by_body) hipLaunchKernelGGL(bh_bound_kernel, dim3((b->nb + kB - 1) / kB), blk, 0, s, b->khi, b->nb, b->bound);   // (a cold frame)
   const int block = kB * b->scan_bpt;

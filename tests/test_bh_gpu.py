@@ -569,11 +569,41 @@ def test_levels_that_only_the_first_body_in_key_order_opens(nb, oracle, n):
             assert st["nodes"] == nodes and st["levels"] >= 20
 
 
+@pytest.mark.timeout(300)
+def test_a_clump_of_thousands_that_share_the_whole_first_key_word(nb, oracle):
+    # A runaway body blows Size up until a whole clump sits in ONE cell of level 21: tens of thousands of bodies agree in the
+    # whole first key word and are told apart by the second.  The radix sort of the larger systems orders such a run by every body
+    # finding its own rank in it (found by the frames fuzz: the run's first thread sorting it by insertion took a minute).
+    # 30000 bodies inside the level-21 cell at the origin, 110000 around: accelerations, draw order, node count and root CoM equal the
+    # oracle's tree in every bit, cold and from the previous order.
+    n, clump = 140000, 30000
+    rng = np.random.default_rng(21)
+    posm = np.concatenate([rng.uniform(-1000, 1000, (n, 3)), 10.0 ** rng.uniform(0, 3, (n, 1))], 1).astype(np.float32)
+    posm[0, :3] = (1000.0, -1000.0, 1000.0)                     # Size = 1000: a cell of level 21 is 1000 / 2^21 = 4.77e-4 wide
+    posm[1:1 + clump, :3] = rng.uniform(1e-5, 4.7e-4, (clump, 3)).astype(np.float32)
+    posm[1:1 + clump, 3] *= np.float32(1e-12)                    # (light: the clump's own forces stay finite in fp32)
+    assert len(np.unique(posm[:, :3], axis=0)) == n
+    pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+    ref, com, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+    _, order = oracle.octree_leaves_f32(pos, m)
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, np.zeros((n, 4), np.float32))
+        for _ in range(2):
+            e.compute_forces()
+            st = e.bh_stats()
+            np.testing.assert_array_equal(e.bh_leaf_order(), order)
+            np.testing.assert_array_equal(st["root_com"], com)
+            np.testing.assert_array_equal(e.accelerations(), ref)
+            assert st["nodes"] == nodes and st["levels"] > 21
+
+
 def test_bh_fuzz_every_byte_of_the_frames_on_random_scenes(nb, oracle):
     """Whole Ticks (.cpp:25-31) on random scenes, driven the ways a host drives them: sizes on both sides of every switch of the
     theta > 0 path, random opening angles and both readings of the CoM division, velocities from a crawl to speeds that tear the
     previous frame's order apart (the sort that starts from it must then give frames up and queue them again), frames queued
-    several at a time (`step`) or one by one with the mirror and Size (`tick`).  After every call every byte of the records —
+    several at a time (`step`), one by one with the mirror and Size (`tick`) or as force pass + update (`step_begin` / `step_end`),
+    and between the calls the host may replace records, change the opening angle or take the position buffer into its own hands.
+    After every call every byte of the records —
     Position, Velocity, Acceleration, Mass — equals the oracle's, and so do Size and the root centre at the end.
     NBODY_FUZZ_SEED / NBODY_FUZZ_TRIALS run it longer."""
     rng = np.random.default_rng(int(os.environ.get("NBODY_FUZZ_SEED", "404")))
@@ -581,7 +611,8 @@ def test_bh_fuzz_every_byte_of_the_frames_on_random_scenes(nb, oracle):
     ran = warm_total = retries_total = 0
     for trial in range(trials):
         u = rng.random()
-        n = (int(rng.integers(2, 4097)) if u < 0.3 else int(rng.integers(4097, 21000)) if u < 0.75 else int(rng.integers(21000, 70000)))
+        n = (int(rng.integers(2, 4097)) if u < 0.3 else int(rng.integers(4097, 21000)) if u < 0.72 else
+             int(rng.integers(21000, 70000)) if u < 0.96 else int(rng.integers(70000, 300000)))
         theta = float(rng.choice([1.0, 1.0, 0.5, 1.7]))
         div_mode = int(rng.integers(0, 2))
         posm = _fuzz_scene(rng, n)
@@ -595,20 +626,36 @@ def test_bh_fuzz_every_byte_of_the_frames_on_random_scenes(nb, oracle):
         with nb.NBodyEngine(n, theta=theta, bh_div_mode=div_mode) as e:
             e.set_state(posm, vel)
             try:
-                for call in range(int(rng.integers(2, 5))):
-                    if rng.random() < 0.5:
+                for call in range(int(rng.integers(2, 6))):
+                    size_dev = None
+                    how = rng.random()
+                    if how < 0.4:
                         k = int(rng.integers(1, 4))
                         e.step(dt, k)
                         out = e.particles()
-                        size_dev = None
-                    else:
+                    elif how < 0.8:
                         k = 1
                         size_dev, out = e.tick(dt)
+                    else:                                        # the two-call step: force pass, then the update kernel
+                        k = 1
+                        e.step_begin(); e.step_end(dt)
+                        out = e.particles()
                     for _ in range(k):
                         com, size = oracle.tick_aos_f32(q, dt, theta=theta, root_com=com, size=size, pow_mode=3, div_mode=div_mode)
                     assert out.tobytes() == q.tobytes(), (what, call)
                     if size_dev is not None:
                         assert size_dev == size, (what, call)
+                    between = rng.random()                       # what a host may do between frames
+                    if between < 0.15:                           # ... replace some records (bodies jump: the order on the device is stale)
+                        some = rng.random(n) < rng.choice([0.001, 0.05, 0.9])
+                        q["Position"][some] = (q["Position"][some] * np.float32(rng.choice([0.5, 1.0, 3.0])) +
+                                               rng.normal(0, 1.0, (int(some.sum()), 3)).astype(np.float32))
+                        e.push_particles(q)
+                    elif between < 0.25:                         # ... change the opening angle
+                        theta = float(rng.choice([1.0, 0.5, 0.7, 1.7]))
+                        e.set_theta(theta)
+                    elif between < 0.3:                          # ... ask for the position buffer: it is the caller's from now on
+                        e.device_ptr(nb.BUF_POSM)
             except nb.NBodyError as err:                          # deeper than 42 levels: the reference would recurse on
                 assert "42" in str(err) or "deep" in str(err).lower(), (what, err)
                 continue
