@@ -311,6 +311,34 @@ def test_c_octree_agrees_with_an_independent_python_restatement(oracle, n, seed,
     assert np.abs(got2 - want).max() <= np.abs(want).max() * 2.0 ** -22
 
 
+@pytest.mark.parametrize("theta", [0.5, 1.0])
+def test_c_octree_agrees_with_the_python_restatement_on_deep_chains(oracle, theta):
+    # the scenes round 4's device fuzz tripped over, small enough for the recursive restatement: a pair of near-twins in a corner
+    # of the box (a chain of single-child cells twenty levels deep that only the first body in depth-first order opens) and a
+    # clump inside ONE cell of level 21 at the origin (its bodies differ only below the 21st octant digit)
+    rng = np.random.default_rng(5)
+    n = 48
+    pos = rng.uniform(-1000, 1000, (n, 3)).astype(np.float32)
+    mass = rng.uniform(1, 5000, n).astype(np.float32)
+    pos[0] = (1000.0, -1000.0, 1000.0)                      # Size = 1000
+    for k, (sx, sy, sz) in enumerate([(-1, -1, -1), (1, 1, 1), (-1, 1, -1)]):
+        corner = np.array([sx, sy, sz], np.float32) * np.float32(999.5)
+        pos[1 + 2 * k] = corner
+        pos[2 + 2 * k] = corner + np.float32(2.0 ** -11) * np.array([1, -1, 1], np.float32)
+    pos[10:22] = rng.uniform(1e-5, 4.7e-4, (12, 3)).astype(np.float32)
+    mass[10:22] *= np.float32(1e-12)
+    assert len(np.unique(pos, axis=0)) == n
+    origin = np.zeros(3, np.float32)
+    size = oracle.bounds_f32(pos)
+    assert size == 1000.0
+    with np.errstate(over="ignore"):
+        want, want_com = _py_create_octree(pos, mass, theta, origin, size)
+    got, got_com, nodes = oracle.octree_forces_f32(pos, mass, theta, root_origin=origin, root_size=size, pow_mode=0)
+    np.testing.assert_array_equal(got_com, want_com)
+    np.testing.assert_array_equal(got, want)
+    assert nodes > 8 * 25                                   # the chains are there
+
+
 @pytest.mark.parametrize("n,seed", [(9, 1), (200, 3)])
 def test_c_octree_draw_order_and_division_reading(oracle, n, seed):
     # what DrawOctreeBoxes draws (occupied leaves depth first, .cpp:36-45) and the second reading of `/=` in ComputeMass
