@@ -136,6 +136,127 @@ def cpu_baseline(posm, target_seconds):
     return out
 
 
+PEAK_FP64_TFLOPS = PEAK_FP32_TFLOPS / 2    # 78.6: MI355X vector fp64 peak (MI355X_MICROARCH.md)
+
+
+def baseline_config_row(nb, n, precision, eps, steps, warmup, settle_seconds, dt=0.01):
+    """One more of BASELINE.json's configs on this GPU, after the headline's timed region: a seeded Plummer sphere of n bodies,
+    `steps` whole steps timed from the host (state resident, force pass + kick-drift), the force pass's own time from HIP events
+    on the launch stream (nbody_kernel_time), and the sampled parity check of the benched instantiation at the benched size."""
+    import numpy as np
+    f64 = precision == "f64"
+    dtype = np.float64 if f64 else np.float32
+    posm, vel = nb.ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
+    if f64:
+        posm, vel = posm.astype(np.float64), vel.astype(np.float64)
+    with nb.NBodyEngine(n, precision=precision, eps=eps, time_kernels=True) as e:
+        e.set_state(posm, vel)
+        cfg = e.launch_config()
+        t0 = time.perf_counter()
+        e.compute_forces(); e.synchronize()
+        one = max(time.perf_counter() - t0, 1e-5)
+        for _ in range(int(min(2000, max(1, settle_seconds / one)))):
+            e.compute_forces()
+        e.step(dt, warmup); e.synchronize()
+        e.kernel_time_reset()
+        t0 = time.perf_counter()
+        e.step(dt, steps); e.synchronize()
+        elapsed = time.perf_counter() - t0
+        f_ms, f_n = e.kernel_time(nb.KERNEL_FORCES)
+        clk = clock_fields(e, f_ms / max(f_n, 1) * 1e-3, float(n) * float(n))
+        equal_mass = e.equal_mass_form()
+        p_end = e.state(dtype)[0]
+        e.compute_forces()
+        acc = e.accelerations(dtype)
+    bodies = sample_bodies(0, n, cfg["super_tile"], cfg["i_per_thread"])
+    err = sampled_force_error(p_end, acc, 0, bodies, 1.0e4, eps)
+    tol = {"f32": 2e-5, "f32_kahan": 2e-6 if eps > 0 else 2e-5, "f64": 1e-12}[precision]
+    finite = bool(np.isfinite(p_end).all())
+    if not (finite and err < tol):
+        raise SystemExit(f"bench.py: configs row N={n} {precision}: the benched force pass disagrees with the fp64 direct sum on "
+                         f"sampled bodies: max rel err {err:.3e} >= {tol:.1e} (finite={finite})")
+    pairs = float(n) * float(n)
+    peak = PEAK_FP64_TFLOPS if f64 else PEAK_FP32_TFLOPS
+    avg_launch_s = f_ms / max(f_n, 1) * 1e-3
+    achieved = pairs * FLOP_PER_PAIR / avg_launch_s * 1e-12
+    traffic = TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, 1, cfg["i_per_thread"], precision, equal_mass), (None, None))
+    return {"workload": f"N={n} all-pairs {precision}, seeded Plummer sphere (equal masses), G=1e4, eps={eps}, dt={dt}",
+            "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "value": pairs * steps / elapsed,
+            "unit": "pair-interactions/s", "dtype": "f64" if f64 else "f32", "accumulate": precision,
+            "algorithm": cfg["algorithm"], "kernel": cfg["kernel"], "i_per_lane": cfg["i_per_thread"], "lds_tile_bodies": cfg["tile"],
+            "equal_mass_form": equal_mass,
+            "roofline": {"bound": "valu_fp64" if f64 else "valu_fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
+                         "whole_step_frac": pairs * FLOP_PER_PAIR / (elapsed / steps) * 1e-12 / peak,
+                         "traffic": traffic[0], "traffic_source": traffic[1], **clk},
+            "max_rel_err_sampled": err, "bodies_sampled": len(bodies), "rel_err_tolerance": tol, "finite": finite}
+
+
+def barnes_hut_row(nb, n, frames, warmup, parity_frames, theta=1.0, dt=0.01, size=1000.0):
+    """The reference's SHIPPED algorithm (OctreeSearch.cpp:74-89 at Theta = 1.0, .cpp:85) on its shipped kind of scene
+    (CreateSpacePoints(N, 1000), .cpp:58-72): whole frames — ComputeCubeSize, the tree rooted at the previous tree's CoM,
+    ComputeMass, every body's walk, kick-drift — queued by nbody_step with one host wait per call.  Before the timing, on a
+    context of its own: `parity_frames` whole Ticks compared in EVERY BYTE of the FParticle records, Size and the root centre
+    with the oracle's restatement of OctreeSearch.h:60-108 / .cpp:25-31 (cube correctly rounded: pow_mode 3) — whose time on this
+    box's host cores is the row's cpu_baseline."""
+    import numpy as np
+    from oracle import oracle as O
+    posm, vel = nb.ic_reference_box(n, size, seed=1)
+    q = np.zeros(n, nb.PARTICLE_DTYPE)
+    q["Mass"] = posm[:, 3]; q["Position"] = posm[:, :3]; q["Velocity"] = vel[:, :3]
+    com, sz, cpu_s = None, 0.0, []
+    with nb.NBodyEngine(n, theta=theta) as e:
+        e.set_state(posm, vel)
+        for frame in range(parity_frames):
+            size_dev, out = e.tick(dt)
+            t0 = time.perf_counter()
+            com, sz = O.tick_aos_f32(q, dt, theta=theta, root_com=com, size=sz, pow_mode=3)
+            cpu_s.append(time.perf_counter() - t0)
+            same = size_dev == sz and out.tobytes() == q.tobytes() and bool(np.all(e.bh_stats()["root_com"] == com))
+            if not same:
+                raise SystemExit(f"bench.py: Barnes-Hut row N={n}: frame {frame} differs from the oracle's (Size {size_dev} vs {sz}, "
+                                 f"{int((out['Acceleration'] != q['Acceleration']).any(axis=1).sum())} bodies' accelerations differ)")
+        st = e.bh_stats()
+    with nb.NBodyEngine(n, theta=theta) as e:
+        e.set_state(posm, vel)
+        e.step(dt, warmup); e.synchronize()
+        t0 = time.perf_counter()
+        e.step(dt, frames); e.synchronize()
+        elapsed = time.perf_counter() - t0
+        done = e.steps_done()
+        finite = bool(np.isfinite(e.state()[0]).all())
+    if done != warmup + frames or not finite:
+        raise SystemExit(f"bench.py: Barnes-Hut row N={n}: {done} of {warmup + frames} frames built, finite={finite}")
+    cores = min(O.max_threads(), os.cpu_count() or 1)
+    return {"workload": f"N={n} reference box scene (CreateSpacePoints(N, {size:g})), theta={theta}, dt={dt}: whole frames "
+                        f"(Size, tree, ComputeMass, walks, kick-drift)",
+            "frames": frames, "warmup": warmup, "us_per_frame": elapsed / frames * 1e6, "frames_per_s": frames / elapsed,
+            "bodies_per_s": n * frames / elapsed, "tree_nodes": st["nodes"], "tree_levels": st["levels"],
+            "parity": f"every byte of {parity_frames} frame(s) (FParticle records, Size, root centre) equal to the oracle's",
+            "cpu_baseline": {"value": min(cpu_s) * 1e6, "unit": "us/frame", "kind": "port", "cores": cores,
+                             "sample": f"oracle Tick (Octree::Add and ComputeMass on one thread, the walks OpenMP over bodies) of "
+                                       f"the same scene, best of {len(cpu_s)} frame(s)"}}
+
+
+def extra_rows(args, nb):
+    """BASELINE.json's other single-GPU configs and the theta > 0 path, measured in the same driver run AFTER the headline's
+    timed region (the headline's fields are untouched): configs[1] N = 65536 fp32, configs[3] N = 262144 fp64, configs[4]
+    N = 2097152 softened Kahan — each >= 3 timed whole steps with its own sampled parity check and roofline fraction against its
+    own peak — and Barnes-Hut frames at the reference's shipped opening angle."""
+    s = args.settle_seconds
+    configs = {
+        "n65536_f32": baseline_config_row(nb, 1 << 16, "f32", 0.0, steps=100, warmup=5, settle_seconds=s),
+        "n262144_f64": baseline_config_row(nb, 1 << 18, "f64", 0.0, steps=5, warmup=1, settle_seconds=s),
+        "n2097152_kahan_softened": baseline_config_row(nb, 1 << 21, "f32_kahan", 0.5, steps=3, warmup=1, settle_seconds=0.0),
+    }
+    bh = {
+        "n2000": barnes_hut_row(nb, 2000, frames=200, warmup=20, parity_frames=2),
+        "n65536": barnes_hut_row(nb, 1 << 16, frames=100, warmup=10, parity_frames=1),
+        "n1048576": barnes_hut_row(nb, 1 << 20, frames=50, warmup=5, parity_frames=1),
+    }
+    return configs, bh
+
+
 def clock_fields(engine, avg_launch_s, launch_pairs):
     """roofline.clock_ghz / cycles_per_interaction: the shader clock the timed force kernels ran at (read inside the kernels:
     nbody_kernel_clock) and launch time x clock x SIMD lanes / interactions — SIMD cycles per interaction and lane if every SIMD
@@ -534,6 +655,9 @@ def main():
     ap.add_argument("--no-tiled-row", action="store_true",
                     help="multi-GPU: skip the extra timing of the one-sided kernel + all-gather-only step (config.all_gather_only_row)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length; 0 = skip")
+    ap.add_argument("--no-extra-rows", action="store_true",
+                    help="one GPU, default workload: skip BASELINE's other configs (N=65536 fp32, N=262144 fp64, N=2097152 Kahan) "
+                         "and the Barnes-Hut frames that follow the headline's timed region (`configs`, `bh` in the line)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="multi-GPU: every collective in the simulation's one stream order (default: the all-gather of a step's "
                          "positions runs on a stream of its own, under the next force pass's own-slice strips; same bits)")
@@ -742,6 +866,14 @@ def main():
         tiled_row = {"algorithm": "tiled", "parallelism": f"range-partition x{world}, per step 1 RCCL all-gather(posm)",
                      "value": pairs_per_step * args.steps / float(tt[0]), "ms_per_step": float(tt[0]) / args.steps * 1e3}
 
+    # One GPU, the default workload: BASELINE.json's other configs and the theta > 0 frames, each on a context of its own, after
+    # everything of the headline has been measured (its engine released first: N = 2^21 Kahan wants its own pool).
+    extra = None
+    if world == 1 and n == (1 << 20) and args.precision == "f32" and args.eps == 0.0 and args.algorithm == "auto" \
+            and not (args.tile or args.ipt or args.jsplit) and not args.no_extra_rows:
+        sim.close()
+        extra = extra_rows(args, nb)
+
     if rank == 0:
         out = {
             "metric": "body-pair interactions/s at N=2^20" if n == (1 << 20) else f"body-pair interactions/s at N={n}",
@@ -785,6 +917,8 @@ def main():
         }
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(posm, args.cpu_seconds)
+        if extra is not None:
+            out["configs"], out["bh"] = extra
         print_result(out)
     sim.close()
     if world > 1:

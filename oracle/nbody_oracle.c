@@ -120,6 +120,7 @@ typedef struct {
   int count, cap;
   const float *pos, *mass;
   int overflow;
+  int max_depth;         /* deepest node an Add has reached (root = 0): test infrastructure, see oracle_last_max_depth */
   int div_mode;          /* reading of FVector::operator/=(float) in ComputeMass, .h:95: 0 = multiply by the fp32 reciprocal
                             (UE4's implementation as remembered — [external], the engine is not vendored), 1 = divide */
 } otree;
@@ -156,6 +157,7 @@ static inline int node_octant(const otree *t, int k, const float p[3]) {   /* Ge
 
 static void node_add(otree *t, int k, int particle, int depth) {     /* Add .h:60-81 */
   if (t->overflow) return;
+  if (depth > t->max_depth) t->max_depth = depth;
   if (depth > ORACLE_MAX_DEPTH) { t->overflow = 1; return; }         /* reference recurses forever on duplicates */
   if (node_is_leaf(t, k)) {
     if (t->nodes[k].particle == -1) {
@@ -264,6 +266,13 @@ static void node_draw(const otree *t, int k, float *boxes, int *order, int *coun
  * Returns 0, or 1 if insertion exceeded ORACLE_MAX_DEPTH (duplicate positions: the reference
  * would recurse without bound), 2 on allocation failure.
  */
+static int g_last_max_depth = 0;
+/* The deepest node the LAST oracle_octree_f32 / oracle_tick_aos*_f32 call on this thread's library reached while inserting
+ * (root = 0; ORACLE_MAX_DEPTH + 1 when the insertion was cut off).  Two bodies that share their first L octant digits put
+ * leaves at depth L + 1: the device path refuses a frame exactly when this is >= 43 (its keys hold 42 levels), and the
+ * fuzz tests ask here whether a refusal was due. */
+ORACLE_API int oracle_last_max_depth(void) { return g_last_max_depth; }
+
 ORACLE_API int oracle_octree_f32(int n, const float *pos, const float *mass, const float root_origin[3], float root_size,
                                  float theta, double g, int pow_mode, int div_mode, float *acc, float root_com_out[3],
                                  int *node_count_out, float *leaf_boxes, int *leaf_order) {
@@ -273,9 +282,14 @@ ORACLE_API int oracle_octree_f32(int n, const float *pos, const float *mass, con
   int root = node_new(&t, root_origin, root_size);
   if (root < 0) return 2;
   for (int i = 0; i < n && !t.overflow; ++i) node_add(&t, root, i, 0);      /* .cpp:80 */
+  g_last_max_depth = t.max_depth;
   if (t.overflow) { int e = t.overflow; free(t.nodes); return e; }
   node_compute_mass(&t, root);                                              /* .cpp:81 */
-  for (int i = 0; acc && i < n; ++i) {                                      /* .cpp:83-86 */
+  /* (every body's walk reads the finished tree and writes its own three floats: the threads change no bit) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) if (acc && n >= 16384)
+#endif
+  for (int i = 0; i < (acc ? n : 0); ++i) {                                 /* .cpp:83-86 */
     float a[3] = {0.0f, 0.0f, 0.0f};
     node_forces(&t, root, &pos[3 * i], theta, g, pow_mode, a);
     acc[3 * i + 0] = a[0]; acc[3 * i + 1] = a[1]; acc[3 * i + 2] = a[2];

@@ -103,6 +103,7 @@ def lib():
         L.oracle_energy_f64.argtypes = [ctypes.c_int, dp, dp, dp, ctypes.c_double, ctypes.c_double, dp, dp, ctypes.c_int]
         L.oracle_energy_f64.restype = None
         L.oracle_max_threads.restype = ctypes.c_int
+        L.oracle_last_max_depth.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -178,6 +179,25 @@ def octree_leaves_f32(pos, mass, root_origin=(0.0, 0.0, 0.0), root_size=None):
     if rc:
         raise RuntimeError(f"oracle_octree_f32 rc={rc} (1 = duplicate positions)")
     return boxes, order
+
+
+def last_max_depth():
+    """Deepest node (root = 0) the last octree_* / tick_aos_f32 call reached while inserting the bodies."""
+    return int(lib().oracle_last_max_depth())
+
+
+def octree_depth_f32(pos, root_origin=(0.0, 0.0, 0.0), root_size=None):
+    """Octree::Add (OctreeSearch.h:60-81) of these bodies only: how deep the insertion goes (root = 0; 201 = cut off, the
+    reference would recurse without bound).  Bodies that share L octant digits end in leaves of depth L + 1."""
+    pos = _f32(pos)
+    n = pos.shape[0]
+    if root_size is None:
+        root_size = bounds_f32(pos)
+    origin = _f32(np.asarray(root_origin, np.float32))
+    mass = np.ones(n, np.float32)
+    lib().oracle_octree_f32(n, _fp(pos), _fp(mass), _fp(origin), np.float32(root_size), np.float32(1.0), REF_G, 0, 0,
+                            None, None, None, None, None)
+    return last_max_depth()
 
 
 def kick_drift_f32(pos, vel, acc, dt):

@@ -842,6 +842,50 @@ __device__ __forceinline__ void force_term(float cx, float cy, float cz, float M
   tx = s * -ex; ty = s * -ey; tz = s * -ez;
 }
 
+// A context that owns the slice [off, off + count) of the bodies (range partition over GPUs) builds the WHOLE tree — every
+// device the same one, from the replicated positions: each step of the build is the reference's arithmetic in a fixed order — and
+// walks only its own bodies (a body's walk, OctreeSearch.cpp:83-86, reads the finished tree and writes that body alone).  own[j]: the
+// sorted position of the slice's j-th body in key order (neighbours in space share their windows' loads); null on a context that
+// owns all bodies (j is the sorted position itself).  vel / acc / stage hold the slice's bodies, posm all.
+struct WalkSlice {
+  const unsigned int *own;
+  int off;
+};
+__device__ __forceinline__ int walk_place(const WalkSlice &S, int j) { return S.own != nullptr ? (int)S.own[j] : j; }
+
+// own[]: a count per block of kB sorted positions, then every block adds up the counts before it and ranks its own bodies (two
+// launches of a few microseconds; the list has exactly `count` entries whatever the order is)
+__global__ __launch_bounds__(kB) void bh_own_count_kernel(const unsigned int *__restrict__ sidx, int n, unsigned int lo, unsigned int cnt,
+                                                          const int *__restrict__ status, unsigned int *__restrict__ blk) {
+  __shared__ unsigned int s_w[kB / 64];
+  if (*status != 0) return;                                    // a frame refused or given up: there is no order
+  const int i = blockIdx.x * kB + threadIdx.x;
+  const bool mine = i < n && sidx[i] - lo < cnt;
+  const unsigned long long bm = __ballot(mine);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned int)__popcll(bm);
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(kB) void bh_own_list_kernel(const unsigned int *__restrict__ sidx, int n, unsigned int lo, unsigned int cnt,
+                                                         const int *__restrict__ status, const unsigned int *__restrict__ blk,
+                                                         unsigned int *__restrict__ own) {
+  __shared__ unsigned int s_w[kB / 64], s_c[kB / 64];
+  if (*status != 0) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned int before = 0;                                     // own bodies in the blocks before this one
+  for (int q = t; q < (int)blockIdx.x; q += kB) before += blk[q];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+  const int i = blockIdx.x * kB + t;
+  const bool mine = i < n && sidx[i] - lo < cnt;
+  const unsigned long long bm = __ballot(mine);
+  if (lane == 0) { s_w[wave] = before; s_c[wave] = (unsigned int)__popcll(bm); }
+  __syncthreads();
+  unsigned int base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  for (int w = 0; w < wave; ++w) base += s_c[w];
+  if (mine) own[base + (unsigned int)__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned int)i;
+}
+
 // value of lane (l - N) mod 16 of the same 16-lane row (v_mov_b32_dpp row_ror:N: the row rotates right)
 template <int N> __device__ __forceinline__ int row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false); }
 __device__ __forceinline__ int row_or(int v) { v |= row_ror<8>(v); v |= row_ror<4>(v); v |= row_ror<2>(v); v |= row_ror<1>(v); return v; }
@@ -949,14 +993,16 @@ __device__ __forceinline__ void walk_windows(const SmallTree &T, const float4 *s
 // (nbody_tick hands the caller's pinned mirror over).
 // Sixteen lanes per body: the row's first lane lays the ten floats out in the row's LDS slice `rec` and ten lanes store them with
 // ONE instruction — 40 contiguous bytes per body — instead of ten scattered 4-byte stores.
+// own: the context's slice of the bodies (WalkSlice below) — vel, acc and stage hold the slice's bodies only, posm all of them.
 __device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int body, const float4 &p, float ax, float ay, float az,
                                               float4 *__restrict__ posm, float4 *__restrict__ vel, float4 *__restrict__ acc, float dt,
-                                              float *__restrict__ stage, float *rec, unsigned int *__restrict__ next_size = nullptr,
+                                              float *__restrict__ stage, float *rec, int off, unsigned int *__restrict__ next_size = nullptr,
                                               float4 *__restrict__ pos_sorted = nullptr, int k = 0) {
+  const unsigned int lb = body - (unsigned int)off;             // the body's place in the slice's arrays
   if (next_size != nullptr) {                                  // (larger systems, dt > 0: every lane of the wave comes by here)
     float nx = 0.f, ny = 0.f, nz = 0.f;                         // where the body is about to go (the same arithmetic as below)
     if (valid && g == 0) {
-      const float4 u = vel[body];
+      const float4 u = vel[lb];
       nx = mul_add_sep(dt, mul_add_sep(dt, ax, u.x), p.x); ny = mul_add_sep(dt, mul_add_sep(dt, ay, u.y), p.y);
       nz = mul_add_sep(dt, mul_add_sep(dt, az, u.z), p.z);
     }
@@ -965,12 +1011,12 @@ __device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int bo
   if (!valid || (g != 0 && stage == nullptr)) return;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
   if (g == 0) {
-    acc[body] = make_float4(ax, ay, az, 0.f);
-    if ((dt > 0.f || stage != nullptr) && vel != nullptr) v = vel[body];   // (not `vel ? vel[body] : v`: a select of addresses parks v in scratch)
+    acc[lb] = make_float4(ax, ay, az, 0.f);
+    if ((dt > 0.f || stage != nullptr) && vel != nullptr) v = vel[lb];   // (not `vel ? vel[lb] : v`: a select of addresses parks v in scratch)
     if (dt > 0.f) {                                            // v += dt*a; x += dt*v, separate multiply and add
       v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
       x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
-      vel[body] = v;
+      vel[lb] = v;
       posm[body] = x;
     }
     if (pos_sorted != nullptr) pos_sorted[k] = x;              // the positions in key order, for the next frame's key kernel (larger systems)
@@ -979,37 +1025,38 @@ __device__ __forceinline__ void walk_row_tail(bool valid, int g, unsigned int bo
     if (g == 0) { rec[0] = x.w; rec[1] = x.x; rec[2] = x.y; rec[3] = x.z; rec[4] = v.x; rec[5] = v.y; rec[6] = v.z; rec[7] = ax; rec[8] = ay; rec[9] = az; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (g < 10) stage[(size_t)body * 10 + g] = rec[g];
+    if (g < 10) stage[(size_t)lb * 10 + g] = rec[g];
   }
 }
 // ... and the same for a walk with one lane per body
 __device__ __forceinline__ void walk_lane_tail(bool valid, unsigned int body, const float4 &p, float ax, float ay, float az,
                                                float4 *__restrict__ posm, float4 *__restrict__ vel, float4 *__restrict__ acc, float dt,
-                                               float *__restrict__ stage, unsigned int *__restrict__ next_size,
+                                               float *__restrict__ stage, int off, unsigned int *__restrict__ next_size,
                                                float4 *__restrict__ pos_sorted, int k) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), x = p;
+  const unsigned int lb = body - (unsigned int)off;
   if (valid) {
-    acc[body] = make_float4(ax, ay, az, 0.f);
-    if ((dt > 0.f || stage != nullptr) && vel != nullptr) v = vel[body];
+    acc[lb] = make_float4(ax, ay, az, 0.f);
+    if ((dt > 0.f || stage != nullptr) && vel != nullptr) v = vel[lb];
     if (dt > 0.f) {
       v.x = mul_add_sep(dt, ax, v.x); v.y = mul_add_sep(dt, ay, v.y); v.z = mul_add_sep(dt, az, v.z);
       x.x = mul_add_sep(dt, v.x, x.x); x.y = mul_add_sep(dt, v.y, x.y); x.z = mul_add_sep(dt, v.z, x.z);
-      vel[body] = v;
+      vel[lb] = v;
       posm[body] = x;
     }
-    pos_sorted[k] = x;                                         // the positions in key order, for the next frame's key kernel: one coalesced store
+    if (pos_sorted != nullptr) pos_sorted[k] = x;              // the positions in key order, for the next frame's key kernel: one coalesced store (uniform: not on a slice)
   }
   note_next_size(next_size, valid, x.x, x.y, x.z);             // (every lane of the wave comes by here)
   if (!valid) return;
   if (stage != nullptr) {
-    float *o = stage + (size_t)body * 10;
+    float *o = stage + (size_t)lb * 10;
     o[0] = x.w; o[1] = x.x; o[2] = x.y; o[3] = x.z; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = ax; o[8] = ay; o[9] = az;
   }
 }
 
 __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                                  float4 *__restrict__ acc, int n, float theta, double G, float dt,
-                                                                 float *__restrict__ stage) {
+                                                                 float *__restrict__ stage, WalkSlice S) {
   static_assert(kWalkG == 16, "one DPP row per body");
   constexpr int kGroups = kWalkT / kWalkG;
   __shared__ float4 s_a[kSmNodesLds];
@@ -1042,8 +1089,9 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
   }
   const int group = t / kWalkG, g = t % kWalkG;
   const int k = blockIdx.x * kGroups + group;
-  const bool valid = k < n;
-  const unsigned int body = valid ? T.sidx[k] : 0u;
+  const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
+  const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
+  const unsigned int body = valid ? T.sidx[place] : 0u;
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   BH_WALK_CLOCK(10);
@@ -1061,7 +1109,7 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_compact_kernel(SmallTree T, fl
     T.clocks[15] = wall_clock64() - c0;
   }
 #endif
-  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group]);
+  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group], S.off);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1161,7 +1209,7 @@ constexpr int kWvT = 512;                  // small systems: eight waves = eight
 constexpr int kWvK = 128;
 __global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                                     float4 *__restrict__ acc, int n, double G, float dt,
-                                                                    float *__restrict__ stage) {
+                                                                    float *__restrict__ stage, WalkSlice S) {
   constexpr int kWaves = kWvT / 64;
   __shared__ float4 s_a[kSmNodesLds];
   __shared__ float s_m[kSmNodesLds];
@@ -1198,8 +1246,9 @@ __global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T,
   }
   const int wave = t >> 6, lane = t & 63;
   const int k = blockIdx.x * kWaves + wave;
-  const bool valid = k < n;
-  const unsigned int body = valid ? T.sidx[k] : 0u;
+  const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
+  const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
+  const unsigned int body = valid ? T.sidx[place] : 0u;
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   BH_WG_STAMP(1);
@@ -1215,7 +1264,7 @@ __global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T,
     T.clocks[15] = wall_clock64() - c0;
   }
 #endif
-  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave]);
+  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave], S.off);
 }
 
 // ... and on the larger systems' tree in its global arrays: a window is sixty-four consecutive nodes — one coalesced 1 KB load
@@ -1224,7 +1273,7 @@ constexpr int kWvGK = 192;
 __global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                                   float4 *__restrict__ acc, int n, double G, float dt,
                                                                   float *__restrict__ stage, unsigned int *__restrict__ next_size,
-                                                                  float4 *__restrict__ pos_sorted) {
+                                                                  float4 *__restrict__ pos_sorted, WalkSlice S) {
   constexpr int kWaves = kWvGT / 64;
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kWaves][kWvGK];
@@ -1237,20 +1286,22 @@ __global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, f
   const int nodes = T.hdr[0];
   const int wave = t >> 6, lane = t & 63;
   const int k = blockIdx.x * kWaves + wave;
-  const bool valid = k < n;
-  const unsigned int body = valid ? T.sidx[k] : 0u;
+  const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
+  const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
+  const unsigned int body = valid ? T.sidx[place] : 0u;
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;
   walk_wave<false, kWvGK>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[wave],
                           s_term[wave], nodes, valid, p, G, lane, ax, ay, az);
-  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave], next_size, pos_sorted, k);
+  walk_row_tail(valid, lane, body, p, ax, ay, az, posm, vel, acc, dt, stage, s_term[wave], S.off, next_size, pos_sorted, place);
 }
 
 // The same walk for systems whose tree does not go into LDS but that have too few bodies to keep the chip busy with one lane
 // each (bh_walk_lane_kernel): rows of sixteen lanes on the global arrays, no tree copy.
 __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                               float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage,
-                                                              unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted) {
+                                                              unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted,
+                                                              WalkSlice S) {
   constexpr int kGroups = kWalkT / kWalkG;
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kGroups][kWalkK];
@@ -1263,13 +1314,14 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float
   const int nodes = T.hdr[0];
   const int group = t / kWalkG, g = t % kWalkG;
   const int k = blockIdx.x * kGroups + group;
-  const bool valid = k < n;
-  const unsigned int body = valid ? T.sidx[k] : 0u;
+  const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
+  const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
+  const unsigned int body = valid ? T.sidx[place] : 0u;
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;
   walk_windows<false>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[group],
                       s_term[group], nodes, valid, p, G, g, (t & 63) - g, ax, ay, az);
-  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group], next_size, pos_sorted, k);
+  walk_row_tail(valid, g, body, p, ax, ay, az, posm, vel, acc, dt, stage, (float *)s_term[group], S.off, next_size, pos_sorted, place);
 }
 
 // What DrawOctreeBoxes hands to DrawDebugBox (.cpp:39-40) from the compact tree: the leaf's box follows from the body's
@@ -1345,6 +1397,9 @@ __global__ __launch_bounds__(kB) void bh_keys_kernel(SmallTree T, const float4 *
                                                      const unsigned int *__restrict__ size_bits, unsigned int *__restrict__ next_size,
                                                      float theta, unsigned long long *__restrict__ key_hi,
                                                      unsigned long long *__restrict__ key_lo) {
+  // a frame before this one was refused: nothing of this one happens — not the root, not Size in the header, not the next frame's
+  // Size words (uniform: the cold sorts never raise the word themselves; it was set before this launch)
+  if (T.hdr[3] != 0) return;
   const float sz = frame_size(size_bits);
   float o[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
   if (blockIdx.x == 0) bh_frame_setup(T, o, sz, theta, kB, next_size);
@@ -1539,6 +1594,7 @@ __global__ __launch_bounds__(kKhT) void bh_keys_hist_kernel(SmallTree T, const f
                                                             unsigned int *__restrict__ part_hist) {
   __shared__ unsigned int s_h[kRxPasses][kRxBins];
   const int t = threadIdx.x;
+  if (T.hdr[3] != 0) return;                                   // behind a refused frame nothing happens (bh_keys_kernel); the passes return too
   const float sz = frame_size(size_bits);
   const float o0[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
   if (blockIdx.x == 0) bh_frame_setup(T, o0, sz, theta, kKhT, next_size);
@@ -1581,6 +1637,8 @@ struct RadixPass {
   int digit;
   unsigned int *desc;                      // [tiles][256] look-back words of this pass, zero before the launch
   int shift, n;
+  const int *status;                       // the tree's header word 3: behind a refused frame the key kernel wrote no histograms, and a
+                                           // pass must not scatter by counts that belong to other keys
 };
 
 __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
@@ -1591,6 +1649,7 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
   __shared__ unsigned long long s_k[kRxTile];
   __shared__ unsigned int s_v[kRxTile];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (*P.status != 0) return;                                  // (uniform over the launch: no workgroup is left waiting for another's tiles)
   // Workgroup g takes the tiles g, g + gridDim.x, ... in this order.  The host launches no more workgroups than the device can
   // hold at once, so every tile a look-back waits for belongs to a workgroup that is running (or will be as soon as another
   // process's kernel leaves) and that never waits for a later tile: the wait always ends.  (A ticket counter would do the same
@@ -2358,7 +2417,8 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
 // 2^18 316 / 284, 2^20 843 / 710.)
 __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                           float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage,
-                                                          unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted) {
+                                                          unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted,
+                                                          WalkSlice S) {
 #pragma clang fp contract(off)
   __shared__ float s_thr[kMaxLevels + 2];
   hand_verdict(T);
@@ -2366,9 +2426,10 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
   if (threadIdx.x <= kMaxLevels) s_thr[threadIdx.x] = T.thr[threadIdx.x];
   __syncthreads();
   const int k = blockIdx.x * kB + threadIdx.x;
-  const bool valid = k < n;
+  const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
   const int nodes = valid ? T.hdr[0] : 0;
-  const unsigned int body = valid ? T.sidx[k] : 0u;
+  const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
+  const unsigned int body = valid ? T.sidx[place] : 0u;
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   int node = 0;
@@ -2390,7 +2451,7 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
     }
     node = (take || d2 == 0.f) ? past : node + 1;              // ... and ends the subtree; children 0..7 otherwise
   }
-  walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, next_size, pos_sorted, k);
+  walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, S.off, next_size, pos_sorted, place);
 }
 
 
@@ -2441,6 +2502,7 @@ struct BhState {
   float *prev_com = nullptr;   // the previous tree's root CoM (zero before the first frame)
   int last_nodes = 0, last_levels = 0;
   int div_mode = 0;            // reading of `/=` in ComputeMass (sweep_compact_cell)
+  bool level_sweeps = false;   // ComputeMass with a launch per level at any size (NBODY_BH_LEVEL_SWEEPS=1 at creation; always above kChunkSweepMaxN)
 };
 
 #define BH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
@@ -2459,9 +2521,23 @@ int bh_tile_size(int n) {
   return n <= 16384 ? 1024 : (n <= 98304 ? 2048 : 4096);      // frames, tile 1024 / 2048 / 4096: N = 16384 179 / 181 / 203 us, 32768 230 / 226 / 241, 65536 282 / 261 / 265, 131072 404 / 347 / 336 (profiles/r04_bh_tile_size_sweep.txt)
 }
 
+static hipError_t bh_create_state(BhState *b, int n);
+
+// The hipMemset calls of bh_create_state go to the NULL stream and return before they have run; the frames run on the context's
+// stream, which is non-blocking — it does not wait for the null stream.  This state is created by the first theta > 0 call, right
+// in front of its first frame: without the wait here a memset could land in the middle of that frame (larger systems: the Size
+// words cleared after part of the bounds kernel's maxima were in — a first frame with a root box too small, round 4's frames fuzz,
+// one large scene in ten; small systems: the header's frame count or the previous tree's CoM zeroed after the first frame wrote
+// them — a second tree rooted at zero).  EVERY way out of the creation passes through this wait, the small systems' included.
 hipError_t bh_create(BhState **out, int n) {
   BhState *b = new BhState();
   *out = b;                    // the caller destroys it whatever happens below
+  const hipError_t e = bh_create_state(b, n);
+  const hipError_t w = hipStreamSynchronize(nullptr);
+  return e != hipSuccess ? e : w;
+}
+
+static hipError_t bh_create_state(BhState *b, int n) {
   if (n > (int)kLinkMask) return hipErrorInvalidValue;      // a leaf's word holds its body's index in 25 bits
   b->n = n;
   b->small = n <= kSmBodies;
@@ -2498,6 +2574,7 @@ hipError_t bh_create(BhState **out, int n) {
   BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
   t.klo_by_body = 1;           // the second key words stay where the key kernel put them (second_word())
   b->radix = n > bh_merge_max_n();
+  { const char *e = getenv("NBODY_BH_LEVEL_SWEEPS"); b->level_sweeps = e && e[0] == '1'; }   // read at every bh_create, like the sorts' switch
   b->tile_size = bh_tile_size(n);
   { const int budget = n <= 131072 ? kNodeSmp / 4 : 512;       // many workgroups: a smaller table each (its fill is traffic; only cells of more than 127 bodies look at it)
     while ((((n - 1) >> b->smp_shift) + 1) > budget) ++b->smp_shift; }
@@ -2533,11 +2610,6 @@ hipError_t bh_create(BhState **out, int n) {
     BH_TRY(hipMalloc(&b->kids, sizeof(int) * 8 * (size_t)(kMaxLevels + 1) * nchunks));
   }
   BH_TRY(hipEventCreateWithFlags(&b->ev, hipEventDisableTiming));
-  // The hipMemset calls above go to the NULL stream and return before they have run; the frames run on the context's stream, which
-  // is non-blocking — it does not wait for the null stream.  This state is created by the first theta > 0 call, right in front of
-  // its first frame: without this wait a memset could land in the middle of that frame (the Size words cleared after part of the
-  // bounds kernel's maxima were in: a first frame with a root box too small — round 4's frames fuzz, one large scene in ten).
-  BH_TRY(hipStreamSynchronize(nullptr));
   return hipSuccess;
 }
 
@@ -2630,7 +2702,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
       P.kout = (d & 1) ? b->khi : b->khi2; P.vout = (d & 1) ? b->idx : b->idx2;
       P.slice_hist = b->slice_hist; P.digit = d;
       P.desc = b->rx_desc + (size_t)d * tiles * kRxBins;
-      P.shift = 8 * d; P.n = n;
+      P.shift = 8 * d; P.n = n; P.status = b->counters + 3;
       hipLaunchKernelGGL(bh_radix_pass_kernel, dim3(pass_grid), dim3(kRxT), 0, s, P);
     }
     // (b->idx2 and b->klo_sorted are free here: the passes ended in b->idx, and a cold frame's second words stay in body order)
@@ -2646,9 +2718,8 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   // chunk of kB bodies, then the few that do not, by one workgroup); above it a launch per level over all bodies — there the
   // one workgroup of the second launch would have more than a chunk per thread to look at per level (chunks are 256 bodies up to
   // N = 262144, 1024 bodies above) — and for that the host must know the deepest level: the frame's one wait.
-  // NBODY_BH_LEVEL_SWEEPS=1: a launch per level at any size (A/B).
-  static const bool level_sweeps = [] { const char *e = getenv("NBODY_BH_LEVEL_SWEEPS"); return e && e[0] == '1'; }();
-  if (level_sweeps || n > kChunkSweepMaxN) {
+  // NBODY_BH_LEVEL_SWEEPS=1: a launch per level at any size (A/B and tests; read at bh_create).
+  if (b->level_sweeps || n > kChunkSweepMaxN) {
     BH_TRY(hipMemcpyAsync(b->h_counters, b->counters, sizeof(int) * kHdrWords, hipMemcpyDeviceToHost, s));
     BH_TRY(hipStreamSynchronize(s));
     int maxl = -1;

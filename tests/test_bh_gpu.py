@@ -13,6 +13,9 @@ from conftest import particles_from, rel_err
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 REF_THETA = 1.0     # OctreeSearch.cpp:85
+# The device's path keys hold 42 octant digits: a frame is refused when two bodies share all of them — exactly when Octree::Add
+# (OctreeSearch.h:60-81) of the same scene splits a cell of depth 42, i.e. reaches depth 43 (oracle.last_max_depth, root = 0).
+REFUSED_FROM_DEPTH = 43
 
 
 def _check_same(a, ref):
@@ -327,7 +330,7 @@ def test_bh_fuzz_every_bit_of_the_force_pass_on_random_scenes(nb, oracle):
     NBODY_FUZZ_TRIALS run it longer."""
     rng = np.random.default_rng(int(os.environ.get("NBODY_FUZZ_SEED", "77")))
     trials = int(os.environ.get("NBODY_FUZZ_TRIALS", "24"))
-    ran = 0
+    ran = refused = 0
     for trial in range(trials):
         u = rng.random()
         n = (int(rng.integers(2, 4097)) if u < 0.35 else int(rng.integers(4097, 21000)) if u < 0.7 else
@@ -343,14 +346,21 @@ def test_bh_fuzz_every_bit_of_the_force_pass_on_random_scenes(nb, oracle):
                 e.compute_forces()
             except nb.NBodyError as err:                          # deeper than 42 levels: the reference would recurse on
                 assert "42" in str(err) or "deep" in str(err).lower(), err
+                # ... and the refusal was due only if the reference's own insertion of this scene goes that deep
+                depth = oracle.octree_depth_f32(pos)
+                assert depth >= REFUSED_FROM_DEPTH, f"trial {trial}: n={n} refused, but Octree::Add of the scene stops at depth {depth}"
+                refused += 1
                 continue
             a = e.accelerations()
             st = e.bh_stats()
         ref, com, nodes = oracle.octree_forces_f32(pos, m, theta, pow_mode=3, div_mode=div_mode)
+        assert oracle.last_max_depth() < REFUSED_FROM_DEPTH, (trial, n)      # (a frame that should have been refused and was not)
         np.testing.assert_array_equal(a, ref, err_msg=f"trial {trial}: n={n} theta={theta} div_mode={div_mode}")
         np.testing.assert_array_equal(st["root_com"], com)
         assert st["nodes"] == nodes, (trial, n)
         ran += 1
+    print(f"force-pass fuzz: {ran} of {trials} scenes compared in every bit, {refused} refused and confirmed "
+          f"(the oracle's insertion of the same scene passes depth 42)")
     assert ran >= trials * 2 // 3, ran
 
 
@@ -608,7 +618,7 @@ def test_bh_fuzz_every_byte_of_the_frames_on_random_scenes(nb, oracle):
     NBODY_FUZZ_SEED / NBODY_FUZZ_TRIALS run it longer."""
     rng = np.random.default_rng(int(os.environ.get("NBODY_FUZZ_SEED", "404")))
     trials = int(os.environ.get("NBODY_FUZZ_TRIALS", "30"))
-    ran = warm_total = retries_total = 0
+    ran = warm_total = retries_total = refused = 0
     for trial in range(trials):
         u = rng.random()
         n = (int(rng.integers(2, 4097)) if u < 0.3 else int(rng.integers(4097, 21000)) if u < 0.72 else
@@ -642,6 +652,7 @@ def test_bh_fuzz_every_byte_of_the_frames_on_random_scenes(nb, oracle):
                         out = e.particles()
                     for _ in range(k):
                         com, size = oracle.tick_aos_f32(q, dt, theta=theta, root_com=com, size=size, pow_mode=3, div_mode=div_mode)
+                        assert oracle.last_max_depth() < REFUSED_FROM_DEPTH, (what, call)   # (a frame that should have been refused)
                     assert out.tobytes() == q.tobytes(), (what, call)
                     if size_dev is not None:
                         assert size_dev == size, (what, call)
@@ -658,6 +669,22 @@ def test_bh_fuzz_every_byte_of_the_frames_on_random_scenes(nb, oracle):
                         e.device_ptr(nb.BUF_POSM)
             except nb.NBodyError as err:                          # deeper than 42 levels: the reference would recurse on
                 assert "42" in str(err) or "deep" in str(err).lower(), (what, err)
+                # The refusal was due only if the reference's own insertion goes that deep in one of this call's k frames: the
+                # oracle runs them from the state the call started from; the frames before the refused one must be on the device
+                # (a refused frame and everything queued behind it leave the state alone).
+                confirmed = False
+                for _ in range(k):
+                    root = np.zeros(3, np.float32) if com is None else com
+                    depth = oracle.octree_depth_f32(q["Position"], root_origin=root)
+                    if depth >= REFUSED_FROM_DEPTH:
+                        confirmed = True
+                        break
+                    com, size = oracle.tick_aos_f32(q, dt, theta=theta, root_com=com, size=size, pow_mode=3, div_mode=div_mode)
+                assert confirmed, f"{what}, call {call} ({k} frames): refused, but Octree::Add of no frame passes depth 42"
+                got = e.particles()
+                for f in ("Position", "Velocity", "Mass"):
+                    np.testing.assert_array_equal(got[f], q[f], err_msg=f"{what}: {f} after the refused frame")
+                refused += 1
                 continue
             np.testing.assert_array_equal(e.bh_stats()["root_com"], com, err_msg=what)
             if n > 4096:
@@ -665,7 +692,8 @@ def test_bh_fuzz_every_byte_of_the_frames_on_random_scenes(nb, oracle):
                 warm_total += w; retries_total += r
         ran += 1
     assert ran >= trials // 2, ran
-    print(f"frames fuzz: {ran} of {trials} scenes ran to the end; larger systems: {warm_total} frames sorted from the previous order, "
+    print(f"frames fuzz: {ran} of {trials} scenes ran to the end, {refused} refused and confirmed (the oracle's insertion of the "
+          f"refused frame passes depth 42); larger systems: {warm_total} frames sorted from the previous order, "
           f"{retries_total} times frames were queued again")
 
 
@@ -693,9 +721,113 @@ def test_both_sides_of_the_round_four_switches_cold_and_warm(nb, oracle, n):
                 e.compute_forces()
             except nb.NBodyError as err:                          # deeper than 42 levels: the reference would recurse on
                 assert "42" in str(err) or "deep" in str(err).lower(), err
+                assert oracle.octree_depth_f32(pos) >= REFUSED_FROM_DEPTH
                 pytest.skip("two bodies closer than Size / 2^42")
             np.testing.assert_array_equal(e.accelerations(), ref)
             np.testing.assert_array_equal(e.bh_leaf_order(), order)
             st = e.bh_stats()
             np.testing.assert_array_equal(st["root_com"], com)
             assert st["nodes"] == nodes
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 1, 1500000, 1 << 21])
+def test_a_million_bodies_and_more_equal_the_oracle_in_every_bit(nb, oracle, n):
+    # N = 2^20 is the largest system whose ComputeMass runs in two launches (every thread of bh_sweep_top_kernel owns one chunk of
+    # 1024 bodies: nchunks == kTopT) and the size of every headline theta > 0 figure; above it the host waits for the deepest level
+    # and launches one bh_sweep_level_kernel per level + bh_finish_kernel (OctreeSearch.h:83-97 level by level).  The shipped kind
+    # of scene (CreateSpacePoints, .cpp:58-72) at the shipped opening angle: one cold force pass — accelerations, node count, root
+    # CoM — and two whole Ticks that start from the previous order (.cpp:25-31: Size, tree rooted at the previous CoM, walk,
+    # kick-drift), every bit / byte against the oracle.
+    posm, vel = nb.ic_reference_box(n, 1000.0, seed=n % 1000 + 1)
+    pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+    ref, com0, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+    assert oracle.last_max_depth() < REFUSED_FROM_DEPTH
+    q = particles_from(nb, posm, vel)
+    com, size = None, 0.0
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()                                     # cold sorts, Size from the bounds kernel; the next root stays at zero
+        st = e.bh_stats()
+        np.testing.assert_array_equal(e.accelerations(), ref)
+        np.testing.assert_array_equal(st["root_com"], com0)
+        assert st["nodes"] == nodes
+        for frame in range(2):
+            size_dev, out = e.tick(0.01)
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+            assert size_dev == size, frame
+            np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
+            assert out.tobytes() == q.tobytes(), frame
+        warm, _ = _sort_counts(e)
+        assert warm >= 2                                       # (both Ticks started from the previous frame's order)
+
+
+@pytest.mark.parametrize("n", [5000, 30000, 140000])
+def test_compute_mass_with_a_launch_per_level_at_sizes_that_are_cheap_to_check(nb, oracle, monkeypatch, n):
+    # NBODY_BH_LEVEL_SWEEPS=1 (read when the theta > 0 state is created) sends a system of any size down the branch systems above
+    # 2^20 bodies take: host wait for the deepest level, one launch per level, bh_finish_kernel.  Clumpy scenes (deep chains), a
+    # cold pass and four Ticks, two of them queued in one call (the wait sits INSIDE the queueing of each frame): every bit / byte.
+    monkeypatch.setenv("NBODY_BH_LEVEL_SWEEPS", "1")
+    rng = np.random.default_rng(n + 5)
+    posm = _fuzz_scene(rng, n)
+    while len(np.unique(posm[:, :3], axis=0)) != n or oracle.octree_depth_f32(posm[:, :3]) >= REFUSED_FROM_DEPTH:
+        posm = _fuzz_scene(rng, n)
+    posm[:, 3] *= np.float32(1e-4)                              # (light: the clumps do not collapse within four frames)
+    vel = np.concatenate([rng.uniform(-20, 20, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+    ref, com0, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+    q = particles_from(nb, posm, vel)
+    com, size = None, 0.0
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        e.compute_forces()
+        st = e.bh_stats()
+        np.testing.assert_array_equal(e.accelerations(), ref)
+        np.testing.assert_array_equal(st["root_com"], com0)
+        assert st["nodes"] == nodes
+        for k in (1, 2, 1):
+            try:
+                e.step(0.01, k)
+            except nb.NBodyError as err:                        # a narrow clump can put two bodies on one path for 42 levels as it moves:
+                assert "42" in str(err), err                    # the refusal must be the oracle's finding too, on the same frame
+                for _ in range(k):
+                    if oracle.octree_depth_f32(q["Position"], root_origin=np.zeros(3, np.float32) if com is None else com) >= REFUSED_FROM_DEPTH:
+                        break
+                    com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+                else:
+                    raise AssertionError("refused, but Octree::Add of no frame of the call passes depth 42")
+                got = e.particles()
+                np.testing.assert_array_equal(got["Position"], q["Position"])
+                np.testing.assert_array_equal(got["Velocity"], q["Velocity"])
+                return
+            for _ in range(k):
+                com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+                assert oracle.last_max_depth() < REFUSED_FROM_DEPTH
+            assert e.particles().tobytes() == q.tobytes(), k
+        np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
+
+
+def test_the_first_two_frames_right_after_creation_of_small_systems(nb, oracle):
+    # The theta > 0 state is created by the first theta > 0 call, right in front of its first frame, and its creation clears
+    # device words with hipMemset on the NULL stream while the frames run on the context's non-blocking stream.  Round 4 waited for
+    # the null stream only behind the larger systems' part of the creation (the advisor's finding): for N <= 4096 a late fill could
+    # zero the header's frame count or the previous tree's CoM after the first frame had written them — a wrong steps_done, a second
+    # tree rooted at zero.  Forty systems, each created and ticked twice at once: every byte, Size, the root centre, steps_done.
+    rng = np.random.default_rng(4096)
+    for trial in range(40):
+        n = int(rng.integers(2, 4097))
+        posm = _fuzz_scene(rng, n)
+        vel = np.concatenate([rng.uniform(-50, 50, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+        if oracle.octree_depth_f32(posm[:, :3]) >= REFUSED_FROM_DEPTH - 2:
+            continue
+        q = particles_from(nb, posm, vel)
+        com, size = None, 0.0
+        with nb.NBodyEngine(n, theta=REF_THETA) as e:
+            e.set_state(posm, vel)
+            for frame in range(2):
+                size_dev, out = e.tick(0.01)
+                com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+                assert size_dev == size, (trial, n, frame)
+                np.testing.assert_array_equal(e.bh_stats()["root_com"], com, err_msg=f"trial {trial} n={n} frame {frame}")
+                assert out.tobytes() == q.tobytes(), (trial, n, frame)
+            assert e.steps_done() == 2, (trial, n)

@@ -339,6 +339,46 @@ def test_c_octree_agrees_with_the_python_restatement_on_deep_chains(oracle, thet
     assert nodes > 8 * 25                                   # the chains are there
 
 
+def _py_depth(cell, d=0):
+    if cell.kids is None:
+        return d
+    return max(_py_depth(k, d + 1) for k in cell.kids)
+
+
+def test_the_depth_the_oracle_reports_is_the_python_restatements(oracle):
+    # oracle.last_max_depth / octree_depth_f32 (how deep Octree::Add, OctreeSearch.h:60-81, goes; root = 0) is what the GPU fuzz
+    # tests confirm a refused frame with (the device refuses from depth 43 on: its keys hold 42 octant digits).  Against the
+    # recursive Python restatement's deepest cell: random scenes, near-twins at chosen separations — on both sides of the
+    # device's limit — and an exact duplicate (the reference recurses without bound; the oracle cuts off at 201).
+    rng = np.random.default_rng(42)
+    for n in (2, 9, 64):
+        pos = rng.uniform(-100, 100, (n, 3)).astype(np.float32)
+        root = _PyCell(np.zeros(3, np.float32), oracle.bounds_f32(pos))
+        for i in range(n):
+            root.add(i, pos)
+        assert oracle.octree_depth_f32(pos) == _py_depth(root)
+    seen = set()
+    for e in (-3, -10, -20, -21, -22, -30, -35, -38, -39, -40, -41, -42, -45):
+        x0 = 1000.0 * 2.0 ** e                               # a pair about Size * 2^e apart, next to the origin (where fp32 is that fine)
+        pos = np.array([[1000.0, -1000.0, 1000.0], [x0, x0, x0], [2 * x0, x0, x0]], np.float32)
+        assert pos[2, 0] != pos[1, 0]
+        root = _PyCell(np.zeros(3, np.float32), _f(1000.0))
+        for i in range(3):
+            root.add(i, pos)
+        depth = oracle.octree_depth_f32(pos)
+        assert depth == _py_depth(root)
+        assert abs(depth - (-e)) <= 2                        # leaves about log2(Size / separation) deep
+        seen.add(depth >= 43)
+        # and the same number through the whole-frame entry points
+        oracle.octree_forces_f32(pos, np.ones(3, np.float32), 1.0)
+        assert oracle.last_max_depth() == depth
+    assert seen == {False, True}
+    pos = np.array([[1.0, 2.0, 3.0], [5.0, 5.0, 5.0], [5.0, 5.0, 5.0]], np.float32)
+    assert oracle.octree_depth_f32(pos) == 201
+    with pytest.raises(RuntimeError):
+        oracle.octree_forces_f32(pos, np.ones(3, np.float32), 1.0)
+
+
 @pytest.mark.parametrize("n,seed", [(9, 1), (200, 3)])
 def test_c_octree_draw_order_and_division_reading(oracle, n, seed):
     # what DrawOctreeBoxes draws (occupied leaves depth first, .cpp:36-45) and the second reading of `/=` in ComputeMass
