@@ -192,16 +192,22 @@ def baseline_config_row(nb, n, precision, eps, steps, warmup, settle_seconds, dt
             "max_rel_err_sampled": err, "bodies_sampled": len(bodies), "rel_err_tolerance": tol, "finite": finite}
 
 
-def barnes_hut_row(nb, n, frames, warmup, parity_frames, theta=1.0, dt=0.01, size=1000.0):
+def barnes_hut_row(nb, n, frames, warmup, parity_frames, scene="box", theta=1.0, dt=0.01, size=1000.0):
     """The reference's SHIPPED algorithm (OctreeSearch.cpp:74-89 at Theta = 1.0, .cpp:85) on its shipped kind of scene
     (CreateSpacePoints(N, 1000), .cpp:58-72): whole frames — ComputeCubeSize, the tree rooted at the previous tree's CoM,
     ComputeMass, every body's walk, kick-drift — queued by nbody_step with one host wait per call.  Before the timing, on a
     context of its own: `parity_frames` whole Ticks compared in EVERY BYTE of the FParticle records, Size and the root centre
     with the oracle's restatement of OctreeSearch.h:60-108 / .cpp:25-31 (cube correctly rounded: pow_mode 3) — whose time on this
     box's host cores is the row's cpu_baseline."""
+    import ctypes
     import numpy as np
     from oracle import oracle as O
-    posm, vel = nb.ic_reference_box(n, size, seed=1)
+    if scene == "box":
+        posm, vel = nb.ic_reference_box(n, size, seed=1)
+        what = f"reference box scene (CreateSpacePoints(N, {size:g}), OctreeSearch.cpp:58-72)"
+    else:                                                    # BASELINE.json's inputs: a seeded Plummer sphere (the bench's headline scene)
+        posm, vel = nb.ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
+        what = "seeded Plummer sphere (BASELINE's input kind; equal masses)"
     q = np.zeros(n, nb.PARTICLE_DTYPE)
     q["Mass"] = posm[:, 3]; q["Position"] = posm[:, :3]; q["Velocity"] = vel[:, :3]
     com, sz, cpu_s = None, 0.0, []
@@ -225,13 +231,18 @@ def barnes_hut_row(nb, n, frames, warmup, parity_frames, theta=1.0, dt=0.01, siz
         elapsed = time.perf_counter() - t0
         done = e.steps_done()
         finite = bool(np.isfinite(e.state()[0]).all())
+        warm, again = ctypes.c_longlong(), ctypes.c_longlong()
+        if n <= 4096 or e._L.nbody_debug_bh_sort_counts(e._h, ctypes.byref(warm), ctypes.byref(again)) != 0:
+            warm, again = None, None
+        else:
+            warm, again = warm.value, again.value
     if done != warmup + frames or not finite:
         raise SystemExit(f"bench.py: Barnes-Hut row N={n}: {done} of {warmup + frames} frames built, finite={finite}")
     cores = min(O.max_threads(), os.cpu_count() or 1)
-    return {"workload": f"N={n} reference box scene (CreateSpacePoints(N, {size:g})), theta={theta}, dt={dt}: whole frames "
-                        f"(Size, tree, ComputeMass, walks, kick-drift)",
+    return {"workload": f"N={n} {what}, theta={theta}, dt={dt}: whole frames (Size, tree, ComputeMass, walks, kick-drift)",
             "frames": frames, "warmup": warmup, "us_per_frame": elapsed / frames * 1e6, "frames_per_s": frames / elapsed,
             "bodies_per_s": n * frames / elapsed, "tree_nodes": st["nodes"], "tree_levels": st["levels"],
+            "frames_sorted_from_the_previous_order": warm, "times_frames_were_queued_again": again,
             "parity": f"every byte of {parity_frames} frame(s) (FParticle records, Size, root centre) equal to the oracle's",
             "cpu_baseline": {"value": min(cpu_s) * 1e6, "unit": "us/frame", "kind": "port", "cores": cores,
                              "sample": f"oracle Tick (Octree::Add and ComputeMass on one thread, the walks OpenMP over bodies) of "
@@ -251,8 +262,8 @@ def extra_rows(args, nb):
     }
     bh = {
         "n2000": barnes_hut_row(nb, 2000, frames=200, warmup=20, parity_frames=2),
-        "n65536": barnes_hut_row(nb, 1 << 16, frames=100, warmup=10, parity_frames=1),
-        "n1048576": barnes_hut_row(nb, 1 << 20, frames=50, warmup=5, parity_frames=1),
+        "n65536": barnes_hut_row(nb, 1 << 16, frames=100, warmup=10, parity_frames=1, scene="plummer"),
+        "n1048576": barnes_hut_row(nb, 1 << 20, frames=50, warmup=5, parity_frames=1, scene="plummer"),
     }
     return configs, bh
 

@@ -30,8 +30,8 @@ class OctreeSearchActor {
   // ---- build-defined knobs (no reference counterpart) ----
   // Opening angle: the argument the reference hard-codes in `ComputeForces(&Particles[i], 1.0)` (.cpp:85), and the
   // default here too, so that an actor swapped in for AOctreeSearch reproduces its trajectories and its ShowOctree
-  // boxes without further ado: the reference's own tree build, upsweep and walk run on the device (fp32, one device;
-  // other precisions / device lists report NBODY_ERR_UNSUPPORTED in LastStatus).  Set Theta = 0 for the theta -> 0
+  // boxes without further ado: the reference's own tree build, upsweep and walk run on the device (fp32, one device or a
+  // device list; other precisions report NBODY_ERR_UNSUPPORTED in LastStatus).  Set Theta = 0 for the theta -> 0
   // limit of that walk — exact O(N^2) all-pairs, the hot path this engine exists for (any precision, any device list).
   float Theta = 1.0f;
   uint64_t Seed = 0x4E426F6479ull;      // CreateSpacePoints' generator seed (the reference is unseeded)
@@ -39,7 +39,8 @@ class OctreeSearchActor {
   bool MirrorParticles = true;          // refresh `Particles` after every Tick, as the reference's TArray is live
   bool DrawInTick = true;          // Tick ends with DrawOctreeBoxes() (.cpp:33); a host that draws through its own DrawOctreeBoxes(Octree*) turns it off
   int Device = 0;
-  std::vector<int32_t> Devices;         // non-empty: share the bodies over these GPUs (nbody_create_multi; Theta must be 0)
+  std::vector<int32_t> Devices;         // non-empty: share the bodies over these GPUs (nbody_create_multi; any Theta: at Theta > 0 every
+                                        // device builds the whole tree and walks its slice — the frames equal one device's in every byte)
   int Precision = NBODY_PREC_F32;
   double G = 1.0e4;                     // .h:104
   double Eps = 0.0;
@@ -105,6 +106,20 @@ class OctreeSearchActor {
     if (!Initialized) return;
     LastStatus = nbody_push_particles(ctx_, data_, sizeof(FParticle), (int32_t)num_);
     if (LastStatus == NBODY_OK) dirty_ = false;
+  }
+
+  // The host is about to resize or reallocate the array behind AllocateParticles (TArray::Add / SetNum / Empty + refill ...): the
+  // context lets go of the storage FIRST — a page-locked registration must not outlive its allocation (hipHostUnregister on memory
+  // the allocator has already handed back is undefined).  Afterwards the host tells the actor about the new storage with
+  // SetParticles(data, n) before anything else (a UE4 adapter does both in its mutators / at the top of its Tick).
+  void ReleaseStorage() {
+    if (ctx_ && data_ && pinned_) (void)nbody_unpin_host_buffer(ctx_, data_);
+    pinned_ = false;
+  }
+  bool StoragePinned() const { return pinned_; }
+  // ... and the other way round: the storage is where it was after all (same address, same size): page-lock it again
+  void PinStorage() {
+    if (ctx_ && data_ && !pinned_) pinned_ = nbody_pin_host_buffer(ctx_, data_, num_ * sizeof(FParticle)) == NBODY_OK;
   }
 
   // The records (`Particles`, or the host's array behind AllocateParticles) and their number
@@ -187,6 +202,7 @@ class OctreeSearchActor {
     dirty_ = false;
     Particles.clear();
     data_ = nullptr; num_ = 0;          // (a host array behind AllocateParticles is the host's to empty)
+    pinned_ = false;
   }
 
   // Pull the whole device state into the records.
@@ -221,6 +237,7 @@ class OctreeSearchActor {
   void Release() {
     nbody_destroy(ctx_);                // also unpins `Particles`
     ctx_ = nullptr;
+    pinned_ = false;
     Initialized = false;
   }
 
@@ -241,7 +258,7 @@ class OctreeSearchActor {
     // the per-frame records land in the storage straight from the device (an optimisation only: unpinned memory works the
     // same).  The storage must keep its address while the actor is initialised, as the reference's TArray does between
     // CreateSpacePoints and CleanParticles.
-    (void)nbody_pin_host_buffer(ctx_, data_, num_ * sizeof(FParticle));
+    pinned_ = nbody_pin_host_buffer(ctx_, data_, num_ * sizeof(FParticle)) == NBODY_OK;
     Initialized = true;                                                        // .cpp:71
     forces_fresh_ = false;
     dirty_ = false;
@@ -254,6 +271,7 @@ class OctreeSearchActor {
   std::vector<int32_t> order_;
   bool forces_fresh_ = false;
   bool dirty_ = false;
+  bool pinned_ = false;                 // the records' storage is page-locked for ctx_ (nbody_pin_host_buffer)
 };
 
 }  // namespace nbody

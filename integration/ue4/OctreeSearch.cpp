@@ -55,9 +55,20 @@ void AOctreeSearch::AdoptStorage()
 {
   if (!Engine.Initialized) return;
   const nbody::FParticle* Data = reinterpret_cast<const nbody::FParticle*>(Particles.GetData());
-  if (Data == Engine.ParticleData() && (size_t)Particles.Num() == Engine.NumParticles()) return;
+  if (Data == Engine.ParticleData() && (size_t)Particles.Num() == Engine.NumParticles()) {
+    Engine.PinStorage();                                      // (released, and the array stayed where it was after all)
+    return;
+  }
+  // (Here the old storage is gone already.  Had the caller not announced the change with ReleaseStorage(), the old range would
+  //  still be page-locked for the context that SetParticles is about to destroy: unregistering memory the allocator has handed
+  //  back is undefined — hence the rule in OctreeSearch.h.)
   if (Particles.Num() == 0) { Engine.CleanParticles(); return; }
   Engine.SetParticles(Data, Particles.Num());                 // re-creates the context on (and re-pins) the new storage
+}
+
+void AOctreeSearch::ReleaseStorage()
+{
+  Engine.ReleaseStorage();
 }
 
 void AOctreeSearch::PushParticles()

@@ -43,8 +43,10 @@ public:
   TArray<FParticle> Particles;              // OctreeSearch.h:118.  The array's own storage is where the device writes every frame's
                                             // records (it is page-locked for the context; nothing is copied on the host).  The
                                             // simulation state lives on the device: code that EDITS Particles[i] calls
-                                            // PushParticles() afterwards, code that resizes the array needs nothing more —
-                                            // the next Tick sees the new storage and re-creates the engine on it.
+                                            // PushParticles() afterwards; code that RESIZES or reallocates the array (Add /
+                                            // SetNum / Empty + refill) calls ReleaseStorage() first — a page-locked range must
+                                            // not outlive its allocation — and the next Tick (or PushParticles) sees the new
+                                            // storage and re-creates the engine on it.
   Octree* ParticleOctree;                   // OctreeSearch.h:119: NULL until the first force pass and after CleanParticles
                                             // (OctreeSearch.cpp:8, 95); otherwise a token for the device's current tree
   bool Initialized;
@@ -60,7 +62,8 @@ public:
   UPROPERTY(BlueprintReadWrite)
   float Theta;
 
-  // GPUs to share the bodies over (empty = device 0).  More than one needs Theta = 0 (nbody_create_multi).
+  // GPUs to share the bodies over (empty = device 0; nbody_create_multi).  Any Theta: at Theta > 0 every device builds the whole
+  // tree from its copy of the positions and walks its own slice — the frames equal one device's in every byte.
   TArray<int32> Devices;
 
   AOctreeSearch();
@@ -85,6 +88,11 @@ public:
   // previous tree's centre of mass (OctreeSearch.cpp:77-79).
   UFUNCTION(BlueprintCallable, Category = "Octree")
   void PushParticles();
+
+  // new: call BEFORE code resizes or reallocates `Particles`: the engine unpins the array's storage while it is still allocated.
+  // (CreateSpacePoints and CleanParticles do it themselves.)  Frames keep arriving; the new storage is adopted by the next Tick.
+  UFUNCTION(BlueprintCallable, Category = "Octree")
+  void ReleaseStorage();
 
 private:
   nbody::OctreeSearchActor Engine;          // owns the nbody_ctx; never touched from Blueprints

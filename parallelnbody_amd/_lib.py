@@ -172,5 +172,6 @@ def lib():
     sig("nbody_actor_get_particles", c_i32, vp, vp, c_i32)
     sig("nbody_actor_particle_data", vp, vp)
     sig("nbody_actor_push_particles", None, vp, vp, c_i32)
+    sig("nbody_actor_release_storage", None, vp)
     _lib = L
     return L

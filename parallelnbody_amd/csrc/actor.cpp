@@ -78,4 +78,6 @@ void nbody_actor_push_particles(nbody_actor *a, const nbody_particle *p, int32_t
   a->impl.PushParticles();
 }
 
+void nbody_actor_release_storage(nbody_actor *a) { if (a) a->impl.ReleaseStorage(); }
+
 }  // extern "C"

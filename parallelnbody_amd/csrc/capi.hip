@@ -107,6 +107,9 @@ int fail(nbody_ctx *c, int code, const char *fmt, ...) {
   return code;
 }
 
+int run_update(nbody_ctx *c, float dt);   // (defined below; part_bh_queue_frame comes first)
+int queue_forces_bh(nbody_ctx *c, bool diagnostic);
+
 // A call on a multi-device context is answered by its Multi; its message becomes the context's.
 int multi_rc(nbody_ctx *c, int rc) {
   if (rc) c->err = nbody::multi_error(c->multi);
@@ -458,11 +461,12 @@ int ensure_floor(nbody_ctx *c) {
 
 // Barnes-Hut state of a context, on first use.
 int ensure_bh(nbody_ctx *c) {
-  if (c->p.precision != NBODY_PREC_F32 || c->p.i_count != c->p.n_total)
-    return fail(c, NBODY_ERR_UNSUPPORTED, "theta > 0 (Barnes-Hut) needs an fp32 context that owns all bodies");
+  if (c->p.precision != NBODY_PREC_F32)
+    return fail(c, NBODY_ERR_UNSUPPORTED, "theta > 0 (Barnes-Hut) needs an fp32 context");
   if (c->bh) return NBODY_OK;
-  hipError_t e = nbody::bh_create(&c->bh, c->p.n_total);
-  if (e == hipSuccess) e = hipMalloc(&c->bh_acc, (size_t)c->p.n_total * 16);
+  // a context that owns a slice builds the whole tree from the replicated positions and walks its own bodies (kernels_bh.hip, WalkSlice)
+  hipError_t e = nbody::bh_create(&c->bh, c->p.n_total, c->p.i_begin, c->p.i_count);
+  if (e == hipSuccess) e = hipMalloc(&c->bh_acc, (size_t)c->p.i_count * 16);
   if (e != hipSuccess) {
     nbody::bh_destroy(c->bh); c->bh = nullptr;
     if (c->bh_acc) { (void)hipFree(c->bh_acc); c->bh_acc = nullptr; }
@@ -502,17 +506,59 @@ int bh_finish(nbody_ctx *c) {
   return bh_status_error(c, status);
 }
 
+}  // namespace
+
+// ---- for multi.hip (declared in multi.h, not part of the C-ABI): one device's share of a theta > 0 step, in two halves, so that one
+// caller thread can queue every device's frames — and the all-gathers between them — before it waits for any of them.
+namespace nbody {
+int part_bh_queue_frame(nbody_ctx *c, float dt, bool diagnostic) {
+  if (int rc = use_device(c)) return rc;
+  if (int rc = ensure_bh(c)) return rc;
+  if (!(dt > 0.0f)) {                                           // accelerations only (nbody_compute_forces): walk into bh_acc, then the row fold
+    if (int rc = queue_forces_bh(c, diagnostic)) return rc;
+    return run_update(c, 0.0f);
+  }
+  return bh_enqueue(c, dt, 1);
+}
+// status: 0 all frames built; 1 / 2 refused (the error text is the context's); 3 the warm sort gave a frame up — the frames from
+// number *built on did nothing on this device (nor, the build being the same everywhere, on any other) and are the caller's to queue again
+int part_bh_collect(nbody_ctx *c, int *status, int *built) {
+  if (int rc = use_device(c)) return rc;
+  int st = 0, frames = 0;
+  HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &st, &frames, false));
+  *status = st; *built = frames;
+  c->steps_done += frames;
+  if (st == 1 || st == 2) return bh_status_error(c, st);
+  return NBODY_OK;
+}
+// the next tree's root centre (the previous tree's CoM, OctreeSearch.cpp:77-79) of a context that has built a tree: what a checkpoint keeps
+int part_bh_root(nbody_ctx *c, float out[3], int *has_root) {
+  *has_root = 0;
+  if (!c->bh) return NBODY_OK;
+  if (int rc = use_device(c)) return rc;
+  HIP_TRY(c, nbody::bh_get_root_com(c->bh, out, c->stream));
+  *has_root = 1;
+  return NBODY_OK;
+}
+}  // namespace nbody
+
+namespace {
+
 // Barnes-Hut force pass alone: ComputeCubeSize -> CreateOctree -> the walk, accelerations into bh_acc (run_update adds them up
 // and, for nbody_step_end, moves the bodies).  diagnostic: the pass belongs to no frame (nbody_compute_forces) and leaves the
 // next tree's root centre alone.
-int run_forces_bh(nbody_ctx *c, bool diagnostic) {
+int queue_forces_bh(nbody_ctx *c, bool diagnostic) {
   { int rc = ensure_bh(c); if (rc) return rc; }
   EventPair ev;
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
-  int status = 0;
   HIP_TRY(c, nbody::bh_frame(c->bh, c->posm, nullptr, c->bh_acc, c->theta, c->p.G, 0.0f, diagnostic ? 1 : 0, nullptr, c->stream));
   if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
+  return NBODY_OK;
+}
+int run_forces_bh(nbody_ctx *c, bool diagnostic) {
+  { int rc = queue_forces_bh(c, diagnostic); if (rc) return rc; }
+  int status = 0;
   HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &status, nullptr));
   return bh_status_error(c, status);
 }
@@ -573,7 +619,7 @@ int run_update(nbody_ctx *c, float dt) {
   const bool timed = c->p.time_kernels != 0;
   if (timed) { int rc = timer_begin(c, NBODY_KERNEL_UPDATE, &ev); if (rc) return rc; }
   if (c->theta > 0.0f) {
-    HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->bh_acc, 0, c->p.n_total, 1, dt, c->stream));
+    HIP_TRY(c, nbody::launch_update(c->p.precision, c->posm, c->vel, c->acc, c->bh_acc, c->p.i_begin, c->p.i_count, 1, dt, c->stream));
     // bodies moved without the fused update's preparation of the next all-pairs pass: posg and the detector table are
     // those of older positions (the next theta == 0 pass runs the preparation kernel again)
     if (dt > 0.0f) c->sym_posg_valid = false;
@@ -921,7 +967,7 @@ int nbody_create_multi(const nbody_params *pin, const int32_t *devices, int32_t 
   if (rc) { delete c; return fail(nullptr, rc, "%s", why.c_str()); }
   c->p = *pin;
   c->p.i_begin = 0; c->p.i_count = pin->n_total; c->p.device = devices[0];
-  c->theta = 0.0f;
+  c->theta = pin->theta;
   c->elem = (pin->precision == NBODY_PREC_F64) ? 32 : 16;
   *out = c;
   return NBODY_OK;
@@ -1236,6 +1282,12 @@ int nbody_step(nbody_ctx *c, float dt, int32_t nsteps) {
   if (nsteps < 0) return fail(c, NBODY_ERR_INVALID, "nbody_step: nsteps < 0");
   if (!(dt > 0.0f)) return NBODY_OK;   // OctreeSearch.cpp:25: PhDeltaTime <= 0 freezes the physics
   if (c->multi) {
+    if (c->theta > 0.0f) {                                        // whole frames on every device, one wait per batch (multi_bh_steps)
+      int built = 0;
+      rc = multi_rc(c, nbody::multi_bh_steps(c->multi, dt, nsteps, &built));
+      c->steps_done += built;
+      return rc;
+    }
     for (int s = 0; s < nsteps; ++s) {
       if ((rc = multi_rc(c, nbody::multi_forces(c->multi, dt)))) return rc;
       c->steps_done += 1;
@@ -1510,6 +1562,9 @@ int nbody_save_checkpoint(nbody_ctx *c, const char *path) try {
     rc = f64 ? nbody_get_state_soa_f64(c, (double *)posm.data(), (double *)vel.data(), (double *)acc.data())
              : nbody_get_state_soa(c, (float *)posm.data(), (float *)vel.data(), (float *)acc.data());
     if (rc) return rc;
+    int has_root = 0;
+    if ((rc = multi_rc(c, nbody::multi_bh_root(c->multi, h.root_com, &has_root)))) return rc;
+    h.has_root = has_root;
   } else {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(posm.data(), c->posm, posm.size(), hipMemcpyDeviceToHost));
@@ -1541,6 +1596,7 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) t
     const int rc = multi_rc(c, nbody::multi_load_checkpoint(c->multi, path, &n));
     if (rc) return rc;
     c->have_state = true; c->steps_done = n;
+    (void)nbody_get_theta(nbody::multi_part(c->multi, 0), &c->theta);   // the file's opening angle: every device took it over
     if (steps_done) *steps_done = n;
     return NBODY_OK;
   }
@@ -1590,8 +1646,9 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) t
   if (c->bh) nbody::bh_positions_changed(c->bh);
   c->steps_done = h.steps_done;
   // Barnes-Hut: the opening angle and the root of the next tree (the previous tree's CoM, OctreeSearch.cpp:77-79) are
-  // part of the trajectory.  Only contexts that can run the walk take them over.
-  if (c->p.precision == NBODY_PREC_F32 && c->p.i_count == c->p.n_total) {
+  // part of the trajectory.  Only contexts that can run the walk take them over (a slice of a sharded job as well: it builds
+  // the whole tree).
+  if (c->p.precision == NBODY_PREC_F32) {
     c->theta = h.theta;
     if (h.has_root || c->bh) {
       { const int rc2 = ensure_bh(c); if (rc2) return rc2; }
@@ -1609,9 +1666,13 @@ int nbody_load_checkpoint(nbody_ctx *c, const char *path, int64_t *steps_done) t
 int nbody_set_theta(nbody_ctx *c, float theta) {
   if (!c) return NBODY_ERR_INVALID;
   if (!(theta >= 0.0f)) return fail(c, NBODY_ERR_INVALID, "nbody_set_theta: theta must be >= 0");
-  if (c->multi) return theta > 0.0f ? multi_unsupported(c, "nbody_set_theta(theta > 0)") : NBODY_OK;
-  if (theta > 0.0f && (c->p.precision != NBODY_PREC_F32 || c->p.i_count != c->p.n_total))
-    return fail(c, NBODY_ERR_UNSUPPORTED, "nbody_set_theta: Barnes-Hut needs an fp32 context that owns all bodies");
+  if (c->multi) {
+    const int rc = multi_rc(c, nbody::multi_set_theta(c->multi, theta));
+    if (!rc) c->theta = theta;
+    return rc;
+  }
+  if (theta > 0.0f && c->p.precision != NBODY_PREC_F32)
+    return fail(c, NBODY_ERR_UNSUPPORTED, "nbody_set_theta: Barnes-Hut needs an fp32 context");
   if (theta != c->theta) c->sym_posg_valid = false;   // the other force pass moves bodies without preparing the next all-pairs pass
   if (theta != c->theta && c->bh) nbody::bh_positions_changed(c->bh);   // ... nor leaving the next Barnes-Hut frame's Size
   c->theta = theta;
@@ -1620,13 +1681,13 @@ int nbody_set_theta(nbody_ctx *c, float theta) {
 
 int nbody_get_theta(nbody_ctx *c, float *theta) {
   if (!c || !theta) return NBODY_ERR_INVALID;
-  *theta = c->multi ? 0.0f : c->theta;
+  *theta = c->theta;
   return NBODY_OK;
 }
 
 int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com[3]) {
   if (!c) return NBODY_ERR_INVALID;
-  if (c->multi) return fail(c, NBODY_ERR_STATE, "nbody_bh_stats: no tree has been built on this context");
+  if (c->multi) return multi_rc(c, nbody::multi_bh_stats(c->multi, nodes, levels, root_com));   // every device holds the whole tree
   if (!c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_stats: no tree has been built on this context");
   if (int rc = use_device(c)) return rc;
   int n = 0, l = 0;
@@ -1639,7 +1700,8 @@ int nbody_bh_stats(nbody_ctx *c, int32_t *nodes, int32_t *levels, float root_com
 
 int nbody_bh_leaf_boxes(nbody_ctx *c, float *boxes, size_t stride) {
   if (!c || !boxes || stride < 16) return c ? fail(c, NBODY_ERR_INVALID, "nbody_bh_leaf_boxes: null buffer or stride < 16") : NBODY_ERR_INVALID;
-  if (c->multi || !c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_boxes: no tree has been built on this context (theta == 0?)");
+  if (c->multi) return multi_rc(c, nbody::multi_bh_leaf_boxes(c->multi, boxes, stride));
+  if (!c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_boxes: no tree has been built on this context (theta == 0?)");
   if (int rc0 = use_device(c)) return rc0;
   const size_t bytes = (size_t)c->p.n_total * 16;
   int rc = ensure_stage(c, bytes);
@@ -1654,7 +1716,8 @@ int nbody_bh_leaf_boxes(nbody_ctx *c, float *boxes, size_t stride) {
 
 int nbody_bh_leaf_order(nbody_ctx *c, int32_t *order) {
   if (!c || !order) return c ? fail(c, NBODY_ERR_INVALID, "nbody_bh_leaf_order: null buffer") : NBODY_ERR_INVALID;
-  if (c->multi || !c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_order: no tree has been built on this context (theta == 0?)");
+  if (c->multi) return multi_rc(c, nbody::multi_bh_leaf_order(c->multi, order));
+  if (!c->bh) return fail(c, NBODY_ERR_STATE, "nbody_bh_leaf_order: no tree has been built on this context (theta == 0?)");
   if (int rc = use_device(c)) return rc;
   HIP_TRY(c, nbody::bh_leaf_order(c->bh, order, c->stream));
   return NBODY_OK;

@@ -129,7 +129,8 @@ hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *ac
 
 // GPU Barnes-Hut with the reference's tree and opening rule — kernels_bh.hip.  fp32, all bodies in one context.
 struct BhState;
-hipError_t bh_create(BhState **out, int n);                   // *out is set even on failure: bh_destroy it
+// n bodies; the context owns [i_begin, i_begin + i_count) of them (all: 0, n) — a slice builds the whole tree and walks its own bodies
+hipError_t bh_create(BhState **out, int n, int i_begin, int i_count);   // *out is set even on failure: bh_destroy it
 void bh_destroy(BhState *b);
 void bh_positions_changed(BhState *b);                         // a body was moved by something other than a frame's walk
 void bh_positions_external(BhState *b);                        // the caller holds the position buffer from now on
@@ -145,7 +146,7 @@ bool bh_is_small(const BhState *b);
 hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root, float *stage,
                     hipStream_t s);
 float bh_last_size(const BhState *b);                         // Size of the last frame bh_collect has seen
-hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames);
+hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames, bool requeue = true);
 hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t s);   // tuning builds only (tools/bh_phases.py)
 void bh_debug_sort_counts(const BhState *b, long long *warm_frames, long long *retries);   // frames sorted from the previous order; times frames were queued again
 const float *bh_root_device(const BhState *b);                // device (ox, oy, oz, Size) of the last tree (small systems)

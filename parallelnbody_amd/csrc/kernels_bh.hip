@@ -2502,6 +2502,10 @@ struct BhState {
   float *prev_com = nullptr;   // the previous tree's root CoM (zero before the first frame)
   int last_nodes = 0, last_levels = 0;
   int div_mode = 0;            // reading of `/=` in ComputeMass (sweep_compact_cell)
+  // a context that owns a slice of the bodies (range partition over GPUs): the tree is the whole system's, the walk its own bodies'
+  int i_begin = 0, i_count = 0;            // the slice; i_count == n: all bodies
+  bool sliced = false;
+  unsigned int *own = nullptr, *own_blk = nullptr;   // [i_count] sorted positions of the slice's bodies in key order; [blocks of kB] their counts (bh_own_*_kernel)
   bool level_sweeps = false;   // ComputeMass with a launch per level at any size (NBODY_BH_LEVEL_SWEEPS=1 at creation; always above kChunkSweepMaxN)
 };
 
@@ -2521,7 +2525,7 @@ int bh_tile_size(int n) {
   return n <= 16384 ? 1024 : (n <= 98304 ? 2048 : 4096);      // frames, tile 1024 / 2048 / 4096: N = 16384 179 / 181 / 203 us, 32768 230 / 226 / 241, 65536 282 / 261 / 265, 131072 404 / 347 / 336 (profiles/r04_bh_tile_size_sweep.txt)
 }
 
-static hipError_t bh_create_state(BhState *b, int n);
+static hipError_t bh_create_state(BhState *b, int n, int i_begin, int i_count);
 
 // The hipMemset calls of bh_create_state go to the NULL stream and return before they have run; the frames run on the context's
 // stream, which is non-blocking — it does not wait for the null stream.  This state is created by the first theta > 0 call, right
@@ -2529,17 +2533,26 @@ static hipError_t bh_create_state(BhState *b, int n);
 // words cleared after part of the bounds kernel's maxima were in — a first frame with a root box too small, round 4's frames fuzz,
 // one large scene in ten; small systems: the header's frame count or the previous tree's CoM zeroed after the first frame wrote
 // them — a second tree rooted at zero).  EVERY way out of the creation passes through this wait, the small systems' included.
-hipError_t bh_create(BhState **out, int n) {
+hipError_t bh_create(BhState **out, int n, int i_begin, int i_count) {
   BhState *b = new BhState();
   *out = b;                    // the caller destroys it whatever happens below
-  const hipError_t e = bh_create_state(b, n);
+  const hipError_t e = bh_create_state(b, n, i_begin, i_count);
   const hipError_t w = hipStreamSynchronize(nullptr);
   return e != hipSuccess ? e : w;
 }
 
-static hipError_t bh_create_state(BhState *b, int n) {
+static hipError_t bh_create_state(BhState *b, int n, int i_begin, int i_count) {
   if (n > (int)kLinkMask) return hipErrorInvalidValue;      // a leaf's word holds its body's index in 25 bits
+  if (i_begin < 0 || i_count < 1 || i_begin + i_count > n) return hipErrorInvalidValue;
   b->n = n;
+  b->i_begin = i_begin; b->i_count = i_count;
+  b->sliced = i_count != n;
+  if (b->sliced) {
+    b->external = true;        // the other bodies move behind this context's back (the other devices' walks; the all-gather brings them):
+                               // every frame looks at the positions itself for its Size and its keys
+    BH_TRY(hipMalloc(&b->own, sizeof(unsigned int) * (size_t)i_count));
+    BH_TRY(hipMalloc(&b->own_blk, sizeof(unsigned int) * (size_t)((n + kB - 1) / kB)));
+  }
   b->small = n <= kSmBodies;
   BH_TRY(hipMalloc(&b->khi, sizeof(unsigned long long) * n));
   BH_TRY(hipMalloc(&b->klo, sizeof(unsigned long long) * n));
@@ -2615,7 +2628,7 @@ static hipError_t bh_create_state(BhState *b, int n) {
 
 void bh_destroy(BhState *b) {
   if (!b) return;
-  void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->bound, b->pos_sorted, b->slot_hi, b->slot_lo, b->klo_sorted, b->slot_idx, b->gcount, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids,
+  void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->bound, b->pos_sorted, b->slot_hi, b->slot_lo, b->klo_sorted, b->slot_idx, b->gcount, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids, b->own, b->own_blk,
                   b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.lvl, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
@@ -2641,6 +2654,18 @@ static bool bh_wave_walk() {
   return v;
 }
 
+// The walk's view of the context's slice (WalkSlice): for a slice, the list of its bodies' sorted positions is made first —
+// behind the frame's sort, T.sidx final.
+static WalkSlice bh_walk_slice(BhState *b, hipStream_t s) {
+  if (!b->sliced) return WalkSlice{nullptr, 0};
+  const dim3 grd((b->n + kB - 1) / kB), blk(kB);
+  hipLaunchKernelGGL(bh_own_count_kernel, grd, blk, 0, s, b->st.sidx, b->n, (unsigned int)b->i_begin, (unsigned int)b->i_count,
+                     b->counters + 3, b->own_blk);
+  hipLaunchKernelGGL(bh_own_list_kernel, grd, blk, 0, s, b->st.sidx, b->n, (unsigned int)b->i_begin, (unsigned int)b->i_count,
+                     b->counters + 3, b->own_blk, b->own);
+  return WalkSlice{b->own, b->i_begin};
+}
+
 // One CreateOctree (.cpp:74-89) + walk (+ update) of a larger system, queued on the stream.  Up to kChunkSweepMaxN bodies nothing
 // waits for the host; above, the level-by-level ComputeMass needs the deepest level there (one wait inside).
 static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_v, float theta, double G, float dt, int keep_root,
@@ -2659,7 +2684,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
     BH_TRY(launch_bounds(0 /* NBODY_PREC_F32 */, posm, 0, n, cur, s, nullptr));
   }
   unsigned int *next_size = dt > 0.0f ? nxt : nullptr;         // (a pass that moves nothing leaves nothing)
-  b->size_ready = dt > 0.0f;
+  b->size_ready = dt > 0.0f && !b->sliced;
   const unsigned int *size_bits = cur;
   // The order of the 126-bit keys (see "the larger systems' own sort" above).  Either way the sorted first key words end up in
   // b->khi, the bodies in b->idx, and the second key words, still in body order, in b->klo.
@@ -2737,18 +2762,24 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
                        nchunks, b->div_mode, keep_root);   // a thread per chunk: few waves, cheap barriers
   }
   // the walk, with the Tick's update of every body behind it (dt > 0).  One lane per body needs enough bodies to hide its loads;
-  // below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning)
+  // below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning).  A slice walks its own bodies only — the count that
+  // decides — and leaves neither the next frame's Size nor the positions in key order (they would be its own bodies' alone).
   static const int rows_max_n = [] { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); return e && *e ? atoi(e) : kRowsMaxN; }();
   static const int wave_max_n = [] { const char *e = getenv("NBODY_BH_WAVE_MAX_N"); return e && *e ? atoi(e) : kWaveMaxN; }();
-  if (n <= wave_max_n && n <= rows_max_n && bh_wave_walk())
-    hipLaunchKernelGGL(bh_walk_wave_rows_kernel, dim3((n + kWvGT / 64 - 1) / (kWvGT / 64)), dim3(kWvGT), 0, s, b->st, posm, (float4 *)vel,
-                       (float4 *)acc_v, n, G, dt, stage, next_size, b->pos_sorted);
-  else if (n <= rows_max_n)
-    hipLaunchKernelGGL(bh_walk_rows_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, posm, (float4 *)vel,
-                       (float4 *)acc_v, n, G, dt, stage, next_size, b->pos_sorted);
+  const WalkSlice S = bh_walk_slice(b, s);
+  const int nw = b->i_count;
+  float4 *const pos_sorted = b->sliced ? nullptr : b->pos_sorted;
+  if (b->sliced) next_size = nullptr;
+  if (nw <= wave_max_n && nw <= rows_max_n && bh_wave_walk())
+    hipLaunchKernelGGL(bh_walk_wave_rows_kernel, dim3((nw + kWvGT / 64 - 1) / (kWvGT / 64)), dim3(kWvGT), 0, s, b->st, posm, (float4 *)vel,
+                       (float4 *)acc_v, nw, G, dt, stage, next_size, pos_sorted, S);
+  else if (nw <= rows_max_n)
+    hipLaunchKernelGGL(bh_walk_rows_kernel, dim3((nw + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, posm, (float4 *)vel,
+                       (float4 *)acc_v, nw, G, dt, stage, next_size, pos_sorted, S);
   else
-    hipLaunchKernelGGL(bh_walk_lane_kernel, grd, blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, n, G, dt, stage, next_size, b->pos_sorted);
-  b->pos_ready = true;                                          // (every walk writes them, moving or not)
+    hipLaunchKernelGGL(bh_walk_lane_kernel, dim3((nw + kB - 1) / kB), blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, nw, G, dt, stage,
+                       next_size, pos_sorted, S);
+  b->pos_ready = !b->sliced;                                    // (every walk of all bodies writes them, moving or not)
   b->warm = true;                                               // b->khi / b->idx hold an order the next frame can start from
   return hipGetLastError();
 }
@@ -2770,16 +2801,18 @@ hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, d
   hipLaunchKernelGGL(bh_small_build_kernel, dim3(1), dim3(kSmT), 0, s, b->st, (const float4 *)posm, n, P, b->div_mode, keep_root, theta);
   // from kSmGlobalWalkN bodies on the waves walk the tree in its global arrays (the larger systems' kernel): with a 146 KB copy of the
   // tree a CU holds one workgroup of eight bodies, and more bodies than that need second rounds (frames, LDS / global: N = 2000
-  // 50.5 / 52.8 us, 3000 75.3 / 70.6, 4096 106.2 / 94.0)
-  if (bh_wave_walk() && n >= kSmGlobalWalkN)
-    hipLaunchKernelGGL(bh_walk_wave_rows_kernel, dim3((n + kWvGT / 64 - 1) / (kWvGT / 64)), dim3(kWvGT), 0, s, b->st, (float4 *)posm, (float4 *)vel,
-                       (float4 *)acc, n, G, dt, stage, (unsigned int *)nullptr, (float4 *)nullptr);
+  // 50.5 / 52.8 us, 3000 75.3 / 70.6, 4096 106.2 / 94.0).  (A slice walks its own bodies: their number decides.)
+  const WalkSlice S = bh_walk_slice(b, s);
+  const int nw = b->i_count;
+  if (bh_wave_walk() && nw >= kSmGlobalWalkN)
+    hipLaunchKernelGGL(bh_walk_wave_rows_kernel, dim3((nw + kWvGT / 64 - 1) / (kWvGT / 64)), dim3(kWvGT), 0, s, b->st, (float4 *)posm, (float4 *)vel,
+                       (float4 *)acc, nw, G, dt, stage, (unsigned int *)nullptr, (float4 *)nullptr, S);
   else if (bh_wave_walk())
-    hipLaunchKernelGGL(bh_walk_wave_compact_kernel, dim3((n + kWvT / 64 - 1) / (kWvT / 64)), dim3(kWvT), 0, s, b->st, (float4 *)posm,
-                       (float4 *)vel, (float4 *)acc, n, G, dt, stage);
+    hipLaunchKernelGGL(bh_walk_wave_compact_kernel, dim3((nw + kWvT / 64 - 1) / (kWvT / 64)), dim3(kWvT), 0, s, b->st, (float4 *)posm,
+                       (float4 *)vel, (float4 *)acc, nw, G, dt, stage, S);
   else
-    hipLaunchKernelGGL(bh_walk_compact_kernel, dim3((n + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, (float4 *)posm,
-                       (float4 *)vel, (float4 *)acc, n, theta, G, dt, stage);
+    hipLaunchKernelGGL(bh_walk_compact_kernel, dim3((nw + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, (float4 *)posm,
+                       (float4 *)vel, (float4 *)acc, nw, theta, G, dt, stage, S);
   return hipGetLastError();
 }
 
@@ -2789,7 +2822,10 @@ float bh_last_size(const BhState *b) { float f; unsigned int u = (unsigned int)b
 // Wait for the stream and read the verdict of the frames queued since the last call: *status 0 ok, 1 depth limit, 2 node
 // pool; *frames = how many of them were built (a refused frame and everything queued behind it leave the state untouched).
 // A refusal is cleared here, so that the next call starts afresh.
-hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
+// requeue (the default): frames the warm sort gave up are queued again here, the first with the cold sorts, until all are built.
+// Without it — the caller has other devices' frames and collectives to queue in step (multi.hip) — the state is made ready for a
+// cold frame and *status = kStatusRetry (3) says that `queued - *frames` frames are the caller's to queue again.
+hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames, bool requeue) {
   int built = 0;
   for (;;) {
     BH_TRY(hipStreamSynchronize(s));                            // (the frames' walks have left the verdict in page-locked memory: hand_verdict)
@@ -2807,6 +2843,11 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
     BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
     BH_TRY(hipMemsetAsync(b->gcount, 0, sizeof(unsigned int) * 2 * (size_t)b->nb, s));
     b->warm = false;
+    if (!requeue) {
+      *status = kStatusRetry;
+      if (frames) *frames = built;
+      return hipSuccess;
+    }
     const auto a = b->last;
     for (int k = 0; k < left; ++k)
       BH_TRY(bh_frame(b, a.posm, a.vel, a.acc, a.theta, a.G, a.dt, a.keep_root, k == left - 1 ? a.stage : nullptr, s));

@@ -37,4 +37,19 @@ int multi_kernel_time_reset(Multi *m);
 int multi_kernel_clock(Multi *m, double *shader_mhz, int32_t *compute_units);   // the slowest clock among the devices
 int multi_load_checkpoint(Multi *m, const char *path, int64_t *steps_done);
 
+// theta > 0 (the reference's shipped algorithm, OctreeSearch.cpp:74-89 at Theta = 1.0): every device builds the same tree from the
+// replicated positions and walks + integrates its own slice; one in-place all-gather of the positions per frame.
+int multi_set_theta(Multi *m, float theta);
+int multi_bh_steps(Multi *m, float dt, int nsteps, int *built);   // whole frames; *built: how many were (a refused frame ends the call)
+int multi_bh_stats(Multi *m, int32_t *nodes, int32_t *levels, float root_com[3]);
+int multi_bh_leaf_boxes(Multi *m, float *boxes, size_t stride);
+int multi_bh_leaf_order(Multi *m, int32_t *order);
+int multi_bh_root(Multi *m, float root_com[3], int *has_root);
+
+// One device's share of a theta > 0 step in two halves (capi.hip; not part of the C-ABI): queue a frame — dt > 0: tree, walk of the
+// own slice, kick-drift; otherwise the accelerations alone — and, later, the one wait with the frames' verdict.
+int part_bh_queue_frame(nbody_ctx *c, float dt, bool diagnostic);
+int part_bh_collect(nbody_ctx *c, int *status, int *built);
+int part_bh_root(nbody_ctx *c, float out[3], int *has_root);
+
 }  // namespace nbody

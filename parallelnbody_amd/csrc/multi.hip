@@ -74,6 +74,7 @@ bool load_rccl(Rccl *r, std::string *err) {
 
 struct Multi {
   nbody_params p;
+  float theta = 0.0f;                      // > 0: Barnes-Hut frames (multi_bh_frames)
   int n_dev = 0;
   int32_t slice = 0;                       // bodies per device
   bool f64 = false;
@@ -115,11 +116,13 @@ int rccl_fail(Multi *m, ncclResult_t r, const char *what) {
 
 // The owned slices -> every device's full position array: one in-place all-gather per device, grouped — on the gather
 // streams, behind an event the update has recorded; the devices' own streams go on at once.
-int gather_positions(Multi *m) {
+// in_order: on the devices' own streams whatever m->overlap says (a theta > 0 frame reads every position in its first kernel)
+int gather_positions(Multi *m, bool in_order = false) {
   const ncclDataType_t ty = m->f64 ? ncclDouble : ncclFloat;
+  const bool overlap = m->overlap && !in_order;
   for (int k = 0; k < m->n_dev; ++k) {
     (void)hipSetDevice(m->devices[(size_t)k]);
-    if (!m->overlap) continue;
+    if (!overlap) continue;
     if (hipEventRecord(m->ev_updated[(size_t)k], m->stream[(size_t)k]) != hipSuccess ||
         hipStreamWaitEvent(m->gather_stream[(size_t)k], m->ev_updated[(size_t)k], 0) != hipSuccess)
       return fail(m, NBODY_ERR_HIP, "hipEventRecord / hipStreamWaitEvent (update -> gather)");
@@ -129,12 +132,12 @@ int gather_positions(Multi *m) {
     char *base = (char *)m->posm[(size_t)k];
     (void)hipSetDevice(m->devices[(size_t)k]);              // one thread, several devices: each call on its communicator's device
     ncclResult_t r = m->rccl.AllGather(base + (size_t)k * m->slice * m->elem, base, (size_t)m->slice * 4, ty,
-                                       m->overlap ? m->comm_gather[(size_t)k] : m->comm[(size_t)k],
-                                       m->overlap ? m->gather_stream[(size_t)k] : m->stream[(size_t)k]);
+                                       overlap ? m->comm_gather[(size_t)k] : m->comm[(size_t)k],
+                                       overlap ? m->gather_stream[(size_t)k] : m->stream[(size_t)k]);
     if (r != ncclSuccess) { (void)m->rccl.GroupEnd(); return rccl_fail(m, r, "ncclAllGather(positions)"); }
   }
   RCCL_TRY(m, m->rccl.GroupEnd(), "ncclGroupEnd");
-  if (m->overlap) {
+  if (overlap) {
     for (int k = 0; k < m->n_dev; ++k) {
       (void)hipSetDevice(m->devices[(size_t)k]);
       if (hipEventRecord(m->ev_gathered[(size_t)k], m->gather_stream[(size_t)k]) != hipSuccess)
@@ -187,7 +190,8 @@ int multi_create(const nbody_params *pin, const int32_t *devices, int32_t n_dev,
     return bad(NBODY_ERR_INVALID, "nbody_create_multi: the multi-device context owns all bodies (i_begin = 0, i_count = 0)");
   if (pin->n_total <= 0 || pin->n_total % n_dev != 0)
     return bad(NBODY_ERR_INVALID, "nbody_create_multi: n_total must be a positive multiple of n_dev (equal slices)");
-  if (pin->theta > 0.0f) return bad(NBODY_ERR_UNSUPPORTED, "nbody_create_multi: Barnes-Hut (theta > 0) runs on a single-device context");
+  if (pin->theta > 0.0f && pin->precision != NBODY_PREC_F32)
+    return bad(NBODY_ERR_UNSUPPORTED, "nbody_create_multi: theta > 0 (Barnes-Hut) needs an fp32 context");
   // NBODY_MULTI_SHARE_DEVICE=1 (test suites only, together with NBODY_RCCL_LIB: real RCCL refuses two ranks on one device):
   // a device may be listed several times, so that one GPU runs every index of this file that a node of eight would
   const char *share = getenv("NBODY_MULTI_SHARE_DEVICE");
@@ -200,6 +204,7 @@ int multi_create(const nbody_params *pin, const int32_t *devices, int32_t n_dev,
   std::string why;
   if (!load_rccl(&m->rccl, &why)) { delete m; return bad(NBODY_ERR_UNSUPPORTED, "nbody_create_multi: " + why); }
   m->p = *pin;
+  m->theta = pin->theta;
   m->n_dev = n_dev;
   m->slice = pin->n_total / n_dev;
   m->f64 = pin->precision == NBODY_PREC_F64;
@@ -304,7 +309,10 @@ int multi_set_state_soa_f64(Multi *m, const double *posm4, const double *vel4, i
 
 // One Tick body over all devices (OctreeSearch.cpp:27-31): everything is queued on the devices' streams, nothing waits
 // for the host.
+static int multi_bh_frames(Multi *m, float dt, int nframes, bool diagnostic, int *built_out);
+
 int multi_forces(Multi *m, float dt) {
+  if (m->theta > 0.0f) { int built = 0; return multi_bh_frames(m, dt, 1, !(dt > 0.0f), &built); }
   // the strips inside every device's own slice need no other device's positions: they run while the last step's
   // all-gather is still in flight; the rest of the pass is ordered behind it (nbody_step_begin_local / _remote)
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_step_begin_local(m->part[(size_t)k]), "force pass (own slice)");
@@ -313,6 +321,76 @@ int multi_forces(Multi *m, float dt) {
   { const int rc = exchange_sums(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_step_end(m->part[(size_t)k], dt), "update");
   if (dt > 0.0f) return gather_positions(m);
+  return NBODY_OK;
+}
+
+// ---- theta > 0 -----------------------------------------------------------------------------------------------------------------
+// The reference's frame (OctreeSearch.cpp:25-31 with CreateOctree, .cpp:74-89) over several devices: the tree is ONE tree (.cpp:79-81)
+// and each body's walk (.cpp:83-86) reads it and writes that body alone — so every device builds the whole tree from its copy of the
+// positions (the build is the reference's arithmetic in a fixed order: the same bits everywhere), walks and integrates its own slice,
+// and the in-place all-gather brings the moved bodies to everyone: every byte equals the one-device context's.  One caller thread:
+// all devices' frames and the gathers between them are queued first, then every device is waited for once.  A frame the sort from
+// the previous order gives up (kernels_bh.hip) is given up on every device alike; what it and the frames behind it left undone is
+// queued again, the first of them with the cold sorts.
+static int multi_bh_frames(Multi *m, float dt, int nframes, bool diagnostic, int *built_out) {
+  *built_out = 0;
+  { const int rc = wait_gather(m); if (rc) return rc; }
+  const bool moves = dt > 0.0f;
+  int todo = nframes;
+  while (todo > 0) {
+    int left = todo < 64 ? todo : 64;                          // batches, as nbody_step has them: a given-up frame takes the ones queued behind it along
+    todo -= left;
+    while (left > 0) {
+      for (int f = 0; f < left; ++f) {
+        for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, part_bh_queue_frame(m->part[(size_t)k], dt, diagnostic), "Barnes-Hut frame");
+        if (moves) { const int rc = gather_positions(m, true); if (rc) return rc; }
+      }
+      int status = 0, built = 0, refused_rc = NBODY_OK, refused_k = 0;
+      for (int k = 0; k < m->n_dev; ++k) {                     // every device is collected (a refusal is cleared by that), then the verdicts compared
+        int st = 0, b = 0;
+        const int rc = part_bh_collect(m->part[(size_t)k], &st, &b);
+        if (rc && st != 1 && st != 2) return part_fail(m, k, rc, "Barnes-Hut frame");
+        if (rc && !refused_rc) { refused_rc = rc; refused_k = k; }
+        if (k == 0) { status = st; built = b; }
+        else if (st != status || b != built)
+          return fail(m, NBODY_ERR_STATE, "Barnes-Hut frames: device " + std::to_string(m->devices[(size_t)k]) + " built " + std::to_string(b) +
+                      " frames (status " + std::to_string(st) + "), device " + std::to_string(m->devices[0]) + " " + std::to_string(built) +
+                      " (status " + std::to_string(status) + "): the devices' trees differ");
+      }
+      *built_out += built;
+      left -= built;
+      if (refused_rc) return part_fail(m, refused_k, refused_rc, "Barnes-Hut frame");   // the state is that of the frames built, on every device
+      if (status != 3) break;                                  // (3: the warm sort gave a frame up; `left` frames again)
+    }
+  }
+  return NBODY_OK;
+}
+
+int multi_bh_steps(Multi *m, float dt, int nsteps, int *built) { return multi_bh_frames(m, dt, nsteps, false, built); }
+
+int multi_set_theta(Multi *m, float theta) {
+  if (theta > 0.0f && m->f64) return fail(m, NBODY_ERR_UNSUPPORTED, "nbody_set_theta: Barnes-Hut needs an fp32 context");
+  { const int rc = wait_gather(m); if (rc) return rc; }
+  for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_set_theta(m->part[(size_t)k], theta), "nbody_set_theta");
+  m->theta = theta;
+  return NBODY_OK;
+}
+
+// every device holds the whole tree: the first one answers
+int multi_bh_stats(Multi *m, int32_t *nodes, int32_t *levels, float root_com[3]) {
+  PART_TRY(m, 0, nbody_bh_stats(m->part[0], nodes, levels, root_com), "nbody_bh_stats");
+  return NBODY_OK;
+}
+int multi_bh_leaf_boxes(Multi *m, float *boxes, size_t stride) {
+  PART_TRY(m, 0, nbody_bh_leaf_boxes(m->part[0], boxes, stride), "nbody_bh_leaf_boxes");
+  return NBODY_OK;
+}
+int multi_bh_leaf_order(Multi *m, int32_t *order) {
+  PART_TRY(m, 0, nbody_bh_leaf_order(m->part[0], order), "nbody_bh_leaf_order");
+  return NBODY_OK;
+}
+int multi_bh_root(Multi *m, float root_com[3], int *has_root) {
+  PART_TRY(m, 0, part_bh_root(m->part[0], root_com, has_root), "Barnes-Hut root");
   return NBODY_OK;
 }
 
@@ -411,6 +489,7 @@ int multi_kernel_clock(Multi *m, double *shader_mhz, int32_t *compute_units) {
 int multi_load_checkpoint(Multi *m, const char *path, int64_t *steps_done) {
   { const int rc = wait_gather(m); if (rc) return rc; }
   for (int k = 0; k < m->n_dev; ++k) PART_TRY(m, k, nbody_load_checkpoint(m->part[(size_t)k], path, steps_done), "nbody_load_checkpoint");
+  (void)nbody_get_theta(m->part[0], &m->theta);               // the file's opening angle: every device took it over
   return NBODY_OK;
 }
 

@@ -40,8 +40,9 @@ static int run(int32_t n, int precision, double eps, int steps) {
   ctx_for_err = many; CHECK(nbody_set_state_soa(many, posm, vel, n));
   /* the device-plumbing entry points are refused, loudly, on the multi-device context */
   void *ptr = NULL;
-  if (nbody_device_ptr(many, NBODY_BUF_POSM, &ptr, NULL) != NBODY_ERR_UNSUPPORTED || nbody_step_begin(many) != NBODY_ERR_UNSUPPORTED ||
-      nbody_set_theta(many, 1.0f) != NBODY_ERR_UNSUPPORTED) { printf("multi parity: plumbing call not refused\n"); return 1; }
+  if (nbody_device_ptr(many, NBODY_BUF_POSM, &ptr, NULL) != NBODY_ERR_UNSUPPORTED || nbody_step_begin(many) != NBODY_ERR_UNSUPPORTED) {
+    printf("multi parity: plumbing call not refused\n"); return 1;
+  }
 
   float size_one = 0, size_many = 0;
   nbody_particle *rec_one = malloc(sizeof(nbody_particle) * (size_t)n), *rec_many = malloc(sizeof(nbody_particle) * (size_t)n);
@@ -78,8 +79,53 @@ static int run(int32_t n, int precision, double eps, int steps) {
   return bad;
 }
 
+/* theta = 1.0, the reference's shipped opening angle (OctreeSearch.cpp:85), over the same device list: every device builds the
+ * whole tree and walks its slice, so the records equal the one-device context's in EVERY byte whatever n_dev is. */
+static int run_tree(int32_t n, int steps) {
+  int32_t devs[64];
+  int n_dev = nbody_device_count();
+  const char *parts = getenv("NBODY_TEST_PARTS");
+  const int shared = parts && atoi(parts) > 1;
+  if (shared) n_dev = atoi(parts);
+  if (n_dev > 64) n_dev = 64;
+  while (n_dev > 1 && n % n_dev != 0) --n_dev;
+  for (int k = 0; k < n_dev; ++k) devs[k] = shared ? 0 : k;
+  float *posm = malloc(sizeof(float) * 4 * (size_t)n), *vel = malloc(sizeof(float) * 4 * (size_t)n);
+  const float centre[3] = {0.f, 0.f, 0.f};
+  if (nbody_ic_reference_box(n, 1000.0f, centre, 7u, posm, vel)) return 1;
+  nbody_params p;
+  nbody_default_params(&p);
+  p.n_total = n; p.theta = 1.0f;
+  nbody_ctx *one = NULL, *many = NULL;
+  ctx_for_err = NULL;
+  CHECK(nbody_create(&p, &one));
+  CHECK(nbody_create_multi(&p, devs, n_dev, &many));
+  ctx_for_err = one;  CHECK(nbody_set_state_soa(one, posm, vel, n));
+  ctx_for_err = many; CHECK(nbody_set_state_soa(many, posm, vel, n));
+  float size_one = 0, size_many = 0, theta = 0;
+  nbody_particle *rec_one = malloc(sizeof(nbody_particle) * (size_t)n), *rec_many = malloc(sizeof(nbody_particle) * (size_t)n);
+  for (int s = 0; s < steps; ++s) {
+    ctx_for_err = one;  CHECK(nbody_tick(one, 0.01f, &size_one, rec_one, sizeof(nbody_particle)));
+    ctx_for_err = many; CHECK(nbody_tick(many, 0.01f, &size_many, rec_many, sizeof(nbody_particle)));
+  }
+  int32_t nodes_one = 0, nodes_many = 0;
+  ctx_for_err = one;  CHECK(nbody_bh_stats(one, &nodes_one, NULL, NULL));
+  ctx_for_err = many; CHECK(nbody_bh_stats(many, &nodes_many, NULL, NULL));
+  CHECK(nbody_get_theta(many, &theta));
+  const int bad = memcmp(rec_one, rec_many, sizeof(nbody_particle) * (size_t)n) != 0 || size_one != size_many || nodes_one != nodes_many ||
+                  theta != 1.0f;
+  printf("multi parity: N %d theta 1.0 on %d device(s), %d frames: %s (kernel %s, Size %.4f / %.4f, %d / %d nodes)\n", n, n_dev, steps,
+         bad ? "MISMATCH" : "bit-identical", nbody_force_kernel_name(many), size_one, size_many, nodes_one, nodes_many);
+  nbody_destroy(one);
+  nbody_destroy(many);
+  free(posm); free(vel); free(rec_one); free(rec_many);
+  return bad;
+}
+
 int main(void) {
   if (nbody_device_count() <= 0) { printf("multi parity: no HIP device\n"); return 2; }
+  if (run_tree(2000, 4)) return 1;                           /* the shipped scene at the shipped opening angle */
+  if (run_tree(32768, 3)) return 1;
   if (run(16384, NBODY_PREC_F32, 0.0, 4)) return 1;          /* one-sided kernel */
   if (run(65536, NBODY_PREC_F32, 0.0, 4)) return 1;          /* symmetric kernel (with > 1 device: the all-to-all) */
   if (run(65536, NBODY_PREC_F32_KAHAN, 0.5, 3)) return 1;

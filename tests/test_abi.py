@@ -14,7 +14,7 @@ def declared_symbols():
     names = []
     for h in ("nbody.h", "nbody_actor.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
-        names += re.findall(r"NBODY_API[^;]*?\b(nbody_[a-z0-9_]+)\s*\(", text, flags=re.S)
+        names += re.findall(r"NBODY_AMD_API[^;]*?\b(nbody_[a-z0-9_]+)\s*\(", text, flags=re.S)
     return sorted(set(names))
 
 

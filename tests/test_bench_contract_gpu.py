@@ -67,3 +67,24 @@ def test_stdout_is_the_json_line_alone_when_rccl_prints_its_banner():
     assert len(lines) == 1, lines
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["config"]["host"].startswith("single process") and r["value"] > 0
+
+
+def test_the_rows_bench_adds_behind_the_headline_carry_their_own_parity_and_roofline():
+    # `configs` (BASELINE.json's other single-GPU configs) and `bh` (theta = 1 frames) of the default one-GPU line, at their smallest
+    # members so that the test takes seconds: the same functions, the same checks (a row that disagrees with its checker ends the run)
+    sys.path.insert(0, ROOT)
+    import bench
+    import parallelnbody_amd as nb
+    row = bench.baseline_config_row(nb, 1 << 16, "f32", 0.0, steps=5, warmup=1, settle_seconds=0.05)
+    assert row["steps"] == 5 and row["dtype"] == "f32" and row["algorithm"] == "symmetric"
+    assert row["value"] == pytest.approx(65536.0 ** 2 * 5 / (row["ms_per_step"] * 5e-3), rel=1e-6)
+    rf = row["roofline"]
+    assert rf["peak"] == 157.3 and 0.2 < rf["whole_step_frac"] <= rf["frac"] < 1.0 and rf["launches"] == 5
+    assert row["max_rel_err_sampled"] < row["rel_err_tolerance"] == 2e-5 and row["bodies_sampled"] >= 24
+    row64 = bench.baseline_config_row(nb, 1 << 14, "f64", 0.0, steps=3, warmup=1, settle_seconds=0.0)
+    assert row64["dtype"] == "f64" and row64["roofline"]["peak"] == pytest.approx(78.65) and row64["max_rel_err_sampled"] < 1e-12
+    bh = bench.barnes_hut_row(nb, 2000, frames=50, warmup=5, parity_frames=2)
+    assert bh["frames"] == 50 and 5.0 < bh["us_per_frame"] < 2000.0 and "every byte of 2 frame(s)" in bh["parity"]
+    assert bh["tree_nodes"] > 2000 and bh["tree_levels"] >= 8
+    cb = bh["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "us/frame" and cb["value"] > bh["us_per_frame"] and cb["cores"] >= 1

@@ -66,17 +66,19 @@ def test_multi_context_argument_errors(nb):
     with pytest.raises(nb.NBodyError):
         nb.NBodyEngine(1000, devices=[0, 0])        # a device listed twice
     with pytest.raises(nb.NBodyError):
-        nb.NBodyEngine(1000, devices=[0], theta=1.0)   # Barnes-Hut runs on one device
+        nb.NBodyEngine(1000, devices=[0], theta=1.0, precision="f32_kahan")   # the reference's tree walk is plain fp32
     with pytest.raises(nb.NBodyError):
         nb.NBodyEngine(1001, devices=[0, 1])        # equal slices only (and there is one GPU here anyway)
 
 
-def test_actor_over_a_device_list(nb):
-    # the AOctreeSearch mirror on nbody_create_multi: same frames as on one device
+@pytest.mark.parametrize("theta", [0.0, 1.0])
+def test_actor_over_a_device_list(nb, theta):
+    # the AOctreeSearch mirror on nbody_create_multi (real RCCL, one rank): same frames as on one device — also at the actor's
+    # default, the reference's shipped opening angle (every device builds the whole tree and walks its slice: csrc/multi.hip)
     a, b = nb.OctreeSearch(), nb.OctreeSearch()
     b.set_devices([0])
     for act in (a, b):
-        act.set_theta(0.0)
+        act.set_theta(theta)
         act.set_seed(5)
         act.CreateSpacePoints(2000, 1000.0)
         for _ in range(5):

@@ -19,7 +19,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import particles_from, rel_err
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -205,7 +205,7 @@ def test_argument_errors_with_parts(nb, parts_env, monkeypatch):
     with pytest.raises(nb.NBodyError):
         nb.NBodyEngine(1001, devices=[0, 0])                        # equal slices only
     with pytest.raises(nb.NBodyError):
-        nb.NBodyEngine(4096, devices=[0, 0], theta=1.0)             # Barnes-Hut runs on one device
+        nb.NBodyEngine(4096, devices=[0, 0], theta=1.0, precision="f64")   # the reference's tree walk is fp32 (OctreeSearch.h:8-18)
     monkeypatch.delenv("NBODY_MULTI_SHARE_DEVICE")
     with pytest.raises(nb.NBodyError):
         nb.NBodyEngine(4096, devices=[0, 0])                        # without the test switch a device may be listed once
@@ -227,3 +227,149 @@ def test_plain_c_host_over_four_parts(nb, fake_rccl, tmp_path):
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "multi parity: ok" in out.stdout and "on 4 device(s)" in out.stdout and "within tolerance" in out.stdout
+
+
+@pytest.mark.parametrize("n,parts", [(2000, 2), (8192, 2), (8192, 4), (8192, 8), (131072, 2), (131072, 4), (131072, 8)])
+def test_barnes_hut_over_parts_equals_one_context_in_every_byte(nb, oracle, parts_env, n, parts):
+    # theta > 0 — the reference's SHIPPED algorithm (OctreeSearch.cpp:74-89 at Theta = 1.0, .cpp:85) — over several devices: the tree
+    # is one tree (.cpp:79-81) and a body's walk (.cpp:83-86) reads it and writes that body alone, so every device builds the whole
+    # tree from its copy of the positions, walks and integrates its own slice [r N/P, (r+1) N/P), and the in-place all-gather brings
+    # the moved bodies to everyone.  Five Ticks (three queued in one call, then two nbody_tick frames with the records and Size) on
+    # the shipped kind of scene: every byte of the records, Size, the root centre, node and level counts equal the one-device
+    # context's — and, at the sizes the oracle walks in a moment, the oracle's.
+    posm, vel = nb.ic_reference_box(n, 1000.0, seed=9)
+    before = parts_env()
+    with nb.NBodyEngine(n, theta=1.0) as one, nb.NBodyEngine(n, theta=1.0, devices=[0] * parts) as many:
+        assert many.theta() == 1.0
+        for e in (one, many):
+            e.set_state(posm, vel)
+            e.compute_forces()                                     # a diagnostic pass: accelerations only, the next root stays
+        np.testing.assert_array_equal(one.accelerations(), many.accelerations())
+        for e in (one, many):
+            e.step(0.01, 3)
+        assert one.particles().tobytes() == many.particles().tobytes()
+        assert many.steps_done() == 3
+        for _ in range(2):
+            s1, r1 = one.tick(0.01); s2, r2 = many.tick(0.01)
+            assert s1 == s2 and r1.tobytes() == r2.tobytes()
+        st1, st2 = one.bh_stats(), many.bh_stats()
+        assert st1["nodes"] == st2["nodes"] and st1["levels"] == st2["levels"]
+        np.testing.assert_array_equal(st1["root_com"], st2["root_com"])
+        np.testing.assert_array_equal(one.bh_leaf_order(), many.bh_leaf_order())
+        np.testing.assert_array_equal(one.bh_leaf_boxes(), many.bh_leaf_boxes())
+        for x, y in zip(one.state(), many.state()):
+            np.testing.assert_array_equal(x, y)
+        final = many.particles()
+        root = st2["root_com"]
+    after = parts_env()
+    assert after["all_gathers"] - before["all_gathers"] >= 5 * parts     # one grouped in-place all-gather per frame (more if frames were queued again)
+    assert after["sends"] == before["sends"]                       # nothing else changes hands
+    # the oracle (pow_mode 3: the cube correctly rounded, as the device has it), five Ticks of the same scene
+    q = np.zeros(n, nb.PARTICLE_DTYPE)
+    q["Mass"] = posm[:, 3]; q["Position"] = posm[:, :3]; q["Velocity"] = vel[:, :3]
+    com, size = None, 0.0
+    for _ in range(5):
+        com, size = oracle.tick_aos_f32(q, 0.01, theta=1.0, root_com=com, size=size, pow_mode=3)
+    assert final.tobytes() == q.tobytes()
+    np.testing.assert_array_equal(root, com)
+
+
+def test_barnes_hut_over_parts_when_frames_are_given_up_and_refused(nb, oracle, parts_env):
+    # The sort that starts from the previous frame's order gives a frame up when the records are replaced by a scene that has nothing to
+    # do with the order on the devices; every device gives the same frame up, the frames queued behind it do nothing on any device
+    # (the all-gathers between them move unchanged slices), and the front queues them again — gathers included.  Then two bodies
+    # closer than Size / 2^42: the frame is refused on every device alike, the error is reported once and the state stays what it was.
+    n, parts = 16384, 4
+    rng = np.random.default_rng(3)
+    posm, vel = nb.ic_reference_box(n, 1000.0, seed=2)
+    q = np.zeros(n, nb.PARTICLE_DTYPE)
+    q["Mass"] = posm[:, 3] * np.float32(1e-3); q["Position"] = posm[:, :3]; q["Velocity"] = vel[:, :3]
+    com, size = None, 0.0
+
+    def ref(k):
+        nonlocal com, size
+        for _ in range(k):
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=1.0, root_com=com, size=size, pow_mode=3)
+
+    with nb.NBodyEngine(n, theta=1.0, devices=[0] * parts) as e:
+        e.set_particles(q)
+        e.step(0.01, 2); ref(2)
+        assert e.particles().tobytes() == q.tobytes()
+        far = np.float32(0.7) * np.abs(q["Position"]).max()
+        clump = (rng.uniform(-30, 30, (n - 1, 3)) + far).astype(np.float32)
+        assert len(np.unique(clump, axis=0)) == n - 1
+        q["Position"][1:] = clump
+        e.push_particles(q)
+        e.step(0.01, 3); ref(3)                                    # the first of the three is given up everywhere; all three are queued again
+        assert e.particles().tobytes() == q.tobytes()
+        assert e.steps_done() == 5
+        np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
+        q["Position"][7] = q["Position"][9]                        # coincident bodies: the reference's Add would never return
+        e.push_particles(q)
+        with pytest.raises(nb.NBodyError) as err:
+            e.step(0.01, 2)
+        assert "42" in str(err.value)
+        assert e.steps_done() == 5
+        got = e.particles()
+        np.testing.assert_array_equal(got["Position"], q["Position"])
+        np.testing.assert_array_equal(got["Velocity"], q["Velocity"])
+        q["Position"][7] += np.float32(3.0)                        # apart again: the simulation goes on
+        e.push_particles(q)
+        e.step(0.01, 2); ref(2)
+        assert e.particles().tobytes() == q.tobytes()
+
+
+def test_barnes_hut_checkpoints_and_the_opening_angle_over_parts(nb, parts_env, tmp_path):
+    # the file a multi-device context writes at theta > 0 is the one-device context's (theta and the next tree's root centre
+    # included); any partition resumes from it; nbody_set_theta switches a running multi-device context between the two force passes
+    n = 12288
+    posm, vel = nb.ic_reference_box(n, 1000.0, seed=4)
+    path_m, path_s = str(tmp_path / "parts.ckpt"), str(tmp_path / "one.ckpt")
+    with nb.NBodyEngine(n, theta=1.0) as s, nb.NBodyEngine(n, theta=1.0, devices=[0] * 4) as m:
+        s.set_state(posm, vel); m.set_state(posm, vel)
+        s.step(0.01, 2); m.step(0.01, 2)
+        s.save_checkpoint(path_s); m.save_checkpoint(path_m)
+        assert open(path_s, "rb").read() == open(path_m, "rb").read()
+        s.step(0.01, 3)
+        with nb.NBodyEngine(n, devices=[0] * 2) as r:               # created at theta = 0: the file brings its opening angle along
+            assert r.load_checkpoint(path_m) == 2 and r.theta() == 1.0
+            r.step(0.01, 3)
+            for x, y in zip(r.state(), s.state()):
+                np.testing.assert_array_equal(x, y)
+        m.load_checkpoint(path_s); s.load_checkpoint(path_s)
+        for e in (s, m):
+            e.set_theta(0.5); e.step(0.01, 2)                      # another opening angle on the running contexts: still every byte
+        for x, y in zip(s.state(), m.state()):
+            np.testing.assert_array_equal(x, y)
+        for e in (s, m):
+            e.set_theta(0.0); e.compute_forces()                   # ... and back to the all-pairs pass (its own summation order per geometry)
+        assert s.theta() == 0.0 and m.theta() == 0.0
+        assert rel_err(m.accelerations(), s.accelerations()).max() < 2e-5
+
+
+def test_a_slice_context_at_the_shipped_opening_angle_by_hand(nb, parts_env):
+    # what a one-process-per-GPU host does (parallelnbody_amd/sharded.py): contexts that own a slice each, nbody_step on every one,
+    # the positions all-gathered by the host in between — here by hand through the host, two and three slices of unequal work
+    n = 6000
+    posm, vel = nb.ic_reference_box(n, 1000.0, seed=12)
+    with nb.NBodyEngine(n, theta=1.0) as one:
+        one.set_state(posm, vel)
+        one.step(0.01, 3)
+        want = one.state()
+    for ranks in (2, 3):
+        ic = n // ranks
+        engs = [nb.NBodyEngine(n, i_begin=r * ic, i_count=ic, theta=1.0) for r in range(ranks)]
+        try:
+            for e in engs:
+                e.set_state(posm, vel)
+            for _ in range(3):
+                for e in engs:
+                    e.step(0.01, 1)
+                st = [e.state() for e in engs]
+                p = np.concatenate([s[0] for s in st]); v = np.concatenate([s[1] for s in st]); a = np.concatenate([s[2] for s in st])
+                for e in engs:                                     # the all-gather: every context gets the other slices' new positions
+                    e.push_particles(particles_from(nb, p, v))     # (records pushed into a running simulation: history and root stay)
+            np.testing.assert_array_equal(p, want[0]); np.testing.assert_array_equal(v, want[1]); np.testing.assert_array_equal(a, want[2])
+        finally:
+            for e in engs:
+                e.close()

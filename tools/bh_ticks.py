@@ -1,5 +1,5 @@
 """The reference's shipped frame on the device: K Ticks (OctreeSearch.cpp:25-31) at theta = 1.0 (OctreeSearch.cpp:85).
-    python3 tools/bh_ticks.py N [K [mode [theta]]]   mode: step (nbody_step K frames in one call, default) | tick (actor-style
+    python3 tools/bh_ticks.py N [K [mode [theta [scene]]]]   scene: box | plummer (default: box up to 16384 bodies); mode: step (nbody_step K frames in one call, default) | tick (actor-style
                                                  nbody_tick per frame: bounds + step + FParticle mirror, one host sync each);
                                                  theta: 1.0 (default) or e.g. 0 for the all-pairs frame
 Prints wall time per frame; run under `rocprofv3 --kernel-trace --stats` for the per-kernel picture."""
@@ -12,7 +12,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 mode = sys.argv[3] if len(sys.argv) > 3 else "step"
 theta = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
-posm, vel = nb.ic_reference_box(n, 1000.0, seed=1) if n <= 16384 else nb.ic_plummer(n, seed=1)
+scene = sys.argv[5] if len(sys.argv) > 5 else ("box" if n <= 16384 else "plummer")      # the shipped kind of scene / BASELINE's kind
+posm, vel = nb.ic_reference_box(n, 1000.0, seed=1) if scene == "box" else nb.ic_plummer(n, seed=1)
 with nb.NBodyEngine(n, theta=theta) as e:
     e.set_state(posm, vel)
     e.step(0.01, 3); e.synchronize()
@@ -35,4 +36,4 @@ with nb.NBodyEngine(n, theta=theta) as e:
     if theta > 0 and n > 4096 and e._L.nbody_debug_bh_sort_counts(e._h, ctypes.byref(warm), ctypes.byref(retries)) == 0:
         counts = f"; {warm.value} frames sorted from the previous order, {retries.value} times frames were queued again"
     size = e.bounds()
-print(f"N={n} theta={theta} mode={mode}: {best * 1e6:.1f} us per frame (best of 3 runs of {k}); nodes {st['nodes']} levels {st['levels']}{counts}; Size at the end {size:.6g}", flush=True)
+print(f"N={n} theta={theta} mode={mode} scene={scene}: {best * 1e6:.1f} us per frame (best of 3 runs of {k}); nodes {st['nodes']} levels {st['levels']}{counts}; Size at the end {size:.6g}", flush=True)
