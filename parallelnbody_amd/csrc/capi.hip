@@ -480,6 +480,7 @@ int ensure_bh(nbody_ctx *c) {
 int bh_status_error(nbody_ctx *c, int status) {
   if (status == 1) return fail(c, NBODY_ERR_UNSUPPORTED, "Barnes-Hut tree deeper than 42 levels: two bodies closer than Size/2^42 (the reference's Add would recurse without bound on coincident bodies)");
   if (status == 2) return fail(c, NBODY_ERR_NOMEM, "Barnes-Hut node pool exhausted");
+  if (status == 4) return fail(c, NBODY_ERR_STATE, "Barnes-Hut: the sorted path keys are out of order (an internal error of this library; the frame was not built and the state is what it was)");
   return NBODY_OK;
 }
 
@@ -528,7 +529,7 @@ int part_bh_collect(nbody_ctx *c, int *status, int *built) {
   HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &st, &frames, false));
   *status = st; *built = frames;
   c->steps_done += frames;
-  if (st == 1 || st == 2) return bh_status_error(c, st);
+  if (st == 1 || st == 2 || st == 4) return bh_status_error(c, st);
   return NBODY_OK;
 }
 // the next tree's root centre (the previous tree's CoM, OctreeSearch.cpp:77-79) of a context that has built a tree: what a checkpoint keeps
@@ -1736,6 +1737,15 @@ __attribute__((visibility("default"))) int nbody_debug_bh_clocks(nbody_ctx *c, l
 __attribute__((visibility("default"))) int nbody_debug_bh_sort_counts(nbody_ctx *c, long long *warm_frames, long long *retries) {
   if (!c || c->multi || !c->bh || !warm_frames || !retries) return NBODY_ERR_INVALID;
   nbody::bh_debug_sort_counts(c->bh, warm_frames, retries);
+  return NBODY_OK;
+}
+
+// Not in include/nbody.h: fault injection for tests/test_bh_gpu.py — the words the creation memsets clear, set to something else between
+// two frames (what a fill that ran late, or never, would leave): kind 1 = the warm sort's bucket counts := 3 each.
+__attribute__((visibility("default"))) int nbody_debug_bh_poison(nbody_ctx *c, int kind) {
+  if (!c || c->multi || !c->bh) return NBODY_ERR_INVALID;
+  if (int rc = use_device(c)) return rc;
+  HIP_TRY(c, nbody::bh_debug_poison(c->bh, kind, c->stream));
   return NBODY_OK;
 }
 

@@ -1829,17 +1829,18 @@ constexpr int kWarmMu = 224;               // places of the previous order per b
 constexpr int kWarmCap = 384;              // slots per bucket
 constexpr int kWarmWin = 64;               // boundaries a workgroup keeps in LDS
 constexpr int kStatusRetry = 3;            // header word 3: the frame was given up by the warm sort; queue it again with the cold one
+constexpr int kStatusUnsorted = 4;         // ... a COLD sort left keys out of order: an internal error, reported (never seen; bh_lcp_scan_kernel's guard)
 
 __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const float4 *__restrict__ posm, int n,
                                                             const unsigned int *__restrict__ size_bits,
                                                             unsigned int *__restrict__ next_size, float theta,
-                                                            const unsigned long long *__restrict__ bound,
+                                                            const unsigned long long *__restrict__ bound,   // [2][nb]: first, second key words
                                                             const unsigned int *__restrict__ prev_idx,
                                                             const float4 *__restrict__ prev_pos,
                                                             unsigned long long *__restrict__ slot_lo, unsigned long long *__restrict__ slot_hi,
                                                             unsigned int *__restrict__ slot_idx, unsigned int *__restrict__ gcount, int nb) {
 
-  __shared__ unsigned long long s_b[kWarmWin];                 // boundaries jlo .. jhi: the previous order's keys at places 256 j
+  __shared__ unsigned long long s_b[kWarmWin], s_bl[kWarmWin];  // boundaries jlo .. jhi: the previous order's keys (both words) at places 224 j
   __shared__ unsigned int s_cnt[kWarmWin + 1], s_base[kWarmWin + 1];
   __shared__ int s_stop;
   const int t = threadIdx.x, w = blockIdx.x;
@@ -1853,7 +1854,7 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   const int mid_j = (int)(((long long)w * kB + kB / 2) / kWarmMu);   // the bucket this workgroup's places lie in
   const int jlo = max(1, mid_j - (kWarmWin / 2 - 1)), jhi = min(nb - 1, mid_j + kWarmWin / 2);
   const int nwin = jhi - jlo + 1;
-  if (t < nwin) s_b[t] = bound[jlo + t];                       // (the previous order's keys at places 224 j, gathered by its sort: bh_bucket_sort_kernel)
+  if (t < nwin) { s_b[t] = bound[jlo + t]; s_bl[t] = bound[nb + jlo + t]; }   // (the previous order's keys at places 224 j, gathered by its sort: bh_bucket_sort_kernel)
   if (t <= kWarmWin) s_cnt[t] = 0u;
   __syncthreads();
   const int i = w * kB + t;
@@ -1870,15 +1871,20 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
     const bool plain = sz >= 0x1p-58f;
     hi = descend_word(p, o, size, plain);
     lo = descend_word(p, o, size, plain);                       // (goes with the body into its slot: no scattered store by body)
-    int x = 0, y = nwin;                                       // boundaries of the window that are <= hi
-    while (x < y) { const int mid = (x + y) >> 1; if (s_b[mid] <= hi) x = mid + 1; else y = mid; }
+    // A boundary is a WHOLE key — both words, compared first word first: when a runaway body has blown Size up until every other
+    // body sits in one cell of level 21 (the shipped kind of scene does that within a few hundred frames: Size 1e9, the box 1e3), all
+    // first words agree and the second words alone tell the buckets apart (round 4 compared first words only: every body went to ONE
+    // bucket, and every frame was given up and queued again with the cold sorts).
+    auto not_above = [&](unsigned long long bh, unsigned long long bl) { return bh < hi || (bh == hi && bl <= lo); };   // boundary <= (hi, lo)
+    int x = 0, y = nwin;                                       // boundaries of the window that are <= the key
+    while (x < y) { const int mid = (x + y) >> 1; if (not_above(s_b[mid], s_bl[mid])) x = mid + 1; else y = mid; }
     if (x == 0 && jlo > 1) {                                   // below the window: the boundaries 1 .. jlo - 1, in global memory
-      int a = 1, b = jlo;                                      // first boundary in [1, jlo) that is > hi
-      while (a < b) { const int mid = (a + b) >> 1; if (bound[mid] <= hi) a = mid + 1; else b = mid; }
+      int a = 1, b = jlo;                                      // first boundary in [1, jlo) that is > the key
+      while (a < b) { const int mid = (a + b) >> 1; if (not_above(bound[mid], bound[nb + mid])) a = mid + 1; else b = mid; }
       bucket = a - 1;
     } else if (x == nwin && jhi < nb - 1) {                    // above it
       int a = jhi + 1, b = nb;
-      while (a < b) { const int mid = (a + b) >> 1; if (bound[mid] <= hi) a = mid + 1; else b = mid; }
+      while (a < b) { const int mid = (a + b) >> 1; if (not_above(bound[mid], bound[nb + mid])) a = mid + 1; else b = mid; }
       bucket = a - 1;
     } else {
       bucket = jlo - 1 + x;
@@ -1902,13 +1908,14 @@ constexpr int kBsP = 512;                  // the padded bucket at most
 // (N = 65536: 14.2 us against 19.0 with 256); 256 — two elements each — where there are thousands of them (2^20: 47.5 against 53.1)
 // After a cold sort: the sorted keys at every 224th place, side by side, for the frame that follows (bh_keys_bucket_kernel's boundaries;
 // a warm frame's bucket sort gathers them itself)
-__global__ __launch_bounds__(kB) void bh_bound_kernel(const unsigned long long *__restrict__ khi, int nb, unsigned long long *__restrict__ bound) {
+__global__ __launch_bounds__(kB) void bh_bound_kernel(const unsigned long long *__restrict__ khi, const unsigned int *__restrict__ sidx,
+                                                      const unsigned long long *__restrict__ klo_body, int nb, unsigned long long *__restrict__ bound) {
   const int j = blockIdx.x * kB + threadIdx.x;
-  if (j < nb) bound[j] = khi[(size_t)j * kWarmMu];
+  if (j < nb) { bound[j] = khi[(size_t)j * kWarmMu]; bound[nb + j] = klo_body[sidx[(size_t)j * kWarmMu]]; }   // (a cold frame's second words stand in body order)
 }
 
 template <int kBsT>
-__global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int nb, const unsigned int *__restrict__ gcount,
+__global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n, int nb, const unsigned int *__restrict__ gcount,
                                                               unsigned int *__restrict__ gcount_next,
                                                               const unsigned long long *__restrict__ slot_hi,
                                                               const unsigned int *__restrict__ slot_idx,
@@ -1917,12 +1924,13 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
                                                               unsigned long long *__restrict__ out_lo, unsigned long long *__restrict__ bound) {
   static_assert(kWarmCap <= kBsP && kBsP % kBsT == 0, "whole rounds of the workgroup");
   __shared__ unsigned long long s_hi[2][kBsP];
+  __shared__ unsigned long long s_lo[kBsP];                    // the second key words, by slot (looked at where two first words agree: in a
+                                                               // scene whose Size a runaway body owns that is every comparison)
   __shared__ unsigned short s_ix[2][kBsP];
   __shared__ unsigned int s_body[kBsP];
   __shared__ unsigned int s_part[kBsT / 64];
   if (T.hdr[3] != 0) return;                                   // the frame was given up (or an earlier one refused)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
-  (void)nb;
   // where the bucket starts: the counts of the buckets before it
   unsigned int sum = 0u;
   for (int j = t; j < b; j += kBsT) sum += gcount[j];
@@ -1936,12 +1944,22 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
   for (int e = t; e < P; e += kBsT) {
     const bool in = e < cnt;
     s_hi[0][e] = in ? slot_hi[(size_t)b * kWarmCap + e] : ~0ull;
+    s_lo[e] = in ? slot_lo[(size_t)b * kWarmCap + e] : ~0ull;
     s_ix[0][e] = (unsigned short)e;
     s_body[e] = in ? slot_idx[(size_t)b * kWarmCap + e] : 0xFFFFFFFFu;
   }
   __syncthreads();
   unsigned int start = 0u;
   for (int wv = 0; wv < kBsT / 64; ++wv) start += s_part[wv];
+  // The counts must be those of this frame's n bodies: every bucket's range lies inside [0, n) and the last one ends at n.  Counts
+  // that do not add up — words that were not cleared, or were cleared under the key kernel's feet (round 4's creation memsets on the
+  // null stream could do that to a first warm frame: DESIGN 7d) — would send the stores below past the arrays' ends, or leave places
+  // of the order unwritten for the kernels behind this one to chase links through: the frame is given up instead and comes back with
+  // the cold sorts, which count for themselves.  (uniform per workgroup; the words behind T.hdr[3] are read by the next launch)
+  if ((unsigned int)cnt > (unsigned int)kWarmCap || start + (unsigned int)cnt > (unsigned int)n || (b == nb - 1 && start + (unsigned int)cnt != (unsigned int)n)) {
+    if (t == 0) T.hdr[3] = kStatusRetry;
+    return;
+  }
   // merge sort by rank (bh_tile_sort_kernel): runs of L become runs of 2L, every element finds its place by a binary search in
   // the partner run — left run: partner elements strictly before it; right run: partner elements not after it (stable)
   int cur = 0;
@@ -1957,9 +1975,8 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
         const int mid = (x + y) >> 1;
         const unsigned long long hp = s_hi[cur][pbase + mid];
         bool before = hp < h;
-        if (hp == h) {                                         // the whole first key word agrees (rare): the second words decide
-          const int ip = s_ix[cur][pbase + mid];
-          const unsigned long long lp = ip >= cnt ? ~0ull : slot_lo[(size_t)b * kWarmCap + ip], lm = ix >= cnt ? ~0ull : slot_lo[(size_t)b * kWarmCap + ix];
+        if (hp == h) {                                         // the whole first key word agrees: the second words decide
+          const unsigned long long lp = s_lo[s_ix[cur][pbase + mid]], lm = s_lo[ix];
           before = left ? lp < lm : lp <= lm;
         }
         if (before) x = mid + 1; else y = mid;
@@ -1972,8 +1989,10 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
   }
   for (int e = t; e < cnt; e += kBsT) {                        // (the second key words follow into key order: SmallTree::klo_by_body == 0)
     const int ix = s_ix[cur][e];
-    out_hi[start + e] = s_hi[cur][e]; out_idx[start + e] = s_body[ix]; out_lo[start + e] = slot_lo[(size_t)b * kWarmCap + ix];
-    if ((start + e) % kWarmMu == 0u) bound[(start + e) / kWarmMu] = s_hi[cur][e];   // the next frame's bucket boundaries, side by side
+    out_hi[start + e] = s_hi[cur][e]; out_idx[start + e] = s_body[ix]; out_lo[start + e] = s_lo[ix];
+    if ((start + e) % kWarmMu == 0u) {                         // the next frame's bucket boundaries (whole keys), side by side
+      bound[(start + e) / kWarmMu] = s_hi[cur][e]; bound[nb + (start + e) / kWarmMu] = s_lo[ix];
+    }
   }
 }
 
@@ -2022,6 +2041,10 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
       int ln = -1;
       unsigned long long hn = 0;
       if (i + 1 < n) { hn = T.khi[i + 1]; ln = shared_at(h, i, hn, i + 1); }
+      // The kernels behind this one follow links made from the ORDER of the keys (a cell's end, "the node after the subtree"): keys
+      // out of order would have them run backwards or off the arrays.  One compare on words already here: a frame sorted from the
+      // previous order is given up and comes back with the cold sorts; a cold sort that fails it is an error of this library (status 4).
+      if (i + 1 < n && (hn < h || (hn == h && second_word(T, i + 1) < second_word(T, i)))) T.hdr[3] = T.klo_by_body ? kStatusUnsorted : kStatusRetry;
       lcpS[i] = (signed char)lp;
       const int c = (ln > lp ? ln - lp : 0) + 1;
       first_local[i] = c;                                      // the count for now; the scan below turns it into the prefix
@@ -2433,6 +2456,7 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   int node = 0;
+#ifdef NBODY_BH_LANE_NO_PIPELINE                               // round 4's loop, for A/B builds (make variant)
   while (node < nodes) {
     const float4 cm = T.com[node];
     const unsigned int w = T.meta[node];
@@ -2441,16 +2465,43 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
     const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
     float d2 = ex * ex + ey * ey;
     d2 = d2 + ez * ez;
-    const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];   // .h:103 (reading the threshold for leaves as well, without
-                                                                       // the branch around it, costs more than the branch: 2^20 737 us a frame against 662;
-                                                                       // x and y as v_pk_*_f32 pairs: 648 against 638)
-    if (take && d2 != 0.f) {                                   // .h:102: d == 0 adds nothing ...
+    const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];
+    if (take && d2 != 0.f) {
       float tx, ty, tz;
       force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
       ax = ax + tx; ay = ay + ty; az = az + tz;
     }
-    node = (take || d2 == 0.f) ? past : node + 1;              // ... and ends the subtree; children 0..7 otherwise
+    node = (take || d2 == 0.f) ? past : node + 1;
   }
+#else
+  // Where the walk goes next follows from the node's test alone — a compare —, not from its term: the NEXT node's load is issued
+  // before the term (root, double-precision factor: ~100 dependent instructions) is worked out, and is in flight under it.  At
+  // the sizes where a SIMD holds one or two of these waves (N up to ~131072: the walk is a chain of ~220 dependent loads per body,
+  // DESIGN 4.5) that takes the term off the chain; at 2^20, where the waves queue for the VALU anyway, it changes nothing.
+  // (Not round 4's speculative fetch of node + 1 — wrong one step in three, and slower: this is the node the walk does visit.)
+  float4 cm = T.com[0];
+  unsigned int w = T.meta[0];
+  while (node < nodes) {
+    const bool leaf = (w & kLeafBit) != 0u;
+    const int past = leaf ? node + 1 : (int)(w & kLinkMask);
+    const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
+    float d2 = ex * ex + ey * ey;
+    d2 = d2 + ez * ez;
+    const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];   // .h:103 (reading the threshold for leaves as well, without
+                                                                       // the branch around it, costs more than the branch: 2^20 737 us a frame against 662;
+                                                                       // x and y as v_pk_*_f32 pairs: 648 against 638)
+    const int next = (take || d2 == 0.f) ? past : node + 1;    // .h:102: d == 0 adds nothing and ends the subtree; children 0..7 otherwise
+    const int fetch = min(next, nodes - 1);                    // (the last step fetches a node nobody looks at)
+    const float4 cm_next = T.com[fetch];
+    const unsigned int w_next = T.meta[fetch];
+    if (take && d2 != 0.f) {
+      float tx, ty, tz;
+      force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
+      ax = ax + tx; ay = ay + ty; az = az + tz;
+    }
+    cm = cm_next; w = w_next; node = next;
+  }
+#endif
   walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, S.off, next_size, pos_sorted, place);
 }
 
@@ -2479,12 +2530,16 @@ struct BhState {
   int rx_resident = 1;                     // workgroups of bh_radix_pass_kernel the device holds at once
   // the sort of a frame that follows a frame (bh_keys_bucket_kernel): slots of kWarmCap bodies per bucket, the buckets' counts (two
   // arrays that take turns), whether b->khi / b->idx hold a previous frame's order, and what bh_collect needs to queue frames again
-  unsigned long long *bound = nullptr;     // [nb] the sorted keys at places 256 j: the next frame's bucket boundaries
+  unsigned long long *bound = nullptr;     // [2][nb] the sorted keys (first words, then second words) at places 224 j: the next frame's bucket boundaries
   unsigned long long *slot_hi = nullptr, *slot_lo = nullptr, *klo_sorted = nullptr;   // (klo_sorted: a warm frame's second key words, in key order)
   unsigned int *slot_idx = nullptr, *gcount = nullptr;
   int nb = 0, gturn = 0;
   bool warm = false;
   long long warm_frames = 0, retries = 0;  // frames queued with the warm sort; times bh_collect queued frames again (tests, tuning)
+  // Frames the warm sort gives up cost a warm attempt AND a cold frame.  After two collects in a row that met a given-up frame the
+  // library stays with the cold sorts for cold_span frames (8, doubling up to 64 while the giving-up goes on); a collect whose warm
+  // frames all went through starts afresh.
+  int giveups_in_row = 0, cold_left = 0, cold_span = 8, warm_since_collect = 0;
   struct { void *posm, *vel, *acc; float theta; double G; float dt; int keep_root; float *stage; int queued; } last{};
   int *first = nullptr, *first_local = nullptr, *block_sum = nullptr;   // [n + 1] first node of every body's group (absolute / within its scan block), the blocks' totals
   int tile_size = kTs;                     // bodies per tile of the tiles + merge sort (1024, 2048 or 4096: tile_size)
@@ -2605,7 +2660,7 @@ static hipError_t bh_create_state(BhState *b, int n, int i_begin, int i_count) {
   }
   b->nb = (n + kWarmMu - 1) / kWarmMu;
   BH_TRY(hipMalloc(&b->slot_hi, sizeof(unsigned long long) * (size_t)b->nb * kWarmCap));
-  BH_TRY(hipMalloc(&b->bound, sizeof(unsigned long long) * (size_t)b->nb));
+  BH_TRY(hipMalloc(&b->bound, sizeof(unsigned long long) * 2 * (size_t)b->nb));   // both key words
   BH_TRY(hipMalloc(&b->pos_sorted, sizeof(float4) * (size_t)n));
   BH_TRY(hipMalloc(&b->slot_lo, sizeof(unsigned long long) * (size_t)b->nb * kWarmCap));
   BH_TRY(hipMalloc(&b->klo_sorted, sizeof(unsigned long long) * (size_t)n));
@@ -2647,6 +2702,11 @@ hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t 
 }
 const float *bh_root_device(const BhState *b) { return b->root; }
 void bh_debug_sort_counts(const BhState *b, long long *warm_frames, long long *retries) { *warm_frames = b->warm_frames; *retries = b->retries; }
+
+hipError_t bh_debug_poison(BhState *b, int kind, hipStream_t s) {
+  if (b->small || kind != 1) return hipErrorInvalidValue;
+  return hipMemsetD32Async((hipDeviceptr_t)b->gcount, 3, 2 * (size_t)b->nb, s);
+}
 
 // NBODY_BH_WALK=rows: the walks with sixteen lanes per body (round 3) instead of a wave per body — A/B measurements
 static bool bh_wave_walk() {
@@ -2691,8 +2751,11 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   SmallTree &T = b->st;
   T.khi = b->khi; T.sidx = b->idx; T.klo = b->klo; T.klo_by_body = 1;
   static const bool warm_off = [] { const char *e = getenv("NBODY_BH_WARM_SORT"); return e && e[0] == '0'; }();   // A/B, tests
-  if (b->warm && !warm_off) {
+  const bool warm_now = b->warm && !warm_off && b->cold_left == 0;
+  if (b->cold_left > 0) b->cold_left -= 1;                      // (the warm sort keeps giving frames up: cold for a while — BhState::giveups_in_row)
+  if (warm_now) {
     // a frame that follows a frame: the previous order is almost this frame's (bh_keys_bucket_kernel)
+    b->warm_since_collect += 1;
     unsigned int *gc = b->gcount + (size_t)b->gturn * b->nb, *gc_next = b->gcount + (size_t)(b->gturn ^ 1) * b->nb;
     b->gturn ^= 1;
     b->warm_frames += 1;
@@ -2700,10 +2763,10 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
                        (b->pos_ready && !b->external && !size_off) ? b->pos_sorted : nullptr, b->slot_lo, b->slot_hi,
                        b->slot_idx, gc, b->nb);
     if (b->nb <= 1024)
-      hipLaunchKernelGGL(bh_bucket_sort_kernel<512>, dim3(b->nb), dim3(512), 0, s, T, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->slot_lo, b->khi, b->idx,
+      hipLaunchKernelGGL(bh_bucket_sort_kernel<512>, dim3(b->nb), dim3(512), 0, s, T, n, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->slot_lo, b->khi, b->idx,
                          b->klo_sorted, b->bound);
     else
-      hipLaunchKernelGGL(bh_bucket_sort_kernel<256>, dim3(b->nb), dim3(256), 0, s, T, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->slot_lo, b->khi, b->idx,
+      hipLaunchKernelGGL(bh_bucket_sort_kernel<256>, dim3(b->nb), dim3(256), 0, s, T, n, b->nb, gc, gc_next, b->slot_hi, b->slot_idx, b->slot_lo, b->khi, b->idx,
                          b->klo_sorted, b->bound);
     T.klo = b->klo_sorted; T.klo_by_body = 0;                    // (this frame's second key words stand in key order)
   } else if (!b->radix) {
@@ -2734,7 +2797,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
     hipLaunchKernelGGL(bh_ties_gather_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->klo, b->idx2, b->klo_sorted);
     hipLaunchKernelGGL(bh_ties_place_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->idx2, b->klo_sorted);
   }
-  if (T.klo_by_body) hipLaunchKernelGGL(bh_bound_kernel, dim3((b->nb + kB - 1) / kB), blk, 0, s, b->khi, b->nb, b->bound);   // (a cold frame)
+  if (T.klo_by_body) hipLaunchKernelGGL(bh_bound_kernel, dim3((b->nb + kB - 1) / kB), blk, 0, s, b->khi, b->idx, b->klo, b->nb, b->bound);   // (a cold frame)
   const int block = kB * b->scan_bpt;
   hipLaunchKernelGGL(bh_lcp_scan_kernel, dim3((n + block - 1) / block), blk, 0, s, T, n, b->scan_bpt, b->lcpS, b->first_local, b->block_sum);
   hipLaunchKernelGGL(bh_nodes_kernel, grd, blk, sizeof(unsigned long long) * (size_t)(((n - 1) >> b->smp_shift) + 1), s, T, posm, n,
@@ -2839,6 +2902,8 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames, bool 
     const int left = b->last.queued - now;
     b->last.queued = 0;
     b->retries += 1;
+    b->warm_since_collect = 0;
+    if (++b->giveups_in_row >= 2) { b->cold_left = b->cold_span; b->cold_span = std::min(2 * b->cold_span, 64); }
     b->size_ready = false; b->pos_ready = false;                 // (the given-up frame's walk left nothing)
     BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
     BH_TRY(hipMemsetAsync(b->gcount, 0, sizeof(unsigned int) * 2 * (size_t)b->nb, s));
@@ -2853,6 +2918,8 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames, bool 
       BH_TRY(bh_frame(b, a.posm, a.vel, a.acc, a.theta, a.G, a.dt, a.keep_root, k == left - 1 ? a.stage : nullptr, s));
   }
   b->last.queued = 0;
+  if (b->warm_since_collect > 0 && b->h_counters[3] == 0) { b->giveups_in_row = 0; b->cold_span = 8; }   // warm frames that all went through
+  b->warm_since_collect = 0;
   if (b->h_counters[3] != 0) { b->size_ready = false; b->pos_ready = false; }   // a refused frame's walk left nothing either
   *status = b->h_counters[3];
   if (frames) *frames = built;

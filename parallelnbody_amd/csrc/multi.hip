@@ -349,7 +349,7 @@ static int multi_bh_frames(Multi *m, float dt, int nframes, bool diagnostic, int
       for (int k = 0; k < m->n_dev; ++k) {                     // every device is collected (a refusal is cleared by that), then the verdicts compared
         int st = 0, b = 0;
         const int rc = part_bh_collect(m->part[(size_t)k], &st, &b);
-        if (rc && st != 1 && st != 2) return part_fail(m, k, rc, "Barnes-Hut frame");
+        if (rc && st != 1 && st != 2 && st != 4) return part_fail(m, k, rc, "Barnes-Hut frame");
         if (rc && !refused_rc) { refused_rc = rc; refused_k = k; }
         if (k == 0) { status = st; built = b; }
         else if (st != status || b != built)

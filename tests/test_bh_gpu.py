@@ -259,9 +259,12 @@ def test_bh_limits(nb):
         with pytest.raises(nb.NBodyError) as err:
             e.set_theta(1.0)
         assert err.value.code == nb._lib.ERR_UNSUPPORTED
-    with nb.NBodyEngine(1024, i_begin=0, i_count=512) as e:
+    with nb.NBodyEngine(1024, precision="f32_kahan") as e:
         with pytest.raises(nb.NBodyError):
             e.set_theta(0.5)
+    with nb.NBodyEngine(1024, i_begin=0, i_count=512) as e:     # a slice may: it builds the whole tree and walks its own bodies
+        e.set_theta(0.5)                                        # (round 5; tests/test_multi_parts_gpu.py)
+        assert e.theta() == 0.5
     # coincident bodies: the reference's Add recurses without bound; here the frame is refused
     posm = g["posm"].copy(); posm[7, :3] = posm[900, :3]
     with nb.NBodyEngine(1024, theta=1.0) as e:
@@ -814,20 +817,96 @@ def test_the_first_two_frames_right_after_creation_of_small_systems(nb, oracle):
     # zero the header's frame count or the previous tree's CoM after the first frame had written them — a wrong steps_done, a second
     # tree rooted at zero.  Forty systems, each created and ticked twice at once: every byte, Size, the root centre, steps_done.
     rng = np.random.default_rng(4096)
+    ran = 0
     for trial in range(40):
         n = int(rng.integers(2, 4097))
         posm = _fuzz_scene(rng, n)
         vel = np.concatenate([rng.uniform(-50, 50, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
-        if oracle.octree_depth_f32(posm[:, :3]) >= REFUSED_FROM_DEPTH - 2:
-            continue
+        posm[:, 3] *= np.float32(1e-4)                          # (light: no clump collapses within the two frames)
         q = particles_from(nb, posm, vel)
-        com, size = None, 0.0
+        ref, com, size, deep = [], None, 0.0, False
+        for frame in range(2):                                  # the oracle's two frames first: scenes the reference itself could not insert are left out
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3) if not deep else (com, size)
+            deep = deep or oracle.last_max_depth() >= REFUSED_FROM_DEPTH - 1
+            ref.append((q.copy(), com.copy(), size))
+        if deep:
+            continue
+        ran += 1
         with nb.NBodyEngine(n, theta=REF_THETA) as e:
             e.set_state(posm, vel)
             for frame in range(2):
                 size_dev, out = e.tick(0.01)
-                com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+                q, com, size = ref[frame]
                 assert size_dev == size, (trial, n, frame)
                 np.testing.assert_array_equal(e.bh_stats()["root_com"], com, err_msg=f"trial {trial} n={n} frame {frame}")
                 assert out.tobytes() == q.tobytes(), (trial, n, frame)
             assert e.steps_done() == 2, (trial, n)
+    assert ran >= 30, ran
+
+
+@pytest.mark.parametrize("n", [20000, 140000])
+def test_a_runaway_body_that_owns_size_does_not_cost_the_sort_from_the_previous_order(nb, oracle, n):
+    # The shipped kind of scene throws bodies out within a few hundred frames (close encounters at G = 1e4): Size — the largest
+    # |coordinate| about the world origin, OctreeSearch.cpp:47-56 — becomes theirs, 1e7 .. 1e9 for a box of 1e3, and every other body
+    # then lies in ONE cell of level 21 (Size / 2^21 wide): all first key words agree.  The sort that starts from the previous frame's
+    # order used to tell its buckets apart by first words alone: one bucket took every body, EVERY frame was given up and queued again
+    # with the cold sorts (round 5's bench line: 267 give-ups in 300 frames at N = 65536).  Its boundaries are whole keys now: six
+    # Ticks of such a scene, none given up, every byte of the records, Size and the root centre against the oracle.
+    rng = np.random.default_rng(n)
+    posm = np.concatenate([rng.uniform(-1.0, 1.0, (n, 3)) + 3.0, 10.0 ** rng.uniform(-12, -9, (n, 1))], 1).astype(np.float32)
+    posm[5, :3] = (1.0e7, -2.0e6, 3.0e6)                        # the runaway: Size = 1e7, a cell of level 21 is 9.5 wide
+    posm[5, 3] = 1e-24                                          # (light: the trees' root — the previous CoM, .cpp:77-79 — stays with the cloud)
+    assert len(np.unique(posm[:, :3], axis=0)) == n
+    vel = np.concatenate([rng.normal(0, 0.05, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    vel[5, :3] = (3.0e5, 0.0, 0.0)                              # ... and it keeps going: Size grows by 3e3 a frame
+    q = particles_from(nb, posm, vel)
+    com, size = None, 0.0
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        for k in (1, 3, 2):
+            e.step(0.01, k)
+            for _ in range(k):
+                com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+                assert oracle.last_max_depth() < REFUSED_FROM_DEPTH
+            assert e.particles().tobytes() == q.tobytes(), k
+        st = e.bh_stats()
+        np.testing.assert_array_equal(st["root_com"], com)
+        assert st["levels"] > 21                                # (the scene really lives below the first key word)
+        warm, retries = _sort_counts(e)
+        # (frame 1 is rooted at zero, frame 2 at the cloud's own centre: the root box jumps once and that frame is queued again)
+        assert retries <= 1 and warm >= 5, (warm, retries)
+
+
+@pytest.mark.parametrize("n", [9000, 150000])
+def test_bucket_counts_that_do_not_add_up_send_the_frame_back_to_the_cold_sorts(nb, oracle, n):
+    # what a creation fill that ran late (or never) can do to the first frame sorted from the previous order — the bucket
+    # counts are not those of this frame's bodies: ranges past the arrays' ends, places of the order never written, and behind them
+    # kernels that chase links through whatever stands there.  Injected once (nbody_debug_bh_poison: every count word := 3 between
+    # two frames): the bucket sort sees that the counts do not add up to N and gives the frame up, it comes back with the cold
+    # sorts, and every byte of the records equals the oracle's — before, through and after.
+    rng = np.random.default_rng(n)
+    posm = _fuzz_scene(rng, n)
+    posm[:, 3] *= np.float32(1e-5)
+    vel = np.concatenate([rng.uniform(-20, 20, (n, 3)), np.zeros((n, 1))], 1).astype(np.float32)
+    q = particles_from(nb, posm, vel)
+    com, size = None, 0.0
+
+    def ref(k):
+        nonlocal com, size
+        for _ in range(k):
+            com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+            assert oracle.last_max_depth() < REFUSED_FROM_DEPTH
+
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, vel)
+        e.step(0.01, 2); ref(2)
+        assert e.particles().tobytes() == q.tobytes()
+        _, before = _sort_counts(e)
+        assert e._L.nbody_debug_bh_poison(e._h, 1) == 0
+        e.step(0.01, 3); ref(3)
+        assert e.particles().tobytes() == q.tobytes()
+        _, after = _sort_counts(e)
+        assert after == before + 1, (before, after)
+        e.step(0.01, 2); ref(2)
+        assert e.particles().tobytes() == q.tobytes()
+        np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
