@@ -5,6 +5,7 @@
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$1"; TAG="$2"; N="$3"; K="$4"; SCENE="${5:-}"
 mkdir -p "$OUT"
+OUT="$(cd "$OUT" && pwd)"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for cs in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
