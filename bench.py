@@ -421,11 +421,44 @@ def rank_watchdog(args, argv):
                                                           os.getppid() if "TORCHELASTIC_RUN_ID" in os.environ else "x"))
     os.makedirs(run_dir, exist_ok=True)
     for name in os.listdir(run_dir):                      # leftovers of an earlier job under the same name: this rank's own files only
-        if name.endswith(f".rank{rank}") or (rank == 0 and ".verdict" in name):
+        if name.endswith(f".rank{rank}") or (rank == 0 and (".verdict" in name or name == "job")):
             try:
                 os.unlink(os.path.join(run_dir, name))
             except OSError:
                 pass
+    # Files of ANOTHER job that used the same directory name (same port, no launcher id) must never be taken for this job's: rank 0
+    # names the job (start time + pid), every status and verdict file carries that name, and files without it are ignored.
+    # (The directory is node-local: a job over several nodes sets NBODY_BENCH_RUN_DIR to a directory on a shared file system.)
+    job_path = os.path.join(run_dir, "job")
+    t_start = time.time_ns()
+    if rank == 0:
+        job = "%d-%d" % (t_start, os.getpid())
+        _write_atomically(job_path, job)
+    else:
+        # a name left by an earlier job is older than this process by more than the ranks of one launch are apart (60 s allowed):
+        # not ours — rank 0 replaces it as it starts
+        def fresh(name):
+            try:
+                return name is not None and int(name.split("-")[0]) >= t_start - 60 * 10 ** 9
+            except ValueError:
+                return False
+        t_end, job = time.monotonic() + 120.0, None
+        while time.monotonic() < t_end:
+            job = _read(job_path)
+            if fresh(job):
+                break
+            job = None
+            time.sleep(0.05)
+        if job is None:
+            print(f"[bench watchdog rank {rank}] rank 0's watchdog never named the job in {run_dir}", file=sys.stderr, flush=True)
+            return 1
+
+    def read_job_file(path):
+        """the JSON / text of a status or verdict file of THIS job, else None"""
+        text = _read(path)
+        if text is None or not text.startswith(job + "\n"):
+            return None
+        return text[len(job) + 1:]
     attempts = [("as given", [])]
     if args.algorithm == "auto" and not args.no_fallback:
         attempts.append(("all-gather-only step (one-sided kernel, every collective in stream order)", FALLBACK_ARGS))
@@ -465,9 +498,9 @@ def rank_watchdog(args, argv):
                 status = f"fail time limit of {args.child_timeout:.0f} s"
             if status is not None and not os.path.exists(status_path):
                 t_status = time.time()
-                _write_atomically(status_path, json.dumps({"status": status, "t": t_status, "stderr_tail": list(child.tail)}))
+                _write_atomically(status_path, job + "\n" + json.dumps({"status": status, "t": t_status, "stderr_tail": list(child.tail)}))
             if rank == 0:
-                peers = {q: json.loads(_read(os.path.join(run_dir, f"a{k}.rank{q}")) or "null") for q in range(world)}
+                peers = {q: json.loads(read_job_file(os.path.join(run_dir, f"a{k}.rank{q}")) or "null") for q in range(world)}
                 bad = {q: s for q, s in peers.items() if s and s["status"] != "ok"}
                 # a line that is already out counts even if some rank then stumbles in its teardown
                 got = child.json_line() if status == "ok" or (status is None and bad) else None
@@ -495,9 +528,9 @@ def rank_watchdog(args, argv):
                     port = _free_port()
                     verdict = f"retry {port}" if k < len(attempts) else "give up"
                 if verdict is not None:
-                    _write_atomically(verdict_path, verdict)
+                    _write_atomically(verdict_path, job + "\n" + verdict)
             else:
-                verdict = _read(verdict_path)
+                verdict = read_job_file(verdict_path)
                 if verdict is None and time.monotonic() > t_limit + 90.0:
                     verdict = "give up"               # rank 0's watchdog is gone
             if verdict is None:
@@ -525,7 +558,10 @@ def rank_watchdog(args, argv):
             say(f"attempt {k} ({what}) failed; starting a fresh worker: {attempts[k][0]}")
             continue
         say(f"attempt {k} ({what}) failed and there is nothing left to try")
-        return 1
+        break
+    if rank == 0:                                         # every way out takes the directory along (the others have read "give up" or timed out)
+        time.sleep(1.0)
+        shutil.rmtree(run_dir, ignore_errors=True)
     return 1
 
 

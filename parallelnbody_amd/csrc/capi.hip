@@ -88,7 +88,8 @@ struct nbody_ctx {
   // Barnes-Hut mode (kernels_bh.hip)
   float theta = 0.0f;
   nbody::BhState *bh = nullptr;
-  void *bh_acc = nullptr;      // [n_total] float4: the walk's output, summed (j_split = 1) by update_kernel
+  void *bh_acc = nullptr;      // [i_count] float4: the walk's output, summed (j_split = 1) by update_kernel
+  struct { float dt = 0.f; float *stage = nullptr; int queued = 0; bool timed = false; } bh_batch;   // what bh_enqueue queued since the last bh_finish
   KernelTimer timers[2];
   unsigned long long *clk = nullptr;   // time_kernels: {shader-clock cycles, reference-clock ticks} summed over the force kernels' workgroups (pk_common.h)
   int wall_khz = 0, cus = 0;           // hipDeviceAttributeWallClockRate, compute units
@@ -492,19 +493,40 @@ int bh_enqueue(nbody_ctx *c, float dt, int nsteps, float *stage = nullptr) {
     if (timed) { int rc = timer_begin(c, NBODY_KERNEL_FORCES, &ev); if (rc) return rc; }
     HIP_TRY(c, nbody::bh_frame(c->bh, c->posm, c->vel, c->acc, c->theta, c->p.G, dt, 0, s == nsteps - 1 ? stage : nullptr, c->stream));
     if (timed) { int rc = timer_end(c, NBODY_KERNEL_FORCES, ev); if (rc) return rc; }
-    if (timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) { int rc = timer_drain(c, NBODY_KERNEL_FORCES); if (rc) return rc; }
+    // (small systems queue a whole call's frames at once and give none up: bound the number of live events; the larger systems'
+    // batches of 64 never get here, so the pairs of a given-up batch are still there to be taken back)
+    if (timed && nbody::bh_is_small(c->bh) && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) { int rc = timer_drain(c, NBODY_KERNEL_FORCES); if (rc) return rc; }
   }
+  c->bh_batch.dt = dt; c->bh_batch.stage = stage; c->bh_batch.queued += nsteps; c->bh_batch.timed = timed;
   c->sym_posg_valid = false;     // bodies move without the fused all-pairs update's preparation of the next pass
   return NBODY_OK;
 }
 
+// The event pairs of the last `k` frames queued belong to frames that did nothing (the warm sort gave one up and the rest were queued
+// behind it): they are taken back, so that nbody_kernel_time counts every frame once — with the events around the run that built it.
+void timer_take_back(nbody_ctx *c, int which, int k) {
+  KernelTimer &t = c->timers[which];
+  for (; k > 0 && !t.pending.empty(); --k) { t.pool.push_back(t.pending.back()); t.pending.pop_back(); }
+}
+
 // ... and the one wait: the frames that were built count as steps; a refused frame (and all queued behind it) left the
-// state where it was.
+// state where it was.  Frames the sort from the previous order gave up (kernels_bh.hip: a bucket ran over — the records were
+// replaced, the root box jumped) did nothing, nor did the frames queued behind them: they are queued again here, the first of them
+// with the cold sorts, inside event pairs of their own.
 int bh_finish(nbody_ctx *c) {
-  int status = 0, frames = 0;
-  HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &status, &frames));
-  c->steps_done += frames;
-  return bh_status_error(c, status);
+  for (;;) {
+    int status = 0, frames = 0;
+    HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &status, &frames));
+    c->steps_done += frames;
+    const int left = c->bh_batch.queued - frames;
+    c->bh_batch.queued = 0;
+    if (status != 3) {
+      if (c->bh_batch.timed && c->timers[NBODY_KERNEL_FORCES].pending.size() >= 1024) { int rc = timer_drain(c, NBODY_KERNEL_FORCES); if (rc) return rc; }
+      return bh_status_error(c, status);
+    }
+    if (c->bh_batch.timed) timer_take_back(c, NBODY_KERNEL_FORCES, left);
+    if (int rc = bh_enqueue(c, c->bh_batch.dt, left, c->bh_batch.stage)) return rc;
+  }
 }
 
 }  // namespace
@@ -526,9 +548,11 @@ int part_bh_queue_frame(nbody_ctx *c, float dt, bool diagnostic) {
 int part_bh_collect(nbody_ctx *c, int *status, int *built) {
   if (int rc = use_device(c)) return rc;
   int st = 0, frames = 0;
-  HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &st, &frames, false));
+  HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &st, &frames));
   *status = st; *built = frames;
   c->steps_done += frames;
+  if (st == 3 && c->bh_batch.timed) timer_take_back(c, NBODY_KERNEL_FORCES, c->bh_batch.queued - frames);
+  c->bh_batch.queued = 0;
   if (st == 1 || st == 2 || st == 4) return bh_status_error(c, st);
   return NBODY_OK;
 }
@@ -558,10 +582,13 @@ int queue_forces_bh(nbody_ctx *c, bool diagnostic) {
   return NBODY_OK;
 }
 int run_forces_bh(nbody_ctx *c, bool diagnostic) {
-  { int rc = queue_forces_bh(c, diagnostic); if (rc) return rc; }
-  int status = 0;
-  HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &status, nullptr));
-  return bh_status_error(c, status);
+  for (;;) {
+    { int rc = queue_forces_bh(c, diagnostic); if (rc) return rc; }
+    int status = 0;
+    HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &status, nullptr));
+    if (status != 3) return bh_status_error(c, status);
+    if (c->p.time_kernels) timer_take_back(c, NBODY_KERNEL_FORCES, 1);   // given up by the warm sort: once more, with the cold sorts
+  }
 }
 
 // phase (SymLaunch::phase): 0 the whole pass; 1 / 2 the two goes of a sharded fp32 symmetric context (sym_two_goes)

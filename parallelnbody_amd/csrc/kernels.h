@@ -146,7 +146,7 @@ bool bh_is_small(const BhState *b);
 hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root, float *stage,
                     hipStream_t s);
 float bh_last_size(const BhState *b);                         // Size of the last frame bh_collect has seen
-hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames, bool requeue = true);
+hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames);   // *status 3: queue the frames that were not built again
 hipError_t bh_debug_clocks(BhState *b, long long out[16 + 3 * 512], hipStream_t s);   // tuning builds only (tools/bh_phases.py)
 hipError_t bh_debug_poison(BhState *b, int kind, hipStream_t s);   // tests: kind 1 = the warm sort's bucket counts := 3 each (a fill that never ran)
 void bh_debug_sort_counts(const BhState *b, long long *warm_frames, long long *retries);   // frames sorted from the previous order; times frames were queued again

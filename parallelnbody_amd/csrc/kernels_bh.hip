@@ -2540,7 +2540,6 @@ struct BhState {
   // library stays with the cold sorts for cold_span frames (8, doubling up to 64 while the giving-up goes on); a collect whose warm
   // frames all went through starts afresh.
   int giveups_in_row = 0, cold_left = 0, cold_span = 8, warm_since_collect = 0;
-  struct { void *posm, *vel, *acc; float theta; double G; float dt; int keep_root; float *stage; int queued; } last{};
   int *first = nullptr, *first_local = nullptr, *block_sum = nullptr;   // [n + 1] first node of every body's group (absolute / within its scan block), the blocks' totals
   int tile_size = kTs;                     // bodies per tile of the tiles + merge sort (1024, 2048 or 4096: tile_size)
   int smp_shift = 0;                       // bh_nodes_kernel keeps every 2^smp_shift-th sorted key in LDS
@@ -2854,10 +2853,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
 // stage (optional): the walk also writes every body's FParticle record (10 floats, body order) there — the frame's mirror.
 hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, double G, float dt, int keep_root, float *stage,
                     hipStream_t s) {
-  if (!b->small) {
-    b->last = {posm, vel, acc, theta, G, dt, keep_root, stage, b->last.queued + 1};
-    return bh_large_frame(b, posm, vel, acc, theta, G, dt, keep_root, stage, s);
-  }
+  if (!b->small) return bh_large_frame(b, posm, vel, acc, theta, G, dt, keep_root, stage, s);
   const int n = b->n;
   int P = 1;
   while (P < n) P <<= 1;
@@ -2882,51 +2878,37 @@ hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, d
 // Size (ComputeCubeSize) of the last frame bh_collect has seen
 float bh_last_size(const BhState *b) { float f; unsigned int u = (unsigned int)b->h_counters[7]; memcpy(&f, &u, 4); return f; }
 
-// Wait for the stream and read the verdict of the frames queued since the last call: *status 0 ok, 1 depth limit, 2 node
-// pool; *frames = how many of them were built (a refused frame and everything queued behind it leave the state untouched).
-// A refusal is cleared here, so that the next call starts afresh.
-// requeue (the default): frames the warm sort gave up are queued again here, the first with the cold sorts, until all are built.
-// Without it — the caller has other devices' frames and collectives to queue in step (multi.hip) — the state is made ready for a
-// cold frame and *status = kStatusRetry (3) says that `queued - *frames` frames are the caller's to queue again.
-hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames, bool requeue) {
-  int built = 0;
-  for (;;) {
-    BH_TRY(hipStreamSynchronize(s));                            // (the frames' walks have left the verdict in page-locked memory: hand_verdict)
-    memcpy(b->h_counters, b->h_verdict, sizeof(int) * 8);
-    const int now = b->h_counters[4] - b->frames_seen;
-    built += now;
-    b->frames_seen = b->h_counters[4];
-    if (b->small || b->h_counters[3] != kStatusRetry) break;
-    // The warm sort gave a frame up (a bucket ran over): that frame and the ones queued behind it did nothing.  Queue them again,
-    // the first with the cold sorts; the counts start from zero.
-    const int left = b->last.queued - now;
-    b->last.queued = 0;
+// Wait for the stream and read the verdict of the frames queued since the last call: *status 0 ok, 1 depth limit, 2 node pool, 4 a
+// cold sort left keys out of order (an internal error); *frames = how many of them were built (a refused frame and everything queued
+// behind it leave the state untouched).  A refusal is cleared here, so that the next call starts afresh.
+// *status = kStatusRetry (3): the sort from the previous order gave a frame up (a bucket ran over): that frame and the ones queued
+// behind it did nothing and are the caller's to queue again — it knows what they were, has their event pairs, and on several devices
+// the collectives that go between them (capi.hip bh_finish, multi.hip); the state is ready for the first of them to sort cold.
+hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
+  BH_TRY(hipStreamSynchronize(s));                              // (the frames' walks have left the verdict in page-locked memory: hand_verdict)
+  memcpy(b->h_counters, b->h_verdict, sizeof(int) * 8);
+  const int built = b->h_counters[4] - b->frames_seen;
+  b->frames_seen = b->h_counters[4];
+  if (frames) *frames = built;
+  if (b->h_counters[4] > 0 && built > 0) {
+    b->last_nodes = b->n >= 2 ? 1 + 8 * b->h_counters[1] : 1;   // the reference's count: every split makes eight children
+    b->last_levels = b->h_counters[2];
+  }
+  if (!b->small && b->h_counters[3] == kStatusRetry) {
     b->retries += 1;
     b->warm_since_collect = 0;
     if (++b->giveups_in_row >= 2) { b->cold_left = b->cold_span; b->cold_span = std::min(2 * b->cold_span, 64); }
     b->size_ready = false; b->pos_ready = false;                 // (the given-up frame's walk left nothing)
     BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
-    BH_TRY(hipMemsetAsync(b->gcount, 0, sizeof(unsigned int) * 2 * (size_t)b->nb, s));
+    BH_TRY(hipMemsetAsync(b->gcount, 0, sizeof(unsigned int) * 2 * (size_t)b->nb, s));   // the counts start from zero
     b->warm = false;
-    if (!requeue) {
-      *status = kStatusRetry;
-      if (frames) *frames = built;
-      return hipSuccess;
-    }
-    const auto a = b->last;
-    for (int k = 0; k < left; ++k)
-      BH_TRY(bh_frame(b, a.posm, a.vel, a.acc, a.theta, a.G, a.dt, a.keep_root, k == left - 1 ? a.stage : nullptr, s));
+    *status = kStatusRetry;
+    return hipSuccess;
   }
-  b->last.queued = 0;
   if (b->warm_since_collect > 0 && b->h_counters[3] == 0) { b->giveups_in_row = 0; b->cold_span = 8; }   // warm frames that all went through
   b->warm_since_collect = 0;
   if (b->h_counters[3] != 0) { b->size_ready = false; b->pos_ready = false; }   // a refused frame's walk left nothing either
   *status = b->h_counters[3];
-  if (frames) *frames = built;
-  if (b->h_counters[4] > 0) {
-    b->last_nodes = b->n >= 2 ? 1 + 8 * b->h_counters[1] : 1;   // the reference's count: every split makes eight children
-    b->last_levels = b->h_counters[2];
-  }
   if (*status != 0) BH_TRY(hipMemsetAsync(b->counters + 3, 0, sizeof(int), s));
   return hipSuccess;
 }

@@ -89,3 +89,27 @@ def test_the_fallback_rendezvous_is_on_a_port_of_its_own():
     assert out.returncode == 0 and lines[0]["attempt"] == 2
     launcher_port = out.args[out.args.index("--master-port") + 1]
     assert lines[0]["port"] != launcher_port           # the first attempt's store may hold its keys for ever: not reused
+
+
+def test_files_of_another_job_in_the_same_directory_are_not_this_jobs(tmp_path):
+    # The watchdogs agree through small files in a directory whose name another job may have had (same port, no launcher id).  A
+    # leftover `fail` of rank 1 and a leftover `give up` verdict of an earlier job stand in the directory: they carry that job's
+    # name, not this one's, and are ignored — the first attempt succeeds and the line goes out.  The directory is gone afterwards.
+    run_dir = tmp_path / "shared_name"
+    run_dir.mkdir()
+    stale = json.dumps({"status": "fail worker exit code 9", "t": 1.0, "stderr_tail": ["from another job"]})
+    (run_dir / "a1.rank1").write_text("111-222\n" + stale)       # another job's files
+    (run_dir / "a1.verdict").write_text("111-222\ngive up")
+    (run_dir / "job").write_text("111-222")
+    env_before = os.environ.get("NBODY_BENCH_RUN_DIR")
+    os.environ["NBODY_BENCH_RUN_DIR"] = str(run_dir)
+    try:
+        out, lines, _ = run_bench("ok", under_launcher=True)
+    finally:
+        if env_before is None:
+            del os.environ["NBODY_BENCH_RUN_DIR"]
+        else:
+            os.environ["NBODY_BENCH_RUN_DIR"] = env_before
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1 and lines[0]["attempt"] == 1 and "fallback" not in lines[0]["config"]
+    assert not run_dir.exists()
