@@ -85,7 +85,7 @@ struct nbody_ctx {
   bool step_open = false;      // nbody_step_begin done, nbody_step_end pending
   bool step_local = false;     // nbody_step_begin_local done, nbody_step_begin_remote pending
   int64_t steps_done = 0;      // updates applied since the state was set (saved in checkpoints)
-  // Barnes-Hut mode (kernels_bh.hip)
+  // Barnes-Hut mode (bh_frame.hip, kernels_bh_*.hip)
   float theta = 0.0f;
   nbody::BhState *bh = nullptr;
   void *bh_acc = nullptr;      // [i_count] float4: the walk's output, summed (j_split = 1) by update_kernel
@@ -465,7 +465,7 @@ int ensure_bh(nbody_ctx *c) {
   if (c->p.precision != NBODY_PREC_F32)
     return fail(c, NBODY_ERR_UNSUPPORTED, "theta > 0 (Barnes-Hut) needs an fp32 context");
   if (c->bh) return NBODY_OK;
-  // a context that owns a slice builds the whole tree from the replicated positions and walks its own bodies (kernels_bh.hip, WalkSlice)
+  // a context that owns a slice builds the whole tree from the replicated positions and walks its own bodies (bh_common.h, WalkSlice)
   hipError_t e = nbody::bh_create(&c->bh, c->p.n_total, c->p.i_begin, c->p.i_count);
   if (e == hipSuccess) e = hipMalloc(&c->bh_acc, (size_t)c->p.i_count * 16);
   if (e != hipSuccess) {
@@ -510,7 +510,7 @@ void timer_take_back(nbody_ctx *c, int which, int k) {
 }
 
 // ... and the one wait: the frames that were built count as steps; a refused frame (and all queued behind it) left the
-// state where it was.  Frames the sort from the previous order gave up (kernels_bh.hip: a bucket ran over — the records were
+// state where it was.  Frames the sort from the previous order gave up (kernels_bh_sort.hip: a bucket ran over — the records were
 // replaced, the root box jumped) did nothing, nor did the frames queued behind them: they are queued again here, the first of them
 // with the cold sorts, inside event pairs of their own.
 int bh_finish(nbody_ctx *c) {
@@ -976,7 +976,7 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
   }
   if ((e = hipHostMalloc(&c->h_scratch, 64, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   // the hipMemset calls above run on the null stream and return early; the context's own stream is non-blocking and would not
-  // wait for them (kernels_bh.hip, bh_create)
+  // wait for them (bh_frame.hip, bh_create)
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(e, "hipStreamSynchronize after the creation memsets");
   g_create_error.clear();   // e.g. the reason AUTO passed over the symmetric plan: not an error of this call
   *out = c;

@@ -127,7 +127,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s);
 hipError_t launch_update_sym(const SymLaunch &L, void *posm, void *vel, void *acc, int i_begin, int i_count, float dt,
                              hipStream_t s);
 
-// GPU Barnes-Hut with the reference's tree and opening rule — kernels_bh.hip.  fp32, all bodies in one context.
+// GPU Barnes-Hut with the reference's tree and opening rule — bh_frame.hip (host side), kernels_bh_{small,sort,build,walk}.hip, bh_common.h.  fp32.
 struct BhState;
 // n bodies; the context owns [i_begin, i_begin + i_count) of them (all: 0, n) — a slice builds the whole tree and walks its own bodies
 hipError_t bh_create(BhState **out, int n, int i_begin, int i_count);   // *out is set even on failure: bh_destroy it

@@ -330,7 +330,7 @@ int multi_forces(Multi *m, float dt) {
 // positions (the build is the reference's arithmetic in a fixed order: the same bits everywhere), walks and integrates its own slice,
 // and the in-place all-gather brings the moved bodies to everyone: every byte equals the one-device context's.  One caller thread:
 // all devices' frames and the gathers between them are queued first, then every device is waited for once.  A frame the sort from
-// the previous order gives up (kernels_bh.hip) is given up on every device alike; what it and the frames behind it left undone is
+// the previous order gives up (kernels_bh_sort.hip) is given up on every device alike; what it and the frames behind it left undone is
 // queued again, the first of them with the cold sorts.
 static int multi_bh_frames(Multi *m, float dt, int nframes, bool diagnostic, int *built_out) {
   *built_out = 0;

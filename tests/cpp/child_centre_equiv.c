@@ -1,5 +1,5 @@
 /* The child centre of Octree::Add (OctreeSearch.h:71-73) is float(double(o) +- double(Size) * 0.5) and the child's Size
- * float(0.5 * double(Size)) (.h:74).  The device's key computation (csrc/kernels_bh.hip, descend_level) takes them as the plain
+ * float(0.5 * double(Size)) (.h:74).  The device's key computation (csrc/bh_common.h, descend_level) takes them as the plain
  * fp32 o +- 0.5f * Size and 0.5f * Size whenever Size >= 2^-100: this program checks that the two agree in every bit on
  * random operand pairs of all exponent distances (argv[1] = how many, default 2e7).  IEEE arithmetic only: what holds here
  * (SSE) holds on the GPU. */
