@@ -332,6 +332,7 @@ constexpr int kRxKpt = 16;                 // keys per thread
 constexpr int kRxTile = kRxT * kRxKpt;     // 4096 keys per tile
 constexpr int kRxBins = 256;
 constexpr int kRxPasses = 8;               // 63 key bits
+constexpr int kRxHists = 2 * kRxPasses;    // digit histograms kept: the first key word's eight digits, then the second word's (a sort by BOTH words)
 constexpr unsigned int kRxAgg = 1u << 30, kRxIncl = 2u << 30, kRxVal = (1u << 30) - 1u;
 constexpr int kKhT = 1024;                 // threads: four bodies each
 constexpr int kRxSlices = 16;
@@ -346,8 +347,8 @@ constexpr int kBsP = 512;                  // the padded bucket at most
 struct RadixPass {
   const unsigned long long *kin; const unsigned int *vin;
   unsigned long long *kout; unsigned int *vout;
-  const unsigned int *slice_hist;          // [kRxSlices][8][256]: how many keys carry each value of each digit (bh_hist_reduce_kernel)
-  int digit;
+  const unsigned int *slice_hist;          // [kRxSlices][kRxHists][256]: how many keys carry each value of each digit (bh_hist_reduce_kernel)
+  int digit;                               // which histogram: 0 .. 7 the first word's digits, 8 .. 15 the second word's
   unsigned int *desc;                      // [tiles][256] look-back words of this pass, zero before the launch
   int shift, n;
   const int *status;                       // the tree's header word 3: behind a refused frame the key kernel wrote no histograms, and a
@@ -409,10 +410,12 @@ __global__ __launch_bounds__(kKhT) void bh_keys_hist_kernel(SmallTree T, const f
                                                             unsigned int *__restrict__ next_size, float theta,
                                                             unsigned long long *__restrict__ key_hi,
                                                             unsigned long long *__restrict__ key_lo,
-                                                            unsigned int *__restrict__ part_hist);
+                                                            unsigned int *__restrict__ part_hist, int both);
 __global__ __launch_bounds__(kRxBins) void bh_hist_reduce_kernel(const unsigned int *__restrict__ part_hist, int nparts,
                                                                   unsigned int *__restrict__ slice_hist);
 __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P);
+__global__ __launch_bounds__(kB) void bh_gather_words_kernel(int n, const unsigned long long *__restrict__ by_body, const unsigned int *__restrict__ sidx,
+                                                             const int *__restrict__ status, unsigned long long *__restrict__ out);
 __global__ __launch_bounds__(kB) void bh_ties_gather_kernel(int n, const unsigned long long *__restrict__ khi,
                                                             const unsigned int *__restrict__ sidx,
                                                             const unsigned long long *__restrict__ klo_body,

@@ -38,6 +38,8 @@ struct BhState {
   unsigned int *slot_idx = nullptr, *gcount = nullptr;
   int nb = 0, gturn = 0;
   bool warm = false;
+  int ties_seen = -1;                      // neighbours that agreed in the whole first key word in the last frame built (header word 6); -1: none built yet
+  int sort_both = -1;                      // NBODY_BH_SORT_BOTH at creation: 0 / 1 force the cold radix sort by the first word / by both; -1: by what was seen
   long long warm_frames = 0, retries = 0;  // frames queued with the warm sort; times bh_collect queued frames again (tests, tuning)
   // Frames the warm sort gives up cost a warm attempt AND a cold frame.  After two collects in a row that met a given-up frame the
   // library stays with the cold sorts for cold_span frames (8, doubling up to 64 while the giving-up goes on); a collect whose warm
@@ -63,6 +65,7 @@ struct BhState {
   int i_begin = 0, i_count = 0;            // the slice; i_count == n: all bodies
   bool sliced = false;
   unsigned int *own = nullptr, *own_blk = nullptr;   // [i_count] sorted positions of the slice's bodies in key order; [blocks of kB] their counts (bh_own_*_kernel)
+  bool warm_off = false;       // NBODY_BH_WARM_SORT=0 at creation: the cold sorts every frame (A/B measurements, tests)
   bool level_sweeps = false;   // ComputeMass with a launch per level at any size (NBODY_BH_LEVEL_SWEEPS=1 at creation; always above kChunkSweepMaxN)
 };
 
@@ -144,15 +147,17 @@ static hipError_t bh_create_state(BhState *b, int n, int i_begin, int i_count) {
   BH_TRY(hipMalloc(&b->idx2, sizeof(unsigned int) * n));
   t.klo_by_body = 1;           // the second key words stay where the key kernel put them (second_word())
   b->radix = n > bh_merge_max_n();
-  { const char *e = getenv("NBODY_BH_LEVEL_SWEEPS"); b->level_sweeps = e && e[0] == '1'; }   // read at every bh_create, like the sorts' switch
+  { const char *e = getenv("NBODY_BH_LEVEL_SWEEPS"); b->level_sweeps = e && e[0] == '1'; }
+  { const char *e = getenv("NBODY_BH_WARM_SORT"); b->warm_off = e && e[0] == '0'; }
+  { const char *e = getenv("NBODY_BH_SORT_BOTH"); b->sort_both = e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }   // read at every bh_create, like the sorts' switch
   b->tile_size = bh_tile_size(n);
   { const int budget = n <= 131072 ? kNodeSmp / 4 : 512;       // many workgroups: a smaller table each (its fill is traffic; only cells of more than 127 bodies look at it)
     while ((((n - 1) >> b->smp_shift) + 1) > budget) ++b->smp_shift; }
   if (b->radix) {
     const size_t tiles = (size_t)((n + kRxTile - 1) / kRxTile);
-    BH_TRY(hipMalloc(&b->part_hist, sizeof(unsigned int) * tiles * kRxPasses * kRxBins));
-    BH_TRY(hipMalloc(&b->slice_hist, sizeof(unsigned int) * kRxSlices * kRxPasses * kRxBins));
-    b->rx_desc_bytes = sizeof(unsigned int) * tiles * kRxPasses * kRxBins;
+    BH_TRY(hipMalloc(&b->part_hist, sizeof(unsigned int) * tiles * kRxHists * kRxBins));
+    BH_TRY(hipMalloc(&b->slice_hist, sizeof(unsigned int) * kRxSlices * kRxHists * kRxBins));
+    b->rx_desc_bytes = sizeof(unsigned int) * tiles * kRxHists * kRxBins;
     BH_TRY(hipMalloc(&b->rx_desc, b->rx_desc_bytes));
     int per_cu = 0, dev = 0, cus = 0;
     BH_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bh_radix_pass_kernel, kRxT, 0));
@@ -252,8 +257,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   // b->khi, the bodies in b->idx, and the second key words, still in body order, in b->klo.
   SmallTree &T = b->st;
   T.khi = b->khi; T.sidx = b->idx; T.klo = b->klo; T.klo_by_body = 1;
-  static const bool warm_off = [] { const char *e = getenv("NBODY_BH_WARM_SORT"); return e && e[0] == '0'; }();   // A/B, tests
-  const bool warm_now = b->warm && !warm_off && b->cold_left == 0;
+  const bool warm_now = b->warm && !b->warm_off && b->cold_left == 0;
   if (b->cold_left > 0) b->cold_left -= 1;                      // (the warm sort keeps giving frames up: cold for a while — BhState::giveups_in_row)
   if (warm_now) {
     // a frame that follows a frame: the previous order is almost this frame's (bh_keys_bucket_kernel)
@@ -282,22 +286,44 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
     hipLaunchKernelGGL(bh_tile_merge_kernel, grd, blk, 0, s, n, ts, shift, b->khi2, b->idx2, b->klo, b->khi, b->idx);
   } else {
     const int tiles = (n + kRxTile - 1) / kRxTile;
-    BH_TRY(hipMemsetAsync(b->rx_desc, 0, b->rx_desc_bytes, s));
-    hipLaunchKernelGGL(bh_keys_hist_kernel, dim3(tiles), dim3(kKhT), 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->klo, b->part_hist);
-    hipLaunchKernelGGL(bh_hist_reduce_kernel, dim3(kRxPasses, kRxSlices), dim3(kRxBins), 0, s, b->part_hist, tiles, b->slice_hist);
+    // Runs of equal FIRST words are put right by bh_ties_place_kernel, whose rank search is quadratic in a run's length — a handful
+    // of bodies in any ordinary scene.  Where the last frame built found them all over (its count stands in header word 6: a runaway
+    // body owns Size and every other body shares one cell of level 21) the sort goes by BOTH words instead: eight passes on the second
+    // words, the first words gathered into that order, eight passes on them — a stable least-significant-digit sort of the whole
+    // 126-bit key, no ties left to place (2^20 bodies in one run: ~0.3 ms instead of ~0.1 s).
+    // ... and where no frame of this scene has been built yet (a new state: nothing is known) the sixteen passes are the insurance:
+    // ~0.1 ms more on a first frame of 2^20 bodies against ~0.5 s if the scene turns out to be such a run.  NBODY_BH_SORT_BOTH=0|1
+    // (read at creation): always the one or the other (tests, A/B).
+    const bool both = b->sort_both >= 0 ? b->sort_both != 0 : (b->ties_seen < 0 || b->ties_seen > n / 16);
+    BH_TRY(hipMemsetAsync(b->rx_desc, 0, both ? b->rx_desc_bytes : b->rx_desc_bytes / 2, s));
+    hipLaunchKernelGGL(bh_keys_hist_kernel, dim3(tiles), dim3(kKhT), 0, s, T, posm, n, size_bits, nxt, theta, b->khi, b->klo, b->part_hist, both ? 1 : 0);
+    hipLaunchKernelGGL(bh_hist_reduce_kernel, dim3(both ? kRxHists : kRxPasses, kRxSlices), dim3(kRxBins), 0, s, b->part_hist, tiles, b->slice_hist);
     const int pass_grid = std::min(tiles, b->rx_resident);        // all workgroups of a pass resident at once (bh_radix_pass_kernel)
-    for (int d = 0; d < kRxPasses; ++d) {                        // eight passes: the keys are back in b->khi / b->idx at the end
+    auto pass = [&](int hist, const unsigned long long *kin, const unsigned int *vin, unsigned long long *kout, unsigned int *vout) {
       RadixPass P;
-      P.kin = (d & 1) ? b->khi2 : b->khi; P.vin = d == 0 ? nullptr : ((d & 1) ? b->idx2 : b->idx);
-      P.kout = (d & 1) ? b->khi : b->khi2; P.vout = (d & 1) ? b->idx : b->idx2;
-      P.slice_hist = b->slice_hist; P.digit = d;
-      P.desc = b->rx_desc + (size_t)d * tiles * kRxBins;
-      P.shift = 8 * d; P.n = n; P.status = b->counters + 3;
+      P.kin = kin; P.vin = vin; P.kout = kout; P.vout = vout;
+      P.slice_hist = b->slice_hist; P.digit = hist;
+      P.desc = b->rx_desc + (size_t)hist * tiles * kRxBins;
+      P.shift = 8 * (hist % kRxPasses); P.n = n; P.status = b->counters + 3;
       hipLaunchKernelGGL(bh_radix_pass_kernel, dim3(pass_grid), dim3(kRxT), 0, s, P);
+    };
+    if (!both) {
+      for (int d = 0; d < kRxPasses; ++d)                        // eight passes: the keys are back in b->khi / b->idx at the end
+        pass(d, (d & 1) ? b->khi2 : b->khi, d == 0 ? nullptr : ((d & 1) ? b->idx2 : b->idx), (d & 1) ? b->khi : b->khi2, (d & 1) ? b->idx : b->idx2);
+      // (b->idx2 and b->klo_sorted are free here: the passes ended in b->idx, and a cold frame's second words stay in body order)
+      hipLaunchKernelGGL(bh_ties_gather_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->klo, b->idx2, b->klo_sorted);
+      hipLaunchKernelGGL(bh_ties_place_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->idx2, b->klo_sorted);
+    } else {
+      // the second words (b->klo stays what it is: body order): klo -> khi2 / idx2 -> klo_sorted / idx -> ... -> klo_sorted / idx
+      for (int d = 0; d < kRxPasses; ++d)
+        pass(kRxPasses + d, d == 0 ? b->klo : ((d & 1) ? b->khi2 : b->klo_sorted), d == 0 ? nullptr : ((d & 1) ? b->idx2 : b->idx),
+             (d & 1) ? b->klo_sorted : b->khi2, (d & 1) ? b->idx : b->idx2);
+      // the first words in that order, then eight stable passes on them: khi2 / idx -> klo_sorted / idx2 -> ... -> khi / idx
+      hipLaunchKernelGGL(bh_gather_words_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->counters + 3, b->khi2);
+      for (int d = 0; d < kRxPasses; ++d)
+        pass(d, (d & 1) ? b->klo_sorted : b->khi2, (d & 1) ? b->idx2 : b->idx, d == kRxPasses - 1 ? b->khi : ((d & 1) ? b->khi2 : b->klo_sorted),
+             (d & 1) ? b->idx : b->idx2);
     }
-    // (b->idx2 and b->klo_sorted are free here: the passes ended in b->idx, and a cold frame's second words stay in body order)
-    hipLaunchKernelGGL(bh_ties_gather_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->klo, b->idx2, b->klo_sorted);
-    hipLaunchKernelGGL(bh_ties_place_kernel, grd, blk, 0, s, n, b->khi, b->idx, b->idx2, b->klo_sorted);
   }
   if (T.klo_by_body) hipLaunchKernelGGL(bh_bound_kernel, dim3((b->nb + kB - 1) / kB), blk, 0, s, b->khi, b->idx, b->klo, b->nb, b->bound);   // (a cold frame)
   const int block = kB * b->scan_bpt;
@@ -393,6 +419,7 @@ hipError_t bh_collect(BhState *b, hipStream_t s, int *status, int *frames) {
   const int built = b->h_counters[4] - b->frames_seen;
   b->frames_seen = b->h_counters[4];
   if (frames) *frames = built;
+  if (built > 0) b->ties_seen = b->h_counters[6];
   if (b->h_counters[4] > 0 && built > 0) {
     b->last_nodes = b->n >= 2 ? 1 + 8 * b->h_counters[1] : 1;   // the reference's count: every split makes eight children
     b->last_levels = b->h_counters[2];
@@ -423,6 +450,7 @@ void bh_positions_external(BhState *b) { b->external = true; }
 
 hipError_t bh_reset_root(BhState *b, hipStream_t s) {
   b->warm = false;
+  b->ties_seen = -1;
   b->size_ready = false; b->pos_ready = false;                                              // a new scene: the previous order says nothing about it
   return hipMemsetAsync(b->prev_com, 0, sizeof(float) * 3, s);
 }

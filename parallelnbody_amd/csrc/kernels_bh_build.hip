@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
   __syncthreads();
   if (s_stop != 0) return;
   const int i0 = (blockIdx.x * kB + t) * bpt;                  // this thread's bodies: i0 .. i0 + bpt - 1, in key order
-  int sum = 0, deep = -1;
+  int sum = 0, deep = -1, ties = 0;
   auto shared_at = [&](unsigned long long ha, int ia, unsigned long long hb, int ib) {   // digits the bodies at sorted positions ia, ib share
     const unsigned long long x = ha ^ hb;
     if (x != 0ull) return (__clzll((long long)x) - 1) / 3;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
       sum += c;
       if (i == n - 1) lcpS[n] = (signed char)-1;
       if (ln == kMaxLevels) T.hdr[3] = 1;                      // the reference would recurse on: the frame is refused
-      if (ln >= kLevelsPerKey) T.hdr[6] = 1;                   // neighbours that agree in the whole first key word
+      ties += ln >= kLevelsPerKey ? 1 : 0;                     // neighbours that agree in the whole first key word
       deep = max(deep, ln);
       lp = ln; h = hn;
     }
@@ -79,6 +79,13 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
   if (t == 0) {
     for (int w = 1; w < kB / 64; ++w) m = max(m, s_m[w]);
     if (m >= 0) atomicMax(&T.hdr[kHdrDeep + (blockIdx.x % kDeepSlots)], m);
+  }
+  // header word 6: how many neighbours agree in the whole first key word (none, in most scenes: no atomic then) — where that is a
+  // large part of the bodies (a runaway body owns Size: DESIGN 4.5) the next COLD sort goes by both words (bh_large_frame)
+  if (__any(ties != 0)) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ties += __shfl_xor(ties, off, 64);
+    if (lane == 0) atomicAdd(&T.hdr[6], ties);
   }
 }
 

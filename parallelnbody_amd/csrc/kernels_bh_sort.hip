@@ -224,14 +224,16 @@ __global__ __launch_bounds__(kKhT) void bh_keys_hist_kernel(SmallTree T, const f
                                                             unsigned int *__restrict__ next_size, float theta,
                                                             unsigned long long *__restrict__ key_hi,
                                                             unsigned long long *__restrict__ key_lo,
-                                                            unsigned int *__restrict__ part_hist) {
-  __shared__ unsigned int s_h[kRxPasses][kRxBins];
+                                                            unsigned int *__restrict__ part_hist, int both) {
+  // both != 0: the second word's digit histograms as well (bh_large_frame sorts by both words where runs of equal first words are long)
+  __shared__ unsigned int s_h[kRxHists][kRxBins];
   const int t = threadIdx.x;
   if (T.hdr[3] != 0) return;                                   // behind a refused frame nothing happens (bh_keys_kernel); the passes return too
   const float sz = frame_size(size_bits);
   const float o0[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
   if (blockIdx.x == 0) bh_frame_setup(T, o0, sz, theta, kKhT, next_size);
-  for (int q = t; q < kRxPasses * kRxBins; q += kKhT) (&s_h[0][0])[q] = 0u;
+  const int nh = both ? kRxHists : kRxPasses;
+  for (int q = t; q < nh * kRxBins; q += kKhT) (&s_h[0][0])[q] = 0u;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < kRxTile / kKhT; ++r) {
@@ -245,11 +247,15 @@ __global__ __launch_bounds__(kKhT) void bh_keys_hist_kernel(SmallTree T, const f
       key_hi[i] = hi; key_lo[i] = lo;
 #pragma unroll
       for (int d = 0; d < kRxPasses; ++d) atomicAdd(&s_h[d][(hi >> (8 * d)) & 0xFFull], 1u);
+      if (both) {
+#pragma unroll
+        for (int d = 0; d < kRxPasses; ++d) atomicAdd(&s_h[kRxPasses + d][(lo >> (8 * d)) & 0xFFull], 1u);
+      }
     }
   }
   __syncthreads();
-  unsigned int *out = part_hist + (size_t)blockIdx.x * (kRxPasses * kRxBins);
-  for (int q = t; q < kRxPasses * kRxBins; q += kKhT) out[q] = (&s_h[0][0])[q];
+  unsigned int *out = part_hist + (size_t)blockIdx.x * (kRxHists * kRxBins);
+  for (int q = t; q < nh * kRxBins; q += kKhT) out[q] = (&s_h[0][0])[q];
 }
 
 // The workgroups' counts added up in kRxSlices slices: slice_hist[slice][digit][value] = the counts of the workgroups slice,
@@ -258,8 +264,8 @@ __global__ __launch_bounds__(kRxBins) void bh_hist_reduce_kernel(const unsigned 
                                                                   unsigned int *__restrict__ slice_hist) {
   const int d = blockIdx.x, sl = blockIdx.y, v = threadIdx.x;
   unsigned int c = 0;
-  for (int w = sl; w < nparts; w += kRxSlices) c += part_hist[((size_t)w * kRxPasses + d) * kRxBins + v];
-  slice_hist[((size_t)sl * kRxPasses + d) * kRxBins + v] = c;
+  for (int w = sl; w < nparts; w += kRxSlices) c += part_hist[((size_t)w * kRxHists + d) * kRxBins + v];
+  slice_hist[((size_t)sl * kRxHists + d) * kRxBins + v] = c;
 }
 
 
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
   // where the keys of value t start in the whole output: the slices' counts of this digit added up, scanned over the values
   unsigned int all = 0;
 #pragma unroll
-  for (int sl = 0; sl < kRxSlices; ++sl) all += P.slice_hist[((size_t)sl * kRxPasses + P.digit) * kRxBins + t];
+  for (int sl = 0; sl < kRxSlices; ++sl) all += P.slice_hist[((size_t)sl * kRxHists + P.digit) * kRxBins + t];
   unsigned int gincl = all;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const unsigned int u = __shfl_up(gincl, off, 64); if (lane >= off) gincl += u; }
@@ -383,6 +389,15 @@ __global__ __launch_bounds__(kRxT) void bh_radix_pass_kernel(RadixPass P) {
   }
   __syncthreads();                                              // the LDS arrays are the next tile's
   }
+}
+
+// out[i] = by_body[sidx[i]]: a key word that stands in body order, laid out in the order a sort has reached (the sort by both words:
+// the first words behind the eight passes on the second)
+__global__ __launch_bounds__(kB) void bh_gather_words_kernel(int n, const unsigned long long *__restrict__ by_body, const unsigned int *__restrict__ sidx,
+                                                             const int *__restrict__ status, unsigned long long *__restrict__ out) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n || *status != 0) return;
+  out[i] = by_body[sidx[i]];
 }
 
 // After the radix sort on the first key word: runs of bodies that agree in that whole word (closer than Size / 2^21) are put in

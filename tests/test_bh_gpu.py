@@ -940,3 +940,38 @@ def test_kernel_time_counts_every_frame_once_when_frames_are_queued_again(nb, or
         for _ in range(3):
             com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
         assert e.particles().tobytes() == q.tobytes()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("sort_both", ["", "0", "1"])
+def test_cold_sorts_by_both_key_words_where_first_words_agree_all_over(nb, oracle, monkeypatch, sort_both):
+    # Above 131072 bodies a cold frame sorts by radix passes on the FIRST key word and puts runs of equal first words right afterwards,
+    # every body of a run finding its rank by counting — quadratic in the run.  In a scene whose Size a runaway body owns nearly all
+    # bodies are ONE run.  The frame before has counted the neighbours that agree in the first word (header word 6): where they are
+    # all over, the next cold sort goes by both words — eight passes on the second, eight on the first, no ties left to place.
+    # So does the first frame of a new scene (nothing is known yet: insurance).  NBODY_BH_WARM_SORT=0 (read when the theta > 0 state is
+    # created) makes every frame a cold one; NBODY_BH_SORT_BOTH=0 / 1 pins the one sort or the other (the run placed by counting still
+    # has to be right: it is what a cold frame behind an ordinary frame uses).  Accelerations, draw order, node count and root CoM
+    # equal the oracle's tree in every bit, all three ways.
+    monkeypatch.setenv("NBODY_BH_WARM_SORT", "0")
+    monkeypatch.setenv("NBODY_BH_SORT_BOTH", sort_both) if sort_both else monkeypatch.delenv("NBODY_BH_SORT_BOTH", raising=False)
+    n = 150000
+    rng = np.random.default_rng(150)
+    posm = np.concatenate([rng.uniform(-1.0, 1.0, (n, 3)) + 3.0, 10.0 ** rng.uniform(-12, -9, (n, 1))], 1).astype(np.float32)
+    posm[5, :3] = (1.0e7, -2.0e6, 3.0e6); posm[5, 3] = 1e-24       # the runaway: a cell of level 21 is 9.5 wide
+    posm[100:40100, :3] = rng.uniform(-900.0, 900.0, (40000, 3)).astype(np.float32)   # ... and a part of the bodies elsewhere: runs of every length
+    assert len(np.unique(posm[:, :3], axis=0)) == n
+    pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+    ref, com, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+    assert oracle.last_max_depth() < REFUSED_FROM_DEPTH
+    _, order = oracle.octree_leaves_f32(pos, m)
+    with nb.NBodyEngine(n, theta=REF_THETA) as e:
+        e.set_state(posm, np.zeros((n, 4), np.float32))
+        for _ in range(3):
+            e.compute_forces()
+            st = e.bh_stats()
+            np.testing.assert_array_equal(e.bh_leaf_order(), order)
+            np.testing.assert_array_equal(st["root_com"], com)
+            np.testing.assert_array_equal(e.accelerations(), ref)
+            assert st["nodes"] == nodes and st["levels"] > 21
+        assert _sort_counts(e) == (0, 0)                       # (no frame started from the previous order)
