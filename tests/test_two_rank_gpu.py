@@ -20,6 +20,7 @@ def test_two_processes_one_gpu_end_to_end():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "two ranks on one GPU over gloo: algorithm symmetric, exchange ranks 2" in out.stdout
+    assert "at theta = 1.0: four frames, every byte of positions and velocities equal to one context's" in out.stdout
 
 
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

@@ -34,4 +34,17 @@ if rank == 0:
     print(f"two ranks on one GPU over gloo: algorithm {cfg['algorithm']}, exchange ranks {sim.ex_ranks}, max rel position diff vs single context {err:.2e}; "
           "all-gather under the next force pass: bits equal to the sequential order")
     assert err < 1e-6
-dist.barrier(); sim.close(); dist.destroy_process_group()
+dist.barrier(); sim.close()
+# ... and at the reference's shipped opening angle (OctreeSearch.cpp:85): every rank builds the whole tree from the gathered positions
+# and walks + integrates its own slice; EVERY BYTE of positions and velocities equals one context's
+n = 30000
+posm, vel = nb.ic_reference_box(n, 1000.0, seed=4)
+bh = nb.ShardedSimulation(posm, vel, rank=rank, world_size=world, device="cuda:0", theta=1.0)
+bh.step(0.01, 4)
+pb, vb = bh.gather_state()
+if rank == 0:
+    with nb.NBodyEngine(n, theta=1.0) as e:
+        e.set_state(posm, vel); e.step(0.01, 4); pr, vr, _ = e.state()
+    assert np.array_equal(pb, pr) and np.array_equal(vb, vr), "theta = 1 over two ranks differs from one context"
+    print("two ranks on one GPU over gloo at theta = 1.0: four frames, every byte of positions and velocities equal to one context's")
+dist.barrier(); bh.close(); dist.destroy_process_group()
