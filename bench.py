@@ -263,6 +263,9 @@ def extra_rows(args, nb):
     bh = {
         "n2000": barnes_hut_row(nb, 2000, frames=200, warmup=20, parity_frames=2),
         "n65536": barnes_hut_row(nb, 1 << 16, frames=100, warmup=10, parity_frames=1, scene="plummer"),
+        # the reference's own kind of scene at that size: within these frames runaway bodies own Size (1e9 for a box of 1e3) and every
+        # other body shares one cell of level 21 — what round 5's whole-key bucket boundaries are for
+        "n65536_reference_box_scene": barnes_hut_row(nb, 1 << 16, frames=300, warmup=10, parity_frames=1, scene="box"),
         "n1048576": barnes_hut_row(nb, 1 << 20, frames=50, warmup=5, parity_frames=1, scene="plummer"),
     }
     return configs, bh

@@ -550,7 +550,7 @@ int part_bh_collect(nbody_ctx *c, int *status, int *built) {
   int st = 0, frames = 0;
   HIP_TRY(c, nbody::bh_collect(c->bh, c->stream, &st, &frames));
   *status = st; *built = frames;
-  c->steps_done += frames;
+  if (c->bh_batch.queued > 0) c->steps_done += frames;         // (whole frames, not a diagnostic force pass)
   if (st == 3 && c->bh_batch.timed) timer_take_back(c, NBODY_KERNEL_FORCES, c->bh_batch.queued - frames);
   c->bh_batch.queued = 0;
   if (st == 1 || st == 2 || st == 4) return bh_status_error(c, st);
