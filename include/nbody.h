@@ -378,6 +378,18 @@ NBODY_AMD_API int nbody_sym_plan_describe_phased(int32_t n_total, int32_t i_begi
                                              int32_t *n_items, uint64_t *pool_elems, int32_t *items, int32_t items_cap,
                                              int32_t *n_phases, int32_t *phases, int32_t phases_cap);
 
+/* The even-share plan of the symmetric pass (plain fp32 contexts that own all bodies, mid sizes: csrc/sym_plan.h): exactly
+ * n_items_wanted work items (at least one per i-set) of equal cost — a row of the pair matrix, i.e. an i-set against its own
+ * block and then its forward blocks in ring order, cut at equal cumulative cost to four steps of a subtile's 64.  items
+ * receives 8 int32 per work item: i0, j0 (first subtile; the run goes on in ring order, from the system's last granule to
+ * granule 0), n_sub (subtiles touched), flags (4 | 1 if the first subtile lies in the own block), slot_i, slot_j, k0 (first
+ * step of the first subtile), k_skip (steps of the last subtile left to the next item). */
+NBODY_AMD_API int nbody_sym_plan_describe_even(int32_t n_total, int32_t bodies_per_iset, int32_t n_items_wanted, int32_t *n_items,
+                                           uint64_t *pool_elems, int32_t *items, int32_t items_cap);
+
+/* 1 when the context's symmetric pass runs an even-share plan (above), 0 otherwise (guided strips, or not symmetric). */
+NBODY_AMD_API int32_t nbody_sym_plan_is_even(const nbody_ctx *ctx);
+
 /* Host only: register pairs of bodies (2 ... 8; two bodies each) a workgroup of forces_block_pk_kernel owns for a plain fp32
  * system of n_total bodies on a device with `compute_units` CUs — the rule of csrc/capi.hip (smallest ceil(workgroups /
  * CUs) x pairs, larger workgroups on a tie).  No result depends on it; the CPU tests check the rule. */

@@ -136,6 +136,7 @@ def lib():
     sig("nbody_steps_done", c_int, vp, ctypes.POINTER(c_i64))
     # exported for tests and tuning, not in include/nbody.h
     sig("nbody_debug_bh_sort_counts", c_int, vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong))
+    sig("nbody_debug_sym_item_clocks", c_int, vp, ctypes.POINTER(ctypes.c_uint64), c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32))
     sig("nbody_debug_bh_clocks", c_int, vp, ctypes.POINTER(ctypes.c_longlong))
     sig("nbody_ic_reference_box", c_int, c_i32, c_f, fp, ctypes.c_uint64, fp, fp)
     sig("nbody_ic_plummer", c_int, c_i32, c_d, c_d, c_d, ctypes.c_uint64, fp, fp)
@@ -146,6 +147,9 @@ def lib():
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i32), c_i32)
     sig("nbody_sym_plan_describe_phased", c_int, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.c_uint64, ctypes.POINTER(c_i32),
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_i32), c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_i32)
+    sig("nbody_sym_plan_is_even", c_i32, vp)
+    sig("nbody_sym_plan_describe_even", c_int, c_i32, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(ctypes.c_uint64),
+        ctypes.POINTER(c_i32), c_i32)
     # actor mirror (include/nbody_actor.h)
     sig("nbody_actor_create", vp)
     sig("nbody_actor_destroy", None, vp)

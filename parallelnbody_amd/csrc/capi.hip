@@ -65,6 +65,7 @@ struct nbody_ctx {
   std::vector<int> sym_phase_item0;      // pool phases of the plan: phase p = items [p], [p + 1]) (one phase unless the pool had to be shared)
   int sym_n_gran = 0;
   double sym_k = 0.0;
+  bool sym_even = false;                 // the plan is an even-share plan (sym_plan.h)
   size_t sym_pool_elems = 0;
   nbody::SymPlan *plan = nullptr;                  // host copy, dropped once uploaded
   void *sym_pool = nullptr, *sym_items = nullptr, *sym_iptr = nullptr, *sym_ioff = nullptr, *sym_jptr = nullptr,
@@ -91,6 +92,7 @@ struct nbody_ctx {
   void *bh_acc = nullptr;      // [i_count] float4: the walk's output, summed (j_split = 1) by update_kernel
   struct { float dt = 0.f; float *stage = nullptr; int queued = 0; bool timed = false; } bh_batch;   // what bh_enqueue queued since the last bh_finish
   KernelTimer timers[2];
+  int clk_items = 0;                   // NBODY_SYM_ITEM_CLOCKS: work items with stamps of their own behind the eight clock words
   unsigned long long *clk = nullptr;   // time_kernels: {shader-clock cycles, reference-clock ticks} summed over the force kernels' workgroups (pk_common.h)
   int wall_khz = 0, cus = 0;           // hipDeviceAttributeWallClockRate, compute units
   std::string err;
@@ -231,6 +233,11 @@ void choose_geometry(nbody_ctx *c) {
   }
 }
 
+// Which plain fp32 systems take the even-share plan by default (whole steps, general form, same box: DESIGN 4.1b).
+bool sym_even_default(int n_total) {
+  return n_total >= env_int("NBODY_SYM_EVEN_MIN_N", 1 << 30) && n_total < env_int("NBODY_SYM_EVEN_MAX_N", 1 << 30);
+}
+
 // Symmetric algorithm: applicability, bodies per lane, and the work plan (sym_plan.h).  Everything here is a function
 // of the parameters and of the device's CU count and total memory — never of what happens to be free — so that equal
 // GPUs arrive at equal plans (the ranks of a sharded job must) and results are reproducible from box to box.
@@ -303,7 +310,19 @@ void choose_algorithm(nbody_ctx *c) {
   if (!plan) return;
   std::string why;
   bool planned = false;
+  // The even-share plan (sym_plan.h): plain fp32, one context owning all bodies, two register pairs per lane and more —
+  // exactly one workgroup per slot, all of equal cost.  NBODY_SYM_EVEN = 0 / 1 forces the choice (A/B measurements, tests).
+  int even_env = -1;
+  if (const char *e = getenv("NBODY_SYM_EVEN")) { if (e[0] == '0' || e[0] == '1') even_env = e[0] - '0'; }
+  const bool even_ok = !f64 && !kahan && p.i_count == p.n_total && np >= 2;
+  const bool even = even_ok && (even_env == 1 || (even_env < 0 && sym_even_default(p.n_total)));
   try {
+    if (even) {
+      planned = nbody::build_sym_plan_even(p.n_total, bi, c->sym_slots * std::max(1, env_int("NBODY_SYM_EVEN_ROUNDS", 1)), plan, &why,
+                                           env_int("NBODY_SYM_EVEN_COST_SYM", 82), env_int("NBODY_SYM_EVEN_COST_ONE", 74),
+                                           env_int("NBODY_SYM_EVEN_COST_MOVE", 26), env_int("NBODY_SYM_EVEN_OWN_PCT", 100));
+      if (planned) { c->sym_k = 0.0; c->sym_min_sub = 0; }
+    } else
     planned = nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, f64 ? 2 : 1, plan, &why,
                                     0, env_int("NBODY_SYM_MAX_SUB", 0));
   } catch (const std::bad_alloc &) {
@@ -318,7 +337,7 @@ void choose_algorithm(nbody_ctx *c) {
   const bool too_big = !planned ? why.find("2^32") != std::string::npos
                                 : (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0 &&
                                    (double)plan->pool_elems * (f64 ? 32.0 : 16.0) > (double)total_b / 3.0);
-  if (!f64 && (forced_mb > 0 || too_big)) {
+  if (!f64 && !even && (forced_mb > 0 || too_big)) {
     const double cap = 32.0 * 1073741824.0 / 16.0;                                    // elements
     double budget = forced_mb > 0 ? (double)forced_mb * 1048576.0 / 16.0 : 20.0 * 1073741824.0 / 16.0;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -343,6 +362,7 @@ void choose_algorithm(nbody_ctx *c) {
   c->sym_bi = bi; c->sym_np = f64 ? ipt / 2 : np; c->sym_pad = plan->n_pad; c->sym_items_n = (int)plan->items.size();
   c->sym_nsrc = plan->n_src; c->sym_pool_elems = (size_t)plan->pool_elems; c->sym_n_local = plan->n_local;
   c->sym_phase_item0 = plan->phase_item0; c->sym_n_gran = plan->n_gran;
+  c->sym_even = plan->even;
   c->sym = true;
   c->wave = 0;            // the small-system one-launch step belongs to the one-sided path
 }
@@ -363,6 +383,7 @@ nbody::SymLaunch make_sym_launch(const nbody_ctx *c) {
   L.send = c->sym_send; L.recv = c->sym_recv;
   L.n_total = c->p.n_total; L.n_pad = c->sym_pad; L.n_src = c->sym_nsrc;
   L.np = c->sym_np;
+  L.even = c->sym_even ? 1 : 0; L.wrap = c->sym_n_gran * 64;
   L.precision = c->p.precision == NBODY_PREC_F64 ? NBODY_PREC_F64 : NBODY_PREC_F32;
   L.kahan = c->p.precision == NBODY_PREC_F32_KAHAN ? 1 : 0;
   L.G = c->p.G; L.eps2 = c->p.eps * c->p.eps;
@@ -969,8 +990,12 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
   if ((e = hipMalloc(&c->scratch, 64)) != hipSuccess) return bail(e, "hipMalloc scratch");
   if ((e = hipMemset(c->scratch, 0, 64)) != hipSuccess) return bail(e, "hipMemset scratch");
   if (p.time_kernels) {
-    if ((e = hipMalloc(&c->clk, 64)) != hipSuccess) return bail(e, "hipMalloc clock words");
-    if ((e = hipMemset(c->clk, 0, 64)) != hipSuccess) return bail(e, "hipMemset clock words");
+    // NBODY_SYM_ITEM_CLOCKS=1 (tools/even_items.py): room for every work item's own two stamps, word 2 says so
+    c->clk_items = (c->sym && env_int("NBODY_SYM_ITEM_CLOCKS", 0) == 1) ? c->sym_items_n : 0;
+    const size_t clk_bytes = 64 + 16 * (size_t)c->clk_items;
+    if ((e = hipMalloc(&c->clk, clk_bytes)) != hipSuccess) return bail(e, "hipMalloc clock words");
+    if ((e = hipMemset(c->clk, 0, clk_bytes)) != hipSuccess) return bail(e, "hipMemset clock words");
+    if (c->clk_items) { const unsigned long long one = 1; if ((e = hipMemcpy(c->clk + 2, &one, 8, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy clock words"); }
     (void)hipDeviceGetAttribute(&c->wall_khz, hipDeviceAttributeWallClockRate, p.device);
     (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, p.device);
   }
@@ -1751,6 +1776,21 @@ int nbody_bh_leaf_order(nbody_ctx *c, int32_t *order) {
   return NBODY_OK;
 }
 
+// Not in include/nbody.h: tuning aid of tools/even_items.py — the reference-clock stamps (start, end) every work item of the
+// last symmetric force launch left (contexts created with time_kernels under NBODY_SYM_ITEM_CLOCKS=1), and the clock's rate.
+__attribute__((visibility("default"))) int nbody_debug_sym_item_clocks(nbody_ctx *c, unsigned long long *out, int32_t cap, int32_t *n_items,
+                                                                       int32_t *khz) {
+  if (!c || c->multi || !c->clk || c->clk_items <= 0) return NBODY_ERR_INVALID;
+  if (int rc = use_device(c)) return rc;
+  if (n_items) *n_items = c->clk_items;
+  if (khz) *khz = c->wall_khz;
+  if (!out) return NBODY_OK;
+  if (cap < 2 * c->clk_items) return NBODY_ERR_INVALID;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(out, c->clk + 8, 16 * (size_t)c->clk_items, hipMemcpyDeviceToHost));
+  return NBODY_OK;
+}
+
 // Not in include/nbody.h: tuning aid of tools/bh_phases.py (meaningful in -DNBODY_BH_PHASE_CLOCKS builds only).
 __attribute__((visibility("default"))) int nbody_debug_bh_clocks(nbody_ctx *c, long long out[16 + 3 * 512]) {
   if (!c || c->multi || !c->bh || !out) return NBODY_ERR_INVALID;
@@ -1842,6 +1882,12 @@ int nbody_get_algorithm(nbody_ctx *c, int32_t *algorithm, int32_t *super_tile) {
   if (algorithm) *algorithm = c->sym ? NBODY_ALGO_SYMMETRIC : NBODY_ALGO_TILED;
   if (super_tile) *super_tile = c->sym ? c->sym_bi : 0;
   return NBODY_OK;
+}
+
+int32_t nbody_sym_plan_is_even(const nbody_ctx *c) {
+  if (!c) return 0;
+  if (c->multi) return nbody_sym_plan_is_even(nbody::multi_part(c->multi, 0));
+  return c->sym && c->sym_even ? 1 : 0;
 }
 
 int nbody_sym_pool_info(nbody_ctx *c, uint64_t *pool_bytes, int32_t *phases) {

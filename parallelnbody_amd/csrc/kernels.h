@@ -119,6 +119,9 @@ struct SymLaunch {
   int do_prep = 1, do_fold = -1;     // do_fold < 0: as the phase says (phases 0 and 2 fold)
   int fold_accumulate = 0;
   int clear_detector = 1;            // the fold also clears the coincident-body table for the next pass (the pass's LAST fold only)
+  // even-share plan (sym_plan.h, plain fp32 on one context): the items carry first / last steps and follow the ring order,
+  // which goes on at body 0 past `wrap` bodies (64 x granules of the system)
+  int even = 0, wrap = 0;
   void *clk = nullptr;               // fp32: two device uint64 the force kernel's workgroups add their clock intervals to (pk_common.h)
 };
 // forces + fold of the j-side rows into L.send

@@ -71,10 +71,13 @@ constexpr int sym_waves(int np, bool kahan) {
 //   UNI: every body has the same mass.  The lane sums s d = |d|^-3 d on both sides — no mass factor per pair: 14 packed
 //   ops per register pair and step instead of 16, and no -G m_i registers; the common G m is applied once per body
 //   by the update.  The j-side sums travel with the i side's sign and are negated when they come home.
-template <int NP, int P0, bool ONE, int ZMODE, bool BARE, bool UNI>
+//   EVEN (even-share plans, sym_plan.h): the steps ka <= k < kb of the subtile only (multiples of four; the other steps are
+//   another item's).  A sum that starts at step ka in lane l is body (l - ka)'s; after step kb - 1 and its move, lane l
+//   holds body (l - kb)'s sum — the caller stores it there.
+template <int NP, int P0, bool ONE, int ZMODE, bool BARE, bool UNI, bool EVEN = false>
 __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[NP], const f2 (&zi)[NP], const f2 (&nmi)[NP],
                                             Acc3pk<false> (&acc)[NP], const float4 *sp, f2 zp2, f2 one2, float &ox, float &oy,
-                                            float &oz) {
+                                            float &oz, int ka = 0, int kb = 64) {
   constexpr int NA = NP - P0;                                     // active register pairs
   // steps in flight: four for one or two register pairs, two from four pairs up; the own-block forms (a small share
   // of the work) keep one step in flight where many pairs are active, so that they never raise the kernel's register need
@@ -84,10 +87,9 @@ __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[N
   // first copy of the lane's own entry: in bounds, unused) halves the wave-cycles parked on LDS (10.4 % -> 4.8 %) and
   // buys nothing: two waves per SIMD already cover the latency (same-box A/B, N = 2^20: 150.65 vs 150.30 ms,
   // profiles/r02_ab_lds_read_ahead.txt).  Off.
-  constexpr bool kAhead = NBODY_SYM_AHEAD == 2 ? !(NP == 8 && !BARE && !UNI) : (NBODY_SYM_AHEAD == 1 && UNI);
+  constexpr bool kAhead = !EVEN && (NBODY_SYM_AHEAD == 2 ? !(NP == 8 && !BARE && !UNI) : (NBODY_SYM_AHEAD == 1 && UNI));
   float4 pj_next = sp[0];
-#pragma unroll kUnroll
-  for (int k = 0; k < 64; ++k) {
+  auto step = [&](int k) __attribute__((always_inline)) {
     const float4 pj = kAhead ? pj_next : sp[-k];
     if (kAhead) {
       pj_next = sp[-k - 1];
@@ -135,18 +137,29 @@ __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[N
       qx = f2{wave_ror1(qx.x), wave_ror1(qx.y)}; qy = f2{wave_ror1(qy.x), wave_ror1(qy.y)};
       qz = f2{wave_ror1(qz.x), wave_ror1(qz.y)};
     }
+  };
+  if constexpr (EVEN) {
+    // ka, kb and kb - ka are multiples of four, kUnroll divides four: the steps in flight are written out (a loop with a
+    // trip count known only at run time is not unrolled around the cross-lane moves — they are convergent operations)
+    for (int k = ka; k < kb; k += kUnroll) {
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) step(k + u);
+    }
+  } else {
+#pragma unroll kUnroll
+    for (int k = 0; k < 64; ++k) step(k);
   }
   ox = qx.x + qx.y; oy = qy.x + qy.y; oz = qz.x + qz.y;
   if (UNI) { ox = -ox; oy = -oy; oz = -oz; }
 }
 
 // own-block subtile in register pair pc's slots: pick the instantiation (pc is wave-uniform)
-template <int NP, int PC, int ZMODE, bool BARE, bool UNI>
+template <int NP, int PC, int ZMODE, bool BARE, bool UNI, bool EVEN = false>
 __device__ __forceinline__ void own_block_subtile(int pc, const f2 (&xi)[NP], const f2 (&yi)[NP], const f2 (&zi)[NP],
                                                   const f2 (&nmi)[NP], Acc3pk<false> (&acc)[NP], const float4 *sp, f2 zp2,
-                                                  f2 one2, float &ox, float &oy, float &oz) {
-  if (pc == PC) sym_subtile<NP, PC, true, ZMODE, BARE, UNI>(xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
-  else if constexpr (PC + 1 < NP) own_block_subtile<NP, PC + 1, ZMODE, BARE, UNI>(pc, xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz);
+                                                  f2 one2, float &ox, float &oy, float &oz, int ka = 0, int kb = 64) {
+  if (pc == PC) sym_subtile<NP, PC, true, ZMODE, BARE, UNI, EVEN>(xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz, ka, kb);
+  else if constexpr (PC + 1 < NP) own_block_subtile<NP, PC + 1, ZMODE, BARE, UNI, EVEN>(pc, xi, yi, zi, nmi, acc, sp, zp2, one2, ox, oy, oz, ka, kb);
 }
 
 using lds_f4 = __attribute__((address_space(3))) float4;
@@ -159,12 +172,15 @@ using glb_f4 = const __attribute__((address_space(1))) float4;
 // it has no -G m_i registers to keep): ONE launch holds both loops and the detector's verdict picks — systems of
 // 12288 ... 24576 bodies step in ~100 us, and a twin that returns at its first instruction still costs a launch (4-6 us
 // of kernel + the gap in front of it).  BARE is then the form that runs when no two bodies coincide.
-template <int NP, int ZMODE, bool BARE, bool KAHAN, bool UNI>
+// EVEN: the items are an even-share plan's (sym_plan.h): a run of subtiles in the row's ring order — whether a subtile lies in
+// the i-set's own block is asked subtile by subtile, past the system's last granule (`wrap` bodies) the run goes on at body
+// 0 — of which the first starts at step k0 and the last ends at step 64 - k_skip.
+template <int NP, int ZMODE, bool BARE, bool KAHAN, bool UNI, bool EVEN = false>
 __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu(sym_waves(NP, KAHAN), sym_waves(NP, KAHAN))))
 void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ pool, const SymItem *__restrict__ items,
                           float zp, const int *__restrict__ dup_flag, int run_if_dup, const int *__restrict__ general,
-                          int run_if_general, unsigned long long *__restrict__ clk) {
+                          int run_if_general, unsigned long long *__restrict__ clk, int wrap = 0) {
   constexpr bool kCanMerge = BARE && (NP <= 4 || UNI);           // the general form at NP = 8 would spill (52 B of scratch)
   const bool merged = kCanMerge && run_if_dup < 0;
   if (!merged && dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
@@ -178,13 +194,16 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
   const SymItem *__restrict__ itp = items + blockIdx.x;          // wave-uniform: scalar loads
   const int i0 = itp->i0, j0 = itp->j0, n_sub = itp->n_sub;
   const unsigned int slot_i = itp->slot_i, slot_j = itp->slot_j;
-  const bool own_block = (itp->flags & kSymOneSided) != 0;      // the strip lies inside the i-set's own block
+  const bool own_strip = (itp->flags & kSymOneSided) != 0;      // the strip lies inside the i-set's own block
+  const int k_first = EVEN ? itp->k0 : 0, k_last = EVEN ? 64 - itp->k_skip : 64;
   const int n_tiles = (n_sub + 3) >> 2;
 
   // Tile c of the strip -> LDS buffer c & 1: wave w brings subtile w, twice (the doubled image), 1 KiB per DMA.
   auto stage = [&](int c, int wave, int lane) {
     if (4 * c + wave < n_sub) {
-      glb_f4 *src = (glb_f4 *)(posg + j0 + (4 * c + wave) * 64 + lane);
+      int jb = j0 + (4 * c + wave) * 64;
+      if (EVEN && jb >= wrap) jb -= wrap;
+      glb_f4 *src = (glb_f4 *)(posg + jb + lane);
       __builtin_amdgcn_global_load_lds(src, (lds_f4 *)&sh_pos[c & 1][wave][0], 16, 0, 0);
       __builtin_amdgcn_global_load_lds(src, (lds_f4 *)&sh_pos[c & 1][wave][64], 16, 0, 0);
     }
@@ -228,23 +247,30 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
     for (int sub = 0; sub < nsub; ++sub) {
       const float4 *sp = &sh_pos[buf][sub][lane + 64];
       float ox, oy, oz;
+      // EVEN: this subtile's place in the ring, whether it lies in the own block, and which of its steps are this item's
+      int off = j0 - i0 + (4 * c + sub) * 64;                      // offset from the i-set's first body (wave-uniform)
+      if (EVEN && j0 + (4 * c + sub) * 64 >= wrap) off -= wrap;
+      const bool own_block = EVEN ? (unsigned int)off < (unsigned int)(NP * 512) : own_strip;
+      const int kfrom = (EVEN && 4 * c + sub == 0) ? k_first : 0, kto = (EVEN && 4 * c + sub == n_sub - 1) ? k_last : 64;
       if (kCanMerge && guard_all) {
         if (!own_block)
-          sym_subtile<NP, 0, false, ZMODE, false, UNI>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+          sym_subtile<NP, 0, false, ZMODE, false, UNI, EVEN>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz, kfrom, kto);
         else
-          own_block_subtile<NP, 0, ZMODE, false, UNI>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+          own_block_subtile<NP, 0, ZMODE, false, UNI, EVEN>(off >> 9, xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz, kfrom, kto);
       } else if (!own_block)
-        sym_subtile<NP, 0, false, ZMODE, BARE, UNI>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz);
+        sym_subtile<NP, 0, false, ZMODE, BARE, UNI, EVEN>(xi, yi, zi, nmi, a, sp, zp2, one2, ox, oy, oz, kfrom, kto);
       else {   // the subtile's bodies sit in the slots of register pair (offset from the i-set's first body) / 512
         f2 zq = zp2, oq = one2;
         if (BARE && !kCanMerge) { zq = splat2(zp); oq = splat2(1.0f); asm volatile("" : "+v"(zq), "+v"(oq)); }
-        own_block_subtile<NP, 0, ZMODE, BARE, UNI>((j0 - i0 + (4 * c + sub) * 64) >> 9, xi, yi, zi, nmi, a, sp, zq, oq, ox, oy, oz);
+        own_block_subtile<NP, 0, ZMODE, BARE, UNI, EVEN>(off >> 9, xi, yi, zi, nmi, a, sp, zq, oq, ox, oy, oz, kfrom, kto);
       }
       if (KAHAN) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) { ka[p].fold(a[p]); a[p] = Acc3pk<false>(); }
       }
-      sh_acc[wave][0][sub * 64 + lane] = ox; sh_acc[wave][1][sub * 64 + lane] = oy; sh_acc[wave][2][sub * 64 + lane] = oz;
+      // (EVEN: after step kto - 1 the lane holds the sum of body lane - kto of the subtile)
+      const int home = EVEN ? sub * 64 + ((lane - kto) & 63) : sub * 64 + lane;
+      sh_acc[wave][0][home] = ox; sh_acc[wave][1][home] = oy; sh_acc[wave][2][home] = oz;
     }
     __syncthreads();   // the four waves' tile sums are complete; the next tile has landed
     {
@@ -280,7 +306,22 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
     Pi[(2 * p) * kBlock] = make_float4(sx.x, sy.x, sz.x, 0.f);
     Pi[(2 * p + 1) * kBlock] = make_float4(sx.y, sy.y, sz.y, 0.f);
   }
-  clock_end(clk, stamp);
+  clock_end(clk, stamp, (int)blockIdx.x);
+}
+
+// one force launch: the even-share form of the kernel for an even-share plan (plain fp32, two and more register pairs)
+template <int NPV, int ZM, bool BARE, bool KH, bool UNI>
+void launch_sym_kernel(const SymLaunch &L, dim3 grid, dim3 block, hipStream_t s, const SymItem *items, float zp, const int *flag,
+                       int run_if, const int *gate) {
+  if constexpr (!KH && NPV >= 2) {
+    if (L.even) {
+      hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, UNI, true>), grid, block, 0, s, (const float4 *)L.posg,
+                         (float4 *)L.pool, items, zp, flag, run_if, gate, UNI ? 0 : 1, (unsigned long long *)L.clk, L.wrap);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, UNI, false>), grid, block, 0, s, (const float4 *)L.posg,
+                     (float4 *)L.pool, items, zp, flag, run_if, gate, UNI ? 0 : 1, (unsigned long long *)L.clk, 0);
 }
 
 }  // namespace
@@ -292,6 +333,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   if (L.n_total <= 0 || L.n_items <= 0 || L.n_pad < L.n_total || !L.posg || !L.pool || !L.items) return hipErrorInvalidValue;
   if (L.np != 1 && L.np != 2 && L.np != 4 && L.np != 8) return hipErrorInvalidValue;
   if (L.np == 8 && L.kahan) return hipErrorInvalidValue;
+  if (L.even && (L.kahan || L.np < 2 || L.wrap <= 0 || L.wrap % 64 != 0 || L.phase != 0)) return hipErrorInvalidValue;
   if (L.phase < 0 || L.phase > 2 || (L.phase != 0 && (L.fused || L.n_local < 0 || L.n_local > L.n_items))) return hipErrorInvalidValue;
   // which items this call launches, and which bodies it prepares (SymLaunch::phase)
   int item0 = L.phase == 2 ? L.n_local : 0, item1 = L.phase == 1 ? L.n_local : L.n_items;
@@ -327,8 +369,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   if (grid.x == 0) {                                              // nothing to launch in this go (phase 2 of a plan without remote strips)
   } else {
 #define NBODY_SYM_K(NPV, ZM, BARE, KH, UNI, ZP, FLAG, RUNIF)                                                     \
-  hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, UNI>), grid, block, 0, s, (const float4 *)L.posg, \
-                     (float4 *)L.pool, items, (float)(ZP), (const int *)(FLAG), RUNIF, gate, UNI ? 0 : 1, (unsigned long long *)L.clk)
+  launch_sym_kernel<NPV, ZM, BARE, KH, UNI>(L, grid, block, s, items, (float)(ZP), (const int *)(FLAG), RUNIF, gate)
   bool do_uni = run_uni, do_gen = run_gen;                         // which forms the next NBODY_SYM_NP launches
 #define NBODY_SYM_U(NPV, ZM, BARE, KH, ZP, FLAG, RUNIF)                                                          \
   do {                                                                                                           \

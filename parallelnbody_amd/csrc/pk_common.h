@@ -32,10 +32,16 @@ __device__ __forceinline__ ClockStamp clock_begin(const unsigned long long *clk)
   if (clk != nullptr) { s.t = __builtin_amdgcn_s_memtime(); s.r = __builtin_amdgcn_s_memrealtime(); }
   return s;
 }
-__device__ __forceinline__ void clock_end(unsigned long long *clk, const ClockStamp &s) {
+// item >= 0 and clk[2] != 0 (tools/even_items.py; NBODY_SYM_ITEM_CLOCKS=1 at creation sized the buffer for it): the
+// workgroup also leaves its own two reference-clock stamps in clk[8 + 2 item], clk[9 + 2 item].
+__device__ __forceinline__ void clock_end(unsigned long long *clk, const ClockStamp &s, int item = -1) {
   if (clk != nullptr) {
-    const unsigned long long t = __builtin_amdgcn_s_memtime() - s.t, r = __builtin_amdgcn_s_memrealtime() - s.r;
-    if (threadIdx.x == 0) { atomicAdd(clk, t); atomicAdd(clk + 1, r); }
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t = __builtin_amdgcn_s_memtime() - s.t, r = now - s.r;
+    if (threadIdx.x == 0) {
+      atomicAdd(clk, t); atomicAdd(clk + 1, r);
+      if (item >= 0 && clk[2] != 0ull) { clk[8 + 2 * item] = s.r; clk[9 + 2 * item] = now; }
+    }
   }
 }
 

@@ -133,7 +133,7 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
       it.n_sub = n;
       it.flags = r.one_sided ? kSymOneSided : 0;
       if (r.one_sided && own_mode == 0) it.flags |= kSymNoJSide;      // does the item produce j-side sums
-      it.reserved1 = (int32_t)P.items.size();                         // place in the canonical order (= the order of summation)
+      it.k_skip = (int32_t)P.items.size();                         // place in the canonical order (= the order of summation)
       P.items.push_back(it);
       pos += n;
       remaining -= cost;
@@ -153,7 +153,7 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
   // segments share one area of at most that size: the items of a phase run, their j-side sums are folded into `send`, the
   // next phase reuses the area.  The i-side segments (N / bi per strip... a few GB) stay to the end.
   std::vector<size_t> canon(P.items.size());                         // canonical position -> launch position
-  for (size_t k = 0; k < P.items.size(); ++k) canon[(size_t)P.items[k].reserved1] = k;
+  for (size_t k = 0; k < P.items.size(); ++k) canon[(size_t)P.items[k].k_skip] = k;
   uint64_t total_j = 0;
   for (const SymItem &it : P.items) if (!(it.flags & kSymNoJSide)) total_j += (uint64_t)it.n_sub * 64;
   const bool phased = j_budget_elems != 0 && total_j > j_budget_elems;
@@ -163,7 +163,7 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
       if (pool + (uint64_t)bi + (uint64_t)it.n_sub * 64 >= (1ull << 32)) return fail(err, "partial-sum pool exceeds 2^32 elements");
       it.slot_i = (uint32_t)pool; pool += (uint64_t)bi;
       if (!(it.flags & kSymNoJSide)) { it.slot_j = (uint32_t)pool; pool += (uint64_t)it.n_sub * 64; }
-      it.reserved0 = 0;
+      it.k0 = 0;
     }
     P.phase_item0.assign({0, (int)P.items.size()});
   } else {
@@ -181,7 +181,7 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
       it.slot_j = (uint32_t)(jbase + used);
       used += need;
       area = std::max(area, used);
-      it.reserved0 = phase;
+      it.k0 = phase;
     }
     P.phase_item0.push_back((int)P.items.size());
     pool = jbase + area;
@@ -212,7 +212,7 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
     P.j_ptr.assign(stride * (size_t)n_phases, 0);
     for (const SymItem &it : P.items)
       if (!(it.flags & kSymNoJSide))
-        for (int k = 0; k < it.n_sub; ++k) P.j_ptr[stride * (size_t)it.reserved0 + (size_t)(it.j0 / 64 + k) + 1] += 1;
+        for (int k = 0; k < it.n_sub; ++k) P.j_ptr[stride * (size_t)it.k0 + (size_t)(it.j0 / 64 + k) + 1] += 1;
     uint64_t run = 0;
     for (int ph = 0; ph < n_phases; ++ph) {                           // counts -> absolute positions in j_off
       uint32_t *ptr = P.j_ptr.data() + stride * (size_t)ph;
@@ -230,15 +230,168 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
       const SymItem &it = P.items[canon[c]];
       if (it.flags & kSymNoJSide) continue;
       for (int k = 0; k < it.n_sub; ++k)
-        P.j_off[fill[stride * (size_t)it.reserved0 + (size_t)(it.j0 / 64 + k)]++] = it.slot_j + (uint32_t)k * 64u;
+        P.j_off[fill[stride * (size_t)it.k0 + (size_t)(it.j0 / 64 + k)]++] = it.slot_j + (uint32_t)k * 64u;
     }
   }
-  for (SymItem &it : P.items) { it.reserved0 = 0; it.reserved1 = 0; }
+  for (SymItem &it : P.items) { it.k0 = 0; it.k_skip = 0; }
+  *out = std::move(P);
+  return true;
+}
+
+// ---- the even-share plan ------------------------------------------------------------------------------------------------
+bool build_sym_plan_even(int n_total, int bi, int n_items, SymPlan *out, std::string *err, int cost_sym, int cost_one,
+                         int cost_move, int own_pct) {
+  if (n_total <= 0) return fail(err, "bad body range");
+  if (bi < 512 || bi % 512 != 0) return fail(err, "bodies per i-set must be a multiple of 512");
+  if (n_items < 1 || cost_sym < 1 || cost_one < 1 || cost_move < 0 || own_pct < 1) return fail(err, "bad scheduling parameters");
+  SymPlan P;
+  P.even = true;
+  P.bi = bi;
+  P.T = (n_total + bi - 1) / bi;
+  P.n_pad = P.T * bi;
+  P.n_gran = (n_total + 63) / 64;
+  P.own_block0 = 0; P.own_blocks = P.T; P.n_src = 1;
+  P.own_gran0 = 0; P.own_grans = P.n_gran;
+  const int spb = bi / 64, NP = bi / 512;
+  constexpr int kQuant = 4;                                           // a cut falls on a multiple of four steps (the loops' unroll)
+
+  // a row = the subtiles its i-set meets, in ring order: its own block, then the forward blocks (clipped to the granules that
+  // exist; past the last one the run goes on at granule 0).  step_cost[q]: SIMD cycles of ONE step of subtile q.
+  struct Row { int a, first, n_sub; long long cost; std::vector<int> step_cost; };
+  std::vector<Row> rows;
+  long long total = 0;
+  for (int a = 0; a < P.T; ++a) {
+    Row r{a, a * spb, 0, 0, {}};
+    if (r.first >= P.n_gran) continue;                                // (cannot happen: the last block holds a body)
+    const int dn = std::min(spb, P.n_gran - r.first);
+    for (int k = 0; k < dn; ++k) {
+      const int na = NP - (k * 64 >> 9);                              // active register pairs; the first of them one-sided
+      r.step_cost.push_back(std::max(1, (na == 1 ? cost_one : (na - 1) * cost_sym + cost_one + cost_move) * own_pct / 100));
+    }
+    int h = 0;
+    while (h + 1 < P.T && ring_assigned(a, (a + h + 1) % P.T, P.T)) ++h;
+    for (int d = h + 1; d < P.T; ++d)
+      if (ring_assigned(a, (a + d) % P.T, P.T)) return fail(err, "internal: forward blocks not contiguous");
+    const long long ring = (long long)P.T * spb, s = (long long)((a + 1) % P.T) * spb;
+    for (long long x = 0; x < (long long)h * spb; ++x)
+      if ((s + x) % ring < P.n_gran) r.step_cost.push_back(NP * cost_sym + cost_move);
+    r.n_sub = (int)r.step_cost.size();
+    for (int c : r.step_cost) r.cost += 64LL * c;
+    total += r.cost;
+    rows.push_back(std::move(r));
+  }
+  // items per row: in proportion to the rows' cost, largest remainders first; every row at least one, none more than its
+  // steps allow
+  const int R = (int)rows.size();
+  if (n_items < R) n_items = R;
+  std::vector<int> m((size_t)R, 1);
+  {
+    std::vector<std::pair<double, int>> rem;
+    int given = 0;
+    for (int r = 0; r < R; ++r) {
+      const double share = (double)n_items * (double)rows[(size_t)r].cost / (double)total;
+      const int cap = rows[(size_t)r].n_sub * (64 / kQuant);
+      m[(size_t)r] = std::max(1, std::min(cap, (int)share));
+      given += m[(size_t)r];
+      rem.push_back({share - (double)(int)share, r});
+    }
+    std::sort(rem.begin(), rem.end(), [](const std::pair<double, int> &x, const std::pair<double, int> &y) {
+      return x.first != y.first ? x.first > y.first : x.second < y.second; });
+    for (size_t k = 0; given < n_items && k < rem.size(); ++k) {
+      const int r = rem[k].second;
+      if (m[(size_t)r] < rows[(size_t)r].n_sub * (64 / kQuant)) { ++m[(size_t)r]; ++given; }
+    }
+  }
+  uint64_t pool = 0;
+  for (int r = 0; r < R; ++r) {
+    const Row &row = rows[(size_t)r];
+    const int mr = m[(size_t)r];
+    // cut t (0 < t < mr) = the step position (64 q + k, k a multiple of kQuant) whose cumulative cost is nearest t / mr of the row's
+    std::vector<long long> cut((size_t)mr + 1, 0);
+    cut[(size_t)mr] = 64LL * row.n_sub;
+    {
+      int q = 0;
+      long long before = 0;                                           // cost of the subtiles in front of q
+      for (int t = 1; t < mr; ++t) {
+        const double want = (double)row.cost * (double)t / (double)mr;
+        while (q + 1 < row.n_sub && (double)(before + 64LL * row.step_cost[(size_t)q]) <= want) { before += 64LL * row.step_cost[(size_t)q]; ++q; }
+        long long k = (long long)(((want - (double)before) / (double)row.step_cost[(size_t)q]) / kQuant + 0.5) * kQuant;
+        k = std::max(0LL, std::min(64LL, k));
+        long long pos = 64LL * q + k;
+        pos = std::max(pos, cut[(size_t)t - 1] + kQuant);             // every item works at least one quantum
+        pos = std::min(pos, 64LL * row.n_sub - (long long)(mr - t) * kQuant);
+        cut[(size_t)t] = pos;
+      }
+    }
+    for (int t = 0; t < mr; ++t) {
+      const long long p0 = cut[(size_t)t], p1 = cut[(size_t)t + 1];
+      const int q0 = (int)(p0 / 64), q1 = (int)((p1 - 1) / 64);
+      SymItem it{};
+      it.i0 = row.a * bi;
+      int g = row.first + q0;
+      if (g >= P.n_gran) g -= P.n_gran;
+      it.j0 = g * 64;
+      it.n_sub = q1 - q0 + 1;
+      it.flags = kSymEven | ((g * 64 >= it.i0 && g * 64 < it.i0 + bi) ? kSymOneSided : 0);
+      it.k0 = (int32_t)(p0 - 64LL * q0);
+      it.k_skip = (int32_t)(64LL * (q1 + 1) - p1);
+      if (pool + (uint64_t)bi + (uint64_t)it.n_sub * 64 >= (1ull << 32)) return fail(err, "partial-sum pool exceeds 2^32 elements");
+      it.slot_i = (uint32_t)pool; pool += (uint64_t)bi;
+      it.slot_j = (uint32_t)pool; pool += (uint64_t)it.n_sub * 64;
+      P.items.push_back(it);
+    }
+  }
+  P.pool_elems = pool;
+  P.n_local = (int)P.items.size();
+  P.phase_item0.assign({0, (int)P.items.size()});
+  // the lists: item order is the order of summation, as in the guided plans
+  auto gran_of = [&](const SymItem &it, int k) { int g = it.j0 / 64 + k; return g >= P.n_gran ? g - P.n_gran : g; };
+  P.i_ptr.assign((size_t)P.own_grans + 1, 0);
+  for (const SymItem &it : P.items)
+    for (int g = it.i0 / 64; g < it.i0 / 64 + spb && g < P.own_grans; ++g) P.i_ptr[(size_t)g + 1] += 1;
+  for (int g = 0; g < P.own_grans; ++g) P.i_ptr[(size_t)g + 1] += P.i_ptr[(size_t)g];
+  P.i_off.assign(P.i_ptr.back(), 0);
+  {
+    std::vector<uint32_t> fill(P.i_ptr.begin(), P.i_ptr.end() - 1);
+    for (const SymItem &it : P.items)
+      for (int g = it.i0 / 64; g < it.i0 / 64 + spb && g < P.own_grans; ++g)
+        P.i_off[fill[(size_t)g]++] = it.slot_i + (uint32_t)(g - it.i0 / 64) * 64u;
+  }
+  P.j_ptr.assign((size_t)P.n_gran + 1, 0);
+  for (const SymItem &it : P.items)
+    for (int k = 0; k < it.n_sub; ++k) P.j_ptr[(size_t)gran_of(it, k) + 1] += 1;
+  for (int g = 0; g < P.n_gran; ++g) P.j_ptr[(size_t)g + 1] += P.j_ptr[(size_t)g];
+  P.j_off.assign(P.j_ptr.back(), 0);
+  {
+    std::vector<uint32_t> fill(P.j_ptr.begin(), P.j_ptr.end() - 1);
+    for (const SymItem &it : P.items)
+      for (int k = 0; k < it.n_sub; ++k) P.j_off[fill[(size_t)gran_of(it, k)]++] = it.slot_j + (uint32_t)k * 64u;
+  }
   *out = std::move(P);
   return true;
 }
 
 }  // namespace nbody
+
+// C-ABI view of the even-share planner: items as eight words each — i0, j0, n_sub, flags, slot_i, slot_j, k0, k_skip.
+extern "C" int nbody_sym_plan_describe_even(int32_t n_total, int32_t bodies_per_iset, int32_t n_items_wanted, int32_t *n_items,
+                                            uint64_t *pool_elems, int32_t *items, int32_t items_cap) {
+  nbody::SymPlan P;
+  std::string why;
+  if (!nbody::build_sym_plan_even(n_total, bodies_per_iset, n_items_wanted, &P, &why)) return NBODY_ERR_UNSUPPORTED;
+  if (n_items) *n_items = (int32_t)P.items.size();
+  if (pool_elems) *pool_elems = P.pool_elems;
+  if (items) {
+    if (items_cap < (int32_t)P.items.size()) return NBODY_ERR_INVALID;
+    for (size_t k = 0; k < P.items.size(); ++k) {
+      const nbody::SymItem &it = P.items[k];
+      int32_t *o = items + 8 * k;
+      o[0] = it.i0; o[1] = it.j0; o[2] = it.n_sub; o[3] = it.flags;
+      o[4] = (int32_t)it.slot_i; o[5] = (int32_t)it.slot_j; o[6] = it.k0; o[7] = it.k_skip;
+    }
+  }
+  return NBODY_OK;
+}
 
 // C-ABI view of the planner (host only, no device): lets the CPU test suite check that a plan covers every body pair
 // exactly once and that its segments do not overlap.

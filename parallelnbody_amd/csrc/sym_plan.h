@@ -29,10 +29,14 @@ struct SymItem {          // 32 bytes, read by the force kernels with scalar loa
   int32_t flags;          // kSymOneSided, kSymNoJSide
   uint32_t slot_i;        // pool element where the i-side sums of bodies [i0, i0 + bi) start
   uint32_t slot_j;        // pool element where the j-side sums of bodies [j0, j0 + 64 n_sub) start (symmetric items)
-  int32_t reserved0, reserved1;   // zero (the planner's scratch while it works)
+  int32_t k0;             // even-share plans: first step (0..60, multiple of 4) of the item's FIRST subtile; 0 in the guided plans
+  int32_t k_skip;         // even-share plans: steps of the item's LAST subtile left to the next item (it ends at step 64 - k_skip)
+                          // (both are the guided planner's scratch while it works and zero when it is done)
 };
-enum { kSymOneSided = 1,      // the strip lies in the i-set's own block
-       kSymNoJSide = 2 };     // the item writes no j-side sums (own_mode 0 only)
+enum { kSymOneSided = 1,      // the strip lies in the i-set's own block (guided plans; an even-share item: its first subtile does)
+       kSymNoJSide = 2,       // the item writes no j-side sums (own_mode 0 only)
+       kSymEven = 4 };        // item of an even-share plan: its subtiles follow the row's ring order (they may leave the own block
+                              // and wrap from the system's last granule to granule 0), the first and last may be partial
 
 struct SymPlan {
   int bi = 0;             // bodies per i-set
@@ -43,6 +47,7 @@ struct SymPlan {
   int own_gran0 = 0, own_grans = 0;
   int n_src = 1;          // ranks sharing the bodies
   uint64_t pool_elems = 0;
+  bool even = false;      // an even-share plan (build_sym_plan_even): the kernels take the items' k0 / k_skip and ring order
   int n_local = 0;        // items [0, n_local): strips inside the own slice (all of them when the context owns all bodies)
   // pool phases (build_sym_plan's j_budget): phase p = items [phase_item0[p], phase_item0[p + 1]) of the launch order; its
   // j-side lists are j_ptr[p * (n_gran + 1) ...] (absolute positions in j_off).  One phase unless a budget was given and exceeded.
@@ -60,5 +65,19 @@ struct SymPlan {
 // pool elements, and a system whose j-side segments exceed it is run in several phases that share one area (SymPlan).
 bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, double k_guided, int min_sub, int own_mode,
                     SymPlan *out, std::string *err, uint64_t j_budget_elems = 0, int max_sub_arg = 0);
+
+// The even-share plan (round 5; fp32, one context owning all bodies): exactly n_items work items — as many as the chip holds
+// workgroups at a time — of EQUAL cost, so that one round of workgroups starts together and ends together.  Mid-size systems
+// (N = 16k ... 131k) step in 50 us ... 2 ms: the guided plan's two or three rounds of strips pay an i-side segment, a prologue
+// and an epilogue per strip, and a quantum of one subtile (64 steps x bodies per lane: 10 us of a SIMD) is a tenth of what a
+// slot gets.  Here a row — the i-set against its own block and then its forward blocks, ONE run of subtiles in ring order —
+// is cut at equal cumulative cost, to four steps of a subtile's 64: an item is {first subtile, first step, subtiles touched,
+// steps left off the last}; the rows get items in proportion to their cost (largest remainders).  The rest — segments, lists,
+// who adds what in which order — is the guided plan's.  cost_sym / cost_one / cost_move: SIMD cycles of one step of one
+// symmetric register pair, of the one-sided pair of an own-block subtile, and of the travelling sums' moves (the issue model,
+// DESIGN 4.1): an own-block subtile in register pair pc's slots works NP - pc pairs, the first of them one-sided.
+// own_pct: what a step of an own-block subtile costs, in per cent of the model's figure.
+bool build_sym_plan_even(int n_total, int bi, int n_items, SymPlan *out, std::string *err, int cost_sym = 82, int cost_one = 74,
+                         int cost_move = 26, int own_pct = 100);
 
 }  // namespace nbody

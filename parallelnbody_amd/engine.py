@@ -87,6 +87,22 @@ def sym_plan_phased(n_total, j_budget_elems, i_begin=0, i_count=0, bodies_per_is
     return items, pe.value, ph
 
 
+def sym_plan_even(n_total, bodies_per_iset=2048, n_items=768):
+    """The even-share plan of the symmetric pass (csrc/sym_plan.h), host only.  Returns (items[n,8] int32 — i0, j0, n_sub,
+    flags, slot_i, slot_j, k0, k_skip —, pool_elems)."""
+    L = _lib.lib()
+    n, pe = ctypes.c_int32(), ctypes.c_uint64()
+    rc = L.nbody_sym_plan_describe_even(n_total, bodies_per_iset, n_items, ctypes.byref(n), ctypes.byref(pe), None, 0)
+    if rc:
+        raise NBodyError(rc, "nbody_sym_plan_describe_even: this system cannot be planned")
+    items = np.zeros((n.value, 8), np.int32)
+    rc = L.nbody_sym_plan_describe_even(n_total, bodies_per_iset, n_items, ctypes.byref(n), ctypes.byref(pe),
+                                        items.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n.value)
+    if rc:
+        raise NBodyError(rc, "nbody_sym_plan_describe_even: this system cannot be planned")
+    return items, pe.value
+
+
 def device_count():
     return int(_lib.lib().nbody_device_count())
 
@@ -382,4 +398,5 @@ class NBodyEngine:
         cfg["algorithm"] = {_lib.ALGO_TILED: "tiled", _lib.ALGO_SYMMETRIC: "symmetric"}[algo.value]
         cfg["super_tile"] = st.value
         cfg["kernel"] = self._L.nbody_force_kernel_name(self._h).decode()
+        cfg["plan"] = ("even" if self._L.nbody_sym_plan_is_even(self._h) else "guided") if cfg["algorithm"] == "symmetric" else None
         return cfg

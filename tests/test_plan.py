@@ -175,3 +175,80 @@ def test_block_kernel_pairs_per_workgroup_rule():
             best = min(cost(k) for k in range(2, 9))
             assert cost(got) == best and all(cost(k) > best for k in range(got + 1, 9)), (n, cus, got)
     assert L.nbody_block_pairs_describe(0, 256) == 0
+
+
+# ---- the even-share plan (round 5; csrc/sym_plan.h build_sym_plan_even) ------------------------------------------------
+
+def _even_coverage(nb, n, bi, n_items):
+    """cov[a, g, s]: how many items work steps [4 s, 4 s + 4) of 64-body subtile g against block a's i-set; plus the items'
+    costs by the planner's model and the segment check."""
+    items, pool = nb.sym_plan_even(n, bi, n_items)
+    T, G, NP = -(-n // bi), -(-n // 64), bi // 512
+    cov = np.zeros((T, G, 16), np.int32)
+    cost = np.zeros(len(items))
+    segs = []
+    for idx, (i0, j0, n_sub, flags, slot_i, slot_j, k0, k_skip) in enumerate(items):
+        assert flags & 4 and i0 % bi == 0 and j0 % 64 == 0 and 0 <= j0 < G * 64 and n_sub >= 1
+        assert k0 % 4 == 0 and k_skip % 4 == 0 and 0 <= k0 < 64 and 0 <= k_skip < 64
+        assert n_sub > 1 or k0 < 64 - k_skip                       # a single subtile: a non-empty range of steps
+        a = i0 // bi
+        for q in range(n_sub):
+            g = (j0 // 64 + q) % G                                  # ring order: past the last granule comes granule 0
+            s0 = k0 // 4 if q == 0 else 0
+            s1 = (64 - k_skip) // 4 if q == n_sub - 1 else 16
+            cov[a, g, s0:s1] += 1
+            off = g * 64 - i0
+            if 0 <= off < bi:                                       # own block: NP - pc pairs, the first one-sided
+                na = NP - (off >> 9)
+                per_step = 74 if na == 1 else (na - 1) * 82 + 74 + 26
+            else:
+                per_step = NP * 82 + 26
+            cost[idx] += 4 * (s1 - s0) * per_step
+        assert bool(flags & 1) == (0 <= j0 - i0 < bi)
+        segs.append((np.uint32(slot_i), bi))
+        segs.append((np.uint32(slot_j), 64 * n_sub))
+    segs.sort()
+    end = 0
+    for s, ln in segs:
+        assert int(s) >= end
+        end = int(s) + ln
+    assert end <= pool
+    return items, cov, cost
+
+
+@pytest.mark.parametrize("n,bi,n_items", [
+    (16384, 1024, 1024), (16384, 2048, 768), (20480, 2048, 768), (32768, 2048, 768), (32768, 4096, 512), (65536, 4096, 512),
+    (131072, 4096, 512), (17408, 2048, 768), (40000, 2048, 768), (100003, 4096, 512), (20001, 1024, 1024), (5000, 1024, 64),
+    (2000, 512, 16), (65536, 4096, 1024)])
+def test_even_share_plans_cover_every_pair_once_in_equal_shares(nb, n, bi, n_items):
+    items, cov, cost = _even_coverage(nb, n, bi, n_items)
+    T, G, _ = cov.shape
+    assert len(items) == max(n_items, T)
+    blk = np.arange(G) * 64 // bi
+    own = blk[None, :] == np.arange(T)[:, None]
+    # inside its own block an i-set works every step of every subtile exactly once
+    assert np.all(cov[own] == 1)
+    # elsewhere a (row, subtile) is worked in all of its 64 steps or in none ...
+    full = cov.min(axis=2)
+    assert np.array_equal(full, cov.max(axis=2)) and full.max() == 1
+    # ... and of two subtiles of different blocks exactly one row takes the pair
+    E = full[blk, :]
+    off = blk[:, None] != blk[None, :]
+    assert np.array_equal((E + E.T)[off], np.ones(off.sum(), np.int32))
+    # equal shares: within a row to a quantum of four steps, between rows to the rounding of items per row
+    rows = items[:, 0] // bi
+    for a in range(T):
+        c = cost[rows == a]
+        quantum = 4 * ((bi // 512) * 82 + 26)
+        assert c.max() - c.min() <= 2 * quantum, (a, c.min(), c.max())
+    if len(items) >= 8 * T:
+        assert cost.max() <= 1.08 * cost.mean(), (cost.max(), cost.mean())
+
+
+def test_even_share_plan_of_the_mid_sizes_is_even_to_a_percent(nb):
+    # what the library runs at N = 32768 (eight bodies per lane, 768 slots) and 65536 (sixteen, 512)
+    for n, bi, slots in ((32768, 2048, 768), (65536, 4096, 512)):
+        items, cov, cost = _even_coverage(nb, n, bi, slots)
+        assert len(items) == slots and cost.max() <= 1.015 * cost.mean()
+        # an i-side segment per item: 16 B x bodies per i-set x items — 25 MB and 34 MB (the guided plans: 56 MB and 278 MB)
+        assert len(items) * bi * 16 < 35e6
