@@ -233,9 +233,14 @@ void choose_geometry(nbody_ctx *c) {
   }
 }
 
-// Which plain fp32 systems take the even-share plan by default (whole steps, general form, same box: DESIGN 4.1b).
-bool sym_even_default(int n_total) {
-  return n_total >= env_int("NBODY_SYM_EVEN_MIN_N", 1 << 30) && n_total < env_int("NBODY_SYM_EVEN_MAX_N", 1 << 30);
+// Which plain fp32 systems take the even-share plan by default: whole steps without events, one box, both forms of the kernel,
+// every bodies-per-lane choice under both plans (profiles/r05_even_share_vs_guided_by_n.txt; distinct / equal masses, best
+// guided -> best even-share): N = 20480 95.2 / 88.7 us -> 92.3 / 86.4, 24576 128.2 / 119.3 -> 123.7 / 113.4, 32768 206.7 /
+// 190.7 -> 199.6 / 182.3, 40960 302.9 / 281.1 -> 289.8 / 260.6, 65536 722.6 / 658.9 -> 703.3 / 630.7, 81920 1103.8 / 1014.1 ->
+// 1081.2 / 967.3, 98304 1555.6 / 1421.7 -> 1552.3 / 1392.5; N = 18432 and 131072: nothing in it.
+bool sym_even_default(int n_total, bool kahan) {
+  if (kahan) return n_total >= env_int("NBODY_SYM_EVEN_KAHAN_MIN_N", 1 << 30) && n_total < env_int("NBODY_SYM_EVEN_KAHAN_MAX_N", 1 << 30);
+  return n_total >= env_int("NBODY_SYM_EVEN_MIN_N", 20480) && n_total < env_int("NBODY_SYM_EVEN_MAX_N", 106496);
 }
 
 // Symmetric algorithm: applicability, bodies per lane, and the work plan (sym_plan.h).  Everything here is a function
@@ -258,12 +263,24 @@ void choose_algorithm(nbody_ctx *c) {
   if (f64 && !(p.eps > 0.0 || p.zero_mode == NBODY_ZERO_EXACT)) return;
   // bodies per lane.  fp32: 2 * register pairs; more of them amortise the travelling sums' dpp moves over more
   // arithmetic (tools/microbench6.hip) but make the i-set — the quantum of work — larger.  fp64: 2, or 4 at 2 waves/SIMD.
+  // The even-share plan (sym_plan.h): plain fp32, one context owning all bodies, two register pairs per lane and more —
+  // exactly one workgroup per slot, all of equal cost.  NBODY_SYM_EVEN = 0 / 1 forces the choice (A/B measurements, tests).
+  int even_env = -1;
+  if (const char *e = getenv("NBODY_SYM_EVEN")) { if (e[0] == '0' || e[0] == '1') even_env = e[0] - '0'; }
+  // (not where a test forces pool phases on a small system: the phased pass is the guided plan's)
+  const bool even_wanted = !f64 && p.i_count == p.n_total && env_int("NBODY_SYM_POOL_BUDGET_MB", 0) == 0 &&
+                           (even_env == 1 || (even_env < 0 && sym_even_default(p.n_total, kahan)));
   int ipt = p.i_per_thread;
   if (f64) {
     if (ipt == 0) ipt = p.n_total >= 65536 ? 4 : 2;
     if (ipt != 2 && ipt != 4) return;
   } else {
-    if (ipt == 0) {
+    if (ipt == 0 && even_wanted) {
+      // even shares have no quantum of work to keep small: sixteen bodies per lane (the fewest instructions per interaction)
+      // from N = 24576, eight below (same table: N = 20480 93.0 / 86.4 us with eight, 94.3 / 86.5 with sixteen; 22528 107.5 /
+      // 99.2 against 115.4 / 105.4; 24576 125.1 / 115.4 against 123.7 / 113.4; 32768 205.5 / 190.3 against 199.6 / 182.3)
+      ipt = env_int("NBODY_SYM_IPT", p.n_total >= 24576 && !kahan ? 16 : 8);
+    } else if (ipt == 0) {
       // measured on one box, sustained load (profiles/r02_sweep_symmetric_by_n.txt, r02_tune_mid_sizes.txt): sixteen bodies
       // per lane win wherever the symmetric pass runs (N = 32768: 0.206 vs 0.211 ms with eight, 65536: 0.691 vs 0.718,
       // 131072: 2.62 vs 2.70, 2^20: 162 vs 170.5 ms); the Kahan form has no sixteen (its running compensated sums double the
@@ -310,17 +327,12 @@ void choose_algorithm(nbody_ctx *c) {
   if (!plan) return;
   std::string why;
   bool planned = false;
-  // The even-share plan (sym_plan.h): plain fp32, one context owning all bodies, two register pairs per lane and more —
-  // exactly one workgroup per slot, all of equal cost.  NBODY_SYM_EVEN = 0 / 1 forces the choice (A/B measurements, tests).
-  int even_env = -1;
-  if (const char *e = getenv("NBODY_SYM_EVEN")) { if (e[0] == '0' || e[0] == '1') even_env = e[0] - '0'; }
-  const bool even_ok = !f64 && !kahan && p.i_count == p.n_total && np >= 2;
-  const bool even = even_ok && (even_env == 1 || (even_env < 0 && sym_even_default(p.n_total)));
+  const bool even = even_wanted && np >= 2;
   try {
     if (even) {
       planned = nbody::build_sym_plan_even(p.n_total, bi, c->sym_slots * std::max(1, env_int("NBODY_SYM_EVEN_ROUNDS", 1)), plan, &why,
                                            env_int("NBODY_SYM_EVEN_COST_SYM", 82), env_int("NBODY_SYM_EVEN_COST_ONE", 74),
-                                           env_int("NBODY_SYM_EVEN_COST_MOVE", 26), env_int("NBODY_SYM_EVEN_OWN_PCT", 100));
+                                           env_int("NBODY_SYM_EVEN_COST_MOVE", 26), env_int("NBODY_SYM_EVEN_OWN_PCT", nbody::kSymEvenOwnPct));
       if (planned) { c->sym_k = 0.0; c->sym_min_sub = 0; }
     } else
     planned = nbody::build_sym_plan(p.n_total, p.i_begin, p.i_count, bi, c->sym_slots, c->sym_k, c->sym_min_sub, f64 ? 2 : 1, plan, &why,

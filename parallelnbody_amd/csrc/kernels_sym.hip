@@ -313,7 +313,7 @@ void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ 
 template <int NPV, int ZM, bool BARE, bool KH, bool UNI>
 void launch_sym_kernel(const SymLaunch &L, dim3 grid, dim3 block, hipStream_t s, const SymItem *items, float zp, const int *flag,
                        int run_if, const int *gate) {
-  if constexpr (!KH && NPV >= 2) {
+  if constexpr (NPV >= 2) {
     if (L.even) {
       hipLaunchKernelGGL((forces_sym_pk_kernel<NPV, ZM, BARE, KH, UNI, true>), grid, block, 0, s, (const float4 *)L.posg,
                          (float4 *)L.pool, items, zp, flag, run_if, gate, UNI ? 0 : 1, (unsigned long long *)L.clk, L.wrap);
@@ -333,7 +333,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   if (L.n_total <= 0 || L.n_items <= 0 || L.n_pad < L.n_total || !L.posg || !L.pool || !L.items) return hipErrorInvalidValue;
   if (L.np != 1 && L.np != 2 && L.np != 4 && L.np != 8) return hipErrorInvalidValue;
   if (L.np == 8 && L.kahan) return hipErrorInvalidValue;
-  if (L.even && (L.kahan || L.np < 2 || L.wrap <= 0 || L.wrap % 64 != 0 || L.phase != 0)) return hipErrorInvalidValue;
+  if (L.even && (L.np < 2 || L.wrap <= 0 || L.wrap % 64 != 0 || L.phase != 0)) return hipErrorInvalidValue;
   if (L.phase < 0 || L.phase > 2 || (L.phase != 0 && (L.fused || L.n_local < 0 || L.n_local > L.n_items))) return hipErrorInvalidValue;
   // which items this call launches, and which bodies it prepares (SymLaunch::phase)
   int item0 = L.phase == 2 ? L.n_local : 0, item1 = L.phase == 1 ? L.n_local : L.n_items;

@@ -76,8 +76,11 @@ bool build_sym_plan(int n_total, int i_begin, int i_count, int bi, int slots, do
 // who adds what in which order — is the guided plan's.  cost_sym / cost_one / cost_move: SIMD cycles of one step of one
 // symmetric register pair, of the one-sided pair of an own-block subtile, and of the travelling sums' moves (the issue model,
 // DESIGN 4.1): an own-block subtile in register pair pc's slots works NP - pc pairs, the first of them one-sided.
-// own_pct: what a step of an own-block subtile costs, in per cent of the model's figure.
+// own_pct: what a step of an own-block subtile costs, in per cent of the model's figure — measured: its loops keep fewer
+// steps in flight and their one-sided pair is a chain of dependent operations; whole steps are shortest between 120 and 140
+// at every size and in both forms of the kernel (profiles/r05_even_share_knobs.txt).
+constexpr int kSymEvenOwnPct = 130;
 bool build_sym_plan_even(int n_total, int bi, int n_items, SymPlan *out, std::string *err, int cost_sym = 82, int cost_one = 74,
-                         int cost_move = 26, int own_pct = 100);
+                         int cost_move = 26, int own_pct = kSymEvenOwnPct);
 
 }  // namespace nbody

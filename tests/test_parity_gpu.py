@@ -1088,8 +1088,9 @@ def test_stepping_is_reproducible_and_path_independent(nb):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     lines = []
-    assert mod.run(steps=25, sizes=(9000, 12288, 20480, 33000, 49152), out=lines.append) == 0, "\n".join(l for l in lines if "DIFFERENT" in l)
-    assert len(lines) == 5 * 2 * 5
+    # (19000 | 20480: guided strips | even shares; 24000 | 24576: eight | sixteen bodies per lane under even shares)
+    assert mod.run(steps=25, sizes=(9000, 12288, 19000, 20480, 24000, 33000, 49152), out=lines.append) == 0, "\n".join(l for l in lines if "DIFFERENT" in l)
+    assert len(lines) == 7 * 2 * 5 and any("even shares" in l for l in lines)
 
 
 def test_pool_phases_at_small_sizes(nb, oracle):
@@ -1104,11 +1105,15 @@ def test_pool_phases_at_small_sizes(nb, oracle):
     sample = np.arange(17, n, n // 48)
     ref = np.concatenate([oracle.forces_direct_f64(p64[:, :3], p64[:, 3], i0=int(i), i1=int(i) + 1) for i in sample])
     ref_soft = np.concatenate([oracle.forces_direct_f64(p64[:, :3], p64[:, 3], eps=0.5, i0=int(i), i1=int(i) + 1) for i in sample])
-    with nb.NBodyEngine(n) as one:
-        pool1, ph1 = one.sym_pool()
-        assert ph1 == 1
-        one.set_state(posm, vel); one.step(0.01, 2)
-        s_one = one.state()
+    os.environ["NBODY_SYM_EVEN"] = "0"                            # the guided plan in one pass: what the phased pass is cut from
+    try:                                                          # (the default here, even shares, has no phased form)
+        with nb.NBodyEngine(n) as one:
+            pool1, ph1 = one.sym_pool()
+            assert ph1 == 1 and one.launch_config()["plan"] == "guided"
+            one.set_state(posm, vel); one.step(0.01, 2)
+            s_one = one.state()
+    finally:
+        del os.environ["NBODY_SYM_EVEN"]
     os.environ["NBODY_SYM_POOL_BUDGET_MB"] = "2"
     try:
         with nb.NBodyEngine(n) as e:

@@ -62,7 +62,8 @@ def test_every_pair_exactly_once(nb, n, ranks, bi, slots, own_mode):
 
 
 @pytest.mark.parametrize("n,ranks,bi,slots,k,min_sub", [
-    # what capi's choose_algorithm arrives at on a 256-CU device: (bodies per i-set, workgroup slots, K, shortest strip)
+    # what capi's choose_algorithm arrives at on a 256-CU device with the guided plan (the default outside 20480 <= N < 106496,
+    # and for Kahan, fp64 and sharded contexts everywhere): (bodies per i-set, workgroup slots, K, shortest strip)
     (12288, 1, 512, 1024, 1, 2), (16384, 1, 512, 1024, 1, 2), (20480, 1, 1024, 1024, 1, 2), (32768, 1, 2048, 768, 1, 2),
     (65536, 1, 4096, 512, 1.5, 2), (131072, 1, 4096, 512, 1.5, 4), (262144, 1, 4096, 512, 3, 4), (65536, 2, 4096, 512, 1, 2),
     (131072, 8, 4096, 512, 1, 4), (100003, 1, 4096, 512, 1.5, 2)])
@@ -200,7 +201,7 @@ def _even_coverage(nb, n, bi, n_items):
             off = g * 64 - i0
             if 0 <= off < bi:                                       # own block: NP - pc pairs, the first one-sided
                 na = NP - (off >> 9)
-                per_step = 74 if na == 1 else (na - 1) * 82 + 74 + 26
+                per_step = (74 if na == 1 else (na - 1) * 82 + 74 + 26) * 130 // 100     # kSymEvenOwnPct
             else:
                 per_step = NP * 82 + 26
             cost[idx] += 4 * (s1 - s0) * per_step
@@ -239,7 +240,7 @@ def test_even_share_plans_cover_every_pair_once_in_equal_shares(nb, n, bi, n_ite
     rows = items[:, 0] // bi
     for a in range(T):
         c = cost[rows == a]
-        quantum = 4 * ((bi // 512) * 82 + 26)
+        quantum = 4 * ((bi // 512) * 82 + 26) * 130 // 100           # four steps of the dearest kind (own block, every pair at work)
         assert c.max() - c.min() <= 2 * quantum, (a, c.min(), c.max())
     if len(items) >= 8 * T:
         assert cost.max() <= 1.08 * cost.mean(), (cost.max(), cost.mean())

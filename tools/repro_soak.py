@@ -14,7 +14,7 @@ import parallelnbody_amd as nb  # noqa: E402
 
 
 
-def run(steps=60, sizes=(9000, 12288, 16384, 20480, 24576, 33000, 40960, 65536), out=print):
+def run(steps=60, sizes=(9000, 12288, 16384, 19000, 20480, 24000, 24576, 33000, 40960, 65536, 104000, 106496), out=print):
     """Returns the number of configurations whose end states differ."""
     bad = 0
     for n in sizes:
@@ -38,10 +38,11 @@ def run(steps=60, sizes=(9000, 12288, 16384, 20480, 24576, 33000, 40960, 65536),
                             e.set_state(posm, vel)
                             e.step(0.002, steps)
                             ends.append([a.tobytes() for a in e.state(np.float64 if prec == "f64" else np.float32)])
-                            form = e.equal_mass_form(); kern = e.launch_config()["kernel"]
+                            form = e.equal_mass_form(); cfg = e.launch_config()
+                            kern = cfg["kernel"] + (" (even shares)" if cfg["plan"] == "even" else "")
                     ok = ends[0] == ends[1] == ends[2]
                     bad += not ok
-                    out(f"N={n:6d} {prec:9s} eps={eps} equal={equal!s:5s} dup={dup!s:5s} {kern:22s} equal-mass form {form!s:5s} "
+                    out(f"N={n:6d} {prec:9s} eps={eps} equal={equal!s:5s} dup={dup!s:5s} {kern:36s} equal-mass form {form!s:5s} "
                         f"{'identical' if ok else 'DIFFERENT: rerun %s, pointer path %s' % (ends[0] == ends[1], ends[0] == ends[2])}")
     return bad
 
