@@ -40,7 +40,7 @@ FLOP_PER_EVAL_SYM_EQUAL = 23  # its equal-mass form (all bodies of one mass, as 
 # file the number comes from.  Configurations that were not profiled report null.
 TRAFFIC_BYTES_PER_LAUNCH = {
     ("tiled", 1 << 20, 1, 4, "f32", False): (2 * 173606 * 1024 + 262144 * 1024, "profiles/r01_pmc_forces_tile_kernel.txt"),
-    ("symmetric", 1 << 20, 1, 16, "f32", True): (5406016405, "profiles/r05_pmc_forces_sym_kernel_equal_mass_n1048576_ipt16.txt"),   # re-taken on the round-5 build (r03: 5408130091)
+    ("symmetric", 1 << 20, 1, 16, "f32", True): (5441741397, "profiles/r05_pmc_forces_sym_kernel_equal_mass_n1048576_ipt16.txt"),   # re-taken on the round-5 build (r03: 5408130091)
     ("symmetric", 1 << 20, 1, 16, "f32", False): (5396041643, "profiles/r02_pmc_forces_sym_kernel_n1048576_ipt16.txt"),
     ("symmetric", 1 << 16, 1, 16, "f32", True): (182662522, "profiles/r02_pmc_forces_sym_kernel_equal_mass_n65536_ipt16.txt"),
     ("symmetric", 1 << 16, 1, 16, "f32", False): (301033491, "profiles/r02_pmc_forces_sym_kernel_n65536_ipt16.txt"),
@@ -48,6 +48,12 @@ TRAFFIC_BYTES_PER_LAUNCH = {
     ("symmetric", 1 << 21, 1, 8, "f32_kahan", False): (31471647019, "profiles/r02_pmc_forces_sym_kernel_kahan_n2097152_ipt8.txt"),
     ("symmetric", 1 << 18, 1, 4, "f64", True): (2362121984, "profiles/r02_pmc_forces_sym_f64_kernel_equal_mass_n262144_ipt4.txt"),
     ("symmetric", 1 << 18, 1, 4, "f64", False): (2361977562, "profiles/r02_pmc_forces_sym_f64_kernel_n262144_ipt4.txt"),
+}
+
+
+# the same under the even-share plan (csrc/sym_plan.h; plain fp32 systems of 20480 <= N < 106496): (n, bodies per lane, precision, equal-mass form)
+TRAFFIC_BYTES_PER_LAUNCH_EVEN = {
+    (1 << 16, 16, "f32", True): (51951802, "profiles/r05_pmc_forces_sym_kernel_equal_mass_n65536_ipt16_even_shares.txt"),   # guided strips: 182662522
 }
 
 
@@ -180,11 +186,13 @@ def baseline_config_row(nb, n, precision, eps, steps, warmup, settle_seconds, dt
     avg_launch_s = f_ms / max(f_n, 1) * 1e-3
     achieved = pairs * FLOP_PER_PAIR / avg_launch_s * 1e-12
     traffic = TRAFFIC_BYTES_PER_LAUNCH.get((cfg["algorithm"], n, 1, cfg["i_per_thread"], precision, equal_mass), (None, None))
+    if cfg.get("plan") == "even":          # the table's figures for mid sizes are the guided plan's; the even-share plan has its own
+        traffic = TRAFFIC_BYTES_PER_LAUNCH_EVEN.get((n, cfg["i_per_thread"], precision, equal_mass), (None, None))
     return {"workload": f"N={n} all-pairs {precision}, seeded Plummer sphere (equal masses), G=1e4, eps={eps}, dt={dt}",
             "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "value": pairs * steps / elapsed,
             "unit": "pair-interactions/s", "dtype": "f64" if f64 else "f32", "accumulate": precision,
             "algorithm": cfg["algorithm"], "kernel": cfg["kernel"], "i_per_lane": cfg["i_per_thread"], "lds_tile_bodies": cfg["tile"],
-            "equal_mass_form": equal_mass,
+            "plan": cfg.get("plan"), "workgroups": cfg["blocks"], "equal_mass_form": equal_mass,
             "roofline": {"bound": "valu_fp64" if f64 else "valu_fp32", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "avg_launch_ms": avg_launch_s * 1e3, "launches": f_n,
                          "whole_step_frac": pairs * FLOP_PER_PAIR / (elapsed / steps) * 1e-12 / peak,
@@ -942,7 +950,7 @@ def main():
                        "lds_tile_bodies": cfg["tile"], "i_per_lane": cfg["i_per_thread"],
                        "j_split": cfg["j_split"] if cfg["algorithm"] == "tiled" else None,
                        "super_tile_bodies": cfg["super_tile"] or None,
-                       "workgroups": cfg["blocks"], "accumulate": args.precision, "finite": finite,
+                       "workgroups": cfg["blocks"], "plan": cfg.get("plan"), "accumulate": args.precision, "finite": finite,
                        "equal_mass_form": equal_mass,
                        **({"distinct_masses": distinct} if distinct else {}),
                        "max_rel_err_sampled": err, "bodies_sampled": n_sampled, "rel_err_tolerance": tol,

@@ -239,7 +239,10 @@ void choose_geometry(nbody_ctx *c) {
 // 190.7 -> 199.6 / 182.3, 40960 302.9 / 281.1 -> 289.8 / 260.6, 65536 722.6 / 658.9 -> 703.3 / 630.7, 81920 1103.8 / 1014.1 ->
 // 1081.2 / 967.3, 98304 1555.6 / 1421.7 -> 1552.3 / 1392.5; N = 18432 and 131072: nothing in it.
 bool sym_even_default(int n_total, bool kahan) {
-  if (kahan) return n_total >= env_int("NBODY_SYM_EVEN_KAHAN_MIN_N", 1 << 30) && n_total < env_int("NBODY_SYM_EVEN_KAHAN_MAX_N", 1 << 30);
+  // Kahan contexts (eight bodies per lane at most, two waves per SIMD): profiles/r05_even_share_vs_guided_by_n_kahan.txt — N = 12288
+  // 51.1 / 49.3 us -> 49.8 / 47.5, 16384 77.8 / 75.0 -> 74.4 / 70.2, 24576 134.0 / 125.2 -> 127.6 / 116.1, 32768 212.8 / 196.1 ->
+  // 210.8 / 189.2; from 49152 on the guided strips are ahead (427.8 / 391.8 against 439.0 / 394.6)
+  if (kahan) return n_total >= env_int("NBODY_SYM_EVEN_KAHAN_MIN_N", 12288) && n_total < env_int("NBODY_SYM_EVEN_KAHAN_MAX_N", 40960);
   return n_total >= env_int("NBODY_SYM_EVEN_MIN_N", 20480) && n_total < env_int("NBODY_SYM_EVEN_MAX_N", 106496);
 }
 
@@ -279,7 +282,8 @@ void choose_algorithm(nbody_ctx *c) {
       // even shares have no quantum of work to keep small: sixteen bodies per lane (the fewest instructions per interaction)
       // from N = 24576, eight below (same table: N = 20480 93.0 / 86.4 us with eight, 94.3 / 86.5 with sixteen; 22528 107.5 /
       // 99.2 against 115.4 / 105.4; 24576 125.1 / 115.4 against 123.7 / 113.4; 32768 205.5 / 190.3 against 199.6 / 182.3)
-      ipt = env_int("NBODY_SYM_IPT", p.n_total >= 24576 && !kahan ? 16 : 8);
+      // (Kahan: four below 22528 — N = 20480 95.0 / 88.7 us with four, 96.6 / 91.0 with eight —, eight above)
+      ipt = env_int("NBODY_SYM_IPT", kahan ? (p.n_total >= 22528 ? 8 : 4) : (p.n_total >= 24576 ? 16 : 8));
     } else if (ipt == 0) {
       // measured on one box, sustained load (profiles/r02_sweep_symmetric_by_n.txt, r02_tune_mid_sizes.txt): sixteen bodies
       // per lane win wherever the symmetric pass runs (N = 32768: 0.206 vs 0.211 ms with eight, 65536: 0.691 vs 0.718,

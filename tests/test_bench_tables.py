@@ -33,6 +33,16 @@ def test_traffic_table_matches_the_committed_pmc_summaries():
         assert key[0] in ("tiled", "symmetric") and key[4] in ("f32", "f32_kahan", "f64") and isinstance(key[5], bool)
 
 
+def test_even_share_traffic_table_matches_the_committed_pmc_summaries():
+    table = _bench().TRAFFIC_BYTES_PER_LAUNCH_EVEN
+    assert len(table) >= 1
+    for key, (nbytes, source) in table.items():
+        text = open(os.path.join(ROOT, source)).read()
+        m = re.search(r"^traffic_bytes_per_launch,(\d+)", text, re.M)
+        assert m and int(m.group(1)) == nbytes, (key, source)
+        assert 20480 <= key[0] < 106496 and key[2] == "f32" and isinstance(key[3], bool)
+
+
 def test_flop_conventions_are_what_design_states():
     b = _bench()
     assert (b.FLOP_PER_PAIR, b.FLOP_PER_EVAL_SYM, b.FLOP_PER_EVAL_SYM_EQUAL) == (20, 25, 23)

@@ -147,3 +147,26 @@ def test_which_systems_take_even_shares_by_default(nb):
         with nb.NBodyEngine(65536, **kw) as e:
             cfg = e.launch_config()
         assert cfg["algorithm"] == "symmetric" and cfg["plan"] == "guided", (kw, cfg)
+    # compensated sums: even shares between 12288 and 40960 bodies, four bodies per lane below 22528, eight above
+    for n, plan, ipt in ((12287, "guided", 2), (12288, "even", 4), (22528, "even", 8), (40959, "even", 8), (40960, "guided", 8)):
+        with nb.NBodyEngine(n, precision="f32_kahan") as e:
+            cfg = e.launch_config()
+        assert (cfg["algorithm"], cfg["plan"], cfg["i_per_thread"]) == ("symmetric", plan, ipt), (n, cfg)
+
+
+@pytest.mark.parametrize("eps", [0.0, 0.5])
+@pytest.mark.parametrize("n,ipt", [(12288, 4), (20001, 4), (24576, 8), (33000, 8)])
+def test_even_shares_with_compensated_sums(nb, oracle, n, ipt, eps):
+    """The blocked Kahan form (NBODY_PREC_F32_KAHAN) under even shares: a partial subtile's sums are folded, compensated, like a
+    whole one's.  Closer to the fp64 sum than the plain pass, and inside the compensated passes' own tolerance (2e-6 on sampled
+    bodies, tests/test_parity_gpu.py)."""
+    posm, vel = scene(n, 13 * n)
+    with engine(nb, n, True, ipt, precision="f32_kahan", eps=eps) as kh, engine(nb, n, True, ipt if ipt > 4 else 8, eps=eps) as pl:
+        for e in (kh, pl):
+            e.set_state(posm, vel)
+            e.compute_forces()
+        a, b = kh.accelerations(), pl.accelerations()
+    sample = np.unique(np.concatenate([np.arange(0, n, n // 40), [0, 63, 64, 256 * ipt - 1, 256 * ipt, n - 1]]))
+    ref = oracle_sample(oracle, posm, sample, eps=eps)
+    ek, ep = rel_err(a[sample, :3], ref), rel_err(b[sample, :3], ref)
+    assert ek.max() < 2e-6 and np.median(ek) <= np.median(ep)
