@@ -956,8 +956,15 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
     // NBODY_SYM_GUARDED=1 (A/B measurements only): always run the guarded kernel, no coincident-body detector
     const char *guarded = getenv("NBODY_SYM_GUARDED");
     if (p.eps == 0.0 && p.zero_mode == NBODY_ZERO_EXACT && !(guarded && guarded[0] == '1')) {
+      // How sparse: a body's entry is a chain of dependent device-scope compare-and-swaps (linear probing), each a round trip
+      // to memory, and the update kernel ends with the LONGEST chain of the system.  At a power of two >= 2 N slots (load up to
+      // 0.5; rounds 1-4) that chain was most of the fused update of a mid-size system: update kernel, slots >= 2 N / 4 N / 16 N /
+      // 64 N (profiles/r05_ab_detector_table_sparsity.txt, r05_ab_update_kernel_parts.txt): N = 20480 12.6 / 10.6 / 9.8 / 11.3 us,
+      // 32768 20.3 / 12.8 / 11.0 / 12.4, 65536 23.6 / 15.8 / 14.0 / 16.1 — and the table is cleared once per pass, which is what
+      // large systems see: N = 262144 153 / 155 / 166 / 193 us.  Hence 16 N below 131072 bodies, 4 N from there on.
       int slots = 1024;
-      while (slots < 2 * p.n_total) slots *= 2;
+      const int factor = env_int("NBODY_SYM_DUP_FACTOR", p.n_total < 131072 ? 16 : 4);
+      while ((long long)slots < (long long)factor * p.n_total && slots < (1 << 30)) slots *= 2;
       c->sym_dup_slots = slots;
       if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
       if ((e = hipMemset(c->sym_dup_table, 0, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMemset duplicate detector");

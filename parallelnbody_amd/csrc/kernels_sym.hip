@@ -181,7 +181,7 @@ __attribute__((amdgpu_waves_per_eu(sym_waves(NP, KAHAN), sym_waves(NP, KAHAN))))
 void forces_sym_pk_kernel(const float4 *__restrict__ posg, float4 *__restrict__ pool, const SymItem *__restrict__ items,
                           float zp, const int *__restrict__ dup_flag, int run_if_dup, const int *__restrict__ general,
                           int run_if_general, unsigned long long *__restrict__ clk, int wrap = 0) {
-  constexpr bool kCanMerge = BARE && (NP <= 4 || UNI);           // the general form at NP = 8 would spill (52 B of scratch)
+  constexpr bool kCanMerge = BARE && (NP <= 4 || UNI || EVEN);   // the general form at NP = 8 would spill (52 B of scratch); EVEN: see launch_forces_sym
   const bool merged = kCanMerge && run_if_dup < 0;
   if (!merged && dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
   if (general != nullptr && ((*general != 0) ? 1 : 0) != run_if_general) return;
@@ -390,7 +390,7 @@ hipError_t launch_forces_sym(const SymLaunch &L, hipStream_t s) {
   } else if (detect) {
     // exact d == 0 semantics at the unguarded kernel's price: both forms are launched — exactly one of them runs (the
     // other returns at its first instruction)
-    if (L.np <= 4) {
+    if (L.np <= 4 || L.even) {
       NBODY_SYM_NP(Z_CLAMP, true, -0x1p126, flag, -1);            // one launch holds both loops (see the kernel)
     } else {
       do_gen = false;                                             // equal-mass form: one launch at any size

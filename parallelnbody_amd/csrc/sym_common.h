@@ -288,12 +288,18 @@ __global__ __launch_bounds__(2 * kBlock) void update_sym_fused_kernel(float4 *__
   __shared__ float sh[2][kFoldWays][3][64];
   __shared__ float sj[3][64];
   const int t = threadIdx.x, l = t & 63, way = (t >> 6) & (kFoldWays - 1), side = t >> 8, g = blockIdx.x, bl = g * 64 + l;
+#if defined(NBODY_UPD_EXPERIMENT) && NBODY_UPD_EXPERIMENT == 1      // A/B builds only (tools/ab_update_parts.sh): what the launch alone costs
+  return;
+#endif
   if (DETECT) for (int w = g * 2 * kBlock + t; w < cur_words; w += gridDim.x * 2 * kBlock) cur[w] = 0ull;
   float ax, ay, az, cx, cy, cz;
   if (side == 0) fold_way<float, KAHAN>(pool, j_ptr, j_off, g, l, way, ax, ay, az);
   else           fold_way<float, KAHAN>(pool, i_ptr, i_off, g, l, way, ax, ay, az);
   sh[side][way][0][l] = ax; sh[side][way][1][l] = ay; sh[side][way][2][l] = az;
   __syncthreads();
+#if defined(NBODY_UPD_EXPERIMENT) && NBODY_UPD_EXPERIMENT == 2      // ... and the folds
+  if (ax != 12345.678f) return;
+#endif
   cx = 0; cy = 0; cz = 0;
   if (way == 0) {                                                 // ((s0 + s1) + s2) + s3, on both sides (fold_meet)
 #pragma unroll
@@ -319,7 +325,9 @@ __global__ __launch_bounds__(2 * kBlock) void update_sym_fused_kernel(float4 *__
     vel[bl] = v;
     posm[bl] = x;
   }
+#if !(defined(NBODY_UPD_EXPERIMENT) && NBODY_UPD_EXPERIMENT == 3)   // ... and everything but the detector's entry
   if (DETECT) dup_detect<float>(x, next, mask, (int *)(next + (size_t)mask + 1));
+#endif
   x.w *= gscale;
   posg[bl] = x;
 }

@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """Whole steps (no per-kernel events: what a host runs) of plain fp32 mid-size systems with the guided plan and with the
 even-share plan (csrc/sym_plan.h), distinct masses (the general form) and equal masses, by N and bodies per lane.
-   python tools/even_vs_guided.py [--kahan] [N ...]"""
+   python tools/even_vs_guided.py [--kahan] [--default-only] [N ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import parallelnbody_amd as nb
 
 KAHAN = "--kahan" in sys.argv
-sizes = [int(x) for x in sys.argv[1:] if x != "--kahan"] or [12288, 16384, 20480, 24576, 32768, 40960, 49152, 65536, 98304, 131072]
+DEFAULT_ONLY = "--default-only" in sys.argv or "--before-after" in sys.argv
+BEFORE_AFTER = "--before-after" in sys.argv       # same box: guided strips + the detector table of >= 2 N slots (rounds 2-4), then the defaults
+sizes = [int(x) for x in sys.argv[1:] if not x.startswith("--")] or [12288, 16384, 20480, 24576, 32768, 40960, 49152, 65536, 98304, 131072]
 PEAK = 157.3e12
 PREC = dict(precision="f32_kahan") if KAHAN else {}
 
 
 def run(n, posm, vel, even, ipt):
-    os.environ["NBODY_SYM_EVEN"] = "1" if even else "0"
+    if even is None:
+        os.environ.pop("NBODY_SYM_EVEN", None)                       # the library's own choice
+    else:
+        os.environ["NBODY_SYM_EVEN"] = "1" if even else "0"
     kw = dict(algorithm=2, i_per_thread=ipt) if ipt else {}
     with nb.NBodyEngine(n, **kw, **PREC) as e:
         cfg = e.launch_config()
@@ -33,9 +38,15 @@ for n in sizes:
     distinct = posm.copy()
     distinct[:, 3] *= np.random.default_rng(1).uniform(0.5, 1.5, n).astype(np.float32)
     for name, pm in (("distinct", distinct), ("equal", posm)):
-        t0, cfg = run(n, pm, vel, False, 0)                       # the library's default (may be the block kernel)
-        line = f"N={n:7d} {name:8s} default {cfg['kernel']:24s} ipt {cfg['i_per_thread']:2d} {t0 * 1e6:8.1f} us {n * n * 20 / t0 / PEAK * 100:5.1f} %"
-        for ipt in ((4, 8) if KAHAN else (4, 8, 16)):
+        before = ""
+        if BEFORE_AFTER:
+            os.environ["NBODY_SYM_DUP_FACTOR"] = "2"
+            tb, cb = run(n, pm, vel, False, 0)
+            os.environ.pop("NBODY_SYM_DUP_FACTOR")
+            before = f"guided strips, table of >= 2 N slots: ipt {cb['i_per_thread']:2d} {tb * 1e6:8.1f} us {n * n * 20 / tb / PEAK * 100:5.1f} %  ->  "
+        t0, cfg = run(n, pm, vel, None, 0)                        # the library's default (may be the block kernel)
+        line = f"N={n:7d} {name:8s} {before}default {cfg['kernel']:24s} ipt {cfg['i_per_thread']:2d} plan {str(cfg['plan']):6s} {t0 * 1e6:8.1f} us {n * n * 20 / t0 / PEAK * 100:5.1f} %"
+        for ipt in (() if DEFAULT_ONLY else (4, 8) if KAHAN else (4, 8, 16)):
             if n < 256 * ipt:
                 continue
             tg, cg = run(n, pm, vel, False, ipt)
