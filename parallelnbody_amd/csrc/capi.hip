@@ -243,7 +243,11 @@ bool sym_even_default(int n_total, bool kahan) {
   // 51.1 / 49.3 us -> 49.8 / 47.5, 16384 77.8 / 75.0 -> 74.4 / 70.2, 24576 134.0 / 125.2 -> 127.6 / 116.1, 32768 212.8 / 196.1 ->
   // 210.8 / 189.2; from 49152 on the guided strips are ahead (427.8 / 391.8 against 439.0 / 394.6)
   if (kahan) return n_total >= env_int("NBODY_SYM_EVEN_KAHAN_MIN_N", 12288) && n_total < env_int("NBODY_SYM_EVEN_KAHAN_MAX_N", 40960);
-  return n_total >= env_int("NBODY_SYM_EVEN_MIN_N", 20480) && n_total < env_int("NBODY_SYM_EVEN_MAX_N", 106496);
+  // (with the detector's sparse table, profiles/r05_even_share_vs_block_kernel_13k_to_19k.txt: N = 17408 73.0 / 67.7 -> 70.2 / 67.1
+  // with four bodies per lane, 18432 78.4 / 74.6 -> 76.9 / 73.7, 19456 83.8 / 78.3 -> 83.2 / 79.7: everything the symmetric pass
+  // runs below 106496 bodies.  The same table has even shares ahead of the block kernel from N = 15360 — 61.1 / 57.6 -> 57.4 / 54.8,
+  // 16384 67.8 / 63.9 -> 64.4 / 61.2 —; the block kernel keeps those sizes for its one-launch step and what nbody_tick gets from it.)
+  return n_total >= env_int("NBODY_SYM_EVEN_MIN_N", 16385) && n_total < env_int("NBODY_SYM_EVEN_MAX_N", 106496);
 }
 
 // Symmetric algorithm: applicability, bodies per lane, and the work plan (sym_plan.h).  Everything here is a function
@@ -280,10 +284,10 @@ void choose_algorithm(nbody_ctx *c) {
   } else {
     if (ipt == 0 && even_wanted) {
       // even shares have no quantum of work to keep small: sixteen bodies per lane (the fewest instructions per interaction)
-      // from N = 24576, eight below (same table: N = 20480 93.0 / 86.4 us with eight, 94.3 / 86.5 with sixteen; 22528 107.5 /
+      // from N = 24576, eight from 20480, four below (same table: N = 20480 93.0 / 86.4 us with eight, 94.3 / 86.5 with sixteen; 22528 107.5 /
       // 99.2 against 115.4 / 105.4; 24576 125.1 / 115.4 against 123.7 / 113.4; 32768 205.5 / 190.3 against 199.6 / 182.3)
       // (Kahan: four below 22528 — N = 20480 95.0 / 88.7 us with four, 96.6 / 91.0 with eight —, eight above)
-      ipt = env_int("NBODY_SYM_IPT", kahan ? (p.n_total >= 22528 ? 8 : 4) : (p.n_total >= 24576 ? 16 : 8));
+      ipt = env_int("NBODY_SYM_IPT", kahan ? (p.n_total >= 22528 ? 8 : 4) : (p.n_total >= 24576 ? 16 : (p.n_total >= 20480 ? 8 : 4)));
     } else if (ipt == 0) {
       // measured on one box, sustained load (profiles/r02_sweep_symmetric_by_n.txt, r02_tune_mid_sizes.txt): sixteen bodies
       // per lane win wherever the symmetric pass runs (N = 32768: 0.206 vs 0.211 ms with eight, 65536: 0.691 vs 0.718,
@@ -997,8 +1001,9 @@ int nbody_create(const nbody_params *pin, nbody_ctx **out) try {
     if (p.precision != NBODY_PREC_F64 && !c->wave && c->ipt % 2 == 0 && p.eps == 0.0 && p.zero_mode == NBODY_ZERO_EXACT &&
         p.n_total >= 32768 &&
         !(guarded && guarded[0] == '1')) {
-      int slots = 1024;
-      while (slots < 2 * p.n_total) slots *= 2;
+      int slots = 1024;                                              // as sparse as the symmetric pass's (above): short chains
+      const int factor = env_int("NBODY_SYM_DUP_FACTOR", p.n_total < 131072 ? 16 : 4);
+      while ((long long)slots < (long long)factor * p.n_total && slots < (1 << 30)) slots *= 2;
       c->sym_dup_slots = slots;
       if ((e = hipMalloc(&c->sym_dup_table, (size_t)slots * 8 + 64)) != hipSuccess) return bail(e, "hipMalloc duplicate detector");
     }
