@@ -59,3 +59,42 @@ def test_the_written_out_dpp_adds_keep_their_distance():
     # what wave_sum_to_lane63 promises beyond the two wait states: consecutive steps on one register are NV >= 8 instructions apart
     found, n_dpp, _ = isa_hazards.check_object(os.path.join(CSRC, "kernels_block.o"))
     assert not found and n_dpp >= 8000
+
+
+def test_the_scratch_checker_tells_a_spill_inside_a_loop_from_one_around_it():
+    text = """
+0000000000002000 <kern_a>:
+	scratch_store_dword off, v1, off                           // 000000002000: DC000000
+	v_add_f32_e32 v2, v2, v3                                   // 000000002008: 02040702
+	s_cbranch_scc1 4093 <kern_a+0x8>                           // 00000000200C: BF85FFFE
+	scratch_load_dword v1, off, off                            // 000000002010: DC000000
+	s_cbranch_vccnz 4090 <kern_a+0x0>                          // 000000002018: BF87FFF9
+	s_endpgm                                                   // 00000000201C: BF810000
+0000000000003000 <kern_b>:
+	v_add_f32_e32 v2, v2, v3                                   // 000000003000: 02040702
+	scratch_load_dword v1, off, off                            // 000000003004: DC000000
+	s_cbranch_scc1 4093 <kern_b+0x0>                           // 00000000300C: BF85FFFC
+	s_endpgm                                                   // 000000003010: BF810000
+"""
+    assert isa_hazards.scratch_in_innermost_loops_of(text) == {"kern_a": (2, 0), "kern_b": (1, 1)}
+
+
+def test_what_scratch_the_built_kernels_use_lies_around_their_loops():
+    """every kernel compiles to zero scratch but the even-share form of the symmetric kernel at sixteen bodies per
+    lane in the general form (values parked around the 64-step loops) and bh_small_build_kernel (parked between its phases) —
+    and none of their scratch instructions sits inside an innermost loop."""
+    seen = {}
+    for obj in sorted(glob.glob(os.path.join(CSRC, "*.o"))):
+        if ".variant-" in obj:
+            continue
+        try:
+            found = isa_hazards.scratch_in_innermost_loops(obj)
+        except RuntimeError:                                     # a host-only object (sym_plan.o, ic.o, actor.o): no device code inside
+            continue
+        for func, (n, inside) in found.items():
+            seen[func] = (n, inside)
+    assert seen, "build the library first (graft build())"
+    for func, (n, inside) in seen.items():
+        assert inside == 0, (func, n, inside)
+        assert "bh_small_build_kernel" in func or ("forces_sym_pk_kernelILi8E" in func and func.split("EEvP")[0].endswith("Lb0ELb0ELb1E")), func
+    assert any("bh_small_build_kernel" in f for f in seen) and sum("forces_sym_pk_kernel" in f for f in seen) <= 4

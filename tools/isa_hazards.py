@@ -126,6 +126,48 @@ def check_object(obj):
     return check(dis), n_dpp, dis.count("\n")
 
 
+def scratch_in_innermost_loops(obj):
+    """{function: (scratch instructions, of them inside an innermost loop)} for the functions of a built object that touch scratch.
+    A loop = a backward branch; innermost = no other backward branch's range inside its own.  (Spills parked AROUND a hot loop
+    cost a store and a load per trip of the loop around it; spills inside the innermost loops are what a kernel must not have.)"""
+    with tempfile.TemporaryDirectory() as d:
+        co = code_object(obj, d)
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    return scratch_in_innermost_loops_of(dis)
+
+
+def scratch_in_innermost_loops_of(dis):
+    """The same from llvm-objdump -d text."""
+    out, func, insts = {}, None, []
+
+    def close():
+        if func is None or not any("scratch_" in t for _a, t in insts):
+            return
+        loops = []
+        for a, t in insts:
+            m = re.search(r"s_cbranch_\w+\s+\S+\s+<[^>]*\+0x([0-9a-f]+)>|s_branch\s+\S+\s+<[^>]*\+0x([0-9a-f]+)>", t)
+            if m:
+                tgt = base + int(m.group(1) or m.group(2), 16)
+                if tgt <= a:
+                    loops.append((tgt, a))
+        inner = [lp for lp in loops if not any(o != lp and lp[0] <= o[0] and o[1] <= lp[1] for o in loops)]
+        sc = [a for a, t in insts if "scratch_" in t]
+        out[func] = (len(sc), sum(1 for a in sc if any(lo <= a <= hi for lo, hi in inner)))
+
+    base = 0
+    for line in dis.splitlines():
+        m = re.match(r"^([0-9a-f]+) <(.+)>:$", line.strip())
+        if m:
+            close()
+            base, func, insts = int(m.group(1), 16), m.group(2), []
+            continue
+        m = re.search(r"//\s*([0-9A-Fa-f]+):", line)
+        if m and func is not None and parse(line) is not None:
+            insts.append((int(m.group(1), 16), line.split("//")[0]))
+    close()
+    return out
+
+
 def main(argv):
     bad = 0
     for obj in argv:
