@@ -40,7 +40,7 @@ FLOP_PER_EVAL_SYM_EQUAL = 23  # its equal-mass form (all bodies of one mass, as 
 # file the number comes from.  Configurations that were not profiled report null.
 TRAFFIC_BYTES_PER_LAUNCH = {
     ("tiled", 1 << 20, 1, 4, "f32", False): (2 * 173606 * 1024 + 262144 * 1024, "profiles/r01_pmc_forces_tile_kernel.txt"),
-    ("symmetric", 1 << 20, 1, 16, "f32", True): (5441741397, "profiles/r05_pmc_forces_sym_kernel_equal_mass_n1048576_ipt16.txt"),   # re-taken on the round-5 build (r03: 5408130091)
+    ("symmetric", 1 << 20, 1, 16, "f32", True): (5394247488, "profiles/r05_pmc_forces_sym_kernel_equal_mass_n1048576_ipt16.txt"),   # re-taken on the round-5 build (r03: 5408130091)
     ("symmetric", 1 << 20, 1, 16, "f32", False): (5396041643, "profiles/r02_pmc_forces_sym_kernel_n1048576_ipt16.txt"),
     ("symmetric", 1 << 16, 1, 16, "f32", True): (182662522, "profiles/r02_pmc_forces_sym_kernel_equal_mass_n65536_ipt16.txt"),
     ("symmetric", 1 << 16, 1, 16, "f32", False): (301033491, "profiles/r02_pmc_forces_sym_kernel_n65536_ipt16.txt"),
@@ -53,7 +53,7 @@ TRAFFIC_BYTES_PER_LAUNCH = {
 
 # the same under the even-share plan (csrc/sym_plan.h; plain fp32 systems of 16385 <= N < 106496): (n, bodies per lane, precision, equal-mass form)
 TRAFFIC_BYTES_PER_LAUNCH_EVEN = {
-    (1 << 16, 16, "f32", True): (51951802, "profiles/r05_pmc_forces_sym_kernel_equal_mass_n65536_ipt16_even_shares.txt"),   # guided strips: 182662522
+    (1 << 16, 16, "f32", True): (51966002, "profiles/r05_pmc_forces_sym_kernel_equal_mass_n65536_ipt16_even_shares.txt"),   # guided strips: 182662522
 }
 
 
