@@ -338,7 +338,7 @@ void choose_algorithm(nbody_ctx *c) {
   const bool even = even_wanted && np >= 2;
   try {
     if (even) {
-      planned = nbody::build_sym_plan_even(p.n_total, bi, c->sym_slots * std::max(1, env_int("NBODY_SYM_EVEN_ROUNDS", 1)), plan, &why,
+      planned = nbody::build_sym_plan_even(p.n_total, bi, std::max(1, (int)((long long)c->sym_slots * env_int("NBODY_SYM_EVEN_ROUNDS", 1) * env_int("NBODY_SYM_EVEN_ITEMS_PCT", 100) / 100)), plan, &why,
                                            env_int("NBODY_SYM_EVEN_COST_SYM", 82), env_int("NBODY_SYM_EVEN_COST_ONE", 74),
                                            env_int("NBODY_SYM_EVEN_COST_MOVE", 26), env_int("NBODY_SYM_EVEN_OWN_PCT", nbody::kSymEvenOwnPct));
       if (planned) { c->sym_k = 0.0; c->sym_min_sub = 0; }

@@ -81,7 +81,10 @@ __device__ __forceinline__ void sym_subtile(const f2 (&xi)[NP], const f2 (&yi)[N
   constexpr int NA = NP - P0;                                     // active register pairs
   // steps in flight: four for one or two register pairs, two from four pairs up; the own-block forms (a small share
   // of the work) keep one step in flight where many pairs are active, so that they never raise the kernel's register need
-  constexpr int kUnroll = ONE ? (NA >= 5 ? 1 : 2) : ((NA >= 4) ? NBODY_SYM_UNROLL4 : NBODY_SYM_UNROLL);
+#ifndef NBODY_SYM_OWN_UNROLL_LOW
+#define NBODY_SYM_OWN_UNROLL_LOW 2     // A/B builds: steps in flight of an own-block subtile with one or two active register pairs
+#endif
+  constexpr int kUnroll = ONE ? (NA >= 5 ? 1 : (NA >= 3 ? 2 : NBODY_SYM_OWN_UNROLL_LOW)) : ((NA >= 4) ? NBODY_SYM_UNROLL4 : NBODY_SYM_UNROLL);
   f2 qx = splat2(0.f), qy = splat2(0.f), qz = splat2(0.f);        // (lo, hi) partial sums
   // Reading the next step's body one step ahead (pinned with a scheduling barrier; the last read, sp[-64], is the image's
   // first copy of the lane's own entry: in bounds, unused) halves the wave-cycles parked on LDS (10.4 % -> 4.8 %) and
