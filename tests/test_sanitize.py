@@ -59,7 +59,15 @@ int main(void) {
     free(items);
     if (nbody_sym_plan_describe(100003, 0, 0, 2048, 768, 6, 1, 2, &n_items, &pool, NULL, 0) != 0) return 12;
     if (nbody_sym_plan_describe(65536, 16384, 16384, 1024, 1024, 3, 1, 1, &n_items, &pool, NULL, 0) != 0) return 13;
-    if (nbody_sym_plan_describe(65536, 100, 300, 1024, 1024, 3, 1, 1, &n_items, &pool, NULL, 0) == 0) return 14; }
+    if (nbody_sym_plan_describe(65536, 100, 300, 1024, 1024, 3, 1, 1, &n_items, &pool, NULL, 0) == 0) return 14;
+    /* the even-share planner: the library's mid sizes, a ragged system, more items wanted than a tiny system has steps for */
+    if (nbody_sym_plan_describe_even(65536, 4096, 512, &n_items, &pool, NULL, 0) != 0 || n_items != 512) return 15;
+    items = malloc(sizeof(int32_t) * 8 * (size_t)n_items);
+    if (nbody_sym_plan_describe_even(65536, 4096, 512, &n_items, &pool, items, n_items) != 0) return 16;
+    free(items);
+    if (nbody_sym_plan_describe_even(100003, 2048, 768, &n_items, &pool, NULL, 0) != 0 || n_items != 768) return 17;
+    if (nbody_sym_plan_describe_even(700, 512, 100000, &n_items, &pool, NULL, 0) != 0 || n_items < 2) return 18;
+    if (nbody_sym_plan_describe_even(65536, 1000, 512, &n_items, &pool, NULL, 0) == 0) return 19; }
   printf("sanitized run ok, nodes %d, |a0| %g\n", nodes, sqrt(acc[0]*acc[0] + acc[1]*acc[1] + acc[2]*acc[2]));
   free(posm); free(vel); free(pos); free(v3); free(m); free(acc); free(acc2);
   return 0;
