@@ -171,3 +171,23 @@ def test_even_shares_with_compensated_sums(nb, oracle, n, ipt, eps):
     ref = oracle_sample(oracle, posm, sample, eps=eps)
     ek, ep = rel_err(a[sample, :3], ref), rel_err(b[sample, :3], ref)
     assert ek.max() < 2e-6 and np.median(ek) <= np.median(ep)
+
+
+@pytest.mark.parametrize("n,equal", [(24576, False), (65536, True)])
+def test_checkpoint_resume_on_an_even_share_context_continues_bit_for_bit(nb, tmp_path, n, equal):
+    """The library's own choice at these sizes (even shares, fused update, two detector tables taking turns): five steps, a
+    checkpoint, five more — and a fresh context resumed from the file ends in the same bytes (the plan is a function of the
+    parameters and the device, the file carries positions, velocities and accelerations)."""
+    posm, vel = scene(n, 17 * n, equal)
+    path = str(tmp_path / "even.ckpt")
+    with nb.NBodyEngine(n) as e:
+        assert e.launch_config()["plan"] == "even"
+        e.set_state(posm, vel)
+        e.step(0.01, 5)
+        e.save_checkpoint(path)
+        e.step(0.01, 5)
+        want = e.particles()
+    with nb.NBodyEngine(n) as e:
+        assert e.load_checkpoint(path) == 5
+        e.step(0.01, 5)
+        assert e.steps_done() == 10 and e.particles().tobytes() == want.tobytes()
