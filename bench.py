@@ -257,6 +257,43 @@ def barnes_hut_row(nb, n, frames, warmup, parity_frames, scene="box", theta=1.0,
                                        f"the same scene, best of {len(cpu_s)} frame(s)"}}
 
 
+def mid_size_row(nb, n, seconds=0.25, dt=0.002):
+    """A mid-size system in the kernel's GENERAL form — the bodies of a seeded Plummer sphere with every mass scaled by its own
+    factor in [0.5, 1.5), what the reference's own scene (masses 1 ... 5000, OctreeSearch.cpp:66) runs — stepped as a host steps it:
+    the library's defaults, no per-kernel events, `nbody_step` in one call, best of three timed stretches.  `frac` is the WHOLE
+    step (force pass + update) against the fp32 vector peak at the 20-flop convention; the benched pass is compared with the fp64
+    direct sum on sampled bodies first."""
+    import numpy as np
+    from oracle import oracle as O
+    posm, vel = nb.ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
+    posm[:, 3] *= np.random.default_rng(n).uniform(0.5, 1.5, n).astype(np.float32)
+    with nb.NBodyEngine(n) as e:
+        cfg = e.launch_config()
+        e.set_state(posm, vel)
+        e.compute_forces()
+        a = e.accelerations()
+        bodies = sorted(set(int(i) for i in np.random.default_rng(5).choice(n, 16, replace=False)) | {0, n - 1})
+        p64 = posm.astype(np.float64)
+        err = 0.0
+        for i in bodies:
+            ref = O.forces_direct_f64(p64[:, :3], p64[:, 3], i0=i, i1=i + 1)[0]
+            err = max(err, float(np.linalg.norm(a[i, :3] - ref) / np.linalg.norm(ref)))
+        if not (err < 2e-5):
+            raise SystemExit(f"bench.py: mid_sizes row N={n}: the force pass disagrees with the fp64 direct sum: max rel err {err:.3e}")
+        e.step(dt, 200); e.synchronize()
+        k = max(100, int(seconds / (n * float(n) / 6e12 + 1e-5)))
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter(); e.step(dt, k); e.synchronize()
+            best = min(best, (time.perf_counter() - t0) / k)
+        general = not e.equal_mass_form()
+    return {"workload": f"N={n} all-pairs f32, Plummer positions, distinct masses (the general form), G=1e4, eps=0, dt={dt}",
+            "us_per_step": best * 1e6, "value": n * float(n) / best, "unit": "pair-interactions/s", "steps_timed": 3 * k,
+            "whole_step_frac": n * float(n) * FLOP_PER_PAIR / best * 1e-12 / PEAK_FP32_TFLOPS, "general_form": general,
+            "kernel": cfg["kernel"], "plan": cfg.get("plan"), "i_per_lane": cfg["i_per_thread"], "workgroups": cfg["blocks"],
+            "max_rel_err_sampled": err, "bodies_sampled": len(bodies), "rel_err_tolerance": 2e-5}
+
+
 def extra_rows(args, nb):
     """BASELINE.json's other single-GPU configs and the theta > 0 path, measured in the same driver run AFTER the headline's
     timed region (the headline's fields are untouched): configs[1] N = 65536 fp32, configs[3] N = 262144 fp64, configs[4]
@@ -276,7 +313,9 @@ def extra_rows(args, nb):
         "n65536_reference_box_scene": barnes_hut_row(nb, 1 << 16, frames=300, warmup=10, parity_frames=1, scene="box"),
         "n1048576": barnes_hut_row(nb, 1 << 20, frames=50, warmup=5, parity_frames=1, scene="plummer"),
     }
-    return configs, bh
+    # mid sizes in the general form (the round-4 review's item 4): whole steps as a host runs them
+    mid = {f"n{n}_distinct_masses": mid_size_row(nb, n) for n in (20480, 32768, 65536)}
+    return configs, bh, mid
 
 
 def clock_fields(engine, avg_launch_s, launch_pairs):
@@ -976,7 +1015,7 @@ def main():
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(posm, args.cpu_seconds)
         if extra is not None:
-            out["configs"], out["bh"] = extra
+            out["configs"], out["bh"], out["mid_sizes"] = extra
         print_result(out)
     sim.close()
     if world > 1:

@@ -88,3 +88,8 @@ def test_the_rows_bench_adds_behind_the_headline_carry_their_own_parity_and_roof
     assert bh["tree_nodes"] > 2000 and bh["tree_levels"] >= 8
     cb = bh["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "us/frame" and cb["value"] > bh["us_per_frame"] and cb["cores"] >= 1
+    # `mid_sizes`: the general form as a host steps it (no events), sampled parity first
+    mid = bench.mid_size_row(nb, 20480, seconds=0.05)
+    assert mid["general_form"] and mid["plan"] == "even" and mid["kernel"] == "forces_sym_pk_kernel"
+    assert mid["max_rel_err_sampled"] < mid["rel_err_tolerance"] == 2e-5 and 0.3 < mid["whole_step_frac"] < 1.0
+    assert mid["value"] == pytest.approx(20480.0 ** 2 / (mid["us_per_step"] * 1e-6), rel=1e-9)
