@@ -264,20 +264,14 @@ def mid_size_row(nb, n, seconds=0.25, dt=0.002):
     step (force pass + update) against the fp32 vector peak at the 20-flop convention; the benched pass is compared with the fp64
     direct sum on sampled bodies first."""
     import numpy as np
-    from oracle import oracle as O
     posm, vel = nb.ic_plummer(n, total_mass=1000.0, scale_radius=100.0, G=1.0e4, seed=20261003)
     posm[:, 3] *= np.random.default_rng(n).uniform(0.5, 1.5, n).astype(np.float32)
     with nb.NBodyEngine(n) as e:
         cfg = e.launch_config()
         e.set_state(posm, vel)
         e.compute_forces()
-        a = e.accelerations()
-        bodies = sorted(set(int(i) for i in np.random.default_rng(5).choice(n, 16, replace=False)) | {0, n - 1})
-        p64 = posm.astype(np.float64)
-        err = 0.0
-        for i in bodies:
-            ref = O.forces_direct_f64(p64[:, :3], p64[:, 3], i0=i, i1=i + 1)[0]
-            err = max(err, float(np.linalg.norm(a[i, :3] - ref) / np.linalg.norm(ref)))
+        bodies = sample_bodies(0, n, cfg["super_tile"], cfg["i_per_thread"])
+        err = sampled_force_error(posm, e.accelerations(), 0, bodies, 1.0e4, 0.0)
         if not (err < 2e-5):
             raise SystemExit(f"bench.py: mid_sizes row N={n}: the force pass disagrees with the fp64 direct sum: max rel err {err:.3e}")
         e.step(dt, 200); e.synchronize()
