@@ -51,7 +51,7 @@ TRAFFIC_BYTES_PER_LAUNCH = {
 }
 
 
-# the same under the even-share plan (csrc/sym_plan.h; plain fp32 systems of 16385 <= N < 106496): (n, bodies per lane, precision, equal-mass form)
+# the same under the even-share plan (csrc/sym_plan.h; plain fp32 systems of 16385 <= N < 139264): (n, bodies per lane, precision, equal-mass form)
 TRAFFIC_BYTES_PER_LAUNCH_EVEN = {
     (1 << 16, 16, "f32", True): (51966002, "profiles/r05_pmc_forces_sym_kernel_equal_mass_n65536_ipt16_even_shares.txt"),   # guided strips: 182662522
 }

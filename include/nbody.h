@@ -127,7 +127,7 @@ NBODY_AMD_API int nbody_default_params(nbody_params *p);
  * parameters and from two facts about the device: its compute-unit count (workgroup slots of the symmetric pass's work
  * plan) and, beyond N = 2^22, its total memory (whether the partial-sum pool is shared by phases); the strip-length
  * divisor K of that plan also follows an estimate of the pass's duration from rates measured on MI355X (6.6e12 / 6.0e12 /
- * 2.7e12 interactions/s: fp32 / compensated / fp64); between 16385 and 106496 bodies (compensated: 12288 ... 40960) a context
+ * 2.7e12 interactions/s: fp32 / compensated / fp64); between 16385 and 139264 bodies (compensated: 12288 ... 40960) a context
  * that owns all bodies runs the even-share plan instead — one work item per slot, a function of the body count, the bodies
  * per lane and the CU count (nbody_sym_plan_is_even).  Results are therefore reproducible on every MI355X, and across
  * library versions only where the release notes say so; on a part with another CU count they agree to rounding, not in

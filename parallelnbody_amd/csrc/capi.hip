@@ -245,9 +245,13 @@ bool sym_even_default(int n_total, bool kahan) {
   if (kahan) return n_total >= env_int("NBODY_SYM_EVEN_KAHAN_MIN_N", 12288) && n_total < env_int("NBODY_SYM_EVEN_KAHAN_MAX_N", 40960);
   // (with the detector's sparse table, profiles/r05_even_share_vs_block_kernel_13k_to_19k.txt: N = 17408 73.0 / 67.7 -> 70.2 / 67.1
   // with four bodies per lane, 18432 78.4 / 74.6 -> 76.9 / 73.7, 19456 83.8 / 78.3 -> 83.2 / 79.7: everything the symmetric pass
-  // runs below 106496 bodies.  The same table has even shares ahead of the block kernel from N = 15360 — 61.1 / 57.6 -> 57.4 / 54.8,
+  // runs below 106496 bodies (and, below, up to 139264).  The same table has even shares ahead of the block kernel from N = 15360 — 61.1 / 57.6 -> 57.4 / 54.8,
   // 16384 67.8 / 63.9 -> 64.4 / 61.2 —; the block kernel keeps those sizes for its one-launch step and what nbody_tick gets from it.)
-  return n_total >= env_int("NBODY_SYM_EVEN_MIN_N", 16385) && n_total < env_int("NBODY_SYM_EVEN_MAX_N", 106496);
+  // Upper end, with TWO items per slot from 90112 bodies on — passes of 1.5 ms and more: slots of unequal speed drift apart —
+  // (profiles/r05_even_share_rounds_at_larger_n.txt; guided -> one round -> two, distinct | equal masses): N = 98304 1596 -> 1590 ->
+  // 1566 us | 1450 -> 1420 -> 1403, 114688 2073 -> 2063 -> 2037 | 1894 -> 1855 -> 1831, 131072 2650 -> 2664 -> 2645 | 2428 -> 2392 ->
+  // 2381; from 147456 on nothing in it either way (3453 -> 3535 -> 3484 | 3160 -> 3185 -> 3118): even shares below 139264 bodies.
+  return n_total >= env_int("NBODY_SYM_EVEN_MIN_N", 16385) && n_total < env_int("NBODY_SYM_EVEN_MAX_N", 139264);
 }
 
 // Symmetric algorithm: applicability, bodies per lane, and the work plan (sym_plan.h).  Everything here is a function
@@ -338,7 +342,8 @@ void choose_algorithm(nbody_ctx *c) {
   const bool even = even_wanted && np >= 2;
   try {
     if (even) {
-      planned = nbody::build_sym_plan_even(p.n_total, bi, std::max(1, (int)((long long)c->sym_slots * env_int("NBODY_SYM_EVEN_ROUNDS", 1) * env_int("NBODY_SYM_EVEN_ITEMS_PCT", 100) / 100)), plan, &why,
+      const int rounds = env_int("NBODY_SYM_EVEN_ROUNDS", (!kahan && p.n_total >= 90112) ? 2 : 1);       // items per slot (sym_even_default)
+      planned = nbody::build_sym_plan_even(p.n_total, bi, std::max(1, (int)((long long)c->sym_slots * rounds * env_int("NBODY_SYM_EVEN_ITEMS_PCT", 100) / 100)), plan, &why,
                                            env_int("NBODY_SYM_EVEN_COST_SYM", 82), env_int("NBODY_SYM_EVEN_COST_ONE", 74),
                                            env_int("NBODY_SYM_EVEN_COST_MOVE", 26), env_int("NBODY_SYM_EVEN_OWN_PCT", nbody::kSymEvenOwnPct));
       if (planned) { c->sym_k = 0.0; c->sym_min_sub = 0; }

@@ -40,7 +40,7 @@ def test_even_share_traffic_table_matches_the_committed_pmc_summaries():
         text = open(os.path.join(ROOT, source)).read()
         m = re.search(r"^traffic_bytes_per_launch,(\d+)", text, re.M)
         assert m and int(m.group(1)) == nbytes, (key, source)
-        assert 16385 <= key[0] < 106496 and key[2] == "f32" and isinstance(key[3], bool)
+        assert 16385 <= key[0] < 139264 and key[2] == "f32" and isinstance(key[3], bool)
 
 
 def test_flop_conventions_are_what_design_states():

@@ -132,16 +132,16 @@ def test_even_shares_step_the_same_bits_every_time(nb, oracle, n, ipt):
 
 
 def test_which_systems_take_even_shares_by_default(nb):
-    """Plain fp32, one context owning all bodies, 16385 <= N < 106496 — every size the symmetric pass runs below 106496 —
+    """Plain fp32, one context owning all bodies, 16385 <= N < 139264 — every size the symmetric pass runs below 139264 —
     (csrc/capi.hip sym_even_default): sixteen bodies per lane from 24576, eight from 20480, four below; fp64 and sharded contexts and
     larger systems keep the guided strips."""
     for n, plan, ipt in ((16385, "even", 4), (20479, "even", 4), (20480, "even", 8), (24575, "even", 8), (24576, "even", 16), (65536, "even", 16),
-                         (106495, "even", 16), (106496, "guided", 16), (1 << 18, "guided", 16)):
+                         (90111, "even", 16), (90112, "even", 16), (139263, "even", 16), (139264, "guided", 16), (1 << 18, "guided", 16)):
         with nb.NBodyEngine(n) as e:
             cfg = e.launch_config()
         assert (cfg["algorithm"], cfg["plan"], cfg["i_per_thread"]) == ("symmetric", plan, ipt), (n, cfg)
         if plan == "even":
-            assert cfg["blocks"] == {4: 1024, 8: 768, 16: 512}[ipt]
+            assert cfg["blocks"] == {4: 1024, 8: 768, 16: 512}[ipt] * (2 if n >= 90112 else 1)     # two items per slot from 90112 bodies on
     with nb.NBodyEngine(16384) as e:
         assert e.launch_config()["kernel"] == "forces_block_pk_kernel" and e.launch_config()["plan"] is None
     for kw in (dict(precision="f32_kahan"), dict(precision="f64"), dict(i_begin=0, i_count=32768)):

@@ -62,7 +62,7 @@ def test_every_pair_exactly_once(nb, n, ranks, bi, slots, own_mode):
 
 
 @pytest.mark.parametrize("n,ranks,bi,slots,k,min_sub", [
-    # what capi's choose_algorithm arrives at on a 256-CU device with the guided plan (the default outside 16385 <= N < 106496,
+    # what capi's choose_algorithm arrives at on a 256-CU device with the guided plan (the default outside 16385 <= N < 139264,
     # and for Kahan, fp64 and sharded contexts everywhere): (bodies per i-set, workgroup slots, K, shortest strip)
     (12288, 1, 512, 1024, 1, 2), (16384, 1, 512, 1024, 1, 2), (20480, 1, 1024, 1024, 1, 2), (32768, 1, 2048, 768, 1, 2),
     (65536, 1, 4096, 512, 1.5, 2), (131072, 1, 4096, 512, 1.5, 4), (262144, 1, 4096, 512, 3, 4), (65536, 2, 4096, 512, 1, 2),

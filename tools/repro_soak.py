@@ -14,7 +14,7 @@ import parallelnbody_amd as nb  # noqa: E402
 
 
 
-def run(steps=60, sizes=(9000, 12288, 16384, 19000, 20480, 24000, 24576, 33000, 40960, 65536, 104000, 106496), out=print):
+def run(steps=60, sizes=(9000, 12288, 16384, 19000, 20480, 24000, 24576, 33000, 40960, 65536, 88000, 90112, 135000, 139264), out=print):
     """Returns the number of configurations whose end states differ."""
     bad = 0
     for n in sizes:
