@@ -118,6 +118,9 @@ constexpr int kRowsMaxN = 20480;           // larger systems up to here walk wit
 struct SmallTree {
   float4 *com;                  // [cap] preorder nodes: centre of mass, total mass
   unsigned int *meta;           // [cap] leaf bit | level << 25 | (internal: the node after the subtree; leaf: the body)
+  uint2 *hop;                   // [cap] what one step of the lane walk needs besides the CoM, in one 8-byte load: x = leaf bit | the node a walk
+                                // that does not descend goes to (a leaf's: the next node), y = the acceptance threshold of the node's level
+                                // (thr[level]; +0 for a leaf).  Only systems that walk with a lane per body hold it (nullptr otherwise).
   unsigned long long *khi, *klo;   // [n] sorted path keys (what the leaf boxes are rebuilt from).  klo: the second key words — in key
                                    // order when klo_by_body == 0 (small systems), in BODY order otherwise (larger systems: only the
                                    // first words go through the sort, and the second ones are looked at only where two first

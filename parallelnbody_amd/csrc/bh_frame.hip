@@ -141,6 +141,7 @@ static hipError_t bh_create_state(BhState *b, int n, int i_begin, int i_count) {
   BH_TRY(hipHostGetDevicePointer((void **)&t.verdict, b->h_verdict, 0));
   t.cap = b->node_cap;
   if (b->small) return hipSuccess;
+  BH_TRY(hipMalloc(&t.hop, sizeof(uint2) * (size_t)b->node_cap));   // (every word a walk reads is written by the frame's bh_nodes_kernel)
   BH_TRY(hipMalloc(&b->size_words, 2 * kSizeSlots * sizeof(unsigned int)));
   BH_TRY(hipMemset(b->size_words, 0, 2 * kSizeSlots * sizeof(unsigned int)));
   BH_TRY(hipMalloc(&b->khi2, sizeof(unsigned long long) * n));
@@ -191,7 +192,7 @@ static hipError_t bh_create_state(BhState *b, int n, int i_begin, int i_count) {
 void bh_destroy(BhState *b) {
   if (!b) return;
   void *ptrs[] = {b->khi, b->klo, b->khi2, b->idx, b->idx2, b->bound, b->pos_sorted, b->slot_hi, b->slot_lo, b->klo_sorted, b->slot_idx, b->gcount, b->size_words, b->part_hist, b->slice_hist, b->rx_desc, b->first, b->first_local, b->block_sum, b->lcpS, b->straddle, b->kids, b->own, b->own_blk,
-                  b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.leaf_level, b->st.thr, b->st.lvl, b->st.clocks};
+                  b->counters, b->root, b->prev_com, b->st.com, b->st.meta, b->st.hop, b->st.leaf_level, b->st.thr, b->st.lvl, b->st.clocks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (b->h_counters) (void)hipHostFree(b->h_counters);
   if (b->h_verdict) (void)hipHostFree(b->h_verdict);

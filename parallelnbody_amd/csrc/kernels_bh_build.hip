@@ -119,6 +119,8 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
   __shared__ int s_tmp[kB / 64];
   extern __shared__ unsigned long long s_smp[];                // every 2^smp_shift-th sorted first key word (lower_bound_sampled): dynamic LDS
   if (T.hdr[3] != 0) return;                                   // a frame given up or refused: there is no order to number (uniform: set before this launch)
+  __shared__ unsigned int s_thr_bits[kMaxLevels + 2];          // the frame's acceptance thresholds by level (the key kernel's frame setup): T.hop carries them
+  if (threadIdx.x <= kMaxLevels + 1) s_thr_bits[threadIdx.x] = T.hop ? __float_as_uint(T.thr[min((int)threadIdx.x, kMaxLevels)]) : 0u;   // (waited for by the scan's barriers)
   const int nblocks = (n + (1 << block_shift) - 1) >> block_shift;
   {
     const int nsmp = (n + (1 << smp_shift) - 1) >> smp_shift;   // eight loads in flight per thread: the fill is a chain of L2 round trips otherwise
@@ -189,7 +191,9 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
           upper = lower_bound_sampled(T.khi, n, s_smp, smp_shift, (pre + 1ull) << sh);
         }
       }
-      T.meta[s_m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first_of(upper);
+      const unsigned int past = (unsigned int)first_of(upper);
+      T.meta[s_m0 + q] = ((unsigned int)l << kLevelShift) | past;
+      if (T.hop) T.hop[s_m0 + q] = make_uint2(past, s_thr_bits[l]);
     }
   }
   if (!valid) return;
@@ -202,12 +206,15 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
         const int mid = (x + y) >> 1;
         if (same_prefix(T.khi[mid], second_word(T, mid), h0, l0, l)) x = mid + 1; else y = mid;
       }
-      T.meta[m0 + q] = ((unsigned int)l << kLevelShift) | (unsigned int)first_of(x);
+      const unsigned int past = (unsigned int)first_of(x);
+      T.meta[m0 + q] = ((unsigned int)l << kLevelShift) | past;
+      if (T.hop) T.hop[m0 + q] = make_uint2(past, s_thr_bits[l]);
     }
   }
   const int level = (lp > ln ? lp : ln) + 1;                   // the leaf: one level below the deepest cell the body shares
   const unsigned int body = T.sidx[i];
   T.meta[m0 + open] = kLeafBit | ((unsigned int)level << kLevelShift) | body;
+  if (T.hop) T.hop[m0 + open] = make_uint2(kLeafBit | (unsigned int)(m0 + open + 1), 0u);   // a leaf is taken whatever the distance (.h:103)
   T.com[m0 + open] = posm[body];                               // CenterOfMass = Position, TotalMass = Mass (.h:85-88)
   T.leaf_level[i] = (unsigned char)level;
 }

@@ -551,11 +551,13 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
                                                           unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted,
                                                           WalkSlice S) {
 #pragma clang fp contract(off)
-  __shared__ float s_thr[kMaxLevels + 2];
   hand_verdict(T);
   if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
+#if defined(NBODY_BH_LANE_NO_PIPELINE) || defined(NBODY_BH_LANE_META_WORD)
+  __shared__ float s_thr[kMaxLevels + 2];
   if (threadIdx.x <= kMaxLevels) s_thr[threadIdx.x] = T.thr[threadIdx.x];
   __syncthreads();
+#endif
   const int k = blockIdx.x * kB + threadIdx.x;
   const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
   const int nodes = valid ? T.hdr[0] : 0;
@@ -581,12 +583,8 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
     }
     node = (take || d2 == 0.f) ? past : node + 1;
   }
-#else
-  // Where the walk goes next follows from the node's test alone — a compare —, not from its term: the NEXT node's load is issued
-  // before the term (root, double-precision factor: ~100 dependent instructions) is worked out, and is in flight under it.  At
-  // the sizes where a SIMD holds one or two of these waves (N up to ~131072: the walk is a chain of ~220 dependent loads per body,
-  // DESIGN 4.5) that takes the term off the chain; at 2^20, where the waves queue for the VALU anyway, it changes nothing.
-  // (Not round 4's speculative fetch of node + 1 — wrong one step in three, and slower: this is the node the walk does visit.)
+#elif defined(NBODY_BH_LANE_META_WORD)                         // this round's first loop (the next node's load under the term; the node's
+                                                               // word unpacked and its level's threshold read from LDS inside the step), for A/B builds
   float4 cm = T.com[0];
   unsigned int w = T.meta[0];
   while (node < nodes) {
@@ -595,11 +593,9 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
     const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
     float d2 = ex * ex + ey * ey;
     d2 = d2 + ez * ez;
-    const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];   // .h:103 (reading the threshold for leaves as well, without
-                                                                       // the branch around it, costs more than the branch: 2^20 737 us a frame against 662;
-                                                                       // x and y as v_pk_*_f32 pairs: 648 against 638)
-    const int next = (take || d2 == 0.f) ? past : node + 1;    // .h:102: d == 0 adds nothing and ends the subtree; children 0..7 otherwise
-    const int fetch = min(next, nodes - 1);                    // (the last step fetches a node nobody looks at)
+    const bool take = leaf || d2 >= s_thr[(w >> kLevelShift) & 63u];
+    const int next = (take || d2 == 0.f) ? past : node + 1;
+    const int fetch = min(next, nodes - 1);
     const float4 cm_next = T.com[fetch];
     const unsigned int w_next = T.meta[fetch];
     if (take && d2 != 0.f) {
@@ -608,6 +604,33 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
       ax = ax + tx; ay = ay + ty; az = az + tz;
     }
     cm = cm_next; w = w_next; node = next;
+  }
+#else
+  // Where the walk goes next follows from the node's test alone — a compare —, not from its term: the NEXT node's load is issued
+  // before the term (root, double-precision factor: ~100 dependent instructions) is worked out, and is in flight under it.  At
+  // the sizes where a SIMD holds one or two of these waves (N up to ~131072: the walk is a chain of ~220 dependent loads per body,
+  // DESIGN 4.5) that takes the term off the chain; at 2^20, where the waves queue for the VALU anyway, it changes nothing.
+  // (Not round 4's speculative fetch of node + 1 — wrong one step in three, and slower: this is the node the walk does visit.)
+  // What is left ON the chain between a node's arrival and the next node's address is kept short: the node's hop word (T.hop,
+  // written by bh_nodes_kernel next to the node's packed word) carries the node to go to and the level's threshold ready-made, so
+  // a step has no unpacking, no LDS round trip for the threshold and no branch around it: eight fp32 operations, three compares.
+  float4 cm = T.com[0];
+  uint2 h = T.hop[0];
+  while (node < nodes) {
+    const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
+    float d2 = ex * ex + ey * ey;
+    d2 = d2 + ez * ez;
+    const bool take = (int)h.x < 0 || d2 >= __uint_as_float(h.y);   // .h:103: a leaf, or Size / d < Theta as a threshold on d2 (a NaN distance: leaves only, as there)
+    const int next = (take || d2 == 0.f) ? (int)(h.x & ~kLeafBit) : node + 1;   // .h:102: d == 0 adds nothing and ends the subtree; children 0..7 otherwise
+    const unsigned int fetch = (unsigned int)min(next, nodes - 1);   // (the last step fetches a node nobody looks at)
+    const float4 cm_next = *(const float4 *)((const char *)T.com + (fetch << 4));   // 32-bit byte offsets on the arrays' bases: at most 2^25 nodes
+    const uint2 h_next = *(const uint2 *)((const char *)T.hop + (fetch << 3));
+    if (take && d2 != 0.f) {
+      float tx, ty, tz;
+      force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
+      ax = ax + tx; ay = ay + ty; az = az + tz;
+    }
+    cm = cm_next; h = h_next; node = next;
   }
 #endif
   walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, S.off, next_size, pos_sorted, place);
