@@ -318,6 +318,20 @@ struct WalkSlice {
 __device__ __forceinline__ int walk_place(const WalkSlice &S, int j) { return S.own != nullptr ? (int)S.own[j] : j; }
 
 
+// Workgroups are dealt round-robin over the eight XCDs, each with an L2 of its own: with the plain numbering every XCD walks bodies
+// from all over the key order.  Renumbered so that workgroups b, b + 8, b + 16, ... — one XCD's — take CONSECUTIVE runs of the key
+// order: neighbours in space, whose walks read the same nodes (speed only: which workgroup walks which bodies changes no result;
+// a bijection of [0, gridDim.x) for every grid size).  The lane-per-body walk's numbering (frames 0.5-2 % shorter from N = 65536 on,
+// profiles/r05_ab_walk_xcd_runs.txt; the window walks of the smaller systems gained nothing from it and keep the plain one).
+__device__ __forceinline__ int xcd_run_block() {
+#ifdef NBODY_BH_NO_XCD_MAP
+  return (int)blockIdx.x;
+#else
+  const int g = (int)gridDim.x, x = (int)blockIdx.x & 7, q = g >> 3, r = g & 7;   // XCD x holds q + (x < r) workgroups
+  return x * q + min(x, r) + ((int)blockIdx.x >> 3);
+#endif
+}
+
 // ---- walks (kernels_bh_walk.hip)
 constexpr int kWvT = 512;                  // small systems: eight waves = eight bodies per workgroup next to the LDS tree
 constexpr int kWvK = 128;

@@ -558,7 +558,8 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
   if (threadIdx.x <= kMaxLevels) s_thr[threadIdx.x] = T.thr[threadIdx.x];
   __syncthreads();
 #endif
-  const int k = blockIdx.x * kB + threadIdx.x;
+  const int wg = xcd_run_block();
+  const int k = wg * kB + threadIdx.x;
   const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
   const int nodes = valid ? T.hdr[0] : 0;
   const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
@@ -610,7 +611,10 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
   // before the term (root, double-precision factor: ~100 dependent instructions) is worked out, and is in flight under it.  At
   // the sizes where a SIMD holds one or two of these waves (N up to ~131072: the walk is a chain of ~220 dependent loads per body,
   // DESIGN 4.5) that takes the term off the chain; at 2^20, where the waves queue for the VALU anyway, it changes nothing.
-  // (Not round 4's speculative fetch of node + 1 — wrong one step in three, and slower: this is the node the walk does visit.)
+  // (Not round 4's speculative fetch of node + 1 — wrong one step in three, and slower: this is the node the walk does visit.
+  // Nor the node AND its successor per round trip with the second step taken from registers where the walk goes there: a wave
+  // takes as many round trips as its slowest lane — 256 became 218, not the 155 of a lane alone — and pays both steps' tests and
+  // terms every time: N = 65536 175 us a frame against 152, profiles/r05_ab_lane_walk_node_and_successor.txt.)
   // What is left ON the chain between a node's arrival and the next node's address is kept short: the node's hop word (T.hop,
   // written by bh_nodes_kernel next to the node's packed word) carries the node to go to and the level's threshold ready-made, so
   // a step has no unpacking, no LDS round trip for the threshold and no branch around it: eight fp32 operations, three compares.
@@ -635,7 +639,6 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
 #endif
   walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, S.off, next_size, pos_sorted, place);
 }
-
 
 
 }  // namespace bh
