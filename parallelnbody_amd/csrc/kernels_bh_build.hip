@@ -176,6 +176,7 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
         const unsigned long long hs = ((unsigned long long)hh << 32) | hl;
         const int sh = 3 * (kLevelsPerKey - l);
         const unsigned long long pre = hs >> sh;
+#ifdef NBODY_BH_NODES_STEP_SEARCH                              // round 4's search, a step after the other, for A/B builds (make variant)
         int x = blockIdx.x * kB + (threadIdx.x & ~63) + src, step = 1;   // x: a body of the cell
         bool found = false;
         while (step <= 64) {
@@ -191,6 +192,37 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
           upper = lower_bound_sampled(T.khi, n, s_smp, smp_shift, (pre + 1ull) << sh);
         }
       }
+#else
+        // (Seven probes side by side, then seven more — the keys are sorted and a cell's bodies contiguous, so "in the cell" is
+        // monotone along them —: three round trips to memory where steps one after the other took up to thirteen, and a wave
+        // waits for the longest chain among its lanes' cells.)
+        const int x0 = blockIdx.x * kB + (threadIdx.x & ~63) + src;   // a body of the cell
+        unsigned long long probe[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) probe[u] = T.khi[min(x0 + (2 << u) - 1, n - 1)];   // bodies x0 + 1, 3, 7, ... 127
+        int inside = 0;                                            // (monotone: the number of probes inside = the first one outside)
+#pragma unroll
+        for (int u = 0; u < 7; ++u) inside += (x0 + (2 << u) - 1 < n && (probe[u] >> sh) == pre) ? 1 : 0;
+        if (inside < 7) {
+          int x = x0 + (1 << inside) - 1, y = min(x0 + (2 << inside) - 1, n);   // the first body behind the cell lies in (x, y]
+          while (y - x > 1) {                                      // the stretch cut in eight: at most 64 -> 8 -> 1
+            const int w = y - x;
+#pragma unroll
+            for (int u = 0; u < 7; ++u) probe[u] = T.khi[x + ((w * (u + 1)) >> 3)];    // (x <= j < y <= n)
+            int lo = x, hi = y;
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+              const int j = x + ((w * (u + 1)) >> 3);
+              if (j > x) { if ((probe[u] >> sh) == pre) lo = max(lo, j); else hi = min(hi, j); }
+            }
+            x = lo; y = hi;
+          }
+          upper = y;
+        } else {
+          upper = lower_bound_sampled(T.khi, n, s_smp, smp_shift, (pre + 1ull) << sh);
+        }
+      }
+#endif
       const unsigned int past = (unsigned int)first_of(upper);
       T.meta[s_m0 + q] = ((unsigned int)l << kLevelShift) | past;
       if (T.hop) T.hop[s_m0 + q] = make_uint2(past, s_thr_bits[l]);
