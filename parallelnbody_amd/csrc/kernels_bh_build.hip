@@ -21,10 +21,14 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // a frame the warm sort gave up (or one queued behind a refused frame) has no order to look at — and must keep its verdict: one
   // thread asks (other workgroups of this launch may be refusing the frame right now)
+  const int i0 = (blockIdx.x * kB + t) * bpt;                  // this thread's bodies: i0 .. i0 + bpt - 1, in key order
+  // (a fresh kernel's first look at anything is a trip to memory other XCDs wrote, ~1 us: this thread's first keys go out together
+  // with the verdict, not behind it and its barrier)
+  const unsigned long long h_pre = i0 < n ? T.khi[i0] : 0ull, hp_pre = (i0 < n && i0 > 0) ? T.khi[i0 - 1] : 0ull,
+                           hn_pre = i0 + 1 < n ? T.khi[i0 + 1] : 0ull;
   if (t == 0) s_stop = T.hdr[3];
   __syncthreads();
   if (s_stop != 0) return;
-  const int i0 = (blockIdx.x * kB + t) * bpt;                  // this thread's bodies: i0 .. i0 + bpt - 1, in key order
   int sum = 0, deep = -1, ties = 0;
   auto shared_at = [&](unsigned long long ha, int ia, unsigned long long hb, int ib) {   // digits the bodies at sorted positions ia, ib share
     const unsigned long long x = ha ^ hb;
@@ -32,14 +36,14 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
     return shared_digits(ha, second_word(T, ia), hb, second_word(T, ib));
   };
   if (i0 < n) {
-    unsigned long long h = T.khi[i0];
-    int lp = i0 > 0 ? shared_at(T.khi[i0 - 1], i0 - 1, h, i0) : -1;
+    unsigned long long h = h_pre;
+    int lp = i0 > 0 ? shared_at(hp_pre, i0 - 1, h, i0) : -1;
     for (int q = 0; q < bpt; ++q) {
       const int i = i0 + q;
       if (i >= n) break;
       int ln = -1;
       unsigned long long hn = 0;
-      if (i + 1 < n) { hn = T.khi[i + 1]; ln = shared_at(h, i, hn, i + 1); }
+      if (i + 1 < n) { hn = q == 0 ? hn_pre : T.khi[i + 1]; ln = shared_at(h, i, hn, i + 1); }
       // The kernels behind this one follow links made from the ORDER of the keys (a cell's end, "the node after the subtree"): keys
       // out of order would have them run backwards or off the arrays.  One compare on words already here: a frame sorted from the
       // previous order is given up and comes back with the cold sorts; a cold sort that fails it is an error of this library (status 4).
@@ -118,9 +122,20 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
   __shared__ int s_base[kScanBlocks + 1];
   __shared__ int s_tmp[kB / 64];
   extern __shared__ unsigned long long s_smp[];                // every 2^smp_shift-th sorted first key word (lower_bound_sampled): dynamic LDS
-  if (T.hdr[3] != 0) return;                                   // a frame given up or refused: there is no order to number (uniform: set before this launch)
+  // A fresh kernel's first look at anything is a trip to memory another XCD wrote, ~1 us, and the kernel is a handful of such trips:
+  // this body's words are asked for together with the frame's verdict — not behind it, nor behind the table's fill and the barriers of
+  // the block totals' scan (the arrays are there whatever the verdict; nothing is written before it is known).
+  const int i = blockIdx.x * kB + threadIdx.x;
+  const bool valid = i < n;
+  const int status = T.hdr[3];
+  const int lp_pre = valid ? (int)lcpS[i] : 0, ln_pre = valid ? (int)lcpS[i + 1] : 0, fl_pre = valid ? first_local[i] : 0;
+  const unsigned long long h0_pre = valid ? T.khi[i] : 0ull;
+  const unsigned int body_pre = valid ? T.sidx[i] : 0u;
+  const unsigned int thr_pre = T.hop ? __float_as_uint(T.thr[min((int)threadIdx.x, kMaxLevels)]) : 0u;
+  if (status != 0) return;                                     // a frame given up or refused: there is no order to number (uniform: set before this launch)
+  const float4 pos_pre = posm[body_pre];                       // (the leaf's CoM, at the kernel's end)
   __shared__ unsigned int s_thr_bits[kMaxLevels + 2];          // the frame's acceptance thresholds by level (the key kernel's frame setup): T.hop carries them
-  if (threadIdx.x <= kMaxLevels + 1) s_thr_bits[threadIdx.x] = T.hop ? __float_as_uint(T.thr[min((int)threadIdx.x, kMaxLevels)]) : 0u;   // (waited for by the scan's barriers)
+  if (threadIdx.x <= kMaxLevels + 1) s_thr_bits[threadIdx.x] = thr_pre;   // (waited for by the scan's barriers)
   const int nblocks = (n + (1 << block_shift) - 1) >> block_shift;
   {
     const int nsmp = (n + (1 << smp_shift) - 1) >> smp_shift;   // eight loads in flight per thread: the fill is a chain of L2 round trips otherwise
@@ -135,18 +150,16 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
   scan_block_sums<kB>(block_sum, nblocks, s_base, s_tmp);
   const int total = s_base[nblocks];
   auto first_of = [&](int j) { return j < n ? s_base[j >> block_shift] + first_local[j] : total; };   // first node of body j's group
-  const int i = blockIdx.x * kB + threadIdx.x;
-  const bool valid = i < n;
   if (total > T.cap) {                                         // (a pool sized for 42 cells per body cannot run out below 2^25 nodes)
     if (i == 0) { T.hdr[0] = 0; T.hdr[3] = 2; }
     return;
   }
   if (i == 0) T.hdr[0] = total;
-  const int lp = valid ? (int)lcpS[i] : 0, ln = valid ? (int)lcpS[i + 1] : 0, m0 = valid ? first_of(i) : 0;
+  const int lp = lp_pre, ln = ln_pre, m0 = valid ? s_base[i >> block_shift] + fl_pre : 0;
   if (valid) first[i] = m0;                                    // absolute node numbers for the kernels that follow
   if (i == n - 1) first[n] = total;
   const int open = ln > lp ? ln - lp : 0;
-  const unsigned long long h0 = valid ? T.khi[i] : 0ull;
+  const unsigned long long h0 = h0_pre;
   // The cells a body opens, levels lp + 1 .. ln: where each ends is a search, and a wave's bodies open anything from none to a
   // ladder of twenty — so the WAVE shares them out: the cells of its 64 bodies are numbered through (a scan of the counts), lane k
   // takes cells k, k + 64, ... and fetches what it needs of the owning lane by shuffles.  (Cells below the first key word's 21
@@ -244,10 +257,10 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
     }
   }
   const int level = (lp > ln ? lp : ln) + 1;                   // the leaf: one level below the deepest cell the body shares
-  const unsigned int body = T.sidx[i];
+  const unsigned int body = body_pre;
   T.meta[m0 + open] = kLeafBit | ((unsigned int)level << kLevelShift) | body;
   if (T.hop) T.hop[m0 + open] = make_uint2(kLeafBit | (unsigned int)(m0 + open + 1), 0u);   // a leaf is taken whatever the distance (.h:103)
-  T.com[m0 + open] = posm[body];                               // CenterOfMass = Position, TotalMass = Mass (.h:85-88)
+  T.com[m0 + open] = pos_pre;                                  // CenterOfMass = Position, TotalMass = Mass (.h:85-88)
   T.leaf_level[i] = (unsigned char)level;
 }
 
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(NT) void bh_sweep_chunks_kernel(SmallTree T, const 
   __shared__ unsigned int s_mask[2];
   __shared__ int s_strad[kMaxLevels + 1];
   const int chunk = blockIdx.x, base = chunk * NT, t = threadIdx.x;
-  if (T.hdr[3] != 0) return;                                    // a refused frame (uniform)
+  const int status = T.hdr[3];                                  // (looked at below, behind the loads that go out with it)
   if (t <= kMaxLevels) s_strad[t] = -1;
   if (t < 2) s_mask[t] = 0u;
   int lp[BPT], ln[BPT], m0[BPT];
@@ -321,6 +334,7 @@ __global__ __launch_bounds__(NT) void bh_sweep_chunks_kernel(SmallTree T, const 
     if (ln[q] > lp[q]) mask |= ((2ull << ln[q]) - 1ull) & ~((1ull << (lp[q] + 1)) - 1ull);
   }
   const int chunk_start = first[base], chunk_end = first[min(base + NT, n)];   // the chunk's nodes: [chunk_start, chunk_end)
+  if (status != 0) return;                                      // a refused frame (uniform: set before this launch; nothing was written so far)
   const int nr = chunk_end - chunk_start;
   const bool in_lds = nr <= kChunkNodes<NT>;
   if (in_lds)
@@ -409,8 +423,11 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
                                                              int nchunks, int div_mode, int keep_root) {
 #pragma clang fp contract(off)
   __shared__ int s_deep;
-  if (T.hdr[3] != 0) return;
-  const int deep = deepest_level(T, &s_deep);
+  __shared__ int s_lvl[128];
+  const int status = T.hdr[3];                                 // (the verdict, the levels' counts and the deepest level go out together:
+  if (threadIdx.x < 128) s_lvl[threadIdx.x] = T.lvl[threadIdx.x];   //  one trip to memory — a fresh kernel's first looks are ~1 us each)
+  const int deep = deepest_level(T, &s_deep);                  // (its barrier covers s_lvl)
+  if (status != 0) return;
   // one chunk per thread (nchunks <= kTopT up to kChunkSweepMaxN bodies); the cell of the NEXT level and its children's
   // node numbers — which depend on none of the sums — are fetched while this level's sums are formed
   const int c = threadIdx.x;
@@ -439,9 +456,6 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
   // A level's sums must be out in memory before the next level reads them (the store's way to L2 and back: ~1 us a level) — unless
   // nobody reads another thread's: level l has no cell here, or level l - 1 has none, or each has one and both are one chunk's (its
   // own register).  The first launch has counted (T.lvl).
-  __shared__ int s_lvl[128];
-  if (threadIdx.x < 128) s_lvl[threadIdx.x] = T.lvl[threadIdx.x];
-  __syncthreads();
   for (int l = deep; l >= 0; --l) {
     const int m = m_nx;
     const int kid[8] = {ka_nx.x, ka_nx.y, ka_nx.z, ka_nx.w, kb_nx.x, kb_nx.y, kb_nx.z, kb_nx.w};

@@ -174,7 +174,18 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
   __shared__ int s_lvl[64];                                    // cells per level, then where each level's list starts, then where it ends
   __shared__ int s_maxl, s_err, s_tie, s_bmax;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (T.hdr[3] != 0) return;                                   // an earlier frame of this call was refused: stay there
+  // A fresh kernel's first look at anything is a trip to memory the previous launch wrote (~1 us): the verdict, the frame count, the
+  // previous root centre, this thread's bodies and its sample's body of the previous order all go out together (the arrays are there
+  // whatever the verdict; nothing is written before it is known).
+  const int status = T.hdr[3], frames_pre = T.hdr[4];
+  const float pc0 = T.prev_com[0], pc1 = T.prev_com[1], pc2 = T.prev_com[2];
+  float4 mine[kSmBodies / kSmT];                               // this thread's bodies: t, t + 1024, ...
+#pragma unroll
+  for (int r = 0; r < kSmBodies / kSmT; ++r) { const int i = t + r * kSmT; mine[r] = posm[min(i, n - 1)]; }
+  const int smp_cap = n > 2048 ? kSmSamples : kSmSamples / 2, nsmp = min(smp_cap, n);
+  int sample_body = min((int)(((long long)min(t, nsmp - 1) * n + n / 2) / nsmp), n - 1);
+  const int sample_prev = (int)T.sidx[sample_body];            // (the previous frame's order; the first frame's is not used)
+  if (status != 0) return;                                     // an earlier frame of this call was refused: stay there
   BH_CLOCK(0);
   unsigned long long *lo_by_body = (unsigned long long *)(raw + 2 * kSmBuf);   // [n] second key word of body i
   unsigned short *cells = (unsigned short *)(raw + kSmRegionA + kSmNodesLds * 4);   // [cells] the cells by level
@@ -186,20 +197,17 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
 
   // ---- ComputeCubeSize (.cpp:47-56) and the root (.cpp:77-79)
   float mx = 0.0f;
-  float4 mine[kSmBodies / kSmT];                               // this thread's bodies: t, t + 1024, ...
 #pragma unroll
   for (int r = 0; r < kSmBodies / kSmT; ++r) {
     const int i = t + r * kSmT;
-    mine[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) { mine[r] = posm[i]; mx = fmaxf(mx, fmaxf(fmaxf(fabsf(mine[r].x), fabsf(mine[r].y)), fabsf(mine[r].z))); }
+    if (i < n) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(mine[r].x), fabsf(mine[r].y)), fabsf(mine[r].z)));
+    else mine[r] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // the sample: every (n / samples)-th body of the PREVIOUS frame's key order — bodies move little in a frame, so these stand close
   // to the quantiles of this frame's order too and the buckets come out even (any bodies would do: the first frame takes
   // every (n / samples)-th body as numbered)
-  const int smp_cap = n > 2048 ? kSmSamples : kSmSamples / 2, nsmp = min(smp_cap, n);
-  int sample_body = 0;
-  if (t < nsmp) { sample_body = (int)(((long long)t * n + n / 2) / nsmp); sample_body = min(sample_body, n - 1);
-                  if (T.hdr[4] > 0) sample_body = min((int)T.sidx[sample_body], n - 1); }
+  if (frames_pre > 0) sample_body = min(sample_prev, n - 1);
+  if (t >= nsmp) sample_body = 0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   if (lane == 0) s_red[wave] = mx;
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(kSmT) void bh_small_build_kernel(SmallTree T, const
   if (t == 0) {
     float m = s_red[0];
     for (int w = 1; w < kSmT / 64; ++w) m = fmaxf(m, s_red[w]);
-    s_root[0] = T.prev_com[0]; s_root[1] = T.prev_com[1]; s_root[2] = T.prev_com[2]; s_root[3] = m;
+    s_root[0] = pc0; s_root[1] = pc1; s_root[2] = pc2; s_root[3] = m;
     T.root[0] = s_root[0]; T.root[1] = s_root[1]; T.root[2] = s_root[2]; T.root[3] = m;
     T.hdr[7] = (int)__float_as_uint(m);                        // Size travels with the verdict (nbody_tick)
   }

@@ -475,11 +475,18 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   __shared__ unsigned int s_cnt[kWarmWin + 1], s_base[kWarmWin + 1];
   __shared__ int s_stop;
   const int t = threadIdx.x, w = blockIdx.x;
+  // A fresh kernel's first look at anything is a trip to memory other XCDs wrote (~1 us): the body at this thread's place of the
+  // previous order, its position, Size and the root's centre are asked for together with the verdict, not behind it and its barrier
+  // (the arrays are there whatever the verdict; nothing is written before it is known).
+  const int i = w * kB + t;
+  const bool valid = i < n;
+  const unsigned int body_pre = valid ? prev_idx[i] : 0u;
+  const float4 pos_pre = (valid && prev_pos != nullptr) ? prev_pos[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   if (t == 0) s_stop = T.hdr[3];                               // (one thread asks: other workgroups of this launch may be giving the frame up)
-  __syncthreads();
-  if (s_stop != 0) return;                                     // a frame before this one was refused: nothing of this one happens
   const float sz = frame_size(size_bits);
   float o[3] = {T.prev_com[0], T.prev_com[1], T.prev_com[2]};
+  __syncthreads();
+  if (s_stop != 0) return;                                     // a frame before this one was refused: nothing of this one happens
   if (w == 0) bh_frame_setup(T, o, sz, theta, kB, next_size);
   // bucket(h) = the largest j in 1 .. nb - 1 with boundary j <= h, or 0; the window: boundaries jlo .. jhi around this workgroup's own
   const int mid_j = (int)(((long long)w * kB + kB / 2) / kWarmMu);   // the bucket this workgroup's places lie in
@@ -488,16 +495,14 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   if (t < nwin) { s_b[t] = bound[jlo + t]; s_bl[t] = bound[nb + jlo + t]; }   // (the previous order's keys at places 224 j, gathered by its sort: bh_bucket_sort_kernel)
   if (t <= kWarmWin) s_cnt[t] = 0u;
   __syncthreads();
-  const int i = w * kB + t;
-  const bool valid = i < n;
   unsigned int body = 0u, local = 0u;
   unsigned long long hi = 0ull, lo = 0ull;
   int bucket = 0, q = -1;
   if (valid) {
-    body = prev_idx[i];
+    body = body_pre;
     // (the previous frame's walk left the positions in its key order — this kernel's order — where nothing else has moved a body
     // since: a coalesced read instead of a 16-byte record out of every 64-byte sector)
-    const float4 p = prev_pos != nullptr ? prev_pos[i] : posm[body];
+    const float4 p = prev_pos != nullptr ? pos_pre : posm[body];
     float size = sz;
     const bool plain = sz >= 0x1p-58f;
     hi = descend_word(p, o, size, plain);
@@ -559,24 +564,31 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
   __shared__ unsigned short s_ix[2][kBsP];
   __shared__ unsigned int s_body[kBsP];
   __shared__ unsigned int s_part[kBsT / 64];
-  if (T.hdr[3] != 0) return;                                   // the frame was given up (or an earlier one refused)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+  // A fresh kernel's first look at anything is a trip to memory other XCDs wrote (~1 us): the verdict, the counts and this thread's
+  // first slot of the bucket go out together (a slot beyond the bucket's count holds an older frame's words: loaded, not used; nothing
+  // is written before the verdict is known).
+  const int status = T.hdr[3];
+  const size_t slot_pre = (size_t)b * kWarmCap + min(t, kWarmCap - 1);
+  const unsigned long long hi_pre = slot_hi[slot_pre], lo_pre = slot_lo[slot_pre];
+  const unsigned int body_pre = slot_idx[slot_pre];
   // where the bucket starts: the counts of the buckets before it
   unsigned int sum = 0u;
   for (int j = t; j < b; j += kBsT) sum += gcount[j];
+  const int cnt = (int)gcount[b];
+  if (status != 0) return;                                     // the frame was given up (or an earlier one refused)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
   if (lane == 0) s_part[wave] = sum;
-  const int cnt = (int)gcount[b];
   if (t == 0) gcount_next[b] = 0u;                             // the next frame counts there
   int P = 64;
   while (P < cnt) P <<= 1;
   for (int e = t; e < P; e += kBsT) {
-    const bool in = e < cnt;
-    s_hi[0][e] = in ? slot_hi[(size_t)b * kWarmCap + e] : ~0ull;
-    s_lo[e] = in ? slot_lo[(size_t)b * kWarmCap + e] : ~0ull;
+    const bool in = e < cnt, pre = e == t && t < kWarmCap;
+    s_hi[0][e] = in ? (pre ? hi_pre : slot_hi[(size_t)b * kWarmCap + e]) : ~0ull;
+    s_lo[e] = in ? (pre ? lo_pre : slot_lo[(size_t)b * kWarmCap + e]) : ~0ull;
     s_ix[0][e] = (unsigned short)e;
-    s_body[e] = in ? slot_idx[(size_t)b * kWarmCap + e] : 0xFFFFFFFFu;
+    s_body[e] = in ? (pre ? body_pre : slot_idx[(size_t)b * kWarmCap + e]) : 0xFFFFFFFFu;
   }
   __syncthreads();
   unsigned int start = 0u;

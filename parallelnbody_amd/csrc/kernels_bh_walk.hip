@@ -413,39 +413,56 @@ __global__ __launch_bounds__(kWvT) void bh_walk_wave_compact_kernel(SmallTree T,
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned short s_list[kWaves][kWvK];
   __shared__ __attribute__((aligned(16))) float s_term[kWaves][3 * kWvK];
-  hand_verdict(T);
-  if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
-  BH_WG_STAMP(0);
+  // A fresh kernel's first look at anything is a trip to memory the build's workgroup wrote (~1 us), and this kernel is a handful of
+  // such trips and a walk in LDS: the verdict, the node count, the thresholds, the body's number AND the first 2048 nodes go out
+  // together (the arrays are there whatever the verdict, and hold T.cap nodes whatever the count; nothing is written before the verdict).
   const int t = threadIdx.x;
-  const int nodes = T.hdr[0];
-  const bool in_lds = nodes <= kSmNodesLds;
-  if (t <= kMaxLevels) s_thr[t] = T.thr[t];
-  __syncthreads();
-  if (in_lds) {
-    for (int m0 = t; m0 < nodes; m0 += 4 * kWvT) {               // four nodes' loads in flight per thread: the fill is round trips to L2
-      float4 c[4];
-      unsigned int w[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int m = min(m0 + u * kWvT, nodes - 1); c[u] = T.com[m]; w[u] = T.meta[m]; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int m = m0 + u * kWvT;
-        if (m < nodes) {
-          const bool leaf = (w[u] & kLeafBit) != 0u;
-          s_a[m] = make_float4(c[u].x, c[u].y, c[u].z, leaf ? 0.0f : s_thr[(w[u] >> kLevelShift) & 63u]);
-          s_m[m] = c[u].w;
-          s_past[m] = (unsigned short)(leaf ? m + 1 : (int)(w[u] & kLinkMask));
-        }
-      }
-    }
-    __syncthreads();
-  }
   const int wave = t >> 6, lane = t & 63;
   const int k = blockIdx.x * kWaves + wave;
   const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
   const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
   const unsigned int body = valid ? T.sidx[place] : 0u;
+  const int status = T.hdr[3], nodes = T.hdr[0];
+  const float thr_pre = T.thr[min(t, kMaxLevels)];
+  float4 c0[4];
+  unsigned int w0[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int m = min(t + u * kWvT, T.cap - 1); c0[u] = T.com[m]; w0[u] = T.meta[m]; }
+  hand_verdict(T);
+  if (status != 0) return;                                     // the frame was refused: nothing moves
+  BH_WG_STAMP(0);
   const float4 p = posm[body];
+  const bool in_lds = nodes <= kSmNodesLds;
+  if (t <= kMaxLevels) s_thr[t] = thr_pre;
+  __syncthreads();
+  if (in_lds) {
+    auto put = [&](int m, const float4 &c, unsigned int w) {
+      const bool leaf = (w & kLeafBit) != 0u;
+      s_a[m] = make_float4(c.x, c.y, c.z, leaf ? 0.0f : s_thr[(w >> kLevelShift) & 63u]);
+      s_m[m] = c.w;
+      s_past[m] = (unsigned short)(leaf ? m + 1 : (int)(w & kLinkMask));
+    };
+    float4 c[4];
+    unsigned int w[4];
+    const bool more = 4 * kWvT < nodes;                         // (uniform) the next nodes' loads go out before the first ones are put away
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int m = min(t + (4 + u) * kWvT, nodes - 1); c[u] = T.com[m]; w[u] = T.meta[m]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int m = t + u * kWvT; if (m < nodes) put(m, c0[u], w0[u]); }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int m = t + (4 + u) * kWvT; if (m < nodes) put(m, c[u], w[u]); }
+    }
+    for (int m0 = t + 8 * kWvT; m0 < nodes; m0 += 4 * kWvT) {   // four nodes' loads in flight per thread: the fill is round trips to L2
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int m = min(m0 + u * kWvT, nodes - 1); c[u] = T.com[m]; w[u] = T.meta[m]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int m = m0 + u * kWvT; if (m < nodes) put(m, c[u], w[u]); }
+    }
+    __syncthreads();
+  }
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   BH_WG_STAMP(1);
   if (in_lds)
@@ -472,17 +489,20 @@ __global__ __launch_bounds__(kWvGT) void bh_walk_wave_rows_kernel(SmallTree T, f
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kWaves][kWvGK];
   __shared__ __attribute__((aligned(16))) float s_term[kWaves][3 * kWvGK];
-  hand_verdict(T);
-  if (T.hdr[3] != 0) return;
+  // (a fresh kernel's first look at anything is a trip to memory other XCDs wrote, ~1 us: the body's number, the node count and the
+  // thresholds go out together with the verdict, not behind it)
   const int t = threadIdx.x;
-  if (t <= kMaxLevels) s_thr[t] = T.thr[t];
-  __syncthreads();
-  const int nodes = T.hdr[0];
   const int wave = t >> 6, lane = t & 63;
   const int k = blockIdx.x * kWaves + wave;
   const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
   const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
   const unsigned int body = valid ? T.sidx[place] : 0u;
+  const int status = T.hdr[3], nodes = T.hdr[0];
+  const float thr_pre = T.thr[min(t, kMaxLevels)];
+  hand_verdict(T);
+  if (status != 0) return;
+  if (t <= kMaxLevels) s_thr[t] = thr_pre;
+  __syncthreads();
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;
   walk_wave<false, kWvGK>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[wave],
@@ -500,17 +520,18 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float
   __shared__ float s_thr[kMaxLevels + 2];
   __shared__ unsigned int s_list[kGroups][kWalkK];
   __shared__ float4 s_term[kGroups][kWalkK];
-  hand_verdict(T);
-  if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
   const int t = threadIdx.x;
-  if (t <= kMaxLevels) s_thr[t] = T.thr[t];
-  __syncthreads();
-  const int nodes = T.hdr[0];
   const int group = t / kWalkG, g = t % kWalkG;
   const int k = blockIdx.x * kGroups + group;
   const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
   const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
-  const unsigned int body = valid ? T.sidx[place] : 0u;
+  const unsigned int body = valid ? T.sidx[place] : 0u;         // (asked for together with the verdict, as in bh_walk_wave_rows_kernel)
+  const int status = T.hdr[3], nodes = T.hdr[0];
+  const float thr_pre = T.thr[min(t, kMaxLevels)];
+  hand_verdict(T);
+  if (status != 0) return;                                     // the frame was refused: nothing moves
+  if (t <= kMaxLevels) s_thr[t] = thr_pre;
+  __syncthreads();
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;
   walk_windows<false>(T, (const float4 *)nullptr, (const float *)nullptr, (const unsigned short *)nullptr, s_thr, s_list[group],
@@ -551,19 +572,26 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
                                                           unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted,
                                                           WalkSlice S) {
 #pragma clang fp contract(off)
+  // A fresh kernel's first look at anything is a trip to memory other XCDs wrote (~1 us): the body's number and the root's words are
+  // asked for together with the frame's verdict, not behind it (the arrays are there whatever the verdict; nothing is written before it).
+  const int wg = xcd_run_block();
+  const int k = wg * kB + threadIdx.x;
+  const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
+  const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
+  const unsigned int body = valid ? T.sidx[place] : 0u;
+  const int status = T.hdr[3], nodes_all = T.hdr[0];
+#if !defined(NBODY_BH_LANE_NO_PIPELINE) && !defined(NBODY_BH_LANE_META_WORD)
+  float4 cm = T.com[0];
+  uint2 h = T.hop[0];
+#endif
   hand_verdict(T);
-  if (T.hdr[3] != 0) return;                                   // the frame was refused: nothing moves
+  if (status != 0) return;                                     // the frame was refused: nothing moves
 #if defined(NBODY_BH_LANE_NO_PIPELINE) || defined(NBODY_BH_LANE_META_WORD)
   __shared__ float s_thr[kMaxLevels + 2];
   if (threadIdx.x <= kMaxLevels) s_thr[threadIdx.x] = T.thr[threadIdx.x];
   __syncthreads();
 #endif
-  const int wg = xcd_run_block();
-  const int k = wg * kB + threadIdx.x;
-  const bool valid = k < n;                                    // (n: the bodies this context walks — all, or its slice's)
-  const int nodes = valid ? T.hdr[0] : 0;
-  const int place = valid ? walk_place(S, k) : 0;               // the body's sorted position
-  const unsigned int body = valid ? T.sidx[place] : 0u;
+  const int nodes = valid ? nodes_all : 0;
   const float4 p = posm[body];
   float ax = 0.f, ay = 0.f, az = 0.f;                          // Acceleration = ZeroVector, .cpp:84
   int node = 0;
@@ -618,8 +646,6 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
   // What is left ON the chain between a node's arrival and the next node's address is kept short: the node's hop word (T.hop,
   // written by bh_nodes_kernel next to the node's packed word) carries the node to go to and the level's threshold ready-made, so
   // a step has no unpacking, no LDS round trip for the threshold and no branch around it: eight fp32 operations, three compares.
-  float4 cm = T.com[0];
-  uint2 h = T.hop[0];
   while (node < nodes) {
     const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
     float d2 = ex * ex + ey * ey;
