@@ -365,7 +365,11 @@ __global__ __launch_bounds__(NT) void bh_sweep_chunks_kernel(SmallTree T, const 
       atomicAdd(&T.lvl[l], 1);
       if (l > 0 && s_strad[l - 1] >= 0) atomicAdd(&T.lvl[64 + l], 1);
     }
+#ifdef NBODY_BH_SWEEP_EXPERIMENT                               // A/B builds only (wrong sums): what the chains of the children's links cost
+    if (m >= 0 && nchunks < 0) {
+#else
     if (m >= 0) {
+#endif
       const int end = (int)(T.meta[m] & kLinkMask);
       int *k8 = kids + ((size_t)l * nchunks + chunk) * 8;
       int k = 0;
