@@ -112,8 +112,12 @@ constexpr int kWalkT = 256;                // threads per workgroup of the compa
 constexpr int kWalkG = 16;                 // lanes per body there
 constexpr int kWalkK = 48;                 // taken nodes a body lists before their terms are worked out and added
 constexpr int kWaveMaxN = 12288;           // ... and up to here with a whole wave per body (frames: N = 8192 157 us against 168, 16384 192 / 186: profiles/r04_bh_walk_ab.txt)
-constexpr int kRowsMaxN = 20480;           // larger systems up to here walk with sixteen lanes per body on the global tree
-                                           // (frames: N = 8192 208 us against 275 with a lane per body, 16384 231 / 270, 32768 321 / 272)
+constexpr int kRowsMaxN = 12288;           // larger systems up to here walk with windows on the global tree, above with a lane per body.  (Round 3:
+                                           // 20480 — sixteen lanes per body between kWaveMaxN and there; frames: N = 8192 208 us against 275 with a lane per body,
+                                           // 16384 231 / 270, 32768 321 / 272.  Since round 5's hop word the lane walk wins from ~11 000 bodies in Plummer spheres —
+                                           // N = 12288 130.7 against 138.6 us, 16384 133.6 / 148.1, 20480 136.1 / 167.9 — and loses 3 % at 16384 in the reference's box
+                                           // scene, whose runaway bodies make the walks long: profiles/r05_bh_walk_by_size.txt.  The sixteen-lane walk stays for
+                                           // NBODY_BH_ROWS_MAX_N / NBODY_BH_WALK=rows and the tests that drive it.)
 
 struct SmallTree {
   float4 *com;                  // [cap] preorder nodes: centre of mass, total mass

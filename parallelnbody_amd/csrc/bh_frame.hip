@@ -15,6 +15,7 @@ struct BhState {
   int n = 0, node_cap = 0;
   bool small = false;          // n <= kSmBodies: one workgroup builds the tree in LDS (bh_small_build_kernel)
   SmallTree st{};              // the compact tree (either path)
+  int rows_max_n = kRowsMaxN, wave_max_n = kWaveMaxN;   // larger systems: the largest walked with windows / with a wave per body (bh_large_frame)
   int frames_seen = 0;         // st.hdr[4] at the last bh_collect
   unsigned int *size_words = nullptr;   // larger systems: two sets of kSizeSlots device words for ComputeCubeSize that take turns (frame_size)
   int size_word = 0;
@@ -150,6 +151,8 @@ static hipError_t bh_create_state(BhState *b, int n, int i_begin, int i_count) {
   b->radix = n > bh_merge_max_n();
   { const char *e = getenv("NBODY_BH_LEVEL_SWEEPS"); b->level_sweeps = e && e[0] == '1'; }
   { const char *e = getenv("NBODY_BH_WARM_SORT"); b->warm_off = e && e[0] == '0'; }
+  { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); b->rows_max_n = e && *e ? atoi(e) : kRowsMaxN; }   // which walk for which size: read at every
+  { const char *e = getenv("NBODY_BH_WAVE_MAX_N"); b->wave_max_n = e && *e ? atoi(e) : kWaveMaxN; }   // bh_create, like the sorts' switches (tests, tuning)
   { const char *e = getenv("NBODY_BH_SORT_BOTH"); b->sort_both = e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }   // read at every bh_create, like the sorts' switch
   b->tile_size = bh_tile_size(n);
   { const int budget = n <= 131072 ? kNodeSmp / 4 : 512;       // many workgroups: a smaller table each (its fill is traffic; only cells of more than 127 bodies look at it)
@@ -356,8 +359,7 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   // the walk, with the Tick's update of every body behind it (dt > 0).  One lane per body needs enough bodies to hide its loads;
   // below that, sixteen lanes per body (NBODY_BH_ROWS_MAX_N: tuning).  A slice walks its own bodies only — the count that
   // decides — and leaves neither the next frame's Size nor the positions in key order (they would be its own bodies' alone).
-  static const int rows_max_n = [] { const char *e = getenv("NBODY_BH_ROWS_MAX_N"); return e && *e ? atoi(e) : kRowsMaxN; }();
-  static const int wave_max_n = [] { const char *e = getenv("NBODY_BH_WAVE_MAX_N"); return e && *e ? atoi(e) : kWaveMaxN; }();
+  const int rows_max_n = b->rows_max_n, wave_max_n = b->wave_max_n;   // (NBODY_BH_ROWS_MAX_N / NBODY_BH_WAVE_MAX_N as they stood at creation)
   const WalkSlice S = bh_walk_slice(b, s);
   const int nw = b->i_count;
   float4 *const pos_sorted = b->sliced ? nullptr : b->pos_sorted;

@@ -5,6 +5,12 @@
 namespace nbody {
 namespace bh {
 
+#ifdef NBODY_BH_BUILD_NO_XCD_RUNS                              // A/B builds (make variant)
+#define BH_BUILD_XCD_RUNS 0
+#else
+#define BH_BUILD_XCD_RUNS 1
+#endif
+
 
 // lcpS[i] = lcp(i - 1) (-1 at both ends), and the numbering of the nodes: body i (key order) opens max(lcp(i) - lcp(i-1), 0)
 // cells and has one leaf; the exclusive scan of these counts numbers all nodes in preorder.  The scan is done HERE, in the same
@@ -125,7 +131,8 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
   // A fresh kernel's first look at anything is a trip to memory another XCD wrote, ~1 us, and the kernel is a handful of such trips:
   // this body's words are asked for together with the frame's verdict — not behind it, nor behind the table's fill and the barriers of
   // the block totals' scan (the arrays are there whatever the verdict; nothing is written before it is known).
-  const int i = blockIdx.x * kB + threadIdx.x;
+  const int wg = BH_BUILD_XCD_RUNS ? xcd_run_block() : (int)blockIdx.x;   // (one XCD's workgroups take consecutive bodies: bh_sweep_chunks_kernel)
+  const int i = wg * kB + threadIdx.x;
   const bool valid = i < n;
   const int status = T.hdr[3];
   const int lp_pre = valid ? (int)lcpS[i] : 0, ln_pre = valid ? (int)lcpS[i + 1] : 0, fl_pre = valid ? first_local[i] : 0;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
         const int sh = 3 * (kLevelsPerKey - l);
         const unsigned long long pre = hs >> sh;
 #ifdef NBODY_BH_NODES_STEP_SEARCH                              // round 4's search, a step after the other, for A/B builds (make variant)
-        int x = blockIdx.x * kB + (threadIdx.x & ~63) + src, step = 1;   // x: a body of the cell
+        int x = wg * kB + (threadIdx.x & ~63) + src, step = 1;   // x: a body of the cell
         bool found = false;
         while (step <= 64) {
           const int j = x + step;
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(kB) void bh_nodes_kernel(SmallTree T, const float4 
         // (Seven probes side by side, then seven more — the keys are sorted and a cell's bodies contiguous, so "in the cell" is
         // monotone along them —: three round trips to memory where steps one after the other took up to thirteen, and a wave
         // waits for the longest chain among its lanes' cells.)
-        const int x0 = blockIdx.x * kB + (threadIdx.x & ~63) + src;   // a body of the cell
+        const int x0 = wg * kB + (threadIdx.x & ~63) + src;   // a body of the cell
         unsigned long long probe[7];
 #pragma unroll
         for (int u = 0; u < 7; ++u) probe[u] = T.khi[min(x0 + (2 << u) - 1, n - 1)];   // bodies x0 + 1, 3, 7, ... 127
@@ -319,7 +326,10 @@ __global__ __launch_bounds__(NT) void bh_sweep_chunks_kernel(SmallTree T, const 
   __shared__ unsigned int s_meta[kChunkNodes<NT>];
   __shared__ unsigned int s_mask[2];
   __shared__ int s_strad[kMaxLevels + 1];
-  const int chunk = blockIdx.x, base = chunk * NT, t = threadIdx.x;
+  // One XCD's workgroups take CONSECUTIVE chunks here and consecutive bodies in bh_nodes_kernel (xcd_run_block): what a chunk reads of
+  // its neighbours' nodes — the links of its straddling cells' children, chains of dependent loads — another workgroup of the same
+  // XCD wrote a launch ago, through the same L2.
+  const int chunk = BH_BUILD_XCD_RUNS ? xcd_run_block() : (int)blockIdx.x, base = chunk * NT, t = threadIdx.x;
   const int status = T.hdr[3];                                  // (looked at below, behind the loads that go out with it)
   if (t <= kMaxLevels) s_strad[t] = -1;
   if (t < 2) s_mask[t] = 0u;
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(NT) void bh_sweep_chunks_kernel(SmallTree T, const 
 #else
     if (m >= 0) {
 #endif
-      const int end = (int)(T.meta[m] & kLinkMask);
+      const int end = (int)((in_lds ? s_meta[m - chunk_start] : T.meta[m]) & kLinkMask);   // (the cell itself lies in the chunk)
       int *k8 = kids + ((size_t)l * nchunks + chunk) * 8;
       int k = 0;
       for (int c = m + 1; c != end;) {

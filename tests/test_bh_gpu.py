@@ -808,6 +808,38 @@ def test_compute_mass_with_a_launch_per_level_at_sizes_that_are_cheap_to_check(n
         np.testing.assert_array_equal(e.bh_stats()["root_com"], com)
 
 
+@pytest.mark.parametrize("walk,rows_max,wave_max,sizes", [
+    ("a lane per body", "0", "0", (4100, 9000)),
+    ("sixteen lanes per body", "1000000", "0", (9000, 15000)),
+    ("a wave per body", "1000000", "1000000", (15000, 30000)),
+])
+def test_every_walk_of_the_larger_systems_at_sizes_it_does_not_get_by_default(nb, oracle, monkeypatch, walk, rows_max, wave_max, sizes):
+    # Which walk a system above 4096 bodies gets follows from its size (a wave per body up to 12288, a lane per body above; sixteen
+    # lanes per body only on request since round 5); NBODY_BH_ROWS_MAX_N / NBODY_BH_WAVE_MAX_N (read when the theta > 0 state is
+    # created) move the boundaries.  Every walk on both kinds of scene at sizes the defaults give to another one: a cold pass and two
+    # Ticks, every bit / byte.
+    monkeypatch.setenv("NBODY_BH_ROWS_MAX_N", rows_max)
+    monkeypatch.setenv("NBODY_BH_WAVE_MAX_N", wave_max)
+    for n in sizes:
+        for posm, vel in (nb.ic_reference_box(n, 1000.0, seed=n % 97 + 1), nb.ic_plummer(n, seed=n % 89 + 1)):
+            pos = np.ascontiguousarray(posm[:, :3]); m = np.ascontiguousarray(posm[:, 3])
+            ref, com0, nodes = oracle.octree_forces_f32(pos, m, REF_THETA, pow_mode=3)
+            assert oracle.last_max_depth() < REFUSED_FROM_DEPTH
+            q = particles_from(nb, posm, vel)
+            com, size = None, 0.0
+            with nb.NBodyEngine(n, theta=REF_THETA) as e:
+                e.set_state(posm, vel)
+                e.compute_forces()
+                np.testing.assert_array_equal(e.accelerations(), ref)
+                assert e.bh_stats()["nodes"] == nodes
+                for frame in range(2):
+                    size_dev, out = e.tick(0.01)
+                    com, size = oracle.tick_aos_f32(q, 0.01, theta=REF_THETA, root_com=com, size=size, pow_mode=3)
+                    assert oracle.last_max_depth() < REFUSED_FROM_DEPTH
+                    assert size_dev == size, (walk, n, frame)
+                    assert out.tobytes() == q.tobytes(), (walk, n, frame)
+
+
 def test_the_first_two_frames_right_after_creation_of_small_systems(nb, oracle):
     # The theta > 0 state is created by the first theta > 0 call, right in front of its first frame, and its creation clears
     # device words with hipMemset on the NULL stream while the frames run on the context's non-blocking stream.  Round 4 waited for
