@@ -336,6 +336,15 @@ __device__ __forceinline__ int xcd_run_block() {
 #endif
 }
 
+// The kernels of a larger system's frame all number their workgroups this way (BH_BUILD_XCD_RUNS; A/B builds: make variant
+// EXTRA=-DNBODY_BH_BUILD_NO_XCD_RUNS): the x-th eighth of the key order is one XCD's from the key kernel to the walk, so what a
+// launch reads of the launch before — slots, sorted keys, shared digits, nodes — was written through the same L2.
+#ifdef NBODY_BH_BUILD_NO_XCD_RUNS
+#define BH_BUILD_XCD_RUNS 0
+#else
+#define BH_BUILD_XCD_RUNS 1
+#endif
+
 // ---- walks (kernels_bh_walk.hip)
 constexpr int kWvT = 512;                  // small systems: eight waves = eight bodies per workgroup next to the LDS tree
 constexpr int kWvK = 128;

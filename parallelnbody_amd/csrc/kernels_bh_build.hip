@@ -5,12 +5,6 @@
 namespace nbody {
 namespace bh {
 
-#ifdef NBODY_BH_BUILD_NO_XCD_RUNS                              // A/B builds (make variant)
-#define BH_BUILD_XCD_RUNS 0
-#else
-#define BH_BUILD_XCD_RUNS 1
-#endif
-
 
 // lcpS[i] = lcp(i - 1) (-1 at both ends), and the numbering of the nodes: body i (key order) opens max(lcp(i) - lcp(i-1), 0)
 // cells and has one leaf; the exclusive scan of these counts numbers all nodes in preorder.  The scan is done HERE, in the same
@@ -27,7 +21,8 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // a frame the warm sort gave up (or one queued behind a refused frame) has no order to look at — and must keep its verdict: one
   // thread asks (other workgroups of this launch may be refusing the frame right now)
-  const int i0 = (blockIdx.x * kB + t) * bpt;                  // this thread's bodies: i0 .. i0 + bpt - 1, in key order
+  const int wg = BH_BUILD_XCD_RUNS ? xcd_run_block() : (int)blockIdx.x;   // (one XCD's workgroups take consecutive bodies, as in every kernel of the frame)
+  const int i0 = (wg * kB + t) * bpt;                          // this thread's bodies: i0 .. i0 + bpt - 1, in key order
   // (a fresh kernel's first look at anything is a trip to memory other XCDs wrote, ~1 us: this thread's first keys go out together
   // with the verdict, not behind it and its barrier)
   const unsigned long long h_pre = i0 < n ? T.khi[i0] : 0ull, hp_pre = (i0 < n && i0 > 0) ? T.khi[i0 - 1] : 0ull,
@@ -84,7 +79,7 @@ __global__ __launch_bounds__(kB) void bh_lcp_scan_kernel(SmallTree T, int n, int
     first_local[i] = run;
     run += c;
   }
-  if (t == kB - 1) block_sum[blockIdx.x] = run;
+  if (t == kB - 1) block_sum[wg] = run;
   // deepest level: one atomic per workgroup, spread over kDeepSlots words (sixteen thousand waves on ONE address queue for 0.2 ms)
   if (t == 0) {
     for (int w = 1; w < kB / 64; ++w) m = max(m, s_m[w]);

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kB) void bh_keys_bucket_kernel(SmallTree T, const f
   __shared__ unsigned long long s_b[kWarmWin], s_bl[kWarmWin];  // boundaries jlo .. jhi: the previous order's keys (both words) at places 224 j
   __shared__ unsigned int s_cnt[kWarmWin + 1], s_base[kWarmWin + 1];
   __shared__ int s_stop;
-  const int t = threadIdx.x, w = blockIdx.x;
+  const int t = threadIdx.x, w = BH_BUILD_XCD_RUNS ? xcd_run_block() : (int)blockIdx.x;   // (bh_common.h: one XCD, one eighth of the key order)
   // A fresh kernel's first look at anything is a trip to memory other XCDs wrote (~1 us): the body at this thread's place of the
   // previous order, its position, Size and the root's centre are asked for together with the verdict, not behind it and its barrier
   // (the arrays are there whatever the verdict; nothing is written before it is known).
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kBsT) void bh_bucket_sort_kernel(SmallTree T, int n
   __shared__ unsigned short s_ix[2][kBsP];
   __shared__ unsigned int s_body[kBsP];
   __shared__ unsigned int s_part[kBsT / 64];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = BH_BUILD_XCD_RUNS ? xcd_run_block() : (int)blockIdx.x;
   // A fresh kernel's first look at anything is a trip to memory other XCDs wrote (~1 us): the verdict, the counts and this thread's
   // first slot of the bucket go out together (a slot beyond the bucket's count holds an older frame's words: loaded, not used; nothing
   // is written before the verdict is known).
