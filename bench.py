@@ -317,7 +317,8 @@ def clock_fields(engine, avg_launch_s, launch_pairs):
     nbody_kernel_clock) and launch time x clock x SIMD lanes / interactions — SIMD cycles per interaction and lane if every SIMD
     of the device was busy for the whole launch.  The force loops are power-limited and boxes hold different clocks under them;
     the cycles do not depend on the box: ~20 in the equal-mass form of the symmetric kernel, ~22 in its general form, ~37 one-sided
-    (DESIGN.md 4.1, 4.1b).  None for kernels without the stamps (fp64)."""
+    (DESIGN.md 4.1, 4.1b), ~51-55 in the fp64 symmetric kernel (whose power draw moves the clock most from box to box: 24.4 to 28.7 ms
+    a step of configs[3] within one afternoon).  None for kernels without the stamps (the generic scalar kernels)."""
     try:
         mhz, cus = engine.kernel_clock()
     except Exception:  # noqa: BLE001

@@ -474,7 +474,9 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
 #pragma unroll
       for (int k = 0; k < 8; ++k) {                              // up to eight loads in flight
         ch[k] = r_own;
+#if !defined(NBODY_BH_TOP_EXPERIMENT) || (NBODY_BH_TOP_EXPERIMENT & 2) == 0   // A/B builds only (wrong sums; tools/top_experiment.sh): the children's loads
         if (kid[k] >= 0 && kid[k] != m_own) ch[k] = T.com[kid[k]];
+#endif
       }
       float M = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
 #pragma unroll
@@ -485,10 +487,12 @@ __global__ __launch_bounds__(kTopT) void bh_sweep_top_kernel(SmallTree T, const 
       T.com[m] = r_own;
     }
     const int here = s_lvl[l], above = l > 0 ? s_lvl[l - 1] : 0;
+#if !defined(NBODY_BH_TOP_EXPERIMENT) || (NBODY_BH_TOP_EXPERIMENT & 1) == 0   // ... and the levels' hand-over through memory
     if (!(here == 0 || above == 0 || (here == 1 && above == 1 && s_lvl[64 + l] == 1))) {
       __threadfence_block();
       __syncthreads();
     }
+#endif
   }
   if (threadIdx.x == 0) {
     if (!keep_root) { const float4 c = T.com[0]; T.prev_com[0] = c.x; T.prev_com[1] = c.y; T.prev_com[2] = c.z; }   // .cpp:78

@@ -80,9 +80,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(IPT == 4
 void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict__ pool,
                            const SymItem *__restrict__ items, int n_total, double gscale, double eps2,
                            const int *__restrict__ dup_flag, int run_if_dup, const int *__restrict__ general,
-                           int run_if_general) {
+                           int run_if_general, unsigned long long *__restrict__ clk) {
   if (dup_flag != nullptr && ((*dup_flag != 0) ? 1 : 0) != run_if_dup) return;
   if (general != nullptr && ((*general != 0) ? 1 : 0) != run_if_general) return;
+  const ClockStamp stamp = clock_begin(clk);   // time_kernels: the shader clock this pass ran at (nbody_kernel_clock; four scalar registers)
   // subtile images, doubled: entries l and l+64 hold body l.  Two 16-byte planes (x, y) and (z, G m) rather than one
   // 32-byte record: a per-lane ds_read_b128 at a 32-byte stride is a 2-way bank conflict (1.1e9 conflict cycles per
   // N = 262144 pass, profiles/r02_pmc_forces_sym_f64_kernel_n262144_ipt4.txt), at a 16-byte stride it is conflict-free
@@ -156,6 +157,7 @@ void forces_sym_f64_kernel(const double4 *__restrict__ posm, double4 *__restrict
   double4 *__restrict__ Pi = pool + (size_t)slot_i + t;
 #pragma unroll
   for (int q = 0; q < IPT; ++q) { double4 o; o.x = ax[q]; o.y = ay[q]; o.z = az[q]; o.w = 0.0; Pi[q * kBlock] = o; }
+  clock_end(clk, stamp);
 }
 
 }  // namespace
@@ -174,7 +176,8 @@ hipError_t launch_forces_sym64(const SymLaunch &L, hipStream_t s) {
                        L.n_total, general);
 #define NBODY_SYM64_K(BARE, SOFT, IPTV, UNI, FLAG, RUNIF)                                                         \
   hipLaunchKernelGGL((forces_sym_f64_kernel<BARE, SOFT, IPTV, UNI>), grid, block, 0, s, (const double4 *)L.posm,   \
-                     (double4 *)L.pool, (const SymItem *)L.items, L.n_total, L.G, L.eps2, (const int *)(FLAG), RUNIF, gate, UNI ? 0 : 1)
+                     (double4 *)L.pool, (const SymItem *)L.items, L.n_total, L.G, L.eps2, (const int *)(FLAG), RUNIF, gate, UNI ? 0 : 1,  \
+                     (unsigned long long *)L.clk)
 #define NBODY_SYM64_I(BARE, SOFT, IPTV, FLAG, RUNIF)                                                              \
   do { if (run_uni) NBODY_SYM64_K(BARE, SOFT, IPTV, true, FLAG, RUNIF); NBODY_SYM64_K(BARE, SOFT, IPTV, false, FLAG, RUNIF); } while (0)
 #define NBODY_SYM64(BARE, SOFT, FLAG, RUNIF)                                                                      \

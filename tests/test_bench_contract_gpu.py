@@ -83,6 +83,9 @@ def test_the_rows_bench_adds_behind_the_headline_carry_their_own_parity_and_roof
     assert row["max_rel_err_sampled"] < row["rel_err_tolerance"] == 2e-5 and row["bodies_sampled"] >= 24
     row64 = bench.baseline_config_row(nb, 1 << 14, "f64", 0.0, steps=3, warmup=1, settle_seconds=0.0)
     assert row64["dtype"] == "f64" and row64["roofline"]["peak"] == pytest.approx(78.65) and row64["max_rel_err_sampled"] < 1e-12
+    if row64["kernel"] == "forces_sym_f64_kernel":              # the clock the fp64 pass ran at, from stamps inside the kernel (round 5)
+        rf64 = row64["roofline"]
+        assert 1.0 < rf64["clock_ghz"] <= 2.45 and rf64["compute_units"] == 256 and 40.0 < rf64["cycles_per_interaction"] < 400.0, rf64
     bh = bench.barnes_hut_row(nb, 2000, frames=50, warmup=5, parity_frames=2)
     assert bh["frames"] == 50 and 5.0 < bh["us_per_frame"] < 2000.0 and "every byte of 2 frame(s)" in bh["parity"]
     assert bh["tree_nodes"] > 2000 and bh["tree_levels"] >= 8
