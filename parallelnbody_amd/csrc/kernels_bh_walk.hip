@@ -646,22 +646,43 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
   // What is left ON the chain between a node's arrival and the next node's address is kept short: the node's hop word (T.hop,
   // written by bh_nodes_kernel next to the node's packed word) carries the node to go to and the level's threshold ready-made, so
   // a step has no unpacking, no LDS round trip for the threshold and no branch around it: eight fp32 operations, three compares.
-  while (node < nodes) {
-    const float ex = p.x - cm.x, ey = p.y - cm.y, ez = p.z - cm.z;
-    float d2 = ex * ex + ey * ey;
-    d2 = d2 + ez * ez;
-    const bool take = (int)h.x < 0 || d2 >= __uint_as_float(h.y);   // .h:103: a leaf, or Size / d < Theta as a threshold on d2 (a NaN distance: leaves only, as there)
-    const int next = (take || d2 == 0.f) ? (int)(h.x & ~kLeafBit) : node + 1;   // .h:102: d == 0 adds nothing and ends the subtree; children 0..7 otherwise
-    const unsigned int fetch = (unsigned int)min(next, nodes - 1);   // (the last step fetches a node nobody looks at)
-    const float4 cm_next = *(const float4 *)((const char *)T.com + (fetch << 4));   // 32-bit byte offsets on the arrays' bases: at most 2^25 nodes
-    const uint2 h_next = *(const uint2 *)((const char *)T.hop + (fetch << 3));
-    if (take && d2 != 0.f) {
-      float tx, ty, tz;
-      force_term(cm.x, cm.y, cm.z, cm.w, p, G, tx, ty, tz);
-      ax = ax + tx; ay = ay + ty; az = az + tz;
-    }
-    cm = cm_next; h = h_next; node = next;
+  // One step: the node in (CA, HA) is looked at, the node the walk goes to is asked for into (CB, HB).  Two steps to a turn of the
+  // loop with the two register sets changing places, so that no step ends with the moves of "next becomes current" (two 64-bit moves
+  // behind the loads' arrival, 4 % of the walk's instructions where the waves queue for the VALU).
+#define BH_LANE_STEP(CA, HA, CB, HB)                                                                                                   \
+  {                                                                                                                                    \
+    const float ex = p.x - CA.x, ey = p.y - CA.y, ez = p.z - CA.z;                                                                     \
+    float d2 = ex * ex + ey * ey;                                                                                                      \
+    d2 = d2 + ez * ez;                                                                                                                 \
+    /* .h:103: a leaf, or Size / d < Theta as a threshold on d2 (a NaN distance: leaves only, as there) */                            \
+    const bool take = (int)HA.x < 0 || d2 >= __uint_as_float(HA.y);                                                                    \
+    /* .h:102: d == 0 adds nothing and ends the subtree; children 0..7 otherwise */                                                   \
+    const int next = (take || d2 == 0.f) ? (int)(HA.x & ~kLeafBit) : node + 1;                                                         \
+    const unsigned int fetch = (unsigned int)min(next, nodes - 1);   /* (the last step fetches a node nobody looks at) */            \
+    CB = *(const float4 *)((const char *)T.com + (fetch << 4));      /* 32-bit byte offsets on the arrays' bases: at most 2^25 nodes */ \
+    HB = *(const uint2 *)((const char *)T.hop + (fetch << 3));                                                                        \
+    if (take && d2 != 0.f) {                                                                                                           \
+      float tx, ty, tz;                                                                                                                \
+      force_term(CA.x, CA.y, CA.z, CA.w, p, G, tx, ty, tz);                                                                            \
+      ax = ax + tx; ay = ay + ty; az = az + tz;                                                                                        \
+    }                                                                                                                                  \
+    node = next;                                                                                                                       \
   }
+#ifdef NBODY_BH_LANE_ONE_STEP_A_TURN                           // A/B builds (make variant): a step to a turn, "next becomes current" by moves
+  while (node < nodes) {
+    float4 cm2; uint2 h2;
+    BH_LANE_STEP(cm, h, cm2, h2)
+    cm = cm2; h = h2;
+  }
+#else
+  float4 cm2 = cm;
+  uint2 h2 = h;
+  while (node < nodes) {
+    BH_LANE_STEP(cm, h, cm2, h2)
+    if (node < nodes) BH_LANE_STEP(cm2, h2, cm, h)
+  }
+#endif
+#undef BH_LANE_STEP
 #endif
   walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, S.off, next_size, pos_sorted, place);
 }
