@@ -112,6 +112,7 @@ constexpr int kWalkT = 256;                // threads per workgroup of the compa
 constexpr int kWalkG = 16;                 // lanes per body there
 constexpr int kWalkK = 48;                 // taken nodes a body lists before their terms are worked out and added
 constexpr int kWaveMaxN = 12288;           // ... and up to here with a whole wave per body (frames: N = 8192 157 us against 168, 16384 192 / 186: profiles/r04_bh_walk_ab.txt)
+constexpr int kLaneTwoStepsMinN = 131072;      // a lane per body takes two steps to a turn of its loop from here on (the waves queue for the VALU)
 constexpr int kRowsMaxN = 12288;           // larger systems up to here walk with windows on the global tree, above with a lane per body.  (Round 3:
                                            // 20480 — sixteen lanes per body between kWaveMaxN and there; frames: N = 8192 208 us against 275 with a lane per body,
                                            // 16384 231 / 270, 32768 321 / 272.  Since round 5's hop word the lane walk wins from ~11 000 bodies in Plummer spheres —
@@ -511,7 +512,8 @@ __global__ __launch_bounds__(kWalkT) void bh_walk_rows_kernel(SmallTree T, float
                                                               unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted,
                                                               WalkSlice S);
 __global__ __launch_bounds__(kB) void bh_small_leaf_boxes_kernel(SmallTree T, int n, float4 *__restrict__ out);
-// kernels_bh_walk.hip
+// kernels_bh_walk.hip (TWO: two steps to a turn of the loop, the two register sets changing places)
+template <bool TWO>
 __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                           float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage,
                                                           unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted,

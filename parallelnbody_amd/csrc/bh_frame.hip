@@ -370,9 +370,12 @@ static hipError_t bh_large_frame(BhState *b, void *posm_v, void *vel, void *acc_
   else if (nw <= rows_max_n)
     hipLaunchKernelGGL(bh_walk_rows_kernel, dim3((nw + kWalkT / kWalkG - 1) / (kWalkT / kWalkG)), dim3(kWalkT), 0, s, b->st, posm, (float4 *)vel,
                        (float4 *)acc_v, nw, G, dt, stage, next_size, pos_sorted, S);
+  else if (nw >= kLaneTwoStepsMinN)
+    hipLaunchKernelGGL(bh_walk_lane_kernel<true>, dim3((nw + kB - 1) / kB), blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, nw, G, dt,
+                       stage, next_size, pos_sorted, S);
   else
-    hipLaunchKernelGGL(bh_walk_lane_kernel, dim3((nw + kB - 1) / kB), blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, nw, G, dt, stage,
-                       next_size, pos_sorted, S);
+    hipLaunchKernelGGL(bh_walk_lane_kernel<false>, dim3((nw + kB - 1) / kB), blk, 0, s, b->st, posm, (float4 *)vel, (float4 *)acc_v, nw, G, dt,
+                       stage, next_size, pos_sorted, S);
   b->pos_ready = !b->sliced;                                    // (every walk of all bodies writes them, moving or not)
   b->warm = true;                                               // b->khi / b->idx hold an order the next frame can start from
   return hipGetLastError();

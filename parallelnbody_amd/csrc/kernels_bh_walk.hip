@@ -567,6 +567,7 @@ __global__ __launch_bounds__(kB) void bh_small_leaf_boxes_kernel(SmallTree T, in
 // (Fetching the NEXT node of the preorder while a node is looked at — the walk goes there whenever it descends or the node is a
 // leaf, two steps in three — was tried in round 4: slower at every size, N = 32768 200 us a frame against 185, 65536 213 / 197,
 // 2^18 316 / 284, 2^20 843 / 710.)
+template <bool TWO>
 __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *__restrict__ posm, float4 *__restrict__ vel,
                                                           float4 *__restrict__ acc, int n, double G, float dt, float *__restrict__ stage,
                                                           unsigned int *__restrict__ next_size, float4 *__restrict__ pos_sorted,
@@ -668,25 +669,30 @@ __global__ __launch_bounds__(kB) void bh_walk_lane_kernel(SmallTree T, float4 *_
     }                                                                                                                                  \
     node = next;                                                                                                                       \
   }
-#ifdef NBODY_BH_LANE_ONE_STEP_A_TURN                           // A/B builds (make variant): a step to a turn, "next becomes current" by moves
-  while (node < nodes) {
-    float4 cm2; uint2 h2;
-    BH_LANE_STEP(cm, h, cm2, h2)
-    cm = cm2; h = h2;
+  // (TWO: from 131072 bodies on, where the waves queue for the VALU — N = 2^20 568.8 -> 561.6 us a frame, 2^18 210.6 -> 207.7; below, the
+  // second step's own end-of-walk test costs what the moves cost: N = 65536 146.3 -> 147.8.  profiles/r05_ab_lane_walk_two_steps_a_turn.txt)
+  if constexpr (!TWO) {
+    while (node < nodes) {
+      float4 cm2; uint2 h2;
+      BH_LANE_STEP(cm, h, cm2, h2)
+      cm = cm2; h = h2;
+    }
+  } else {
+    float4 cm2 = cm;
+    uint2 h2 = h;
+    while (node < nodes) {
+      BH_LANE_STEP(cm, h, cm2, h2)
+      if (node < nodes) BH_LANE_STEP(cm2, h2, cm, h)
+    }
   }
-#else
-  float4 cm2 = cm;
-  uint2 h2 = h;
-  while (node < nodes) {
-    BH_LANE_STEP(cm, h, cm2, h2)
-    if (node < nodes) BH_LANE_STEP(cm2, h2, cm, h)
-  }
-#endif
 #undef BH_LANE_STEP
 #endif
   walk_lane_tail(valid, body, p, ax, ay, az, posm, vel, acc, dt, stage, S.off, next_size, pos_sorted, place);
 }
 
+
+template __global__ void bh_walk_lane_kernel<false>(SmallTree, float4 *, float4 *, float4 *, int, double, float, float *, unsigned int *, float4 *, WalkSlice);
+template __global__ void bh_walk_lane_kernel<true>(SmallTree, float4 *, float4 *, float4 *, int, double, float, float *, unsigned int *, float4 *, WalkSlice);
 
 }  // namespace bh
 }  // namespace nbody
