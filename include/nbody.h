@@ -326,10 +326,11 @@ NBODY_AMD_API int nbody_kernel_time(nbody_ctx *ctx, int32_t which, double *total
 NBODY_AMD_API int nbody_kernel_time_reset(nbody_ctx *ctx);
 
 /* The shader clock the timed force kernels actually ran at since the last nbody_kernel_time_reset, in MHz (needs
- * params.time_kernels): every workgroup of forces_sym_pk_kernel / forces_tile_pk_kernel reads the shader-clock counter and the
- * fixed reference counter at both ends and the ratio of the sums is reported — the power-limited force loops hold a different
- * clock on different boxes (2.13 - 2.33 GHz seen), and time x clock is what tells a slower box from slower code.  0 when no
- * instrumented kernel has run (fp64, block and Barnes-Hut kernels are not instrumented).  compute_units: of the context's device.
+ * params.time_kernels): every workgroup of forces_sym_pk_kernel / forces_tile_pk_kernel / forces_sym_f64_kernel reads the
+ * shader-clock counter and the fixed reference counter at both ends and the ratio of the sums is reported — the power-limited force
+ * loops hold a different clock on different boxes (2.13 - 2.33 GHz seen; the fp64 loop moves it most), and time x clock is what tells
+ * a slower box from slower code.  0 when no instrumented kernel has run (the generic scalar, block and Barnes-Hut kernels are not
+ * instrumented).  compute_units: of the context's device.
  * A multi-device context reports its slowest device.  Synchronises. */
 NBODY_AMD_API int nbody_kernel_clock(nbody_ctx *ctx, double *shader_mhz, int32_t *compute_units);
 
