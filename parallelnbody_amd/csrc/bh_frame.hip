@@ -15,6 +15,7 @@ struct BhState {
   int n = 0, node_cap = 0;
   bool small = false;          // n <= kSmBodies: one workgroup builds the tree in LDS (bh_small_build_kernel)
   SmallTree st{};              // the compact tree (either path)
+  int small_global_walk_n = kSmGlobalWalkN;   // small systems: from here on the walk reads the tree's global arrays (bh_frame)
   int rows_max_n = kRowsMaxN, wave_max_n = kWaveMaxN;   // larger systems: the largest walked with windows / with a wave per body (bh_large_frame)
   int frames_seen = 0;         // st.hdr[4] at the last bh_collect
   unsigned int *size_words = nullptr;   // larger systems: two sets of kSizeSlots device words for ComputeCubeSize that take turns (frame_size)
@@ -141,6 +142,7 @@ static hipError_t bh_create_state(BhState *b, int n, int i_begin, int i_count) {
   t.khi = b->khi; t.klo = b->klo; t.sidx = b->idx; t.hdr = b->counters; t.root = b->root; t.prev_com = b->prev_com;
   BH_TRY(hipHostGetDevicePointer((void **)&t.verdict, b->h_verdict, 0));
   t.cap = b->node_cap;
+  { const char *e = getenv("NBODY_BH_SMALL_GLOBAL_WALK_N"); b->small_global_walk_n = e && *e ? atoi(e) : kSmGlobalWalkN; }   // (tuning; read at every bh_create)
   if (b->small) return hipSuccess;
   BH_TRY(hipMalloc(&t.hop, sizeof(uint2) * (size_t)b->node_cap));   // (every word a walk reads is written by the frame's bh_nodes_kernel)
   BH_TRY(hipMalloc(&b->size_words, 2 * kSizeSlots * sizeof(unsigned int)));
@@ -398,7 +400,7 @@ hipError_t bh_frame(BhState *b, void *posm, void *vel, void *acc, float theta, d
   // 50.5 / 52.8 us, 3000 75.3 / 70.6, 4096 106.2 / 94.0).  (A slice walks its own bodies: their number decides.)
   const WalkSlice S = bh_walk_slice(b, s);
   const int nw = b->i_count;
-  if (bh_wave_walk() && nw >= kSmGlobalWalkN)
+  if (bh_wave_walk() && nw >= b->small_global_walk_n)
     hipLaunchKernelGGL(bh_walk_wave_rows_kernel, dim3((nw + kWvGT / 64 - 1) / (kWvGT / 64)), dim3(kWvGT), 0, s, b->st, (float4 *)posm, (float4 *)vel,
                        (float4 *)acc, nw, G, dt, stage, (unsigned int *)nullptr, (float4 *)nullptr, S);
   else if (bh_wave_walk())
