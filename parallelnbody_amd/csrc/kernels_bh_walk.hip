@@ -561,9 +561,9 @@ __global__ __launch_bounds__(kB) void bh_small_leaf_boxes_kernel(SmallTree T, in
 
 
 
-// Octree::ComputeForces (.h:99-108) on the compact tree, one lane per body in key order, node by node: a 16-byte and a
-// 4-byte load, the squared distance and a compare per node (accept_threshold); root, double-precision factor and the three
-// multiply-adds only where a term is added.
+// Octree::ComputeForces (.h:99-108) on the compact tree, one lane per body in key order, node by node: a 16-byte and an
+// 8-byte load (CoM and mass; the hop word), the squared distance and a compare per node (accept_threshold); root, double-precision
+// factor and the three multiply-adds only where a term is added.
 // (Fetching the NEXT node of the preorder while a node is looked at — the walk goes there whenever it descends or the node is a
 // leaf, two steps in three — was tried in round 4: slower at every size, N = 32768 200 us a frame against 185, 65536 213 / 197,
 // 2^18 316 / 284, 2^20 843 / 710.)
